@@ -1,0 +1,183 @@
+/*
+ * smx.h -- C ABI of libsmx.so: the MI355X (gfx950) kernels of the per-frame reenactment
+ * hot path of ShaelynZ/synergize-motion-appearance.
+ *
+ * The reference has NO native boundary on this path: its hot path is
+ * stock ATen calls made from `basicsr/archs/*.py`.  The drop-in boundary is therefore the
+ * Python plugin surface (ARCH_REGISTRY names / options/test.yml kwargs / checkpoint keys),
+ * mirrored by `synergize_motion_appearance_amd/archs`, and THIS header is what that host
+ * layer binds (ctypes).  Each entry point names the reference call
+ * sites (file:line under /root/reference/basicsr) whose ATen op sequence it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated; activations are NHWC
+ *     ([B][H][W][C], C fastest) -- tokens [B][1024][E] are the same layout at 32x32;
+ *   - no allocation, no synchronisation, no retained pointers; kernels are enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return 0 on success, negative SMX_E* on a rejected argument / launch failure;
+ *   - channel-sliced views: (ptr, ld = channels of the underlying buffer) -- a producer
+ *     can write straight into a slice of a concat buffer, so torch.cat never materialises.
+ */
+#ifndef SMX_H
+#define SMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMX_OK 0
+#define SMX_EINVAL (-22)
+#define SMX_ELAUNCH (-5)
+
+/* activation codes for fused epilogues */
+enum { SMX_ACT_NONE = 0, SMX_ACT_RELU = 1, SMX_ACT_LRELU02 = 2, SMX_ACT_SWISH = 3,
+       SMX_ACT_GELU = 4, SMX_ACT_SIGMOID = 5 };
+
+/* library identification: returns a static string "smx <version> gfx950" */
+const char* smx_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / batched NT-GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   C[g][m][n] = epi( alpha * sum_k A[g][m][k] * Bt[g][n][k] )
+ * A is gathered on the fly from an NHWC tensor (im2col never materialises):
+ *   m -> (img, oy, ox), k -> (ky, kx, c); zero padding; optional virtual nearest x2
+ *   upsampling of the input (`up2`) and asymmetric pads (pad_t/pad_l + implied bottom/right).
+ * Bt is [N][K] row-major (k fastest): conv weights repacked [Cout][kh][kw][Cin], or an
+ * activation (attention K / V^T).  g = g0*nb1+g1 is a two-level batch (frame, head).
+ * epi: + bias (per n, or per m when bias_per_row), activation, + residual, then an
+ * optional depth-to-space scatter (un-patchify: n = (p1*p+p2)*dc + c).
+ *
+ * Replaces: every `aten::convolution` / `addmm` / `bmm` on the path -- ResBlock, Upsample,
+ * Downsample, AttnBlock q/k/v/proj + both bmm (archs/vqgan_arch.py:144-253), Hourglass
+ * blocks with BN folded (utils/motion_estimator_util.py:214-230,363-380), 7x7 heads
+ * (archs/keypoint_detector_arch.py:65,74; archs/dense_motion_arch.py:134,158),
+ * nn.MultiheadAttention projections + QK^T + PV and the conv-FFN
+ * (archs/appmotioncodebook_arch.py:69-74,101-121), patch (un)embedding Linear layers
+ * (:222-240), BasicMotionEncoder/RefineFlow/to_context (:129-167,:296-301), SFT fusion
+ * (:28-52,:259).
+ * ------------------------------------------------------------------------------------- */
+typedef struct smx_gemm_desc {
+  const float* a;    int64_t a_bs0, a_bs1;     /* batch strides in elements (0 = shared) */
+  const float* bt;   int64_t bt_bs0, bt_bs1;
+  float* c;          int64_t c_bs0, c_bs1;
+  const float* bias;                            /* [N] (or [M] if bias_per_row) or NULL */
+  const float* res;  int64_t res_bs0, res_bs1; /* residual, same indexing as c, or NULL */
+  int32_t nb0, nb1;
+  int32_t M, N, K;                              /* per batch; K = kh*kw*Cin */
+  int32_t lda, ldb, ldc, ldres;                 /* A pixel stride (channels of the buffer), Bt row stride, C row stride */
+  int32_t Hin, Win, Cin, Ho, Wo;                /* im2col geometry; images per batch = M/(Ho*Wo) */
+  int32_t kh, kw, stride, pad_t, pad_l, up2;
+  int32_t act; float alpha;
+  int32_t bias_per_row;
+  int32_t d2s_p, d2s_c;                         /* 0 = plain store */
+  int32_t tile;                                 /* 0 = auto; else force a tile config id (tests/tuning) */
+} smx_gemm_desc;
+
+int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GroupNorm(32 groups, eps) [+ swish] on NHWC.   normalize/swish archs/vqgan_arch.py:14-20.
+ * Two launches inside: per-(b,chunk,c) partial moments -> per-(b,c) scale/shift -> apply.
+ * ws: workspace of smx_groupnorm_ws_floats(B,HW,C) floats.
+ * ------------------------------------------------------------------------------------- */
+int64_t smx_groupnorm_ws_floats(int B, int HW, int C);
+int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float* gamma, const float* beta,
+                                 float* y, int ldy, int B, int HW, int C, int groups, float eps,
+                                 int swish, float* ws, void* stream);
+
+/* LayerNorm over E (eps) on tokens [T][E]; also writes y_pos = LN(x) + pos[t % npos] when
+ * y_pos != NULL.  TransformerLayer.norm1/2/3 + with_pos_embed (appmotioncodebook_arch.py:97-119). */
+int smx_layernorm_pos_f32(const float* x, const float* gamma, const float* beta, const float* pos,
+                          float* y, float* y_pos, int T, int E, int npos, float eps, void* stream);
+
+/* Row softmax in place over [R][S] (ld = row stride): softmax(scale * s + mask) with an
+ * optional key-padding mask uint8 [R / rows_per_mask][S] (1 = -inf).  F.softmax at
+ * vqgan_arch.py:243 and inside nn.MultiheadAttention (appmotioncodebook_arch.py:101-115). */
+int smx_softmax_rows_f32(float* s, int ld, int R, int S, float scale, const uint8_t* mask,
+                         int rows_per_mask, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A7: fused backward warp.  deform_input + occlude_input, appmotioncodebook_arch.py:349-362:
+ * flow [B][Hf][Wf][2] bilinear-resized (align_corners=True) to HxW, grid_sample bilinear /
+ * zeros / align_corners=True of feat [Bf][H][W][C] (Bf = 1 broadcasts the cached source
+ * features over B driving frames), times occ [B][Hf][Wf] resized likewise (NULL = no occlusion).
+ * ------------------------------------------------------------------------------------- */
+int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float* flow, const float* occ,
+                      float* out, int B, int H, int W, int C, int Hf, int Wf, void* stream);
+
+/* bilinear resize, align_corners=True, NHWC slices (F.interpolate at :354,:360,:390,:414,:418,:488,:571,:671) */
+int smx_resize_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int B, int Hin, int Win,
+                                    int Hout, int Wout, int C, void* stream);
+
+/* relu(1x1conv(x)) evaluated only at the align_corners bilinear taps is NOT exact (relu is
+ * non-linear) -- not provided; see DESIGN.md. */
+
+/* avg_pool2d 2x2 NHWC (DownBlock2d.pool, utils/motion_estimator_util.py:374) */
+int smx_avgpool2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int B, int Hin, int Win, int C, void* stream);
+
+/* A1: AntiAliasInterpolation2d (utils/motion_estimator_util.py:636-645): depthwise KxK (zero pad K/2)
+ * evaluated only at every `step`-th pixel.  img NCHW [B][C][H][W] -> out NHWC slice. w: [C][K][K]. */
+int smx_antialias_down_f32(const float* img_nchw, const float* w, float* out, int ldo, int B, int C,
+                           int H, int W, int K, int step, void* stream);
+
+/* A3: KP head.  softmax(logits/T) over HW positions per (b,k), E[grid] and heatmap-weighted
+ * jacobian sums (archs/keypoint_detector_arch.py:48-58,66-85).  logits NHWC [B][H][W][ldl]
+ * (channels 0..K-1), jac maps NHWC [B][H][W][ldj] (channel 4k+j).  value [B][K][2], jac [B][K][4]. */
+int smx_kp_head_f32(const float* logits, int ldl, const float* jmaps, int ldj, float* value, float* jac,
+                    int B, int H, int W, int K, float temperature, void* stream);
+
+/* A4-A6: heatmaps + sparse motions + 16 sparse warps fused (archs/dense_motion_arch.py:65-116).
+ * src NHWC [Bs][H][W][3] (Bs = 1 broadcasts); kp value [B][K][2], jacobian [B][K][4].
+ * hg_in: NHWC [B][H][W][ldh], channel 4k+0 = heatmap_k (k=0 background = 0), 4k+1..3 = deformed rgb.
+ * sparse: [B][K+1][H][W][2]; drv_heat: NHWC [B][H][W][K] (driving gaussians). */
+int smx_sparse_motion_f32(const float* src, int src_batch, const float* kpd_value, const float* kpd_jac,
+                          const float* kps_value, const float* kps_jac, int kps_batch,
+                          float* hg_in, int ldh, float* sparse, float* drv_heat,
+                          int B, int H, int W, int K, float kp_variance, void* stream);
+
+/* A6b: softmax over the K+1 mask logits and deformation = sum_k mask_k * T_k
+ * (archs/dense_motion_arch.py:134-140). mask_logits NHWC [B][H][W][ldm]; deformation [B][H][W][2];
+ * mask_out NHWC [B][H][W][K+1] or NULL. */
+int smx_mask_deformation_f32(const float* mask_logits, int ldm, const float* sparse, float* deformation,
+                             float* mask_out, int B, int H, int W, int K1, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * small fused elementwise stages of AppMotionCompFormer.forward
+ * ------------------------------------------------------------------------------------- */
+/* flow_res = (flow - grid) * (H-1)/2 ; grid = make_coordinate_grid (appmotioncodebook_arch.py:562-577) */
+int smx_flow_to_residual_f32(const float* flow, float* res, int B, int H, int W, void* stream);
+/* m_com = flow + r[...,0:2]/half ; res_norm = r[...,0:2]/half ; occ_out = sigmoid(occ_prev + r[...,2])
+ * (:590-601, :689-710).  r: NHWC [B][H][W][3]. */
+int smx_flow_occ_update_f32(const float* flow, const float* r, const float* occ_prev, float* m_com,
+                            float* res_norm, float* occ_out, int B, int H, int W, void* stream);
+/* motion_ignore[b][n] = any(|flow32|>1) with flow bilinear-resized (ac=True) to 32x32 (:487-492) */
+int smx_motion_ignore_f32(const float* flow, uint8_t* ignore, int B, int Hf, int Wf, int Ht, int Wt, void* stream);
+/* out = dec + w*(dec*scale + shift)  (Fuse_sft_block.forward :50-51), n elements */
+int smx_sft_combine_f32(const float* dec, const float* scale, const float* shift, float* out, float w,
+                        int64_t n, void* stream);
+/* y = a + b (n elements) */
+int smx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* copy a channel slice: y[.., 0:C] (ld ldy) = x[.., 0:C] (ld ldx) over P pixels */
+int smx_copy_slice_f32(const float* x, int ldx, float* y, int ldy, int64_t P, int C, void* stream);
+
+/* layout + A14 */
+int smx_nchw_to_nhwc_f32(const float* x, float* y, int ldy, int B, int C, int H, int W, void* stream);
+int smx_nhwc_to_nchw_f32(const float* x, int ldx, float* y, int B, int C, int H, int W, void* stream);
+/* tensor2img (utils/img_util.py:70,93): clamp[lo,hi] -> (x-lo)/(hi-lo)*255 -> round-half-even -> uint8, HWC */
+int smx_to_uint8_f32(const float* x, uint8_t* y, int64_t n, float lo, float hi, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * A12: VectorQuantizer.forward (archs/vqgan_arch.py:33-93), fused: d = |z|^2 + |e|^2 - 2 z.e
+ * over the first Ks rows, first-minimum argmin, gather, z_q = z + (e - z).
+ * z tokens [N][D]; codebook [Ks..][D]; idx int64 [N]; zq [N][D]; dmin [N] (min distance, optional);
+ * sqerr: one float, += sum (zq-z)^2 (optional; zero it first).
+ * ------------------------------------------------------------------------------------- */
+int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, float* zq, float* dmin,
+                       float* sqerr, int N, int D, int Ks, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMX_H */

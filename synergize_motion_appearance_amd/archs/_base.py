@@ -1,0 +1,36 @@
+"""Common behaviour of the HIP-backed arch modules: parameters live in a ParamNode tree
+(checkpoint contract); the packed-weight engine is rebuilt lazily whenever parameters may
+have changed (load_state_dict, .cuda()/.to())."""
+import torch
+from torch import nn
+
+from ..lib import SmxError
+from ..paramtree import attach
+
+
+class HipArch(nn.Module):
+    def __init__(self, manifest):
+        super().__init__()
+        attach(self, manifest)
+        self._engine = None
+
+    # any of these may change parameter storage -> drop the packed engine
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def refresh(self):
+        """re-pack weights after in-place parameter edits."""
+        self._engine = None
+
+    def _params_on_device(self):
+        P = dict(self.state_dict(keep_vars=False))
+        dev = next(iter(P.values())).device
+        if dev.type != "cuda":
+            raise SmxError(f"{type(self).__name__}: parameters are on '{dev}'. The hot path runs as HIP kernels on an "
+                           "MI355X only (call .cuda()); there is no CPU fallback.")
+        return {k: (v.detach().float() if v.is_floating_point() else v) for k, v in P.items()}

@@ -1,0 +1,88 @@
+"""`AppMotionCompFormer` -- drop-in for reference
+`basicsr/archs/appmotioncodebook_arch.py:170-764` (inference branch), executing
+`engine_netg.NetGEngine` (HIP) instead of ATen modules."""
+import torch
+
+from ..engine_netg import NetGEngine
+from ..manifest import netg_manifest
+from .. import ops
+from ..registry import ARCH_REGISTRY
+from ._base import HipArch
+
+
+@ARCH_REGISTRY.register()
+class AppMotionCompFormer(HipArch):
+    def __init__(self, img_size=256, nf=64, ch_mult=[1, 2, 2, 4], res_blocks=2, attn_resolutions=[32],
+                 quantizer_type="nearest", beta=0.25,
+                 codebook_size_motion=1024, embed_dim_motion=32, codebook_size_app=1024, embed_dim_app=256,
+                 n_head=8, dim_embd_motion=32, n_layers_motion=2, dim_embd_app=256, n_layers_app=2, split=1,
+                 num_kp=15, with_position_emb=True, warp_s_d_kp_query=True, MRFA_motion_enc=True,
+                 motion_codebook_split=True, detach_motion_query=True, multiscale_feature_fusion=True,
+                 multiscale_sft=True, app_codebook_split=True, wo_motion_cdbk_share=False, wo_app_cdbk_share=False,
+                 connect_list=['64', '128', '256'], connect_app_list=['32', '64', '128', '256'],
+                 fix_modules=[], ae_path=None):
+        supported = (img_size == 256 and quantizer_type == "nearest" and split == 1 and with_position_emb
+                     and warp_s_d_kp_query and MRFA_motion_enc and motion_codebook_split and multiscale_feature_fusion
+                     and multiscale_sft and app_codebook_split and not wo_motion_cdbk_share and not wo_app_cdbk_share
+                     and list(connect_list) == ['64', '128', '256'] and list(connect_app_list) == ['32', '64', '128', '256']
+                     and embed_dim_motion == dim_embd_motion and embed_dim_app == dim_embd_app and list(attn_resolutions) == [32])
+        if not supported:
+            raise NotImplementedError("only the options/test.yml flag set has a HIP plan (SURVEY.md section 8b)")
+        self.cfg = dict(img_size=img_size, nf=nf, ch_mult=list(ch_mult), res_blocks=res_blocks,
+                        attn_resolutions=list(attn_resolutions), n_head=n_head, dim_embd_motion=dim_embd_motion,
+                        n_layers_motion=n_layers_motion, dim_embd_app=dim_embd_app, n_layers_app=n_layers_app,
+                        num_kp=num_kp, connect_list=list(connect_list), connect_app_list=list(connect_app_list))
+        super().__init__(netg_manifest(img_size, nf, tuple(ch_mult), res_blocks, tuple(attn_resolutions),
+                                       codebook_size_motion, embed_dim_motion, codebook_size_app, embed_dim_app,
+                                       dim_embd_motion, n_layers_motion, dim_embd_app, n_layers_app, split, num_kp,
+                                       tuple(connect_list), tuple(connect_app_list)))
+        self.beta = beta
+        if ae_path is not None:
+            self.load_state_dict(torch.load(ae_path, map_location='cpu')['params_ema'])
+        self.full_outputs = True      # return every key of the reference's out_dict (NCHW copies)
+        self.cache_source = True      # reuse the source encoding across calls with the same tensor
+        self._src_key, self._src_cache = None, None
+
+    def engine(self):
+        if self._engine is None:
+            self._engine = NetGEngine(self._params_on_device(), self.cfg)
+            self._src_key = None
+        return self._engine
+
+    @torch.no_grad()
+    def encode_source(self, x):
+        """frame-invariant encoder taps (the reference recomputes them every frame, demo.py:130)."""
+        key = (x.data_ptr(), x._version, tuple(x.shape))
+        if self.cache_source and key == self._src_key:
+            return self._src_cache
+        c = self.engine().encode_source(x.float())
+        self._src_key, self._src_cache = key, c
+        return c
+
+    @torch.no_grad()
+    def forward(self, x, dense_motion, w=1, inference=False, vis_app_before_comp=False, gt=None,
+                visualize_app_feat=False):
+        if not inference or gt is not None or vis_app_before_comp or visualize_app_feat:
+            raise NotImplementedError("only forward(..., inference=True) has a HIP plan; the training / visualisation "
+                                      "branches are out of scope this round (SURVEY.md section 8f, N2)")
+        eng = self.engine()
+        flow = dense_motion["deformation"]
+        B = flow.shape[0]
+        if x.shape[0] not in (1, B):
+            raise ValueError("source batch must be 1 or equal to the dense_motion batch")
+        cache = self.encode_source(x)
+        heat = dense_motion.get("_heat_nhwc")
+        if heat is None:
+            heat = ops.nchw_to_nhwc(dense_motion["driving_kp_heatmap"].float())
+        occ = dense_motion["occlusion_map"]
+        if isinstance(occ, list):
+            raise NotImplementedError("multi_mask occlusion lists are not part of options/test.yml")
+        st = eng.forward(cache, flow.float(), occ.float().reshape(B, 64, 64), heat, float(w))
+        out = {"_out_nhwc": st["out"], "out": ops.nhwc_to_nchw(st["out"]), "lq_feat": ops.nhwc_to_nchw(st["lq"]),
+               "out_occ": [o.view(B, 1, 64, 64) for o in st["occ"][1:]],
+               "deformation_list": st["flows"], "res_deform_list": st["res"]}
+        if self.full_outputs:
+            out["app_before_comp_list"] = [ops.nhwc_to_nchw(t) for t in st["before"]]
+            out["deform_feat_list"] = out["app_before_comp_list"]     # same values (:615/:714 repeat the warp)
+            out["app_comp_list"] = [ops.nhwc_to_nchw(t) for t in st["comp"]]
+        return out

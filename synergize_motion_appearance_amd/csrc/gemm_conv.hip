@@ -1,0 +1,295 @@
+// Implicit-GEMM convolution / batched NT-GEMM for gfx950 on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
+//
+//   C[g][m][n] = epi(alpha * sum_k A[g][m][k] * Bt[g][n][k])
+//
+// A rows are gathered from an NHWC tensor on the fly (m -> pixel, k -> (ky,kx,c)); Bt is
+// [N][K] with k contiguous.  Both operand tiles are staged global -> registers -> LDS as
+// [rows][32 k + 4 pad] fp32 (row stride 36 dwords: conflict-free for the 16-lane groups of
+// ds_read_b128), double-buffered, one barrier per 32-deep K slice.  A wave64 reads its
+// fragments with ONE ds_read_b128 per 32x8 sub-tile: lane l holds row (l&31), k = 4*(l>>5)+j,
+// j=0..3, and MFMA j of the 8-deep step pairs k=j (lanes 0-31) with k=4+j (lanes 32-63) --
+// the k pairing is free because A and Bt fragments use the same map.
+//
+// Tile configs (256 threads = 4 waves): 128x128, 128x64, 128x32, 64x128, 64x64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smx.h"
+#include "smx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+struct GP {
+  const float* a; const float* bt; float* c; const float* bias; const float* res;
+  long long a_bs0, a_bs1, bt_bs0, bt_bs1, c_bs0, c_bs1, res_bs0, res_bs1;
+  int nb1;
+  int M, N, K;
+  int lda, ldb, ldc, ldres;
+  int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
+  int act; float alpha; int bias_per_row; int d2s_p, d2s_c;
+  int tiles_n; int is1x1;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case SMX_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SMX_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
+    case SMX_ACT_SWISH: return v / (1.f + expf(-v));
+    case SMX_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case SMX_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int RA = BM / 32, RB = BN / 32;          // rows per thread in the staging pass
+  static_assert(WGM * WGN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                   // [2][BM][LDS_LD]
+  float* Bs = smem + 2 * BM * LDS_LD;                 // [2][BN][LDS_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int g = blockIdx.y, g0 = g / p.nb1, g1 = g - g0 * p.nb1;
+  const float* __restrict__ A = p.a + g0 * p.a_bs0 + g1 * p.a_bs1;
+  const float* __restrict__ Bt = p.bt + g0 * p.bt_bs0 + g1 * p.bt_bs1;
+
+  // ---- per-thread staging coordinates ------------------------------------------------
+  const int c4 = tid & 7, r0 = tid >> 3;
+  long long a_base[RA]; int a_iy0[RA], a_ix0[RA]; bool a_ok[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = tile_m * BM + r0 + 32 * i;
+    a_ok[i] = m < p.M;
+    if (p.is1x1) {
+      a_base[i] = (long long)m * p.lda; a_iy0[i] = 0; a_ix0[i] = 0;
+    } else {
+      int img = m / HoWo, rem = m - img * HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_base[i] = (long long)img * p.Hin * p.Win * p.lda;
+      a_iy0[i] = oy * p.stride - p.pad_t; a_ix0[i] = ox * p.stride - p.pad_l;
+    }
+  }
+  long long b_base[RB]; bool b_ok[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int n = tile_n * BN + r0 + 32 * i;
+    b_ok[i] = n < p.N; b_base[i] = (long long)n * p.ldb;
+  }
+  const int Hlim = p.up2 ? 2 * p.Hin : p.Hin, Wlim = p.up2 ? 2 * p.Win : p.Win;
+
+  float4 areg[RA], breg[RB];
+  int tap_c0 = 0, tap_ky = 0, tap_kx = 0;             // VEC path: running (ky,kx,c0) of the slice
+
+  auto load_slice = [&](int k0) {
+    if (VEC) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_ok[i]) {
+          if (p.is1x1) {
+            v = *reinterpret_cast<const float4*>(A + a_base[i] + k0 + c4 * 4);
+          } else {
+            int iy = a_iy0[i] + tap_ky, ix = a_ix0[i] + tap_kx;
+            if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim) {
+              if (p.up2) { iy >>= 1; ix >>= 1; }
+              v = *reinterpret_cast<const float4*>(A + a_base[i] + ((long long)iy * p.Win + ix) * p.lda + tap_c0 + c4 * 4);
+            }
+          }
+        }
+        areg[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b_ok[i]) v = *reinterpret_cast<const float4*>(Bt + b_base[i] + k0 + c4 * 4);
+        breg[i] = v;
+      }
+      tap_c0 += BK;
+      if (tap_c0 >= p.Cin) { tap_c0 = 0; if (++tap_kx == p.kw) { tap_kx = 0; ++tap_ky; } }
+    } else {
+      // generic path: any Cin / K / alignment -- per-element index math, scalar loads
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int k = k0 + c4 * 4 + e; float x = 0.f;
+          if (a_ok[i] && k < p.K) {
+            int tap = k / p.Cin, cc = k - tap * p.Cin;
+            int ky = tap / p.kw, kx = tap - ky * p.kw;
+            int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim) {
+              if (p.up2) { iy >>= 1; ix >>= 1; }
+              x = A[a_base[i] + ((long long)iy * p.Win + ix) * p.lda + cc];
+            }
+          }
+          v[e] = x;
+        }
+        areg[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int k = k0 + c4 * 4 + e;
+          v[e] = (b_ok[i] && k < p.K) ? Bt[b_base[i] + k] : 0.f;
+        }
+        breg[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+  auto store_slice = [&](int buf) {
+    float* as = As + buf * BM * LDS_LD; float* bs = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<float4*>(as + (r0 + 32 * i) * LDS_LD + c4 * 4) = areg[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<float4*>(bs + (r0 + 32 * i) * LDS_LD + c4 * 4) = breg[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nslices = (p.K + BK - 1) / BK;
+  load_slice(0);
+  store_slice(0);
+  __syncthreads();
+  const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
+  for (int s = 0; s < nslices; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslices) load_slice((s + 1) * BK);
+    const float* as = As + buf * BM * LDS_LD + (wm * WTM) * LDS_LD + frag_off;
+    const float* bs = Bs + buf * BN * LDS_LD + (wn * WTN) * LDS_LD + frag_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (s + 1 < nslices) store_slice(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------
+  float* __restrict__ C = p.c + g0 * p.c_bs0 + g1 * p.c_bs1;
+  const float* __restrict__ R = p.res ? p.res + g0 * p.res_bs0 + g1 * p.res_bs1 : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = tile_n * BN + wn * WTN + j * 32 + (lane & 31);
+    if (n >= p.N) continue;
+    const float bn = (p.bias && !p.bias_per_row) ? p.bias[n] : 0.f;
+    int dq = 0, dcn = n;
+    if (p.d2s_p) { dq = n / p.d2s_c; dcn = n - dq * p.d2s_c; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = tile_m * BM + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = p.alpha * acc[i][j][r] + bn;
+        if (p.bias && p.bias_per_row) v += p.bias[m];
+        v = apply_act(v, p.act);
+        long long off;
+        if (p.d2s_p) {
+          int img = m / HoWo, rem = m - img * HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          int p1 = dq / p.d2s_p, p2 = dq - p1 * p.d2s_p;
+          off = (((long long)img * (p.Ho * p.d2s_p) + oy * p.d2s_p + p1) * (p.Wo * p.d2s_p) + ox * p.d2s_p + p2) * p.ldc + dcn;
+        } else {
+          off = (long long)m * p.ldc + n;
+        }
+        if (R) v += R[p.d2s_p ? off / p.ldc * p.ldres + dcn : (long long)m * p.ldres + n];
+        C[off] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_cfg(const GP& p, int nb, bool vec, hipStream_t st) {
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  GP q = p; q.tiles_n = tiles_n;
+  dim3 grid(tiles_m * tiles_n, nb), block(256);
+  size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  if (vec) {
+    auto k = gemm_conv_kernel<BM, BN, WGM, WGN, true>;
+    if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, block, lds, st, q);
+  } else {
+    auto k = gemm_conv_kernel<BM, BN, WGM, WGN, false>;
+    if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, block, lds, st, q);
+  }
+  return smx_launch_status();
+}
+
+}  // namespace
+
+extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
+  if (!d || !d->a || !d->bt || !d->c) return SMX_EINVAL;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->nb0 <= 0 || d->nb1 <= 0) return SMX_EINVAL;
+  if (d->kh <= 0 || d->kw <= 0 || d->Cin <= 0 || d->K != d->kh * d->kw * d->Cin) return SMX_EINVAL;
+  if (d->Ho <= 0 || d->Wo <= 0 || d->M % (d->Ho * d->Wo) != 0) return SMX_EINVAL;
+  if (d->stride <= 0 || d->lda < d->Cin || d->ldb < d->K) return SMX_EINVAL;
+  if (d->d2s_p ? (d->d2s_c <= 0 || d->N != d->d2s_p * d->d2s_p * d->d2s_c || d->ldc < d->d2s_c) : d->ldc < d->N) return SMX_EINVAL;
+  const long long nb = (long long)d->nb0 * d->nb1;
+  if (nb > 65535) return SMX_EINVAL;
+  GP p;
+  p.a = d->a; p.bt = d->bt; p.c = d->c; p.bias = d->bias; p.res = d->res;
+  p.a_bs0 = d->a_bs0; p.a_bs1 = d->a_bs1; p.bt_bs0 = d->bt_bs0; p.bt_bs1 = d->bt_bs1;
+  p.c_bs0 = d->c_bs0; p.c_bs1 = d->c_bs1; p.res_bs0 = d->res_bs0; p.res_bs1 = d->res_bs1;
+  p.nb1 = d->nb1; p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldres = d->res ? d->ldres : 0;
+  p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up2 = d->up2;
+  p.act = d->act; p.alpha = d->alpha; p.bias_per_row = d->bias_per_row; p.d2s_p = d->d2s_p; p.d2s_c = d->d2s_c;
+  p.tiles_n = 1;
+  p.is1x1 = (d->kh == 1 && d->kw == 1 && d->stride == 1 && !d->up2 && d->pad_t == 0 && d->pad_l == 0 &&
+             d->Hin == d->Ho && d->Win == d->Wo) ? 1 : 0;
+  const bool vec = (d->Cin % BK == 0) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) &&
+                   (((uintptr_t)d->a & 15) == 0) && (((uintptr_t)d->bt & 15) == 0) &&
+                   (d->a_bs0 % 4 == 0) && (d->a_bs1 % 4 == 0) && (d->bt_bs0 % 4 == 0) && (d->bt_bs1 % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  int tile = d->tile;
+  if (tile == 0) {
+    const long long t128 = ((d->M + 127) / 128) * nb;
+    const bool small_m = t128 * ((d->N + 127) / 128) < 512;   // fewer than 2 blocks per CU at BM=128
+    if (d->N <= 32) tile = 3;
+    else if (d->N <= 64) tile = small_m ? 5 : 2;
+    else tile = small_m ? 4 : 1;
+  }
+  switch (tile) {
+    case 1: return launch_cfg<128, 128, 2, 2>(p, (int)nb, vec, st);
+    case 2: return launch_cfg<128, 64, 2, 2>(p, (int)nb, vec, st);
+    case 3: return launch_cfg<128, 32, 4, 1>(p, (int)nb, vec, st);
+    case 4: return launch_cfg<64, 128, 1, 4>(p, (int)nb, vec, st);
+    case 5: return launch_cfg<64, 64, 2, 2>(p, (int)nb, vec, st);
+    default: return SMX_EINVAL;
+  }
+}

@@ -1,0 +1,328 @@
+// Keypoint head, sparse-motion stage, mask/deformation, and the small fused elementwise
+// stages of the compensation loop; layout converters and the uint8 packer -- gfx950.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "smx.h"
+#include "smx_common.h"
+
+namespace {
+
+inline int grid_for(long long total) { int g = smx_cdiv(total, 256); return g > 16384 ? 16384 : (g < 1 ? 1 : g); }
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  // 256 threads: wave shuffle then 4-entry LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o, 64); v = is_max ? fmaxf(v, t) : v + t; }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+
+// ---- A3: soft-argmax keypoints + heatmap-weighted jacobians; one block per (b,k) -----------
+__global__ __launch_bounds__(256) void kp_head_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ jm,
+                                                      int ldj, float* __restrict__ value, float* __restrict__ jac,
+                                                      int H, int W, int K, float temperature) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / K, k = blockIdx.x % K, HW = H * W;
+  const float* lb = logits + (long long)b * HW * ldl + k;
+  float mx = -INFINITY;
+  for (int p = threadIdx.x; p < HW; p += 256) mx = fmaxf(mx, lb[(long long)p * ldl] / temperature);
+  mx = block_reduce(mx, red, true);
+  float s = 0.f, sx = 0.f, sy = 0.f, j0 = 0.f, j1 = 0.f, j2 = 0.f, j3 = 0.f;
+  const float* jb = jm ? jm + (long long)b * HW * ldj + 4 * k : nullptr;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const float e = expf(lb[(long long)p * ldl] / temperature - mx);
+    const int y = p / W, x = p - y * W;
+    const float gx = 2.f * ((float)x / (float)(W - 1)) - 1.f, gy = 2.f * ((float)y / (float)(H - 1)) - 1.f;
+    s += e; sx += e * gx; sy += e * gy;
+    if (jb) {
+      const float4 j = *reinterpret_cast<const float4*>(jb + (long long)p * ldj);
+      j0 += e * j.x; j1 += e * j.y; j2 += e * j.z; j3 += e * j.w;
+    }
+  }
+  s = block_reduce(s, red, false); sx = block_reduce(sx, red, false); sy = block_reduce(sy, red, false);
+  if (jb) { j0 = block_reduce(j0, red, false); j1 = block_reduce(j1, red, false); j2 = block_reduce(j2, red, false); j3 = block_reduce(j3, red, false); }
+  if (threadIdx.x == 0) {
+    value[(b * K + k) * 2] = sx / s; value[(b * K + k) * 2 + 1] = sy / s;
+    if (jb) { float* o = jac + (b * K + k) * 4; o[0] = j0 / s; o[1] = j1 / s; o[2] = j2 / s; o[3] = j3 / s; }
+  }
+}
+
+// ---- A4-A6: heatmaps + sparse motions + sparse warps -> hourglass input -------------------
+__global__ __launch_bounds__(256) void sparse_motion_kernel(const float* __restrict__ src, long long src_bs,
+                                                            const float* __restrict__ kdv, const float* __restrict__ kdj,
+                                                            const float* __restrict__ ksv, const float* __restrict__ ksj,
+                                                            int ks_bs, float* __restrict__ hg, int ldh,
+                                                            float* __restrict__ sparse, float* __restrict__ dheat,
+                                                            long long total, int H, int W, int K, float var) {
+  const int K1 = K + 1;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % K1); long long p = i / K1;
+    const int x = (int)(p % W); p /= W; const int y = (int)(p % H); const int b = (int)(p / H);
+    const float zx = 2.f * ((float)x / (float)(W - 1)) - 1.f, zy = 2.f * ((float)y / (float)(H - 1)) - 1.f;
+    float tx = zx, ty = zy, heat = 0.f;
+    if (k > 0) {
+      const int kk = k - 1;
+      const float* dv = kdv + ((long long)b * K + kk) * 2; const float* dj = kdj + ((long long)b * K + kk) * 4;
+      const float* sv = ksv + ((long long)b * ks_bs * K + kk) * 2; const float* sj = ksj + ((long long)b * ks_bs * K + kk) * 4;
+      // J = J_s * inv(J_d), closed-form 2x2 inverse
+      const float a = dj[0], bb = dj[1], c = dj[2], d = dj[3];
+      const float det = a * d - bb * c;
+      const float i00 = d / det, i01 = -bb / det, i10 = -c / det, i11 = a / det;
+      const float J00 = sj[0] * i00 + sj[1] * i10, J01 = sj[0] * i01 + sj[1] * i11;
+      const float J10 = sj[2] * i00 + sj[3] * i10, J11 = sj[2] * i01 + sj[3] * i11;
+      const float cx = zx - dv[0], cy = zy - dv[1];
+      tx = J00 * cx + J01 * cy + sv[0]; ty = J10 * cx + J11 * cy + sv[1];
+      const float ddx = zx - dv[0], ddy = zy - dv[1], sdx = zx - sv[0], sdy = zy - sv[1];
+      const float gd = expf(-0.5f * (ddx * ddx + ddy * ddy) / var);
+      heat = gd - expf(-0.5f * (sdx * sdx + sdy * sdy) / var);
+      dheat[(((long long)b * H + y) * W + x) * K + kk] = gd;
+    }
+    *reinterpret_cast<float2*>(sparse + ((((long long)b * K1 + k) * H + y) * W + x) * 2) = make_float2(tx, ty);
+    // grid_sample bilinear, zeros, align_corners=False
+    const float ix = ((tx + 1.f) * W - 1.f) / 2.f, iy = ((ty + 1.f) * H - 1.f) / 2.f;
+    float r = 0.f, g = 0.f, bl = 0.f;
+    if (ix > -2.f && ix < (float)W + 1.f && iy > -2.f && iy < (float)H + 1.f) {
+      const float fx = floorf(ix), fy = floorf(iy); const int x0 = (int)fx, y0 = (int)fy;
+      const float ax = ix - fx, ay = iy - fy;
+      const float* sb = src + (long long)b * src_bs;
+      auto tap = [&](int yy, int xx, float w) {
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const float* q = sb + ((long long)yy * W + xx) * 3;
+          r += q[0] * w; g += q[1] * w; bl += q[2] * w;
+        }
+      };
+      tap(y0, x0, (1.f - ax) * (1.f - ay)); tap(y0, x0 + 1, ax * (1.f - ay));
+      tap(y0 + 1, x0, (1.f - ax) * ay); tap(y0 + 1, x0 + 1, ax * ay);
+    }
+    *reinterpret_cast<float4*>(hg + (((long long)b * H + y) * W + x) * ldh + 4 * k) = make_float4(heat, r, g, bl);
+  }
+}
+
+// ---- A6b: mask softmax + deformation ------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_deformation_kernel(const float* __restrict__ ml, int ldm,
+                                                               const float* __restrict__ sparse, float* __restrict__ deform,
+                                                               float* __restrict__ mask_out, long long npix, int HW, int K1) {
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+    const int b = (int)(p / HW); const int rem = (int)(p - (long long)b * HW);
+    const float* l = ml + p * ldm;
+    float mx = -INFINITY;
+    for (int k = 0; k < K1; ++k) mx = fmaxf(mx, l[k]);
+    float s = 0.f;
+    for (int k = 0; k < K1; ++k) s += expf(l[k] - mx);
+    float dx = 0.f, dy = 0.f;
+    for (int k = 0; k < K1; ++k) {
+      const float m = expf(l[k] - mx) / s;
+      const float2 t = *reinterpret_cast<const float2*>(sparse + (((long long)b * K1 + k) * HW + rem) * 2);
+      dx += t.x * m; dy += t.y * m;
+      if (mask_out) mask_out[p * K1 + k] = m;
+    }
+    *reinterpret_cast<float2*>(deform + p * 2) = make_float2(dx, dy);
+  }
+}
+
+// ---- compensation-loop elementwise stages -------------------------------------------------
+__global__ void flow_to_residual_kernel(const float* __restrict__ flow, float* __restrict__ res, long long npix, int H, int W) {
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    // torch.linspace(-1,1,n): start + i*step for the first half, end - (n-1-i)*step for the second
+    const float stepx = 2.f / (float)(W - 1), stepy = 2.f / (float)(H - 1);
+    const float gx = x < W / 2 ? -1.f + stepx * x : 1.f - stepx * (W - 1 - x);
+    const float gy = y < H / 2 ? -1.f + stepy * y : 1.f - stepy * (H - 1 - y);
+    const float2 f = *reinterpret_cast<const float2*>(flow + p * 2);
+    const float half = ((float)H - 1.f) / 2.f;
+    *reinterpret_cast<float2*>(res + p * 2) = make_float2((f.x - gx) * half, (f.y - gy) * half);
+  }
+}
+
+__global__ void flow_occ_update_kernel(const float* __restrict__ flow, const float* __restrict__ r,
+                                       const float* __restrict__ occ_prev, float* __restrict__ m_com,
+                                       float* __restrict__ res_norm, float* __restrict__ occ_out, long long npix, float half) {
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+    const float rx = r[p * 3] / half, ry = r[p * 3 + 1] / half;
+    const float2 f = *reinterpret_cast<const float2*>(flow + p * 2);
+    *reinterpret_cast<float2*>(res_norm + p * 2) = make_float2(rx, ry);
+    *reinterpret_cast<float2*>(m_com + p * 2) = make_float2(f.x + rx, f.y + ry);
+    const float o = occ_prev[p] + r[p * 3 + 2];
+    occ_out[p] = 1.f / (1.f + expf(-o));
+  }
+}
+
+__device__ __forceinline__ void ac_src2(int o, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float real = scale * o;
+  i0 = (int)real; if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = fminf(fmaxf(real - i0, 0.f), 1.f); l0 = 1.f - l1;
+}
+
+__global__ void motion_ignore_kernel(const float* __restrict__ flow, uint8_t* __restrict__ ign, long long total,
+                                     int Hf, int Wf, int Ht, int Wt) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % Wt), y = (int)((i / Wt) % Ht); const int b = (int)(i / ((long long)Wt * Ht));
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    ac_src2(y, Hf, Ht, y0, y1, ly0, ly1); ac_src2(x, Wf, Wt, x0, x1, lx0, lx1);
+    const float* fb = flow + (long long)b * Hf * Wf * 2;
+    const float2 f00 = *reinterpret_cast<const float2*>(fb + (y0 * Wf + x0) * 2);
+    const float2 f01 = *reinterpret_cast<const float2*>(fb + (y0 * Wf + x1) * 2);
+    const float2 f10 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x0) * 2);
+    const float2 f11 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x1) * 2);
+    const float gx = ly0 * (lx0 * f00.x + lx1 * f01.x) + ly1 * (lx0 * f10.x + lx1 * f11.x);
+    const float gy = ly0 * (lx0 * f00.y + lx1 * f01.y) + ly1 * (lx0 * f10.y + lx1 * f11.y);
+    ign[i] = (gx > 1.f || gx < -1.f || gy > 1.f || gy < -1.f) ? 1 : 0;
+  }
+}
+
+__global__ void sft_combine_kernel(const float4* __restrict__ dec, const float4* __restrict__ sc, const float4* __restrict__ sh,
+                                   float4* __restrict__ out, float w, long long n4) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 d = dec[i], a = sc[i], b = sh[i];
+    out[i] = make_float4(d.x + w * (d.x * a.x + b.x), d.y + w * (d.y * a.y + b.y), d.z + w * (d.z * a.z + b.z), d.w + w * (d.w * a.w + b.w));
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+
+__global__ void copy_slice_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long total, int C) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i / C; const int c = (int)(i - p * C);
+    y[p * ldy + c] = x[p * ldx + c];
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int ldy, long long total, int C, int HW) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C); const long long p = i / C; const long long b = p / HW; const int r = (int)(p - b * HW);
+    y[p * ldy + c] = x[(b * C + c) * HW + r];
+  }
+}
+
+// tiled transpose: NHWC (ld) -> NCHW, coalesced on both sides through LDS
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int C, int HW) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int p = p0 + j, c = c0 + tx;
+    t[j][tx] = (p < HW && c < C) ? x[((long long)b * HW + p) * ldx + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, p = p0 + tx;
+    if (c < C && p < HW) y[((long long)b * C + c) * HW + p] = t[tx][j];
+  }
+}
+
+__global__ void to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict__ y, long long n, float lo, float hi) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = fminf(fmaxf(x[i], lo), hi);
+    v = (v - lo) / (hi - lo);
+    y[i] = (uint8_t)rintf(v * 255.0f);
+  }
+}
+
+}  // namespace
+
+extern "C" const char* smx_version(void) { return "smx 0.1.0 gfx950"; }
+
+extern "C" int smx_kp_head_f32(const float* logits, int ldl, const float* jmaps, int ldj, float* value, float* jac,
+                               int B, int H, int W, int K, float temperature, void* stream) {
+  if (!logits || !value || B <= 0 || H <= 1 || W <= 1 || K <= 0 || ldl < K || temperature <= 0.f) return SMX_EINVAL;
+  if (jmaps && (!jac || ldj < 4 * K || ldj % 4 != 0)) return SMX_EINVAL;
+  hipLaunchKernelGGL(kp_head_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, logits, ldl, jmaps, ldj, value, jac, H, W, K, temperature);
+  return smx_launch_status();
+}
+
+extern "C" int smx_sparse_motion_f32(const float* src, int src_batch, const float* kpd_value, const float* kpd_jac,
+                                     const float* kps_value, const float* kps_jac, int kps_batch,
+                                     float* hg_in, int ldh, float* sparse, float* drv_heat,
+                                     int B, int H, int W, int K, float kp_variance, void* stream) {
+  if (!src || !kpd_value || !kpd_jac || !kps_value || !kps_jac || !hg_in || !sparse || !drv_heat) return SMX_EINVAL;
+  if (B <= 0 || H <= 1 || W <= 1 || K <= 0 || ldh < 4 * (K + 1) || ldh % 4 != 0) return SMX_EINVAL;
+  if ((src_batch != 1 && src_batch != B) || (kps_batch != 1 && kps_batch != B)) return SMX_EINVAL;
+  const long long total = (long long)B * H * W * (K + 1);
+  hipLaunchKernelGGL(sparse_motion_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                     src_batch == 1 ? 0LL : (long long)H * W * 3, kpd_value, kpd_jac, kps_value, kps_jac,
+                     kps_batch == 1 ? 0 : 1, hg_in, ldh, sparse, drv_heat, total, H, W, K, kp_variance);
+  return smx_launch_status();
+}
+
+extern "C" int smx_mask_deformation_f32(const float* mask_logits, int ldm, const float* sparse, float* deformation,
+                                        float* mask_out, int B, int H, int W, int K1, void* stream) {
+  if (!mask_logits || !sparse || !deformation || B <= 0 || H <= 0 || W <= 0 || K1 <= 0 || ldm < K1) return SMX_EINVAL;
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(mask_deformation_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, mask_logits, ldm, sparse,
+                     deformation, mask_out, npix, H * W, K1);
+  return smx_launch_status();
+}
+
+extern "C" int smx_flow_to_residual_f32(const float* flow, float* res, int B, int H, int W, void* stream) {
+  if (!flow || !res || B <= 0 || H <= 1 || W <= 1) return SMX_EINVAL;
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(flow_to_residual_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, flow, res, npix, H, W);
+  return smx_launch_status();
+}
+
+extern "C" int smx_flow_occ_update_f32(const float* flow, const float* r, const float* occ_prev, float* m_com,
+                                       float* res_norm, float* occ_out, int B, int H, int W, void* stream) {
+  if (!flow || !r || !occ_prev || !m_com || !res_norm || !occ_out || B <= 0 || H <= 1 || W <= 1) return SMX_EINVAL;
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(flow_occ_update_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, flow, r, occ_prev, m_com,
+                     res_norm, occ_out, npix, ((float)H - 1.f) / 2.f);
+  return smx_launch_status();
+}
+
+extern "C" int smx_motion_ignore_f32(const float* flow, uint8_t* ignore, int B, int Hf, int Wf, int Ht, int Wt, void* stream) {
+  if (!flow || !ignore || B <= 0 || Hf <= 0 || Wf <= 0 || Ht <= 0 || Wt <= 0) return SMX_EINVAL;
+  const long long total = (long long)B * Ht * Wt;
+  hipLaunchKernelGGL(motion_ignore_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, flow, ignore, total, Hf, Wf, Ht, Wt);
+  return smx_launch_status();
+}
+
+extern "C" int smx_sft_combine_f32(const float* dec, const float* scale, const float* shift, float* out, float w,
+                                   int64_t n, void* stream) {
+  if (!dec || !scale || !shift || !out || n <= 0 || n % 4 != 0) return SMX_EINVAL;
+  hipLaunchKernelGGL(sft_combine_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dec,
+                     (const float4*)scale, (const float4*)shift, (float4*)out, w, (long long)(n / 4));
+  return smx_launch_status();
+}
+
+extern "C" int smx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  if (!a || !b || !y || n <= 0) return SMX_EINVAL;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n);
+  return smx_launch_status();
+}
+
+extern "C" int smx_copy_slice_f32(const float* x, int ldx, float* y, int ldy, int64_t P, int C, void* stream) {
+  if (!x || !y || P <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
+  const long long total = (long long)P * C;
+  hipLaunchKernelGGL(copy_slice_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, C);
+  return smx_launch_status();
+}
+
+extern "C" int smx_nchw_to_nhwc_f32(const float* x, float* y, int ldy, int B, int C, int H, int W, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldy < C) return SMX_EINVAL;
+  const long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, ldy, total, C, H * W);
+  return smx_launch_status();
+}
+
+extern "C" int smx_nhwc_to_nchw_f32(const float* x, int ldx, float* y, int B, int C, int H, int W, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldx < C || B > 65535) return SMX_EINVAL;
+  const int HW = H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(smx_cdiv(HW, 32), smx_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, C, HW);
+  return smx_launch_status();
+}
+
+extern "C" int smx_to_uint8_f32(const float* x, uint8_t* y, int64_t n, float lo, float hi, void* stream) {
+  if (!x || !y || n <= 0 || !(hi > lo)) return SMX_EINVAL;
+  hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, lo, hi);
+  return smx_launch_status();
+}

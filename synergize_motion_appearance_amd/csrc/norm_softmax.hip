@@ -1,0 +1,207 @@
+// GroupNorm(32)+swish on NHWC, LayerNorm(+pos) on tokens, masked row softmax -- gfx950.
+// All three are HBM-bound streaming kernels: float4 (16 B/lane) accesses, wave64 shuffles
+// for the row reductions, LDS only for the cross-wave step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "smx.h"
+#include "smx_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm: pass 1 -- per (b, chunk, c) partial sum / sumsq
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int gn_ppc(int HW) {
+  int p = HW / 64; if (p < 32) p = 32; if (p > 256) p = 256; return p;
+}
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int ldx, float* __restrict__ part,
+                                                         int HW, int C, int ppc, int nch) {
+  extern __shared__ float red[];                       // [rows][C][2]
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cq = C >> 2;                               // float4 columns
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, rows = 256 / cq;
+  const int p0 = chunk * ppc, p1 = min(p0 + ppc, HW);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* xb = x + (long long)b * HW * ldx + tx * 4;
+  for (int p = p0 + ty; p < p1; p += rows) {
+    float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+  }
+  float* r = red + ((ty * C) + tx * 4) * 2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[2 * e] = s[e]; r[2 * e + 1] = q[e]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float ss = 0.f, qq = 0.f;
+    for (int t = 0; t < rows; ++t) { ss += red[(t * C + c) * 2]; qq += red[(t * C + c) * 2 + 1]; }
+    float* o = part + (((long long)b * nch + chunk) * C + c) * 2;
+    o[0] = ss; o[1] = qq;
+  }
+}
+
+// pass 2 -- per (b): reduce chunks (double), per-group mean/rstd -> per-channel scale/shift
+__global__ void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ ss, int HW, int C,
+                                   int groups, int nch, float eps) {
+  extern __shared__ double dred[];                     // [C][2]
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    const float* pp = part + ((long long)b * nch * C + c) * 2;
+    for (int t = 0; t < nch; ++t) { s += pp[(long long)t * C * 2]; q += pp[(long long)t * C * 2 + 1]; }
+    dred[2 * c] = s; dred[2 * c + 1] = q;
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    double s = 0.0, q = 0.0;
+    for (int j = 0; j < cpg; ++j) { s += dred[2 * (g * cpg + j)]; q += dred[2 * (g * cpg + j) + 1]; }
+    const double n = (double)HW * cpg, mean = s / n;
+    double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = rstd * gamma[c];
+    ss[((long long)b * C + c) * 2] = sc;
+    ss[((long long)b * C + c) * 2 + 1] = beta[c] - (float)mean * sc;
+  }
+}
+
+// pass 3 -- y = swish(x*scale + shift)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                       const float* __restrict__ ss, long long total4, int HW, int C, int swish) {
+  const int cq = C >> 2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % cq); const long long pix = i / cq; const int b = (int)(pix / HW);
+    float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c4 * 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(ss + ((long long)b * C + c4 * 4) * 2);
+    const float4 s1 = *reinterpret_cast<const float4*>(ss + ((long long)b * C + c4 * 4) * 2 + 4);
+    float r[4] = {v.x * s0.x + s0.y, v.y * s0.z + s0.w, v.z * s1.x + s1.y, v.w * s1.z + s1.w};
+    if (swish) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = r[e] / (1.f + expf(-r[e]));
+    }
+    *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm (+pos): one wave per token
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <int EPL>   // elements per lane = ceil(E/64)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ pos,
+                                                        float* __restrict__ y, float* __restrict__ ypos, int T, int E,
+                                                        int npos, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float* xr = x + (long long)t * E;
+  float v[EPL]; float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { int c = lane + 64 * e; v[e] = c < E ? xr[c] : 0.f; s += v[e]; }
+  const float mean = wave_sum(s) / E;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { int c = lane + 64 * e; float d = c < E ? v[e] - mean : 0.f; q += d * d; }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / E + eps);
+  const float* pr = pos ? pos + (long long)(t % npos) * E : nullptr;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    int c = lane + 64 * e;
+    if (c < E) {
+      float o = (v[e] - mean) * rstd * gamma[c] + beta[c];
+      y[(long long)t * E + c] = o;
+      if (ypos) ypos[(long long)t * E + c] = o + pr[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// masked row softmax in place: one wave per row, S <= 64*SPL
+// ---------------------------------------------------------------------------------------
+template <int SPL>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int ld, long long R, int S, float scale,
+                                                           const uint8_t* __restrict__ mask, int rows_per_mask) {
+  const int lane = threadIdx.x & 63;
+  const long long r = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float* row = s + r * ld;
+  const uint8_t* mrow = mask ? mask + (r / rows_per_mask) * S : nullptr;
+  float v[SPL]; float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < SPL; ++e) {
+    int c = lane + 64 * e; float t = -INFINITY;
+    if (c < S) { t = row[c] * scale; if (mrow && mrow[c]) t = -INFINITY; }
+    v[e] = t; mx = fmaxf(mx, t);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < SPL; ++e) { int c = lane + 64 * e; v[e] = c < S ? expf(v[e] - mx) : 0.f; sum += v[e]; }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int e = 0; e < SPL; ++e) { int c = lane + 64 * e; if (c < S) row[c] = v[e] / sum; }
+}
+
+}  // namespace
+
+extern "C" int64_t smx_groupnorm_ws_floats(int B, int HW, int C) {
+  int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
+  const int nch = (HW + ppc - 1) / ppc;
+  return (int64_t)B * nch * C * 2 + (int64_t)B * C * 2;
+}
+
+extern "C" int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float* gamma, const float* beta,
+                                            float* y, int ldy, int B, int HW, int C, int groups, float eps,
+                                            int swish, float* ws, void* stream) {
+  if (!x || !y || !gamma || !beta || !ws || B <= 0 || HW <= 0) return SMX_EINVAL;
+  if (C < 4 || C > 1024 || (C & (C - 1)) != 0 || C % groups != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < C || ldy < C) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
+  const int nch = (HW + ppc - 1) / ppc;
+  float* part = ws; float* ss = ws + (int64_t)B * nch * C * 2;
+  const int rows = 256 / (C / 4);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, part, HW, C, ppc, nch);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(C < 64 ? 64 : (C > 256 ? 256 : C)), (size_t)C * 2 * sizeof(double), st,
+                     part, gamma, beta, ss, HW, C, groups, nch, eps);
+  const long long total4 = (long long)B * HW * (C / 4);
+  int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, ss, total4, HW, C, swish);
+  return smx_launch_status();
+}
+
+extern "C" int smx_layernorm_pos_f32(const float* x, const float* gamma, const float* beta, const float* pos,
+                                     float* y, float* y_pos, int T, int E, int npos, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || T <= 0 || E <= 0 || E > 512 || (y_pos && (!pos || npos <= 0))) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(smx_cdiv(T, 4)), block(256);
+  if (E <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
+  else if (E <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
+  return smx_launch_status();
+}
+
+extern "C" int smx_softmax_rows_f32(float* s, int ld, int R, int S, float scale, const uint8_t* mask,
+                                    int rows_per_mask, void* stream) {
+  if (!s || R <= 0 || S <= 0 || S > 1024 || ld < S || (mask && rows_per_mask <= 0)) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(smx_cdiv(R, 4)), block(256);
+  if (S <= 256) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else if (S <= 512) hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  return smx_launch_status();
+}

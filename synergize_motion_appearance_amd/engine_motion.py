@@ -1,0 +1,125 @@
+"""HIP execution plan for the motion estimator (rows A1-A6b of SURVEY.md section 8a):
+keypoint detector (`archs/keypoint_detector_arch.py:60-86`) and dense motion
+(`archs/dense_motion_arch.py:118-161`) of the reference, on NHWC activations.
+
+Design points (MI355X-first, not a translation):
+  * BatchNorm(eval) is folded into the preceding conv weights once at pack time;
+  * every hourglass skip-concat buffer is allocated once per call and its two halves are
+    written in place by their producers (decoder conv / avg-pool), so torch.cat never runs;
+  * nearest x2 upsampling is folded into the consuming conv's gather (`up2`);
+  * heatmaps + 16 sparse motions + 16 sparse warps are one kernel that writes the 64-channel
+    hourglass input directly; mask softmax + flow blend are one kernel;
+  * B driving frames run per launch (the reference loops B=1): the deep hourglass layers are
+    weight-bandwidth bound at B=1 (207 MB of fp32 weights per frame).
+"""
+import torch
+
+from . import ops
+from .manifest import hourglass_channels
+from .ops import Conv, ACT_RELU, ACT_SIGMOID, ACT_NONE
+
+
+def _fold_bn(P, pre):
+    """conv + BN(eval, eps 1e-5) -> one conv (sync_batchnorm/batchnorm.py:48-53 semantics)."""
+    w, b = P[pre + ".conv.weight"], P[pre + ".conv.bias"]
+    g, beta = P[pre + ".norm.weight"], P[pre + ".norm.bias"]
+    rm, rv = P[pre + ".norm.running_mean"], P[pre + ".norm.running_var"]
+    s = g / torch.sqrt(rv + 1e-5)
+    return Conv.from_torch(w * s.view(-1, 1, 1, 1), (b - rm) * s + beta)
+
+
+class HourglassPlan:
+    def __init__(self, P, pre, block_expansion, in_features, num_blocks, max_features):
+        self.down_ch, self.up_ch, self.out_filters = hourglass_channels(block_expansion, in_features, num_blocks, max_features)
+        self.nb = num_blocks
+        self.in_features = in_features
+        self.down = [_fold_bn(P, f"{pre}.encoder.down_blocks.{i}") for i in range(num_blocks)]
+        self.up = [_fold_bn(P, f"{pre}.decoder.up_blocks.{i}") for i in range(num_blocks)]
+
+    def alloc_input(self, B, res, device):
+        """the last concat buffer [B,res,res,cy+in] ; its tail slice is the hourglass input."""
+        cy = self.up_ch[-1][1]
+        buf = torch.empty((B, res, res, cy + self.in_features), device=device, dtype=torch.float32)
+        return buf, buf[..., cy:]
+
+    def run(self, final_buf, B, res):
+        """final_buf from alloc_input with its tail filled -> same buffer, fully written."""
+        nb = self.nb
+        dev = final_buf.device
+        # concat buffers cat[j] for decoder level j: [up_out_j | skip = encoder out (nb-1-j)]
+        cats = [None] * nb
+        cats[nb - 1] = final_buf
+        for j in range(nb - 1):
+            r = res >> (nb - 1 - j)
+            cy = self.up_ch[j][1]
+            cskip = self.down_ch[nb - 2 - j][1]
+            cats[j] = torch.empty((B, r, r, cy + cskip), device=dev, dtype=torch.float32)
+        # encoder: outs[0] = input slice, outs[i] (i>=1) pooled into the skip slice of cat[nb-1-i]
+        cur = final_buf[..., self.up_ch[-1][1]:]
+        r = res
+        for i in range(nb):
+            y = ops.conv(cur, self.down[i], act=ACT_RELU)
+            r //= 2
+            if i < nb - 1:
+                j = nb - 2 - i
+                dst = cats[j][..., self.up_ch[j][1]:]
+                cur = ops.avgpool2(y, out=dst)
+            else:
+                cur = ops.avgpool2(y)
+        # decoder
+        out = cur
+        for j in range(nb):
+            ops.conv(out, self.up[j], out=cats[j][..., :self.up_ch[j][1]], up2=True, act=ACT_RELU)
+            out = cats[j]
+        return out
+
+
+class MotionEngine:
+    """packed weights + forward plans for Motion_Estimator_keypoint_aware."""
+
+    def __init__(self, P, common, dense, kp):
+        self.num_kp = common["num_kp"]
+        self.temperature = kp["temperature"]
+        self.kp_hg = HourglassPlan(P, "kp_detector.predictor", kp["block_expansion"], common["num_channels"],
+                                   kp["num_blocks"], kp["max_features"])
+        self.kp_conv = Conv.from_torch(P["kp_detector.kp.weight"], P["kp_detector.kp.bias"])
+        self.jac_conv = Conv.from_torch(P["kp_detector.jacobian.weight"], P["kp_detector.jacobian.bias"])
+        self.kp_down = P["kp_detector.down.weight"].reshape(common["num_channels"], 13, 13).contiguous()
+        self.dm_hg = HourglassPlan(P, "dense_motion_network.hourglass", dense["block_expansion"],
+                                   (self.num_kp + 1) * (common["num_channels"] + 1), dense["num_blocks"], dense["max_features"])
+        self.mask_conv = Conv.from_torch(P["dense_motion_network.mask.weight"], P["dense_motion_network.mask.bias"])
+        self.occ_conv = Conv.from_torch(P["dense_motion_network.occlusion.weight"], P["dense_motion_network.occlusion.bias"])
+        self.dm_down = P["dense_motion_network.down.weight"].reshape(common["num_channels"], 13, 13).contiguous()
+        self.kp_variance = 0.01
+
+    # ---- A1-A3 -------------------------------------------------------------------------
+    def estimate_kp(self, image_nchw):
+        B = image_nchw.shape[0]
+        buf, inp = self.kp_hg.alloc_input(B, 64, image_nchw.device)
+        ops.antialias_down(image_nchw, self.kp_down, out=inp)
+        fm = self.kp_hg.run(buf, B, 64)                       # [B,64,64,35]
+        logits = ops.conv(fm, self.kp_conv, pad=(0, 0))       # 7x7 valid -> [B,58,58,15]
+        jmaps = ops.conv(fm, self.jac_conv, pad=(0, 0))       # [B,58,58,60]
+        value, jac = ops.kp_head(logits, jmaps, self.num_kp, self.temperature)
+        return {"value": value, "jacobian": jac}
+
+    # ---- A4-A6b ------------------------------------------------------------------------
+    def source_down(self, source_nchw):
+        """frame-invariant: anti-aliased 64x64 source, NHWC (dense_motion_arch.py:119-120)."""
+        return ops.antialias_down(source_nchw, self.dm_down)
+
+    def dense_motion(self, src64, kp_driving, kp_source, want_aux=False):
+        B = kp_driving["value"].shape[0]
+        buf, inp = self.dm_hg.alloc_input(B, 64, src64.device)
+        sparse, heat = ops.sparse_motion(src64, kp_driving["value"], kp_driving["jacobian"].reshape(B, -1, 4),
+                                         kp_source["value"], kp_source["jacobian"].reshape(kp_source["value"].shape[0], -1, 4),
+                                         inp, B, self.num_kp, self.kp_variance)
+        pred = self.dm_hg.run(buf, B, 64)                     # [B,64,64,128]
+        mlog = ops.conv(pred, self.mask_conv)                 # 7x7 pad 3 -> [B,64,64,16]
+        deformation, mask = ops.mask_deformation(mlog, sparse, want_mask=want_aux)
+        occ = ops.conv(pred, self.occ_conv, act=ACT_SIGMOID)  # [B,64,64,1]
+        out = {"deformation": deformation, "occlusion_nhwc": occ, "heat_nhwc": heat, "sparse_motion": sparse}
+        if want_aux:
+            out["mask_nhwc"] = mask
+            out["hg_in_nhwc"] = inp
+        return out

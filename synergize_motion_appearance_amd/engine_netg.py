@@ -1,0 +1,320 @@
+"""HIP execution plan for AppMotionCompFormer.forward(..., inference=True)
+(reference `archs/appmotioncodebook_arch.py:546-764`; rows A7-A13 of SURVEY.md section 8a),
+on NHWC activations -- tokens [B,1024,E] ARE the NHWC layout at 32x32, so the reference's
+reshape/permute traffic between conv maps and transformer tokens does not exist here.
+
+MI355X-first choices:
+  * the source encoder (59 GFLOP, frame-invariant; the reference re-runs it every frame,
+    demo.py:130) is computed once per source and cached; warps broadcast it over B frames;
+  * every conv / Linear / attention contraction is one implicit-GEMM kernel on the fp32 MFMA;
+  * patchify+Linear is a pxp stride-p conv, Linear+un-patchify a 1x1 conv with a
+    depth-to-space store; concatenations are written in place by their producers;
+  * codebook K / V^T projections are input-independent -> precomputed at pack time for the
+    full codebook; a scale's prefix is just a smaller N / K on the same buffers;
+  * sibling convs sharing an input (RefineFlow conv1/convo1, SFT scale.0/shift.0, MHA q/k)
+    are stacked into one wider GEMM;
+  * the redundant third warp per scale (`deform_feat_list`, :615/:714) is not recomputed.
+"""
+import math
+
+import torch
+
+from . import ops
+from .manifest import encoder_plan, generator_plan, CHANNELS
+from .ops import Conv, ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU
+
+_SCALE_K = {32: 1, 64: 2, 128: 3, 256: 4}
+
+
+class _Res:
+    def __init__(self, P, pre):
+        self.n1 = (P[pre + ".norm1.weight"], P[pre + ".norm1.bias"])
+        self.n2 = (P[pre + ".norm2.weight"], P[pre + ".norm2.bias"])
+        self.c1 = Conv.from_torch(P[pre + ".conv1.weight"], P[pre + ".conv1.bias"])
+        self.c2 = Conv.from_torch(P[pre + ".conv2.weight"], P[pre + ".conv2.bias"])
+        self.sc = Conv.from_torch(P[pre + ".conv_out.weight"], P[pre + ".conv_out.bias"]) if (pre + ".conv_out.weight") in P else None
+
+    def __call__(self, x, out=None):
+        """ResBlock.forward archs/vqgan_arch.py:180-191."""
+        h = ops.groupnorm(x, *self.n1, swish=True)
+        h = ops.conv(h, self.c1)
+        h = ops.groupnorm(h, *self.n2, swish=True)
+        skip = x if self.sc is None else ops.conv(x, self.sc)
+        return ops.conv(h, self.c2, out=out, res=skip)
+
+
+class _Attn:
+    """AttnBlock archs/vqgan_arch.py:194-253 (single head, C^-0.5 applied to the scores)."""
+
+    def __init__(self, P, pre):
+        self.n = (P[pre + ".norm.weight"], P[pre + ".norm.bias"])
+        q = Conv.from_torch(P[pre + ".q.weight"], P[pre + ".q.bias"])
+        k = Conv.from_torch(P[pre + ".k.weight"], P[pre + ".k.bias"])
+        self.qk = Conv.cat([q, k])
+        v = Conv.from_torch(P[pre + ".v.weight"], P[pre + ".v.bias"])
+        self.wv, self.bv = v.w, v.b
+        self.proj = Conv.from_torch(P[pre + ".proj_out.weight"], P[pre + ".proj_out.bias"])
+        self.C = q.cout
+
+    def __call__(self, x):
+        B, H, W, Cc = x.shape
+        N = H * W
+        hn = ops.groupnorm(x, *self.n, swish=False)
+        qk = ops.conv(hn, self.qk)                                            # [B,H,W,2C]
+        vt = torch.empty((B, Cc, N), device=x.device, dtype=torch.float32)    # V^T = Wv . hn^T + bv
+        ops.gemm_nt(self.wv, hn, vt, M=Cc, N=N, K=Cc, lda=Cc, ldb=Cc, ldc=N, nb0=B, bt_bs=(N * Cc, 0),
+                    c_bs=(Cc * N, 0), bias=self.bv, bias_per_row=True)
+        s = torch.empty((B, N, N), device=x.device, dtype=torch.float32)
+        ops.gemm_nt(qk, qk, s, M=N, N=N, K=Cc, lda=2 * Cc, ldb=2 * Cc, ldc=N, nb0=B, a_bs=(N * 2 * Cc, 0),
+                    bt_bs=(N * 2 * Cc, 0), c_bs=(N * N, 0), bt_off=Cc)
+        ops.softmax_rows(s, N, float(int(Cc) ** (-0.5)))
+        h = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+        ops.gemm_nt(s, vt, h, M=N, N=Cc, K=N, lda=N, ldb=N, ldc=Cc, nb0=B, a_bs=(N * N, 0), bt_bs=(Cc * N, 0),
+                    c_bs=(N * Cc, 0))
+        return ops.conv(h, self.proj, res=x)
+
+
+class _Transformer:
+    """TransformerLayer archs/appmotioncodebook_arch.py:65-126 with nn.MultiheadAttention
+    restated: codebook K / V^T precomputed for all rows."""
+
+    def __init__(self, P, pre, E, nhead, codebook):
+        self.E, self.H, self.dh = E, nhead, E // nhead
+        W, b = P[pre + ".self_attn.in_proj_weight"], P[pre + ".self_attn.in_proj_bias"]
+        self.s_qk = Conv(W[:2 * E].contiguous(), b[:2 * E].contiguous(), 1, 1, E, 2 * E)
+        self.s_wv, self.s_bv = W[2 * E:].contiguous(), b[2 * E:].contiguous()
+        self.s_out = Conv.from_torch(P[pre + ".self_attn.out_proj.weight"], P[pre + ".self_attn.out_proj.bias"])
+        W, b = P[pre + ".cross_attn.in_proj_weight"], P[pre + ".cross_attn.in_proj_bias"]
+        self.c_q = Conv(W[:E].contiguous(), b[:E].contiguous(), 1, 1, E, E)
+        self.c_out = Conv.from_torch(P[pre + ".cross_attn.out_proj.weight"], P[pre + ".cross_attn.out_proj.bias"])
+        Kc = codebook.shape[0]
+        self.Kc = Kc
+        # Kc = cb Wk^T + bk  [Kc,E];  VcT = Wv cb^T + bv  [E,Kc]   (input independent)
+        self.ck = torch.empty((Kc, E), device=codebook.device, dtype=torch.float32)
+        ops.gemm_nt(codebook, W[E:2 * E].contiguous(), self.ck, M=Kc, N=E, K=E, lda=E, ldb=E, ldc=E, bias=b[E:2 * E].contiguous())
+        self.cvt = torch.empty((E, Kc), device=codebook.device, dtype=torch.float32)
+        ops.gemm_nt(W[2 * E:].contiguous(), codebook, self.cvt, M=E, N=Kc, K=E, lda=E, ldb=E, ldc=Kc,
+                    bias=b[2 * E:].contiguous(), bias_per_row=True)
+        self.n1 = (P[pre + ".norm1.weight"], P[pre + ".norm1.bias"])
+        self.n2 = (P[pre + ".norm2.weight"], P[pre + ".norm2.bias"])
+        self.n3 = (P[pre + ".norm3.weight"], P[pre + ".norm3.bias"])
+        self.f1 = Conv.from_torch(P[pre + ".conv1.weight"], P[pre + ".conv1.bias"])
+        self.f2 = Conv.from_torch(P[pre + ".conv2.weight"], P[pre + ".conv2.bias"])
+
+    def __call__(self, tgt, S, pos, mask=None):
+        """tgt [B,32,32,E] (== tokens [B,1024,E]); S = codebook prefix rows."""
+        B = tgt.shape[0]
+        E, H, dh, N = self.E, self.H, self.dh, 1024
+        # self attention: q = k = LN(x)+pos, v = LN(x)
+        t2, qk_in = ops.layernorm(tgt, *self.n1, pos=pos)
+        qk = ops.conv(qk_in, self.s_qk)                                       # [B,32,32,2E]
+        vt = torch.empty((B, E, N), device=tgt.device, dtype=torch.float32)
+        ops.gemm_nt(self.s_wv, t2, vt, M=E, N=N, K=E, lda=E, ldb=E, ldc=N, nb0=B, bt_bs=(N * E, 0), c_bs=(E * N, 0),
+                    bias=self.s_bv, bias_per_row=True)
+        o = ops.attention(qk, 2 * E, qk, 2 * E, vt, N, N, H, dh, scale_in_gemm=True, k_bs0=N * 2 * E, vt_bs0=E * N,
+                          mask=mask, k_off=E)
+        tgt = ops.conv(o.view(B, 32, 32, E), self.s_out, res=tgt)
+        # cross attention against the codebook prefix
+        t2, q_in = ops.layernorm(tgt, *self.n2, pos=pos)
+        q = ops.conv(q_in, self.c_q)
+        o = ops.attention(q, E, self.ck, E, self.cvt, self.Kc, S, H, dh, scale_in_gemm=True, k_bs0=0, vt_bs0=0)
+        tgt = ops.conv(o.view(B, 32, 32, E), self.c_out, res=tgt)
+        # conv FFN
+        t2, _ = ops.layernorm(tgt, *self.n3)
+        h = ops.conv(t2, self.f1, act=ACT_GELU)
+        return ops.conv(h, self.f2, res=tgt)
+
+
+class SourceCache:
+    """frame-invariant encoder taps of one source (A8 encoder): {32,64,128,256} -> NHWC [1|B,s,s,C]."""
+    __slots__ = ("feats", "batch")
+
+    def __init__(self, feats, batch):
+        self.feats, self.batch = feats, batch
+
+
+class NetGEngine:
+    def __init__(self, P, cfg):
+        self.cfg = cfg
+        nf, ch_mult, rb = cfg["nf"], tuple(cfg["ch_mult"]), cfg["res_blocks"]
+        attn = tuple(cfg["attn_resolutions"])
+        eplan, _ = encoder_plan(nf, ch_mult, rb, cfg["img_size"], attn)
+        self.enc_kinds = [k for k, _, _ in eplan] + ["conv"]
+        self.gen_kinds = [k for k, _, _ in generator_plan(nf, ch_mult, rb, cfg["img_size"], attn, 256)]
+        self.enc = [self._block(P, f"encoder.blocks.{i}", k) for i, k in enumerate(self.enc_kinds)]
+        self.gen = [self._block(P, f"generator.blocks.{i}", k) for i, k in enumerate(self.gen_kinds)]
+        self.nhead = cfg["n_head"]
+        Em, Ea = cfg["dim_embd_motion"], cfg["dim_embd_app"]
+        self.Em, self.Ea = Em, Ea
+        self.cb_motion = P["quantize_motion.embedding.weight"].contiguous()
+        self.cb_app = P["quantize_app.embedding.weight"].contiguous()
+        self.pos_motion = P["position_emb_motion"].contiguous()
+        self.pos_app = P["position_emb_app"].contiguous()
+        self.motion_blocks = [_Transformer(P, f"motion_block.{l}", Em, self.nhead, self.cb_motion) for l in range(cfg["n_layers_motion"])]
+        self.app_blocks = [_Transformer(P, f"app_block.{l}", Ea, self.nhead, self.cb_app) for l in range(cfg["n_layers_app"])]
+        cv = lambda n: Conv.from_torch(P[n + ".weight"], P[n + ".bias"])
+        self.motion_emb0 = cv("motion_emb.0")
+        self.motion_emb1 = cv("motion_emb.1.conv")
+        self.motion_emb2 = _Res(P, "motion_emb.2")
+        self.mq1, self.mq2 = cv("motion_query_enc_1"), cv("motion_query_enc_2")
+        self.kp_enc = cv("driving_kp_enc")
+        self.sizes = [32] + [int(s) for s in cfg["connect_list"]]
+        self.wsrc = {s: cv(f"warped_source_enc_{s}") for s in self.sizes}
+        self.to_ctx = {s: cv(f"to_context.{int(math.log2(s)) - 5}") for s in self.sizes}
+        self.bme = {n: cv("BasicMotionEncoder." + n) for n in ("convc1", "convc2", "convf1", "convf2", "conv")}
+        self.ref_c1 = cv("refine.convc1")
+        self.ref_h = Conv.cat([cv("refine.conv1"), cv("refine.convo1")])      # shared input -> N=256
+        self.ref_flow, self.ref_occ = cv("refine.conv2"), cv("refine.convo2")
+        self.app_in, self.app_out = {}, {}
+        for s in [int(x) for x in cfg["connect_app_list"]]:
+            if s == 32:
+                self.app_in[s], self.app_out[s] = cv("app_feat_emb_32"), cv("to_app_feat_32")
+            else:
+                p, c = s // 32, CHANNELS[str(s)]
+                w = P[f"app_feat_emb_{s}.1.weight"]                           # [256, (p1 p2 c)] == conv pxp K order
+                self.app_in[s] = Conv(w.contiguous(), P[f"app_feat_emb_{s}.1.bias"].contiguous(), p, p, c, w.shape[0])
+                self.app_out[s] = Conv.from_torch(P[f"to_app_feat_{s}.0.weight"], P[f"to_app_feat_{s}.0.bias"])
+        self.sft = {}
+        for s in [int(x) for x in cfg["connect_list"]]:
+            pre = f"fuse_convs_dict.{s}"
+            self.sft[s] = {"res": _Res(P, pre + ".encode_enc"),
+                           "ss0": Conv.cat([cv(pre + ".scale.0"), cv(pre + ".shift.0")]),
+                           "scale2": cv(pre + ".scale.2"), "shift2": cv(pre + ".shift.2"),
+                           "ms": cv(f"fuse_ms_dict.{s}")}
+        self.fuse_after = {9: 64, 12: 128, 15: 256}
+        self.taps_after = {2: 256, 5: 128, 8: 64}
+
+    @staticmethod
+    def _block(P, pre, kind):
+        if kind == "res":
+            return _Res(P, pre)
+        if kind == "attn":
+            return _Attn(P, pre)
+        if kind in ("down", "up"):
+            return Conv.from_torch(P[pre + ".conv.weight"], P[pre + ".conv.bias"])
+        if kind == "gn":
+            return (P[pre + ".weight"], P[pre + ".bias"])
+        return Conv.from_torch(P[pre + ".weight"], P[pre + ".bias"])
+
+    @staticmethod
+    def _run(kind, blk, x):
+        if kind == "conv":
+            return ops.conv(x, blk)
+        if kind in ("res", "attn"):
+            return blk(x)
+        if kind == "down":      # pad (0,1,0,1) + conv3x3 s2 p0  (vqgan_arch.py:144-153)
+            return ops.conv(x, blk, stride=2, pad=(0, 0), out_hw=(x.shape[1] // 2, x.shape[2] // 2))
+        if kind == "up":        # nearest x2 folded into the gather (vqgan_arch.py:156-165)
+            return ops.conv(x, blk, up2=True)
+        if kind == "gn":
+            return ops.groupnorm(x, blk[0], blk[1], swish=False)
+        raise ValueError(kind)
+
+    # ---- A8 encoder: frame-invariant -------------------------------------------------------
+    def encode_source(self, x_nchw):
+        x = ops.nchw_to_nhwc(x_nchw)
+        feats = {}
+        for i, (kind, blk) in enumerate(zip(self.enc_kinds, self.enc)):
+            x = self._run(kind, blk, x)
+            if i in self.taps_after:
+                feats[self.taps_after[i]] = x
+        feats[32] = x
+        return SourceCache(feats, x_nchw.shape[0])
+
+    # ---- A9 -------------------------------------------------------------------------------
+    def _motion_comp(self, flow_res, mq, warp0, s):
+        B = flow_res.shape[0]
+        Em = self.Em
+        m1 = ops.conv(flow_res, self.motion_emb0)                             # [B,64,64,32]
+        m2 = ops.conv(m1, self.motion_emb1, stride=2, pad=(0, 0), out_hw=(32, 32))
+        qin = torch.empty((B, 32, 32, 2 * Em), device=flow_res.device, dtype=torch.float32)
+        self.motion_emb2(m2, out=qin[..., :Em])
+        ops.copy_slice(mq, qin[..., Em:])
+        q = ops.conv(qin, self.mq2)                                           # tokens [B,1024,32]
+        S = self.cb_motion.shape[0] // 4 * _SCALE_K[s]
+        for blk in self.motion_blocks:
+            q = blk(q, S, self.pos_motion)
+        motion_f = ops.resize(q, 64, 64)
+        cf = torch.empty((B, 64, 64, 160), device=q.device, dtype=torch.float32)
+        cor = ops.conv(motion_f, self.bme["convc1"], act=ACT_RELU)
+        ops.conv(cor, self.bme["convc2"], out=cf[..., :96], act=ACT_RELU)
+        flo = ops.conv(flow_res, self.bme["convf1"], act=ACT_RELU)            # 7x7 pad 3
+        ops.conv(flo, self.bme["convf2"], out=cf[..., 96:], act=ACT_RELU)
+        inp = torch.empty((B, 64, 64, 256), device=q.device, dtype=torch.float32)
+        ops.conv(cf, self.bme["conv"], out=inp[..., :126], act=ACT_RELU)
+        ops.copy_slice(flow_res, inp[..., 126:128])
+        wf = ops.conv(warp0, self.to_ctx[s], act=ACT_RELU)                    # [B,s,s,192]
+        if s != 64:
+            wf = ops.resize(wf, 64, 64)
+        ops.conv(wf, self.ref_c1, out=inp[..., 128:], act=ACT_RELU)
+        h = ops.conv(inp, self.ref_h, act=ACT_RELU)                           # [B,64,64,256] = [conv1 | convo1]
+        r = torch.empty((B, 64, 64, 3), device=q.device, dtype=torch.float32)
+        ops.conv(h[..., :128], self.ref_flow, out=r[..., 0:2])
+        ops.conv(h[..., 128:], self.ref_occ, out=r[..., 2:3])
+        return r
+
+    # ---- A10 ------------------------------------------------------------------------------
+    def _app_comp(self, feat, m_com, s, out=None):
+        C = feat.shape[-1]
+        ign = ops.motion_ignore(m_com)
+        if s == 32:
+            q = ops.conv(feat, self.app_in[32])
+        else:
+            p = s // 32
+            q = ops.conv(feat, self.app_in[s], stride=p, pad=(0, 0))
+        S = self.cb_app.shape[0] // 4 * _SCALE_K[s]
+        for l, blk in enumerate(self.app_blocks):
+            q = blk(q, S, self.pos_app, mask=ign if l == 0 else None)
+        if s == 32:
+            return ops.conv(q, self.app_out[32], out=out)
+        return ops.conv(q, self.app_out[s], out=out, d2s=(s // 32, C))
+
+    def _one_scale(self, st, feat, s, first):
+        flow = st["flows"][-1]
+        warp0 = ops.warp(feat, flow)
+        wsrc = warp0 if s == 32 else ops.resize(warp0, 32, 32)
+        B = flow.shape[0]
+        mqin = torch.empty((B, 32, 32, 2 * self.Em), device=flow.device, dtype=torch.float32)
+        ops.conv(wsrc, self.wsrc[s], out=mqin[..., :self.Em], act=ACT_RELU)
+        ops.copy_slice(st["kp_feat"], mqin[..., self.Em:])
+        mq = ops.conv(mqin, self.mq1)
+        r = self._motion_comp(ops.flow_to_residual(flow), mq, warp0, s)
+        m_com, res_norm, occ = ops.flow_occ_update(flow, r, st["occ"][-1])
+        st["flows"].append(m_com)
+        st["res"].append(res_norm)
+        st["occ"].append(occ)
+        warped = ops.warp(feat, m_com, occ)
+        st["before"].append(warped)
+        comp = self._app_comp(warped, m_com, s)
+        st["comp"].append(comp)
+        return comp
+
+    # ---- A13 ------------------------------------------------------------------------------
+    def _fuse(self, s, enc, dec, w):
+        f = self.sft[s]
+        B, H, W, C = dec.shape
+        cat = torch.empty((B, H, W, 2 * C), device=dec.device, dtype=torch.float32)
+        ops.copy_slice(enc, cat[..., :C])
+        ops.copy_slice(dec, cat[..., C:])
+        e = f["res"](cat)
+        ss = ops.conv(e, f["ss0"], act=ACT_LRELU02)                           # [.., 2C] = [scale.0 | shift.0]
+        scale = ops.conv(ss[..., :C], f["scale2"])
+        shift = ops.conv(ss[..., C:], f["shift2"])
+        x = ops.sft_combine(dec, scale, shift, w)
+        return ops.conv(enc, f["ms"], res=x)                                  # x + fuse_ms(enc)
+
+    def forward(self, cache, deformation, occ64, heat_nhwc, w=1.0):
+        """cache: SourceCache; deformation [B,64,64,2]; occ64 [B,64,64]; heat [B,64,64,15] NHWC.
+        -> state dict with NHWC 'out' [B,256,256,3] and the intermediate lists."""
+        st = {"flows": [deformation.contiguous()], "occ": [occ64.contiguous()], "res": [], "before": [], "comp": []}
+        st["kp_feat"] = ops.conv(ops.resize(heat_nhwc, 32, 32), self.kp_enc, act=ACT_RELU)
+        x = self._one_scale(st, cache.feats[32], 32, True)
+        st["lq"] = x
+        for i, (kind, blk) in enumerate(zip(self.gen_kinds, self.gen)):
+            x = self._run(kind, blk, x)
+            if i in self.fuse_after and w > 0:
+                s = self.fuse_after[i]
+                ew = self._one_scale(st, cache.feats[s], s, False)
+                x = self._fuse(s, ew, x, w)
+        st["out"] = x
+        return st

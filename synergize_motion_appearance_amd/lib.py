@@ -1,0 +1,90 @@
+"""ctypes binding of libsmx.so (the C ABI declared in include/smx.h).
+
+There is NO fallback: if the library is missing or was not built, importing this module's
+`load()` raises -- the product path never routes through a CPU implementation."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libsmx.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SWISH, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+
+_p, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+
+class GemmDesc(C.Structure):
+    """mirror of `smx_gemm_desc` (include/smx.h)."""
+    _fields_ = [
+        ("a", _p), ("a_bs0", _i64), ("a_bs1", _i64),
+        ("bt", _p), ("bt_bs0", _i64), ("bt_bs1", _i64),
+        ("c", _p), ("c_bs0", _i64), ("c_bs1", _i64),
+        ("bias", _p),
+        ("res", _p), ("res_bs0", _i64), ("res_bs1", _i64),
+        ("nb0", C.c_int32), ("nb1", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldres", C.c_int32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("up2", C.c_int32),
+        ("act", C.c_int32), ("alpha", C.c_float),
+        ("bias_per_row", C.c_int32),
+        ("d2s_p", C.c_int32), ("d2s_c", C.c_int32),
+        ("tile", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/smx.h declares
+SIGNATURES = {
+    "smx_version": (C.c_char_p, []),
+    "smx_gemm_conv_f32": (_i, [C.POINTER(GemmDesc), _p]),
+    "smx_groupnorm_ws_floats": (_i64, [_i, _i, _i]),
+    "smx_groupnorm_swish_nhwc_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
+    "smx_layernorm_pos_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "smx_softmax_rows_f32": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
+    "smx_warp_nhwc_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_resize_bilinear_ac_nhwc_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_avgpool2_nhwc_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_antialias_down_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_kp_head_f32": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "smx_sparse_motion_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "smx_mask_deformation_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smx_flow_to_residual_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "smx_flow_occ_update_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "smx_motion_ignore_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_sft_combine_f32": (_i, [_p, _p, _p, _p, _f, _i64, _p]),
+    "smx_add_f32": (_i, [_p, _p, _p, _i64, _p]),
+    "smx_copy_slice_f32": (_i, [_p, _i, _p, _i, _i64, _i, _p]),
+    "smx_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_nhwc_to_nchw_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "smx_to_uint8_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
+    "smx_vq_nearest_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class SmxError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libsmx.so and bind every entry point; raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmxError(f"{LIB_PATH} not found: build it with `python -m synergize_motion_appearance_amd.build` "
+                       "(__graft_entry__.build()). There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SmxError(f"{what} failed with code {rc}")

@@ -1,0 +1,336 @@
+"""Host-side launchers: torch device tensors -> libsmx C-ABI calls (include/smx.h).
+
+PyTorch is used for device memory and the current HIP stream only.  Activations are NHWC
+fp32 tensors `[B,H,W,C]`; a channel slice `buf[..., a:b]` is a legal operand (its pixel
+stride is the channel count of `buf`), which is how concatenations are built in place.
+Every launcher raises on CPU tensors: there is no fallback path."""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+from .lib import ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SWISH, ACT_GELU, ACT_SIGMOID  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name="tensor"):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise L.SmxError(f"{name}: the HIP path needs a device tensor (got {type(t).__name__} on "
+                         f"{getattr(t, 'device', '?')}); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise L.SmxError(f"{name}: fp32 expected, got {t.dtype}")
+    return t
+
+
+def _pix(t, name="tensor"):
+    """(ptr, ld) of an NHWC tensor or channel-slice view: last stride 1, dense pixels."""
+    _dev(t, name)
+    if t.dim() < 2 or t.stride(-1) != 1:
+        raise L.SmxError(f"{name}: innermost (channel) stride must be 1")
+    ld = t.stride(-2) if t.shape[-2] > 1 else max(t.shape[-1], t.stride(-2))
+    # pixels must be dense at stride ld
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] > 1 and t.stride(d) != exp:
+            raise L.SmxError(f"{name}: non-dense pixel layout {tuple(t.shape)} / {t.stride()}")
+        exp *= t.shape[d]
+    return t.data_ptr(), int(ld)
+
+
+class Conv:
+    """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout")
+
+    def __init__(self, w, b, kh, kw, cin, cout):
+        self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
+
+    @staticmethod
+    def from_torch(weight, bias):
+        """weight: conv [Cout,Cin,kh,kw] or linear [out,in] (device tensors)."""
+        if weight.dim() == 4:
+            co, ci, kh, kw = weight.shape
+            w = weight.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+        else:
+            co, ci = weight.shape
+            kh = kw = 1
+            w = weight.contiguous()
+        return Conv(w.float(), None if bias is None else bias.contiguous().float(), kh, kw, ci, co)
+
+    @staticmethod
+    def cat(convs):
+        """stack output channels of convs that share their input."""
+        c0 = convs[0]
+        return Conv(torch.cat([c.w for c in convs], 0).contiguous(), torch.cat([c.b for c in convs], 0).contiguous(),
+                    c0.kh, c0.kw, c0.cin, sum(c.cout for c in convs))
+
+
+def gemm_raw(**kw):
+    d = L.GemmDesc()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    L.check(L.load().smx_gemm_conv_f32(C.byref(d), _stream()), "smx_gemm_conv_f32")
+
+
+def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None,
+         d2s=None, tile=0):
+    """y = act(conv(x) + bias) [+ res].  x [B,H,W,Cin] (slice ok) -> out [B,Ho,Wo,Cout] (slice ok).
+    pad: (top, left) (default (kh//2, kw//2)); out_hw for asymmetric pads / strides.
+    d2s=(p, C): un-patchify store, out is [B,Ho*p,Wo*p,C]."""
+    B, H, W, Cin = x.shape
+    if Cin != cv.cin:
+        raise L.SmxError(f"conv: input has {Cin} channels, layer expects {cv.cin}")
+    He, We = (2 * H, 2 * W) if up2 else (H, W)
+    pt, pl = (cv.kh // 2, cv.kw // 2) if pad is None else pad
+    if out_hw is None:
+        Ho = (He + 2 * pt - cv.kh) // stride + 1
+        Wo = (We + 2 * pl - cv.kw) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    if out is None:
+        if d2s:
+            out = torch.empty((B, Ho * d2s[0], Wo * d2s[0], d2s[1]), device=x.device, dtype=torch.float32)
+        else:
+            out = torch.empty((B, Ho, Wo, cv.cout), device=x.device, dtype=torch.float32)
+    a_ptr, lda = _pix(x, "conv input")
+    c_ptr, ldc = _pix(out, "conv output")
+    r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
+    gemm_raw(a=a_ptr, bt=_dev(cv.w).data_ptr(), c=c_ptr, bias=None if cv.b is None else cv.b.data_ptr(),
+             res=r_ptr, nb0=1, nb1=1, M=B * Ho * Wo, N=cv.cout, K=cv.kh * cv.kw * Cin,
+             lda=lda, ldb=cv.w.shape[1], ldc=ldc, ldres=ldr, Hin=H, Win=W, Cin=Cin, Ho=Ho, Wo=Wo,
+             kh=cv.kh, kw=cv.kw, stride=stride, pad_t=pt, pad_l=pl, up2=int(up2), act=act, alpha=1.0,
+             d2s_p=d2s[0] if d2s else 0, d2s_c=d2s[1] if d2s else 0, tile=tile)
+    return out
+
+
+def gemm_nt(a, bt, c, *, M, N, K, lda, ldb, ldc, nb0=1, nb1=1, a_bs=(0, 0), bt_bs=(0, 0), c_bs=(0, 0),
+            bias=None, bias_per_row=False, alpha=1.0, act=ACT_NONE, res=None, ldres=0, res_bs=(0, 0),
+            a_off=0, bt_off=0, c_off=0, tile=0):
+    """batched C[g] = act(alpha * A[g] @ Bt[g]^T + bias) (+res); offsets/strides in elements."""
+    gemm_raw(a=_dev(a).data_ptr() + 4 * a_off, a_bs0=a_bs[0], a_bs1=a_bs[1],
+             bt=_dev(bt).data_ptr() + 4 * bt_off, bt_bs0=bt_bs[0], bt_bs1=bt_bs[1],
+             c=_dev(c).data_ptr() + 4 * c_off, c_bs0=c_bs[0], c_bs1=c_bs[1],
+             bias=None if bias is None else bias.data_ptr(),
+             res=None if res is None else res.data_ptr(), res_bs0=res_bs[0], res_bs1=res_bs[1],
+             nb0=nb0, nb1=nb1, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, ldres=ldres,
+             Hin=M, Win=1, Cin=K, Ho=M, Wo=1, kh=1, kw=1, stride=1, pad_t=0, pad_l=0, up2=0,
+             act=act, alpha=alpha, bias_per_row=int(bias_per_row), d2s_p=0, d2s_c=0, tile=tile)
+    return c
+
+
+def groupnorm(x, gamma, beta, swish=True, out=None, groups=32, eps=1e-6):
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+    xp, ldx = _pix(x, "groupnorm input")
+    yp, ldy = _pix(out, "groupnorm output")
+    lib = L.load()
+    ws = torch.empty(int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)), device=x.device, dtype=torch.float32)
+    L.check(lib.smx_groupnorm_swish_nhwc_f32(xp, ldx, _dev(gamma).data_ptr(), _dev(beta).data_ptr(), yp, ldy, B, H * W,
+                                             Cc, groups, eps, int(swish), ws.data_ptr(), _stream()), "groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, pos=None, eps=1e-5):
+    """x tokens [..., E] contiguous -> (LN(x), LN(x)+pos or None)."""
+    _dev(x)
+    E = x.shape[-1]
+    T = x.numel() // E
+    y = torch.empty_like(x)
+    yp = torch.empty_like(x) if pos is not None else None
+    L.check(L.load().smx_layernorm_pos_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           None if pos is None else pos.data_ptr(), y.data_ptr(),
+                                           None if yp is None else yp.data_ptr(), T, E,
+                                           0 if pos is None else pos.shape[0], eps, _stream()), "layernorm")
+    return y, yp
+
+
+def softmax_rows(s, S, scale=1.0, mask=None, rows_per_mask=0):
+    """in-place softmax over the last dim (S) of contiguous s."""
+    _dev(s)
+    R = s.numel() // S
+    L.check(L.load().smx_softmax_rows_f32(s.data_ptr(), S, R, S, scale, None if mask is None else mask.data_ptr(),
+                                          rows_per_mask, _stream()), "softmax_rows")
+    return s
+
+
+def warp(feat, flow, occ=None, out=None):
+    """deform_input (+occlude_input): feat [1|B,H,W,C], flow [B,Hf,Wf,2], occ [B,Hf,Wf(,1)]."""
+    _dev(feat), _dev(flow)
+    B, Hf, Wf, _ = flow.shape
+    Bf, H, W, Cc = feat.shape
+    if out is None:
+        out = torch.empty((B, H, W, Cc), device=feat.device, dtype=torch.float32)
+    if not (feat.is_contiguous() and flow.is_contiguous() and out.is_contiguous() and (occ is None or occ.is_contiguous())):
+        raise L.SmxError("warp: contiguous operands expected")
+    L.check(L.load().smx_warp_nhwc_f32(feat.data_ptr(), Bf, flow.data_ptr(), None if occ is None else _dev(occ).data_ptr(),
+                                       out.data_ptr(), B, H, W, Cc, Hf, Wf, _stream()), "warp")
+    return out
+
+
+def resize(x, Ho, Wo, out=None):
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    xp, ldx = _pix(x, "resize input")
+    yp, ldy = _pix(out, "resize output")
+    L.check(L.load().smx_resize_bilinear_ac_nhwc_f32(xp, ldx, yp, ldy, B, H, W, Ho, Wo, Cc, _stream()), "resize")
+    return out
+
+
+def avgpool2(x, out=None):
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
+    xp, ldx = _pix(x, "avgpool input")
+    yp, ldy = _pix(out, "avgpool output")
+    L.check(L.load().smx_avgpool2_nhwc_f32(xp, ldx, yp, ldy, B, H, W, Cc, _stream()), "avgpool2")
+    return out
+
+
+def antialias_down(img_nchw, w, out=None, step=4):
+    _dev(img_nchw)
+    B, Cc, H, W = img_nchw.shape
+    K = w.shape[-1]
+    if out is None:
+        out = torch.empty((B, (H + step - 1) // step, (W + step - 1) // step, Cc), device=img_nchw.device, dtype=torch.float32)
+    yp, ldy = _pix(out, "antialias output")
+    L.check(L.load().smx_antialias_down_f32(img_nchw.contiguous().data_ptr(), _dev(w).contiguous().data_ptr(), yp, ldy, B, Cc,
+                                            H, W, K, step, _stream()), "antialias_down")
+    return out
+
+
+def kp_head(logits, jmaps, K, temperature):
+    B, H, W, _ = logits.shape
+    lp, ldl = _pix(logits, "kp logits")
+    jp, ldj = _pix(jmaps, "kp jacobian maps")
+    value = torch.empty((B, K, 2), device=logits.device, dtype=torch.float32)
+    jac = torch.empty((B, K, 2, 2), device=logits.device, dtype=torch.float32)
+    L.check(L.load().smx_kp_head_f32(lp, ldl, jp, ldj, value.data_ptr(), jac.data_ptr(), B, H, W, K, temperature, _stream()), "kp_head")
+    return value, jac
+
+
+def sparse_motion(src64, kpd_value, kpd_jac, kps_value, kps_jac, hg_in, B, K=15, var=0.01):
+    """-> (sparse [B,K+1,H,W,2], drv_heat [B,H,W,K]); hg_in slice [B,H,W,4(K+1)] is written."""
+    Bs, H, W, _ = src64.shape
+    hp, ldh = _pix(hg_in, "hourglass input")
+    sparse = torch.empty((B, K + 1, H, W, 2), device=src64.device, dtype=torch.float32)
+    heat = torch.empty((B, H, W, K), device=src64.device, dtype=torch.float32)
+    for t in (kpd_value, kpd_jac, kps_value, kps_jac):
+        _dev(t)
+    L.check(L.load().smx_sparse_motion_f32(_dev(src64).contiguous().data_ptr(), Bs, kpd_value.contiguous().data_ptr(),
+                                           kpd_jac.contiguous().data_ptr(), kps_value.contiguous().data_ptr(),
+                                           kps_jac.contiguous().data_ptr(), kps_value.shape[0], hp, ldh, sparse.data_ptr(),
+                                           heat.data_ptr(), B, H, W, K, var, _stream()), "sparse_motion")
+    return sparse, heat
+
+
+def mask_deformation(mask_logits, sparse, want_mask=False):
+    B, H, W, K1 = mask_logits.shape
+    mp, ldm = _pix(mask_logits, "mask logits")
+    deform = torch.empty((B, H, W, 2), device=mask_logits.device, dtype=torch.float32)
+    mask = torch.empty((B, H, W, K1), device=mask_logits.device, dtype=torch.float32) if want_mask else None
+    L.check(L.load().smx_mask_deformation_f32(mp, ldm, sparse.data_ptr(), deform.data_ptr(),
+                                              None if mask is None else mask.data_ptr(), B, H, W, K1, _stream()), "mask_deformation")
+    return deform, mask
+
+
+def flow_to_residual(flow):
+    B, H, W, _ = flow.shape
+    res = torch.empty_like(flow)
+    L.check(L.load().smx_flow_to_residual_f32(_dev(flow).data_ptr(), res.data_ptr(), B, H, W, _stream()), "flow_to_residual")
+    return res
+
+
+def flow_occ_update(flow, r, occ_prev):
+    B, H, W, _ = flow.shape
+    m_com, res_norm = torch.empty_like(flow), torch.empty_like(flow)
+    occ = torch.empty((B, H, W), device=flow.device, dtype=torch.float32)
+    L.check(L.load().smx_flow_occ_update_f32(_dev(flow).data_ptr(), _dev(r).data_ptr(), _dev(occ_prev).data_ptr(), m_com.data_ptr(),
+                                             res_norm.data_ptr(), occ.data_ptr(), B, H, W, _stream()), "flow_occ_update")
+    return m_com, res_norm, occ
+
+
+def motion_ignore(flow, Ht=32, Wt=32):
+    B, Hf, Wf, _ = flow.shape
+    ign = torch.empty((B, Ht * Wt), device=flow.device, dtype=torch.uint8)
+    L.check(L.load().smx_motion_ignore_f32(_dev(flow).data_ptr(), ign.data_ptr(), B, Hf, Wf, Ht, Wt, _stream()), "motion_ignore")
+    return ign
+
+
+def sft_combine(dec, scale, shift, w=1.0):
+    out = torch.empty_like(dec)
+    L.check(L.load().smx_sft_combine_f32(_dev(dec).data_ptr(), _dev(scale).data_ptr(), _dev(shift).data_ptr(), out.data_ptr(),
+                                         float(w), dec.numel(), _stream()), "sft_combine")
+    return out
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    L.check(L.load().smx_add_f32(_dev(a).data_ptr(), _dev(b).data_ptr(), y.data_ptr(), a.numel(), _stream()), "add")
+    return y
+
+
+def copy_slice(x, out):
+    xp, ldx = _pix(x, "copy input")
+    yp, ldy = _pix(out, "copy output")
+    Cc = x.shape[-1]
+    L.check(L.load().smx_copy_slice_f32(xp, ldx, yp, ldy, x.numel() // Cc, Cc, _stream()), "copy_slice")
+    return out
+
+
+def nchw_to_nhwc(x, out=None):
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+    yp, ldy = _pix(out, "nhwc output")
+    L.check(L.load().smx_nchw_to_nhwc_f32(_dev(x).contiguous().data_ptr(), yp, ldy, B, Cc, H, W, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x):
+    B, H, W, Cc = x.shape
+    xp, ldx = _pix(x, "nhwc input")
+    y = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+    L.check(L.load().smx_nhwc_to_nchw_f32(xp, ldx, y.data_ptr(), B, Cc, H, W, _stream()), "nhwc_to_nchw")
+    return y
+
+
+def to_uint8(x, lo=-1.0, hi=1.0):
+    y = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    L.check(L.load().smx_to_uint8_f32(_dev(x).contiguous().data_ptr(), y.data_ptr(), x.numel(), lo, hi, _stream()), "to_uint8")
+    return y
+
+
+def vq_nearest(z_tokens, codebook, Ks, want_zq=True):
+    """z_tokens [N,D], codebook [K,D] -> (idx int64 [N], zq [N,D], dmin [N], sum (zq-z)^2)."""
+    _dev(z_tokens), _dev(codebook)
+    N, D = z_tokens.shape
+    idx = torch.empty((N,), device=z_tokens.device, dtype=torch.int64)
+    zq = torch.empty_like(z_tokens) if want_zq else None
+    dmin = torch.empty((N,), device=z_tokens.device, dtype=torch.float32)
+    sq = torch.zeros((1,), device=z_tokens.device, dtype=torch.float32)
+    L.check(L.load().smx_vq_nearest_f32(z_tokens.contiguous().data_ptr(), codebook.contiguous().data_ptr(), idx.data_ptr(),
+                                        None if zq is None else zq.data_ptr(), dmin.data_ptr(), sq.data_ptr(), N, D, Ks,
+                                        _stream()), "vq_nearest")
+    return idx, zq, dmin, sq
+
+
+def attention(q, q_ld, k, k_ld, vt, vt_ld, S, nhead, dh, *, scale_in_gemm, k_bs0, vt_bs0, mask=None, q_off=0, k_off=0):
+    """softmax(q k^T) v for tokens [B,1024,*]: q rows at stride q_ld (head h at +h*dh), k rows
+    [S] at stride k_ld, vt = V^T rows [nhead*dh][S] at stride vt_ld.  *_bs0: batch strides
+    (0 = shared codebook K/V).  Scores are materialised [B,H,1024,S] (round 1)."""
+    B, Lq = q.shape[0], 1024
+    scores = torch.empty((B, nhead, Lq, S), device=q.device, dtype=torch.float32)
+    alpha = dh ** -0.5 if scale_in_gemm else 1.0
+    gemm_nt(q, k, scores, M=Lq, N=S, K=dh, lda=q_ld, ldb=k_ld, ldc=S, nb0=B, nb1=nhead,
+            a_bs=(Lq * q_ld, dh), bt_bs=(k_bs0, dh), c_bs=(nhead * Lq * S, Lq * S), alpha=alpha, a_off=q_off, bt_off=k_off)
+    softmax_rows(scores, S, 1.0 if scale_in_gemm else dh ** -0.5, mask, nhead * Lq)
+    E = nhead * dh
+    o = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
+    gemm_nt(scores, vt, o, M=Lq, N=dh, K=S, lda=S, ldb=vt_ld, ldc=E, nb0=B, nb1=nhead,
+            a_bs=(nhead * Lq * S, Lq * S), bt_bs=(vt_bs0, dh * vt_ld), c_bs=(Lq * E, dh))
+    return o

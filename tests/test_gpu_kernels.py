@@ -1,0 +1,347 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point (include/smx.h) against the
+ATen CPU op / oracle function it replaces, on seeded inputs.  fp32 tolerances are written
+next to each check; integer outputs (VQ indices, masks, uint8) are compared exactly."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import reenact_oracle as O
+from synergize_motion_appearance_amd.synth import synth_input
+from tests.util import maxabs, weights, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from synergize_motion_appearance_amd import ops as _ops
+    from synergize_motion_appearance_amd import lib
+    lib.load()
+    return _ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rnd(name, shape, scale=1.0):
+    return synth_input(name, shape) * scale
+
+
+# ---------------------------------------------------------------------------------------
+# implicit-GEMM convolution
+# ---------------------------------------------------------------------------------------
+CONV_CASES = [
+    # (B, Cin, Cout, H, k, stride, pad(t,l) or None, out_hw, up2, act, tile, tag)
+    (2, 64, 64, 32, 3, 1, None, None, False, 0, 0, "3x3 64->64"),
+    (1, 128, 128, 64, 3, 1, None, None, False, 0, 1, "3x3 128->128 tile1"),
+    (1, 128, 128, 64, 3, 1, None, None, False, 0, 4, "3x3 128->128 tile4"),
+    (2, 256, 128, 16, 3, 1, None, None, False, 1, 0, "3x3 256->128 relu"),
+    (1, 64, 64, 32, 3, 1, None, None, False, 0, 2, "tile2"),
+    (1, 64, 64, 32, 3, 1, None, None, False, 0, 5, "tile5"),
+    (2, 32, 32, 32, 3, 1, None, None, False, 3, 3, "3x3 32->32 swish tile3"),
+    (2, 64, 64, 33, 3, 2, (0, 0), (16, 16), False, 0, 0, "downsample-like odd"),
+    (2, 32, 32, 64, 3, 2, (0, 0), (32, 32), False, 0, 0, "Downsample pad(0,1,0,1) s2"),
+    (2, 64, 64, 16, 3, 1, None, None, True, 0, 0, "Upsample nearest x2 folded"),
+    (2, 3, 64, 32, 3, 1, None, None, False, 0, 0, "3x3 3->64 generic path"),
+    (2, 2, 32, 32, 3, 1, None, None, False, 0, 0, "3x3 2->32 generic"),
+    (2, 2, 128, 24, 7, 1, None, None, False, 1, 0, "7x7 2->128 pad3 relu"),
+    (2, 35, 15, 32, 7, 1, (0, 0), None, False, 0, 0, "7x7 valid 35->15"),
+    (1, 128, 16, 32, 7, 1, None, None, False, 0, 0, "7x7 128->16"),
+    (1, 128, 1, 32, 7, 1, None, None, False, 5, 0, "7x7 128->1 sigmoid"),
+    (2, 256, 192, 32, 1, 1, None, None, False, 1, 0, "1x1 256->192 relu"),
+    (2, 15, 32, 32, 1, 1, None, None, False, 1, 0, "1x1 15->32 generic"),
+    (1, 160, 126, 32, 3, 1, None, None, False, 1, 0, "3x3 160->126 odd Cout"),
+    (1, 64, 3, 64, 3, 1, None, None, False, 0, 0, "3x3 64->3"),
+    (1, 256, 512, 32, 3, 1, None, None, False, 4, 0, "3x3 256->512 gelu"),
+    (1, 1024, 512, 4, 3, 1, None, None, True, 1, 0, "hourglass deep up2"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[-1] for c in CONV_CASES])
+def test_conv(ops, case):
+    B, Cin, Cout, H, k, stride, pad, out_hw, up2, act, tile, tag = case
+    x = rnd("cx" + tag, (B, Cin, H, H))
+    w = rnd("cw" + tag, (Cout, Cin, k, k), 1.0 / math.sqrt(Cin * k * k))
+    b = rnd("cb" + tag, (Cout,), 0.1)
+    xe = F.interpolate(x, scale_factor=2.0, mode="nearest") if up2 else x
+    if pad is None:
+        ref = F.conv2d(xe, w, b, stride=stride, padding=k // 2)
+    else:
+        He = xe.shape[2]
+        if out_hw is not None:       # asymmetric: pad bottom/right so that exactly out_hw rows come out
+            need = (out_hw[0] - 1) * stride + k - He - pad[0]
+            xe = F.pad(xe, (pad[1], max(need, 0), pad[0], max(need, 0)))
+            ref = F.conv2d(xe, w, b, stride=stride)[:, :, :out_hw[0], :out_hw[1]]
+        else:
+            ref = F.conv2d(xe, w, b, stride=stride, padding=pad)
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: O.swish, 4: F.gelu, 5: torch.sigmoid}[act](ref)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    y = ops.conv(nhwc(x), cv, stride=stride, pad=pad, out_hw=out_hw, up2=up2, act=act, tile=tile)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (B, ref.shape[2], ref.shape[3], Cout)
+    assert maxabs(nchw(y), ref) < 2e-5, tag
+
+
+def test_conv_residual_and_slices(ops):
+    """output into a channel slice of a concat buffer, input from a slice, fused residual."""
+    x = rnd("sx", (2, 96, 32, 32))
+    w = rnd("sw", (64, 64, 3, 3), 1 / 24.0)
+    b = rnd("sb", (64,), 0.1)
+    r = rnd("sr", (2, 64, 32, 32))
+    ref = F.conv2d(x[:, 32:], w, b, padding=1) + r
+    buf = torch.full((2, 32, 32, 160), 7.0, device="cuda")
+    xin = nhwc(x)
+    ops.conv(xin[..., 32:], ops.Conv.from_torch(w.cuda(), b.cuda()), out=buf[..., 64:128], res=nhwc(r))
+    torch.cuda.synchronize()
+    assert maxabs(nchw(buf[..., 64:128]), ref) < 2e-5
+    assert float(buf[..., :64].min()) == 7.0 and float(buf[..., 128:].max()) == 7.0
+
+
+def test_patch_embed_and_unpatchify(ops):
+    """Rearrange+Linear == pxp stride-p conv; Linear+Rearrange == 1x1 conv + depth-to-space store."""
+    for s, C in ((64, 128), (128, 128), (256, 64)):
+        p = s // 32
+        x = rnd(f"pe{s}", (1, C, s, s))
+        w = rnd(f"pw{s}", (256, C * p * p), 1 / math.sqrt(C * p * p))
+        b = rnd(f"pb{s}", (256,), 0.1)
+        ref = F.linear(O.patchify(x, p), w, b)                                   # [1,1024,256]
+        cv = ops.Conv(w.cuda().contiguous(), b.cuda(), p, p, C, 256)
+        y = ops.conv(nhwc(x), cv, stride=p, pad=(0, 0))
+        assert maxabs(y.reshape(1, 1024, 256).cpu(), ref) < 3e-5, s
+        w2 = rnd(f"uw{s}", (C * p * p, 256), 1 / 16.0)
+        b2 = rnd(f"ub{s}", (C * p * p,), 0.1)
+        t = rnd(f"ut{s}", (1, 1024, 256))
+        ref2 = O.unpatchify(F.linear(t, w2, b2), p, C)
+        y2 = ops.conv(t.view(1, 32, 32, 256).cuda(), ops.Conv.from_torch(w2.cuda(), b2.cuda()), d2s=(p, C))
+        assert tuple(y2.shape) == (1, s, s, C)
+        assert maxabs(nchw(y2), ref2) < 3e-5, s
+
+
+def test_gemm_nt_batched_heads(ops):
+    """attention-shaped batched NT GEMMs incl. d_head = 4 (generic path) and per-row bias."""
+    for dh, E in ((32, 256), (4, 32)):
+        B, H, N, S = 2, 8, 1024, 256
+        q = rnd(f"gq{dh}", (B, N, E)).cuda()
+        k = rnd(f"gk{dh}", (S, E)).cuda()
+        sc = torch.empty((B, H, N, S), device="cuda")
+        ops.gemm_nt(q, k, sc, M=N, N=S, K=dh, lda=E, ldb=E, ldc=S, nb0=B, nb1=H, a_bs=(N * E, dh), bt_bs=(0, dh),
+                    c_bs=(H * N * S, N * S), alpha=dh ** -0.5)
+        ref = torch.einsum("bnhd,shd->bhns", q.cpu().view(B, N, H, dh), k.cpu().view(S, H, dh)) * dh ** -0.5
+        assert maxabs(sc.cpu(), ref) < 2e-5, dh
+    a = rnd("ga", (64, 64)).cuda()
+    bt = rnd("gb", (3, 100, 64)).cuda()
+    bias = rnd("gbias", (64,)).cuda()
+    c = torch.empty((3, 64, 100), device="cuda")
+    ops.gemm_nt(a, bt, c, M=64, N=100, K=64, lda=64, ldb=64, ldc=100, nb0=3, bt_bs=(100 * 64, 0), c_bs=(64 * 100, 0),
+                bias=bias, bias_per_row=True)
+    ref = torch.einsum("mk,bnk->bmn", a.cpu(), bt.cpu()) + bias.cpu().view(1, 64, 1)
+    assert maxabs(c.cpu(), ref) < 2e-5
+
+
+def test_gemm_rejects_bad_descriptor(ops):
+    from synergize_motion_appearance_amd.lib import SmxError
+    a = torch.zeros((4, 4), device="cuda")
+    with pytest.raises(SmxError):
+        ops.gemm_nt(a, a, a, M=4, N=4, K=8, lda=4, ldb=4, ldc=4)      # ldb < K
+    with pytest.raises(SmxError):
+        ops.conv(torch.zeros(1, 4, 4, 8), ops.Conv.from_torch(torch.zeros(8, 8, 3, 3).cuda(), None))   # CPU tensor
+
+
+# ---------------------------------------------------------------------------------------
+# normalisation / softmax
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,H", [(32, 32), (64, 64), (128, 64), (256, 32), (64, 256)])
+def test_groupnorm_swish(ops, C, H):
+    x = rnd(f"gn{C}{H}", (2, C, H, H)) * 1.7 + 0.3
+    g = 1 + 0.1 * rnd(f"gg{C}", (C,))
+    b = 0.1 * rnd(f"gb{C}", (C,))
+    ref = F.group_norm(x, 32, g, b, 1e-6)
+    y = ops.groupnorm(nhwc(x), g.cuda(), b.cuda(), swish=False)
+    assert maxabs(nchw(y), ref) < 1e-5
+    y = ops.groupnorm(nhwc(x), g.cuda(), b.cuda(), swish=True)
+    assert maxabs(nchw(y), O.swish(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("E", [32, 256])
+def test_layernorm_pos(ops, E):
+    x = rnd(f"ln{E}", (2, 1024, E)) * 2 + 0.5
+    g, b, pos = 1 + 0.1 * rnd("lg", (E,)), 0.1 * rnd("lb", (E,)), 0.2 * rnd("lp", (1024, E))
+    ref = F.layer_norm(x, (E,), g, b, 1e-5)
+    y, yp = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), pos=pos.cuda())
+    assert maxabs(y.cpu(), ref) < 2e-6 and maxabs(yp.cpu(), ref + pos) < 2e-6
+
+
+@pytest.mark.parametrize("S", [256, 512, 768, 1024])
+def test_softmax_rows_masked(ops, S):
+    s = rnd(f"sm{S}", (2, 4, 64, S)) * 3
+    mask = torch.zeros((2, S), dtype=torch.bool)
+    mask[1, ::7] = True
+    ref = torch.softmax((s * 0.5).masked_fill(mask.view(2, 1, 1, S), float("-inf")), -1)
+    d = s.cuda().contiguous()
+    ops.softmax_rows(d, S, 0.5, mask.to(torch.uint8).cuda(), 4 * 64)
+    assert maxabs(d.cpu(), ref) < 2e-7
+
+
+# ---------------------------------------------------------------------------------------
+# warp / resize / pooling / anti-alias
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,s", [(256, 32), (128, 64), (128, 128), (64, 256)])
+def test_warp_four_scales(ops, C, s):
+    """A7 vs deform_input + occlude_input (both ATen and the explicit restatement). Smooth features:
+    two correct fp32 implementations differ by flow rounding x (s-1)/2 x feature gradient."""
+    B = 2
+    feat = F.interpolate(rnd(f"wf{s}", (1, C, 8, 8)), size=(s, s), mode="bicubic", align_corners=True)
+    flow = O.make_coordinate_grid(64, 64, torch.float32)[None] + 0.25 * F.interpolate(
+        rnd(f"wfl{s}", (B, 2, 6, 6)), size=(64, 64), mode="bicubic", align_corners=True).permute(0, 2, 3, 1)
+    occ = torch.sigmoid(rnd(f"wo{s}", (B, 1, 64, 64)))
+    assert float(((flow > 1) | (flow < -1)).float().mean()) > 0.005       # zero padding exercised
+    ref = O.occlude_input(O.deform_input(feat.repeat(B, 1, 1, 1), flow), occ)
+    y = ops.warp(nhwc(feat), flow.cuda(), occ.view(B, 64, 64).cuda())
+    tol = 2e-5 if s <= 64 else 1e-4
+    assert maxabs(nchw(y), ref) < tol
+    y2 = ops.warp(nhwc(feat.repeat(B, 1, 1, 1)), flow.cuda())
+    assert maxabs(nchw(y2), O.deform_input(feat.repeat(B, 1, 1, 1), flow)) < tol
+
+
+def test_resize_avgpool_antialias(ops):
+    x = rnd("rs", (2, 15, 64, 64))
+    assert maxabs(nchw(ops.resize(nhwc(x), 32, 32)), O.resize_ac(x, (32, 32))) < 1e-6
+    x = rnd("rs2", (2, 32, 32, 32))
+    assert maxabs(nchw(ops.resize(nhwc(x), 64, 64)), O.resize_ac(x, (64, 64))) < 1e-6
+    x = rnd("rs3", (1, 64, 256, 256))
+    assert maxabs(nchw(ops.resize(nhwc(x), 32, 32)), O.resize_ac(x, (32, 32))) < 1e-6
+    x = rnd("ap", (2, 64, 32, 32))
+    assert maxabs(nchw(ops.avgpool2(nhwc(x))), F.avg_pool2d(x, 2)) < 1e-6
+    Pm = weights("network_motion_estimator")
+    img = rnd("aa", (2, 3, 256, 256)).clamp(-1, 1)
+    ref = O.antialias_down(Pm, "kp_detector.down", img)
+    y = ops.antialias_down(img.cuda(), Pm["kp_detector.down.weight"].reshape(3, 13, 13).cuda())
+    assert maxabs(nchw(y), ref) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------
+# motion stages
+# ---------------------------------------------------------------------------------------
+def test_kp_head(ops):
+    B, K = 2, 15
+    logits = rnd("kl", (B, K, 58, 58))
+    jm = rnd("kj", (B, 4 * K, 58, 58))
+    heat = torch.softmax(logits.view(B, K, -1) / 0.1, 2).view(B, K, 58, 58)
+    grid = O.make_coordinate_grid(58, 58, torch.float32)
+    value = (heat.unsqueeze(-1) * grid.view(1, 1, 58, 58, 2)).sum((2, 3))
+    jac = (heat.unsqueeze(2) * jm.view(B, K, 4, 58, 58)).view(B, K, 4, -1).sum(-1).view(B, K, 2, 2)
+    v, j = ops.kp_head(nhwc(logits), nhwc(jm), K, 0.1)
+    assert maxabs(v.cpu(), value) < 2e-6 and maxabs(j.cpu(), jac) < 5e-6
+
+
+def test_sparse_motion_and_mask_deformation(ops):
+    from synergize_motion_appearance_amd.synth import synth_keypoints
+    B, K = 2, 15
+    kps, kpd = synth_keypoints(B, seed=11)
+    src = rnd("sm_src", (1, 3, 64, 64))
+    # oracle pieces (dense_motion_arch.py:65-116)
+    heat = O.kp2gaussian(kpd["value"], 64, 64) - O.kp2gaussian(kps["value"], 64, 64)
+    ident = O.make_coordinate_grid(64, 64, torch.float32).view(1, 1, 64, 64, 2)
+    cg = ident - kpd["value"].view(B, K, 1, 1, 2)
+    jac = torch.matmul(kps["jacobian"], torch.inverse(kpd["jacobian"])).unsqueeze(-3).unsqueeze(-3)
+    d2s = torch.matmul(jac, cg.unsqueeze(-1)).squeeze(-1) + kps["value"].view(B, K, 1, 1, 2)
+    sparse = torch.cat([ident.repeat(B, 1, 1, 1, 1), d2s], 1)
+    rep = src.repeat(B * (K + 1), 1, 1, 1)
+    deformed = F.grid_sample(rep, sparse.view(B * (K + 1), 64, 64, 2), align_corners=False).view(B, K + 1, 3, 64, 64)
+    hg = torch.empty((B, 64, 64, 128), device="cuda")
+    sp, dh = ops.sparse_motion(nhwc(src), kpd["value"].cuda(), kpd["jacobian"].reshape(B, K, 4).cuda(),
+                               kps["value"].cuda(), kps["jacobian"].reshape(B, K, 4).cuda(), hg[..., 64:], B, K)
+    assert maxabs(sp.cpu(), sparse) < 2e-6
+    assert maxabs(dh.cpu().permute(0, 3, 1, 2), O.kp2gaussian(kpd["value"], 64, 64)) < 1e-6
+    got = hg[..., 64:].cpu().view(B, 64, 64, 16, 4).permute(0, 3, 4, 1, 2)          # [B,16,4,H,W]
+    assert maxabs(got[:, 1:, 0], heat) < 1e-6 and float(got[:, 0, 0].abs().max()) == 0.0
+    assert maxabs(got[:, :, 1:4], deformed) < 5e-6
+    ml = rnd("ml", (B, 16, 64, 64)) * 2
+    mask = torch.softmax(ml, 1)
+    deformation = (sparse.permute(0, 1, 4, 2, 3) * mask.unsqueeze(2)).sum(1).permute(0, 2, 3, 1)
+    d, m = ops.mask_deformation(nhwc(ml), sp, want_mask=True)
+    assert maxabs(d.cpu(), deformation) < 2e-6 and maxabs(nchw(m), mask) < 1e-6
+
+
+def test_flow_stage_kernels(ops):
+    B = 2
+    flow = O.make_coordinate_grid(64, 64, torch.float32)[None] + 0.2 * rnd("ff", (B, 64, 64, 2))
+    xx = torch.linspace(-1., 1., 64)
+    gx, gy = torch.meshgrid(xx, xx, indexing="xy")
+    grid = torch.stack([gx, gy], -1)[None]
+    assert maxabs(ops.flow_to_residual(flow.cuda()).cpu(), (flow - grid) * 31.5) < 1e-5
+    r = rnd("fr", (B, 64, 64, 3))
+    occ = torch.sigmoid(rnd("fo", (B, 64, 64)))
+    m, rn, o = ops.flow_occ_update(flow.cuda(), r.cuda(), occ.cuda())
+    assert maxabs(rn.cpu(), r[..., :2] / 31.5) < 1e-7 and maxabs(m.cpu(), flow + r[..., :2] / 31.5) < 1e-6
+    assert maxabs(o.cpu(), torch.sigmoid(occ + r[..., 2])) < 1e-6
+    big = O.make_coordinate_grid(64, 64, torch.float32)[None] * 1.2 + 0.1 * rnd("fb", (B, 64, 64, 2))
+    m32 = O.resize_ac(big.permute(0, 3, 1, 2), (32, 32)).reshape(B, 2, 1024)
+    ign = ((m32 > 1) | (m32 < -1)).any(1)
+    got = ops.motion_ignore(big.cuda()).cpu().bool()
+    # flips only allowed where |coord| is within fp32 noise of the threshold 1.0
+    diff = got != ign
+    near = ((m32.abs() - 1).abs() < 1e-5).any(1)
+    assert not (diff & ~near).any() and 0.05 < ign.float().mean() < 0.9
+    d, sc, sh = rnd("s1", (2, 8, 8, 64)), rnd("s2", (2, 8, 8, 64)), rnd("s3", (2, 8, 8, 64))
+    assert maxabs(ops.sft_combine(d.cuda(), sc.cuda(), sh.cuda(), 0.7).cpu(), d + 0.7 * (d * sc + sh)) < 1e-6
+    assert maxabs(ops.add(d.cuda(), sc.cuda()).cpu(), d + sc) == 0.0
+
+
+def test_layout_and_uint8(ops):
+    x = rnd("lay", (2, 5, 33, 17))
+    assert maxabs(ops.nchw_to_nhwc(x.cuda()).cpu(), x.permute(0, 2, 3, 1)) == 0.0
+    assert maxabs(ops.nhwc_to_nchw(x.permute(0, 2, 3, 1).contiguous().cuda()).cpu(), x) == 0.0
+    t = synth_input("tensor2img", (3, 64, 64)) * 0.8
+    got = ops.to_uint8(t.permute(1, 2, 0).contiguous().cuda()).cpu().numpy()
+    assert np.array_equal(got, golden("tensor2img.npz")["img"])                  # reference tensor2img output
+    edge = torch.tensor([-2.0, -1.0, -0.996078431, 0.0, 0.00392156862, 1.0, 3.0]).cuda()
+    assert np.array_equal(ops.to_uint8(edge).cpu().numpy(), O.tensor2img(edge.cpu().view(1, 1, -1).repeat(3, 1, 1))[0, :, 0])
+
+
+# ---------------------------------------------------------------------------------------
+# A12 VQ
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,key,D,scale", [("m256", "quantize_motion", 32, 0.25), ("m1024", "quantize_motion", 32, 1.0),
+                                             ("a512", "quantize_app", 256, 0.5), ("a1024", "quantize_app", 256, None)])
+def test_vq_bit_exact_indices(ops, tag, key, D, scale):
+    """indices must equal the REFERENCE's (golden fixture) -- N(0,1) codebooks keep top-2 gaps wide."""
+    Pg = weights("network_g")
+    g = golden("vq.npz")
+    z = synth_input(f"vq_{tag}", (2, D, 32, 32))
+    cb = Pg[f"{key}.embedding.weight"]
+    Ks = cb.shape[0] if scale is None else int(scale * cb.shape[0])
+    zt = z.permute(0, 2, 3, 1).reshape(-1, D).contiguous()
+    idx, zq, dmin, sq = ops.vq_nearest(zt.cuda(), cb.cuda(), Ks)
+    assert np.array_equal(idx.cpu().numpy().reshape(-1, 1), g[f"{tag}_indices"])
+    r = O.vector_quantizer(z, cb, scale)
+    assert maxabs(zq.cpu(), r["z_q"].permute(0, 2, 3, 1).reshape(-1, D)) == 0.0   # z + (e - z), bit exact
+    assert maxabs(dmin.cpu(), r["d"].min(1).values) < 1e-3 * float(r["d"].min(1).values.abs().max())
+    loss = 1.25 * float(sq) / zt.numel()
+    assert abs(loss - float(g[f"{tag}_loss"])) < 1e-4 * abs(float(g[f"{tag}_loss"]))
+
+
+def test_vq_ties_and_ragged(ops):
+    """first-minimum rule on exact ties; N not a multiple of the 128-token block; Ks not a multiple of 32."""
+    cb = rnd("tie_cb", (100, 32))
+    cb[57] = cb[13]
+    cb[90] = cb[13]
+    z = cb[[13, 57, 90, 5, 99]].clone() + 1e-3
+    z = torch.cat([z, rnd("tie_z", (196, 32))])
+    d = (z ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * z @ cb.t()
+    idx, zq, _, _ = ops.vq_nearest(z.cuda(), cb.cuda(), 100)
+    got = idx.cpu()
+    assert got[:3].tolist() == [13, 13, 13]
+    ref = d.argmin(1)
+    bad = got != ref
+    if bad.any():   # tie-aware: a differing index must be distance-equivalent within fp32 noise
+        assert float((d[bad, got[bad]] - d[bad, ref[bad]]).abs().max()) < 1e-4
