@@ -48,10 +48,10 @@ def build_nets(device):
     return net_g.to(device).eval(), me.to(device).eval(), Pg, Pm
 
 
-def cpu_baseline(Pg, Pm, src, drv, budget_s=12.0, max_frames=12):
+def cpu_baseline(Pg, Pm, src, drv, budget_s=12.0, max_frames=12, threads=None):
     """oracle port of demo.make_animation (B=1, sequential, source re-encoded per frame)."""
     from oracle import reenact_oracle as O
-    cores = os.cpu_count() or 1
+    cores = threads or min(os.cpu_count() or 1, 32)      # torch CPU convs stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     with torch.no_grad():
         s = src.unsqueeze(0)
@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=10, help="driving frames per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,6 +214,20 @@ def main():
                                                     "algorithmic_GBps": round(m["bytes"] / (ms * 1e-3) / 1e9, 1),
                                                     "TFLOPs": round(m["flops"] / (ms * 1e-3) / 1e12, 2)}
         result["kernels"] = kern
+        if args.dump_shapes:
+            tab = {}
+            for n, m, ms in rec.rows:
+                if n != "gemm_conv":
+                    continue
+                key = (m["M"], m["N"], m["K"], m["nb"], m["k"])
+                t = tab.setdefault(key, [0, 0.0, m["flops"]])
+                t[0] += 1
+                t[1] += ms
+            rows = sorted(((k, v) for k, v in tab.items()), key=lambda kv: -kv[1][1])
+            with open(args.dump_shapes, "w") as f:
+                f.write("M N K nb ksize calls/step ms/step TFLOPs\n")
+                for (M_, N_, K_, nb_, ks_), (c, ms, fl) in rows:
+                    f.write(f"{M_} {N_} {K_} {nb_} {ks_} {c / nprof:.1f} {ms / nprof:.3f} {fl * c / (ms * 1e-3) / 1e12:.1f}\n")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(Pg, Pm, src_cpu, drv_cpu)
