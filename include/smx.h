@@ -73,6 +73,8 @@ typedef struct smx_gemm_desc {
   int32_t bias_per_row;
   int32_t d2s_p, d2s_c;                         /* 0 = plain store */
   int32_t tile;                                 /* 0 = auto; else force a tile config id (tests/tuning) */
+  int32_t ksplit;                               /* >1: split K over blockIdx.z (needs ws, nb0=nb1=1, no d2s) */
+  float* ws;                                    /* split-K workspace: ksplit*M*N floats */
 } smx_gemm_desc;
 
 int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream);
@@ -91,6 +93,15 @@ int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float* gamma, co
  * y_pos != NULL.  TransformerLayer.norm1/2/3 + with_pos_embed (appmotioncodebook_arch.py:97-119). */
 int smx_layernorm_pos_f32(const float* x, const float* gamma, const float* beta, const float* pos,
                           float* y, float* y_pos, int T, int E, int npos, float eps, void* stream);
+
+/* Fused multi-head attention o = softmax(scale * q k^T [+ key mask]) v, online softmax, no score
+ * tensor in HBM.  nn.MultiheadAttention core as used by TransformerLayer
+ * (archs/appmotioncodebook_arch.py:101-115).  q rows [L] at stride ldq, head h at column h*dh;
+ * k, v rows [S] likewise; *_bs = batch stride in elements (0 = shared codebook K/V);
+ * key_mask uint8 [B][S] (1 = masked) or NULL.  dh = 32/64: fp32 MFMA; dh = 4: VALU. */
+int smx_attention_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
+                      const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs,
+                      const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream);
 
 /* Row softmax in place over [R][S] (ld = row stride): softmax(scale * s + mask) with an
  * optional key-padding mask uint8 [R / rows_per_mask][S] (1 = -inf).  F.softmax at

@@ -1,0 +1,224 @@
+// Fused multi-head attention for the codebook transformers (nn.MultiheadAttention as used by
+// TransformerLayer, archs/appmotioncodebook_arch.py:69-70,101-115) -- gfx950, fp32 exact.
+//
+// Round-1a materialised the [B,H,1024,S] score tensors (QK^T GEMM -> softmax pass -> PV GEMM):
+// 33.5 MB per (frame, layer) written and read twice, and K = d_head = 4 / 32 GEMMs that are one
+// short K-slice.  Here softmax(q k^T) v is one kernel per layer call, online-softmax, nothing
+// but q, k, v, o and the key-padding mask touches HBM.
+//
+// d_head = 32 (appearance, E=256): fp32 MFMA, "swapped" products so that every softmax
+// statistic is lane-local:
+//     S^T = K Q^T   (A = K tile from LDS,  B = Q^T fragments held in registers)
+//     O^T = V^T P^T (A = V tile from LDS,  B = P^T = exp(S^T - m), straight from the S^T registers)
+//   In the 32x32x2 C layout lane l owns query (l&31) and 16 of the 32 keys of a tile (the other 16
+//   sit in lane l^32), so the row max / sum are 15 in-register ops + ONE wavefront shuffle, the
+//   O rescale is a lane-local scalar, and P feeds the second MFMA with no transpose or LDS trip
+//   (the k-pairing of the MFMA is free: A and B fragments just have to agree).
+// d_head = 4 (motion, E=32): matrix cores would be 8x padded -> VALU kernel, one query per
+//   lane, keys/values broadcast from LDS, 8 keys per online-softmax step.
+// Fully masked rows give NaN exactly like the reference (0/0).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "smx.h"
+#include "smx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct AP {
+  const float* q; const float* k; const float* v; float* o; const uint8_t* mask;
+  long long q_bs, k_bs, v_bs, o_bs;
+  int ldq, ldk, ldv, ldo;
+  int H, L, S; float scale;
+};
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
+  constexpr int TK = 32, KLD = DH + 4, KS = DH / 8, DT = DH / 32;
+  __shared__ __attribute__((aligned(16))) float Ks[2][TK * KLD];
+  __shared__ __attribute__((aligned(16))) float Vs[2][TK * DH];
+  __shared__ uint8_t Ms[2][TK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int hh = lane >> 5;
+  const float* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq + h * DH;
+  const float* K = p.k + b * p.k_bs + h * DH;
+  const float* V = p.v + b * p.v_bs + h * DH;
+  const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
+
+  float4 qf[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    float4 t = *reinterpret_cast<const float4*>(Q + kk * 8 + hh * 4);
+    qf[kk] = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+  }
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  // staging: TK x DH floats per operand = TK*DH/4 float4, 256 threads
+  constexpr int NF4 = TK * DH / 4, PER = (NF4 + 255) / 256;
+  float4 kreg[PER], vreg[PER]; uint8_t mreg = 0;
+  auto load_tile = [&](int key0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      if (f < NF4) {
+        const int r = f / (DH / 4), c4 = f % (DH / 4);
+        kreg[i] = *reinterpret_cast<const float4*>(K + (long long)(key0 + r) * p.ldk + c4 * 4);
+        vreg[i] = *reinterpret_cast<const float4*>(V + (long long)(key0 + r) * p.ldv + c4 * 4);
+      }
+    }
+    if (M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      if (f < NF4) {
+        const int r = f / (DH / 4), c4 = f % (DH / 4);
+        *reinterpret_cast<float4*>(&Ks[buf][r * KLD + c4 * 4]) = kreg[i];
+        *reinterpret_cast<float4*>(&Vs[buf][r * DH + c4 * 4]) = vreg[i];
+      }
+    }
+    if (threadIdx.x < TK) Ms[buf][threadIdx.x] = M ? mreg : 0;
+  };
+
+  const int ntiles = p.S / TK;
+  load_tile(0); store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile((t + 1) * TK);
+    // S^T = K Q^T
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* kp = &Ks[buf][(lane & 31) * KLD + hh * 4];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const float4 kf = *reinterpret_cast<const float4*>(kp + kk * 8);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk].w, s, 0, 0, 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (Ms[buf][key]) s[r] = -INFINITY;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const bool dead = (m_new == -INFINITY);                 // every key so far masked
+    const float alpha = dead ? 1.f : expf(m - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = dead ? 0.f : expf(s[r] - m_new); psum += s[r]; }
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum; m = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    // O^T += V^T P^T
+    const float* vp = &Vs[buf][(lane & 31)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[key * DH + d * 32], s[r], oacc[d], 0, 0, 0);
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  float* O = p.o + b * p.o_bs + (long long)qrow * p.ldo + h * DH;
+  const float inv = 1.f / l;                                  // l == 0 (fully masked row) -> inf * 0 = NaN like the reference
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w = make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+      if (l == 0.f) w = make_float4(NAN, NAN, NAN, NAN);
+      *reinterpret_cast<float4*>(O + d * 32 + 8 * g + 4 * hh) = w;
+    }
+}
+
+// d_head = 4: one query per lane; K/V chunk of 256 keys broadcast from LDS
+__global__ __launch_bounds__(256) void attn_valu4_kernel(AP p) {
+  __shared__ float4 Ks[256];
+  __shared__ float4 Vs[256];
+  __shared__ uint8_t Ms[256];
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int qrow = blockIdx.x * 256 + threadIdx.x;
+  float4 q = *reinterpret_cast<const float4*>(p.q + b * p.q_bs + (long long)qrow * p.ldq + h * 4);
+  q = make_float4(q.x * p.scale, q.y * p.scale, q.z * p.scale, q.w * p.scale);
+  const float* K = p.k + b * p.k_bs + h * 4;
+  const float* V = p.v + b * p.v_bs + h * 4;
+  const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
+  float m = -INFINITY, l = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int key0 = 0; key0 < p.S; key0 += 256) {
+    __syncthreads();
+    Ks[threadIdx.x] = *reinterpret_cast<const float4*>(K + (long long)(key0 + threadIdx.x) * p.ldk);
+    Vs[threadIdx.x] = *reinterpret_cast<const float4*>(V + (long long)(key0 + threadIdx.x) * p.ldv);
+    Ms[threadIdx.x] = M ? M[key0 + threadIdx.x] : 0;
+    __syncthreads();
+    for (int g = 0; g < 256; g += 8) {
+      float s[8]; float tmax = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 kk = Ks[g + i];
+        float t = q.x * kk.x + q.y * kk.y + q.z * kk.z + q.w * kk.w;
+        if (Ms[g + i]) t = -INFINITY;
+        s[i] = t; tmax = fmaxf(tmax, t);
+      }
+      const float m_new = fmaxf(m, tmax);
+      if (m_new == -INFINITY) continue;
+      const float alpha = expf(m - m_new);
+      float4 a2 = make_float4(acc.x * alpha, acc.y * alpha, acc.z * alpha, acc.w * alpha);
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float pe = expf(s[i] - m_new);
+        const float4 vv = Vs[g + i];
+        ps += pe; a2.x += pe * vv.x; a2.y += pe * vv.y; a2.z += pe * vv.z; a2.w += pe * vv.w;
+      }
+      acc = a2; l = l * alpha + ps; m = m_new;
+    }
+  }
+  float4 o = make_float4(acc.x / l, acc.y / l, acc.z / l, acc.w / l);   // l == 0 -> NaN like the reference
+  *reinterpret_cast<float4*>(p.o + b * p.o_bs + (long long)qrow * p.ldo + h * 4) = o;
+}
+
+}  // namespace
+
+extern "C" int smx_attention_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
+                                 const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs,
+                                 const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream) {
+  if (!q || !k || !v || !o || B <= 0 || H <= 0 || L <= 0 || S <= 0 || (long long)B * H > 65535) return SMX_EINVAL;
+  if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || q_bs % 4 || k_bs % 4 || v_bs % 4 || o_bs % 4) return SMX_EINVAL;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SMX_EINVAL;
+  AP p{q, k, v, o, key_mask, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo, H, L, S, scale};
+  hipStream_t st = (hipStream_t)stream;
+  if (dh == 4) {
+    if (L % 256 || S % 256) return SMX_EINVAL;
+    hipLaunchKernelGGL(attn_valu4_kernel, dim3(L / 256, B * H), dim3(256), 0, st, p);
+  } else if (dh == 32 || dh == 64) {
+    if (L % 128 || S % 32) return SMX_EINVAL;
+    if (dh == 32) hipLaunchKernelGGL(attn_mfma_kernel<32>, dim3(L / 128, B * H), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_mfma_kernel<64>, dim3(L / 128, B * H), dim3(256), 0, st, p);
+  } else {
+    return SMX_EINVAL;
+  }
+  return smx_launch_status();
+}

@@ -33,6 +33,7 @@ struct GP {
   int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
   int act; float alpha; int bias_per_row; int d2s_p, d2s_c;
   int tiles_n; int is1x1;
+  int ksplit; float* ws;            // split-K: blockIdx.z owns a K range, raw partials -> ws[z][M][N]
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -89,7 +90,17 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
   const int Hlim = p.up2 ? 2 * p.Hin : p.Hin, Wlim = p.up2 ? 2 * p.Win : p.Win;
 
   float4 areg[RA], breg[RB];
+  const int nslices_all = (p.K + BK - 1) / BK;
+  int s_begin = 0, s_end = nslices_all;
+  if (p.ksplit > 1) {
+    const int per = (nslices_all + p.ksplit - 1) / p.ksplit;
+    s_begin = blockIdx.z * per; s_end = min(nslices_all, s_begin + per);
+  }
   int tap_c0 = 0, tap_ky = 0, tap_kx = 0;             // VEC path: running (ky,kx,c0) of the slice
+  if (VEC && s_begin > 0) {
+    const int k0 = s_begin * BK, tap = k0 / p.Cin;
+    tap_c0 = k0 - tap * p.Cin; tap_ky = tap / p.kw; tap_kx = tap - tap_ky * p.kw;
+  }
 
   auto load_slice = [&](int k0) {
     if (VEC) {
@@ -166,14 +177,13 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nslices = (p.K + BK - 1) / BK;
-  load_slice(0);
-  store_slice(0);
+  const int nslices = s_end - s_begin;
+  if (nslices > 0) { load_slice(s_begin * BK); store_slice(0); }
   __syncthreads();
   const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
   for (int s = 0; s < nslices; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nslices) load_slice((s + 1) * BK);
+    if (s + 1 < nslices) load_slice((s_begin + s + 1) * BK);
     const float* as = As + buf * BM * LDS_LD + (wm * WTM) * LDS_LD + frag_off;
     const float* bs = Bs + buf * BN * LDS_LD + (wn * WTN) * LDS_LD + frag_off;
 #pragma unroll
@@ -198,6 +208,22 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------
+  if (p.ksplit > 1) {                                  // raw partial sums; the reduce kernel finishes
+    float* __restrict__ Wp = p.ws + (long long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = tile_n * BN + wn * WTN + j * 32 + (lane & 31);
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = tile_m * BM + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < p.M) Wp[(long long)m * p.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   float* __restrict__ C = p.c + g0 * p.c_bs0 + g1 * p.c_bs1;
   const float* __restrict__ R = p.res ? p.res + g0 * p.res_bs0 + g1 * p.res_bs1 : nullptr;
 #pragma unroll
@@ -231,11 +257,25 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
   }
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GP p) {
+  const long long total = (long long)p.M * p.N;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
+    float acc = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) acc += p.ws[(long long)z * total + i];
+    float v = p.alpha * acc;
+    if (p.bias) v += p.bias[p.bias_per_row ? m : n];
+    v = apply_act(v, p.act);
+    if (p.res) v += p.res[(long long)m * p.ldres + n];
+    p.c[(long long)m * p.ldc + n] = v;
+  }
+}
+
 template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(const GP& p, int nb, bool vec, hipStream_t st) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   GP q = p; q.tiles_n = tiles_n;
-  dim3 grid(tiles_m * tiles_n, nb), block(256);
+  dim3 grid(tiles_m * tiles_n, nb, p.ksplit > 1 ? p.ksplit : 1), block(256);
   size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   if (vec) {
     auto k = gemm_conv_kernel<BM, BN, WGM, WGN, true>;
@@ -245,6 +285,10 @@ int launch_cfg(const GP& p, int nb, bool vec, hipStream_t st) {
     auto k = gemm_conv_kernel<BM, BN, WGM, WGN, false>;
     if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, block, lds, st, q);
+  }
+  if (p.ksplit > 1) {
+    int blocks = (int)(((long long)p.M * p.N + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, q);
   }
   return smx_launch_status();
 }
@@ -270,6 +314,8 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up2 = d->up2;
   p.act = d->act; p.alpha = d->alpha; p.bias_per_row = d->bias_per_row; p.d2s_p = d->d2s_p; p.d2s_c = d->d2s_c;
   p.tiles_n = 1;
+  p.ksplit = d->ksplit > 1 ? d->ksplit : 1; p.ws = d->ws;
+  if (p.ksplit > 1 && (!d->ws || nb != 1 || d->d2s_p || p.ksplit > (d->K + BK - 1) / BK)) return SMX_EINVAL;
   p.is1x1 = (d->kh == 1 && d->kw == 1 && d->stride == 1 && !d->up2 && d->pad_t == 0 && d->pad_l == 0 &&
              d->Hin == d->Ho && d->Win == d->Wo) ? 1 : 0;
   const bool vec = (d->Cin % BK == 0) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) &&

@@ -82,19 +82,16 @@ class _Transformer:
         self.E, self.H, self.dh = E, nhead, E // nhead
         W, b = P[pre + ".self_attn.in_proj_weight"], P[pre + ".self_attn.in_proj_bias"]
         self.s_qk = Conv(W[:2 * E].contiguous(), b[:2 * E].contiguous(), 1, 1, E, 2 * E)
-        self.s_wv, self.s_bv = W[2 * E:].contiguous(), b[2 * E:].contiguous()
+        self.s_v = Conv(W[2 * E:].contiguous(), b[2 * E:].contiguous(), 1, 1, E, E)
         self.s_out = Conv.from_torch(P[pre + ".self_attn.out_proj.weight"], P[pre + ".self_attn.out_proj.bias"])
         W, b = P[pre + ".cross_attn.in_proj_weight"], P[pre + ".cross_attn.in_proj_bias"]
         self.c_q = Conv(W[:E].contiguous(), b[:E].contiguous(), 1, 1, E, E)
         self.c_out = Conv.from_torch(P[pre + ".cross_attn.out_proj.weight"], P[pre + ".cross_attn.out_proj.bias"])
         Kc = codebook.shape[0]
         self.Kc = Kc
-        # Kc = cb Wk^T + bk  [Kc,E];  VcT = Wv cb^T + bv  [E,Kc]   (input independent)
-        self.ck = torch.empty((Kc, E), device=codebook.device, dtype=torch.float32)
-        ops.gemm_nt(codebook, W[E:2 * E].contiguous(), self.ck, M=Kc, N=E, K=E, lda=E, ldb=E, ldc=E, bias=b[E:2 * E].contiguous())
-        self.cvt = torch.empty((E, Kc), device=codebook.device, dtype=torch.float32)
-        ops.gemm_nt(W[2 * E:].contiguous(), codebook, self.cvt, M=E, N=Kc, K=E, lda=E, ldb=E, ldc=Kc,
-                    bias=b[2 * E:].contiguous(), bias_per_row=True)
+        # [Kc | Vc] = cb [Wk;Wv]^T + [bk;bv]  -> [Kc, 2E]   (input independent, all codebook rows)
+        self.ckv = torch.empty((Kc, 2 * E), device=codebook.device, dtype=torch.float32)
+        ops.gemm_nt(codebook, W[E:].contiguous(), self.ckv, M=Kc, N=2 * E, K=E, lda=E, ldb=E, ldc=2 * E, bias=b[E:].contiguous())
         self.n1 = (P[pre + ".norm1.weight"], P[pre + ".norm1.bias"])
         self.n2 = (P[pre + ".norm2.weight"], P[pre + ".norm2.bias"])
         self.n3 = (P[pre + ".norm3.weight"], P[pre + ".norm3.bias"])
@@ -107,17 +104,14 @@ class _Transformer:
         E, H, dh, N = self.E, self.H, self.dh, 1024
         # self attention: q = k = LN(x)+pos, v = LN(x)
         t2, qk_in = ops.layernorm(tgt, *self.n1, pos=pos)
-        qk = ops.conv(qk_in, self.s_qk)                                       # [B,32,32,2E]
-        vt = torch.empty((B, E, N), device=tgt.device, dtype=torch.float32)
-        ops.gemm_nt(self.s_wv, t2, vt, M=E, N=N, K=E, lda=E, ldb=E, ldc=N, nb0=B, bt_bs=(N * E, 0), c_bs=(E * N, 0),
-                    bias=self.s_bv, bias_per_row=True)
-        o = ops.attention(qk, 2 * E, qk, 2 * E, vt, N, N, H, dh, scale_in_gemm=True, k_bs0=N * 2 * E, vt_bs0=E * N,
-                          mask=mask, k_off=E)
+        qk = ops.conv(qk_in, self.s_qk)                                       # [B,32,32,2E] = [q | k]
+        v = ops.conv(t2, self.s_v)                                            # [B,32,32,E]
+        o = ops.attention(qk[..., :E], qk[..., E:], v, H, dh, N, mask=mask)
         tgt = ops.conv(o.view(B, 32, 32, E), self.s_out, res=tgt)
         # cross attention against the codebook prefix
         t2, q_in = ops.layernorm(tgt, *self.n2, pos=pos)
         q = ops.conv(q_in, self.c_q)
-        o = ops.attention(q, E, self.ck, E, self.cvt, self.Kc, S, H, dh, scale_in_gemm=True, k_bs0=0, vt_bs0=0)
+        o = ops.attention(q, self.ckv[:, :E], self.ckv[:, E:], H, dh, S, k_shared=True)
         tgt = ops.conv(o.view(B, 32, 32, E), self.c_out, res=tgt)
         # conv FFN
         t2, _ = ops.layernorm(tgt, *self.n3)

@@ -31,6 +31,8 @@ class GemmDesc(C.Structure):
         ("bias_per_row", C.c_int32),
         ("d2s_p", C.c_int32), ("d2s_c", C.c_int32),
         ("tile", C.c_int32),
+        ("ksplit", C.c_int32),
+        ("ws", _p),
     ]
 
 
@@ -41,6 +43,7 @@ SIGNATURES = {
     "smx_groupnorm_ws_floats": (_i64, [_i, _i, _i]),
     "smx_groupnorm_swish_nhwc_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
     "smx_layernorm_pos_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "smx_attention_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _f, _p]),
     "smx_softmax_rows_f32": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
     "smx_warp_nhwc_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "smx_resize_bilinear_ac_nhwc_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -133,11 +133,22 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     a_ptr, lda = _pix(x, "conv input")
     c_ptr, ldc = _pix(out, "conv output")
     r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
+    M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
+    ksplit, ws = 1, None
+    if not d2s and K >= 1024:
+        # weight-streaming layers (deep hourglass): few output tiles, long K -> split K over blocks
+        bm = 64 if ((M + 127) // 128) * ((cv.cout + 127) // 128) < 512 else 128
+        blocks = ((M + bm - 1) // bm) * ((cv.cout + 127) // 128 if cv.cout > 64 else 1)
+        if blocks < 128:
+            ksplit = max(1, min(K // 32 // 8, (384 + blocks - 1) // blocks, 32))
+            if ksplit > 1:
+                ws = torch.empty((ksplit, M, cv.cout), device=x.device, dtype=torch.float32)
     gemm_raw(a=a_ptr, bt=_dev(cv.w).data_ptr(), c=c_ptr, bias=None if cv.b is None else cv.b.data_ptr(),
              res=r_ptr, nb0=1, nb1=1, M=B * Ho * Wo, N=cv.cout, K=cv.kh * cv.kw * Cin,
              lda=lda, ldb=cv.w.shape[1], ldc=ldc, ldres=ldr, Hin=H, Win=W, Cin=Cin, Ho=Ho, Wo=Wo,
              kh=cv.kh, kw=cv.kw, stride=stride, pad_t=pt, pad_l=pl, up2=int(up2), act=act, alpha=1.0,
-             d2s_p=d2s[0] if d2s else 0, d2s_c=d2s[1] if d2s else 0, tile=tile)
+             d2s_p=d2s[0] if d2s else 0, d2s_c=d2s[1] if d2s else 0, tile=tile, ksplit=ksplit,
+             ws=None if ws is None else ws.data_ptr())
     return out
 
 
@@ -357,18 +368,20 @@ def vq_nearest(z_tokens, codebook, Ks, want_zq=True):
     return idx, zq, dmin, sq
 
 
-def attention(q, q_ld, k, k_ld, vt, vt_ld, S, nhead, dh, *, scale_in_gemm, k_bs0, vt_bs0, mask=None, q_off=0, k_off=0):
-    """softmax(q k^T) v for tokens [B,1024,*]: q rows at stride q_ld (head h at +h*dh), k rows
-    [S] at stride k_ld, vt = V^T rows [nhead*dh][S] at stride vt_ld.  *_bs0: batch strides
-    (0 = shared codebook K/V).  Scores are materialised [B,H,1024,S] (round 1)."""
-    B, Lq = q.shape[0], 1024
-    scores = torch.empty((B, nhead, Lq, S), device=q.device, dtype=torch.float32)
-    alpha = dh ** -0.5 if scale_in_gemm else 1.0
-    gemm_nt(q, k, scores, M=Lq, N=S, K=dh, lda=q_ld, ldb=k_ld, ldc=S, nb0=B, nb1=nhead,
-            a_bs=(Lq * q_ld, dh), bt_bs=(k_bs0, dh), c_bs=(nhead * Lq * S, Lq * S), alpha=alpha, a_off=q_off, bt_off=k_off)
-    softmax_rows(scores, S, 1.0 if scale_in_gemm else dh ** -0.5, mask, nhead * Lq)
+def attention(q, k, v, nhead, dh, S, *, k_shared=False, mask=None, k_off=0, scale=None):
+    """o = softmax(scale q k^T [+mask]) v per head.  q [B,1024,ldq] (view ok), k/v rows [S] of
+    width ld (head h at column h*dh); k_shared: codebook K/V common to the batch (batch stride 0)."""
+    B = q.shape[0]
+    Lq = q.numel() // B // q.shape[-1]
+    qp, ldq = _pix(q, "attention q")
+    kp, ldk = _pix(k, "attention k")
+    vp, ldv = _pix(v, "attention v")
     E = nhead * dh
     o = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
-    gemm_nt(scores, vt, o, M=Lq, N=dh, K=S, lda=S, ldb=vt_ld, ldc=E, nb0=B, nb1=nhead,
-            a_bs=(nhead * Lq * S, Lq * S), bt_bs=(vt_bs0, dh * vt_ld), c_bs=(Lq * E, dh))
+    kbs = 0 if k_shared else (k.numel() // B // k.shape[-1]) * ldk
+    vbs = 0 if k_shared else (v.numel() // B // v.shape[-1]) * ldv
+    meta = {"flops": 4.0 * B * nhead * Lq * S * dh, "bytes": 4.0 * (2 * B * Lq * E + 2 * (1 if k_shared else B) * S * E)}
+    L.check(_timed(f"attention_d{dh}", meta, L.load().smx_attention_f32, qp, ldq, Lq * ldq, kp + 4 * k_off, ldk, kbs, vp, ldv, vbs,
+                   o.data_ptr(), E, Lq * E, None if mask is None else mask.data_ptr(), B, nhead, Lq, S, dh,
+                   dh ** -0.5 if scale is None else scale, _stream()), "attention")
     return o

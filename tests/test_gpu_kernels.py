@@ -147,6 +147,51 @@ def test_gemm_nt_batched_heads(ops):
     assert maxabs(c.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("dh,E,S,shared,masked", [(32, 256, 1024, False, True), (32, 256, 256, True, False), (32, 256, 768, True, False),
+                                                   (4, 32, 1024, False, False), (4, 32, 512, True, False), (4, 32, 1024, False, True)])
+def test_fused_attention(ops, dh, E, S, shared, masked):
+    """smx_attention_f32 vs the explicit nn.MultiheadAttention core of the oracle (softmax(q k^T) v per head)."""
+    B, H, N = 2, 8, 1024
+    q = rnd(f"aq{dh}{S}", (B, N, E))
+    kv = rnd(f"akv{dh}{S}", ((1 if shared else B), 1024, 2 * E))
+    mask = None
+    if masked:
+        mask = torch.zeros((B, S), dtype=torch.bool)
+        mask[0, 5::9] = True
+        mask[1, :40] = True
+    k, v = kv[..., :E][:, :S], kv[..., E:][:, :S]
+    qh = (q * dh ** -0.5).view(B, N, H, dh).transpose(1, 2)
+    kh = k.expand(B, -1, -1).reshape(B, S, H, dh).transpose(1, 2)
+    vh = v.expand(B, -1, -1).reshape(B, S, H, dh).transpose(1, 2)
+    sc = qh @ kh.transpose(-1, -2)
+    if mask is not None:
+        sc = sc.masked_fill(mask.view(B, 1, 1, S), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, N, E)
+    kvd = kv.cuda()
+    kd, vd = (kvd[0, :, :E], kvd[0, :, E:]) if shared else (kvd[..., :E], kvd[..., E:])
+    o = ops.attention(q.cuda(), kd, vd, H, dh, S, k_shared=shared, mask=None if mask is None else mask.to(torch.uint8).cuda())
+    assert maxabs(o.cpu(), ref) < 5e-6
+
+
+def test_fused_attention_fully_masked_row_is_nan_like_reference(ops):
+    B, H, N, E, dh = 1, 8, 1024, 256, 32
+    q, kv = rnd("nq", (B, N, E)).cuda(), rnd("nkv", (B, N, 2 * E)).cuda()
+    o = ops.attention(q, kv[..., :E], kv[..., E:], H, dh, N, mask=torch.ones((B, N), dtype=torch.uint8, device="cuda"))
+    assert bool(torch.isnan(o).all())
+
+
+def test_conv_split_k(ops):
+    """deep hourglass layer shapes take the split-K path (few tiles, K = 9*1024)."""
+    for (B, Cin, Cout, H, up2) in ((2, 1024, 1024, 4, False), (3, 2048, 512, 4, True), (10, 512, 1024, 4, False)):
+        x = rnd(f"skx{Cin}{up2}", (B, Cin, H, H))
+        w = rnd(f"skw{Cin}{up2}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+        b = rnd(f"skb{Cin}", (Cout,), 0.1)
+        xe = F.interpolate(x, scale_factor=2.0, mode="nearest") if up2 else x
+        ref = F.relu(F.conv2d(xe, w, b, padding=1))
+        y = ops.conv(nhwc(x), ops.Conv.from_torch(w.cuda(), b.cuda()), up2=up2, act=1)
+        assert maxabs(nchw(y), ref) < 3e-5
+
+
 def test_gemm_rejects_bad_descriptor(ops):
     from synergize_motion_appearance_amd.lib import SmxError
     a = torch.zeros((4, 4), device="cuda")
