@@ -48,11 +48,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <int BM, int BN, int WGM, int WGN, bool VEC>
-__global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
+  constexpr int NT = 64 * WGM * WGN, RPP = NT / 8;   // threads; staging rows per pass (8 float4 per 32-k row)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int RA = BM / 32, RB = BN / 32;          // rows per thread in the staging pass
-  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int RA = (BM + RPP - 1) / RPP, RB = (BN + RPP - 1) / RPP;   // rows per thread in the staging pass
+  constexpr bool GA = (BM % RPP) != 0, GB = (BN % RPP) != 0;            // tile has fewer rows than one pass
+  static_assert(TM >= 1 && TN >= 1, "tile / wave grid mismatch");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                   // [2][BM][LDS_LD]
   float* Bs = smem + 2 * BM * LDS_LD;                 // [2][BN][LDS_LD]
@@ -71,8 +73,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    int m = tile_m * BM + r0 + 32 * i;
-    a_ok[i] = m < p.M;
+    int m = tile_m * BM + r0 + RPP * i;
+    a_ok[i] = m < p.M && (!GA || r0 + RPP * i < BM);
     if (p.is1x1) {
       a_base[i] = (long long)m * p.lda; a_iy0[i] = 0; a_ix0[i] = 0;
     } else {
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
   long long b_base[RB]; bool b_ok[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    int n = tile_n * BN + r0 + 32 * i;
-    b_ok[i] = n < p.N; b_base[i] = (long long)n * p.ldb;
+    int n = tile_n * BN + r0 + RPP * i;
+    b_ok[i] = n < p.N && (!GB || r0 + RPP * i < BN); b_base[i] = (long long)n * p.ldb;
   }
   const int Hlim = p.up2 ? 2 * p.Hin : p.Hin, Wlim = p.up2 ? 2 * p.Win : p.Win;
 
@@ -164,9 +166,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GP p) {
   auto store_slice = [&](int buf) {
     float* as = As + buf * BM * LDS_LD; float* bs = Bs + buf * BN * LDS_LD;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<float4*>(as + (r0 + 32 * i) * LDS_LD + c4 * 4) = areg[i];
+    for (int i = 0; i < RA; ++i) if (!GA || r0 + RPP * i < BM) *reinterpret_cast<float4*>(as + (r0 + RPP * i) * LDS_LD + c4 * 4) = areg[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<float4*>(bs + (r0 + 32 * i) * LDS_LD + c4 * 4) = breg[i];
+    for (int i = 0; i < RB; ++i) if (!GB || r0 + RPP * i < BN) *reinterpret_cast<float4*>(bs + (r0 + RPP * i) * LDS_LD + c4 * 4) = breg[i];
   };
 
   f32x16 acc[TM][TN];
@@ -275,7 +277,7 @@ template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(const GP& p, int nb, bool vec, hipStream_t st) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   GP q = p; q.tiles_n = tiles_n;
-  dim3 grid(tiles_m * tiles_n, nb, p.ksplit > 1 ? p.ksplit : 1), block(256);
+  dim3 grid(tiles_m * tiles_n, nb, p.ksplit > 1 ? p.ksplit : 1), block(64 * WGM * WGN);
   size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   if (vec) {
     auto k = gemm_conv_kernel<BM, BN, WGM, WGN, true>;
@@ -324,11 +326,11 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int tile = d->tile;
   if (tile == 0) {
-    const long long t128 = ((d->M + 127) / 128) * nb;
-    const bool small_m = t128 * ((d->N + 127) / 128) < 512;   // fewer than 2 blocks per CU at BM=128
+    // measured on MI355X (profiles/r01_b_gemm_tile_tuning.txt): 16 resident waves per CU win --
+    // 64x64 tiles (4 waves, 4 blocks/CU) almost everywhere, 128x128 with 8 waves for big-M, N%128==0
     if (d->N <= 32) tile = 3;
-    else if (d->N <= 64) tile = small_m ? 5 : 2;
-    else tile = small_m ? 4 : 1;
+    else if (d->N % 128 == 0 && (long long)d->M * nb >= 131072) tile = 8;
+    else tile = 5;
   }
   switch (tile) {
     case 1: return launch_cfg<128, 128, 2, 2>(p, (int)nb, vec, st);
@@ -336,6 +338,16 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
     case 3: return launch_cfg<128, 32, 4, 1>(p, (int)nb, vec, st);
     case 4: return launch_cfg<64, 128, 1, 4>(p, (int)nb, vec, st);
     case 5: return launch_cfg<64, 64, 2, 2>(p, (int)nb, vec, st);
+    case 6: return launch_cfg<256, 128, 4, 2>(p, (int)nb, vec, st);   // 8 waves, 64x64 per wave
+    case 7: return launch_cfg<256, 64, 4, 2>(p, (int)nb, vec, st);    // 8 waves, 64x32 per wave
+    case 8: return launch_cfg<128, 128, 4, 2>(p, (int)nb, vec, st);   // 8 waves, 32x64 per wave
+    case 9: return launch_cfg<128, 128, 4, 4>(p, (int)nb, vec, st);   // 16 waves, 32x32 per wave
+    case 10: return launch_cfg<128, 64, 4, 2>(p, (int)nb, vec, st);   // 8 waves, 32x32 per wave
+    case 11: return launch_cfg<64, 128, 2, 4>(p, (int)nb, vec, st);   // 8 waves, 32x32 per wave
+    case 12: return launch_cfg<256, 128, 8, 2>(p, (int)nb, vec, st);  // 16 waves, 32x64 per wave
+    case 13: return launch_cfg<256, 64, 8, 2>(p, (int)nb, vec, st);   // 16 waves, 32x32 per wave
+    case 14: return launch_cfg<128, 32, 4, 1>(p, (int)nb, vec, st);
+    case 15: return launch_cfg<64, 32, 2, 1>(p, (int)nb, vec, st);    // 2 waves
     default: return SMX_EINVAL;
   }
 }

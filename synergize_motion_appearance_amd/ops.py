@@ -137,10 +137,9 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     ksplit, ws = 1, None
     if not d2s and K >= 1024:
         # weight-streaming layers (deep hourglass): few output tiles, long K -> split K over blocks
-        bm = 64 if ((M + 127) // 128) * ((cv.cout + 127) // 128) < 512 else 128
-        blocks = ((M + bm - 1) // bm) * ((cv.cout + 127) // 128 if cv.cout > 64 else 1)
-        if blocks < 128:
-            ksplit = max(1, min(K // 32 // 8, (384 + blocks - 1) // blocks, 32))
+        blocks = ((M + 63) // 64) * ((cv.cout + 63) // 64)
+        if blocks < 256:
+            ksplit = max(1, min(K // 32 // 8, (1024 + blocks - 1) // blocks, 32))
             if ksplit > 1:
                 ws = torch.empty((ksplit, M, cv.cout), device=x.device, dtype=torch.float32)
     gemm_raw(a=a_ptr, bt=_dev(cv.w).data_ptr(), c=c_ptr, bias=None if cv.b is None else cv.b.data_ptr(),
