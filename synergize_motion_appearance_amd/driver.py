@@ -49,31 +49,59 @@ def shard_frames(n_frames: int, rank: int, world: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
+CACHE_SHAPES = {32: (1, 32, 32, 256), 64: (1, 64, 64, 128), 128: (1, 128, 128, 128), 256: (1, 256, 256, 64)}
+CACHE_ORDER = (32, 64, 128, 256)
+_KP_VALUE, _KP_JAC = 15 * 2, 15 * 4
+
+
+def cache_numel() -> int:
+    n = _KP_VALUE + _KP_JAC
+    for s in CACHE_ORDER:
+        c = 1
+        for d in CACHE_SHAPES[s]:
+            c *= d
+        n += c
+    return n          # 7,077,888 encoder elements (28.3 MB fp32) + 90 keypoint floats
+
+
+def pack_source_cache(cache, kp_source) -> torch.Tensor:
+    """flatten the frame-invariant state of one source into ONE buffer (one collective, not six)."""
+    return torch.cat([cache.feats[s].reshape(-1) for s in CACHE_ORDER] +
+                     [kp_source["value"].reshape(-1), kp_source["jacobian"].reshape(-1)])
+
+
+def unpack_source_cache(flat: torch.Tensor):
+    from .engine_netg import SourceCache
+    feats, off = {}, 0
+    for s in CACHE_ORDER:
+        n = 1
+        for d in CACHE_SHAPES[s]:
+            n *= d
+        feats[s] = flat[off:off + n].view(CACHE_SHAPES[s])
+        off += n
+    kp = {"value": flat[off:off + _KP_VALUE].view(1, 15, 2),
+          "jacobian": flat[off + _KP_VALUE:off + _KP_VALUE + _KP_JAC].view(1, 15, 2, 2)}
+    return SourceCache(feats, 1), kp
+
+
+def broadcast_flat(flat_or_none, device, src=0):
+    """rank `src` passes the packed cache, the others None; everyone returns the broadcast buffer.
+    torch.distributed broadcast == RCCL over xGMI on the GPU box (gloo in the CPU tests)."""
+    import torch.distributed as dist
+    buf = flat_or_none if dist.get_rank() == src else torch.empty(cache_numel(), device=device, dtype=torch.float32)
+    dist.broadcast(buf, src=src)
+    return buf
+
+
 def broadcast_source_cache(net_g, motion_estimator, source, src=0):
     """rank `src` encodes the source once; every rank receives the frame-invariant cache
-    (encoder taps 28.3 MB fp32 + kp_source) with torch.distributed broadcast (RCCL over xGMI)."""
+    (encoder taps 28.3 MB fp32 + kp_source) with ONE broadcast."""
     import torch.distributed as dist
-    from .engine_netg import SourceCache
-    rank = dist.get_rank()
-    shapes = {32: (1, 32, 32, 256), 64: (1, 64, 64, 128), 128: (1, 128, 128, 128), 256: (1, 256, 256, 64)}
-    if rank == src:
+    flat = None
+    if dist.get_rank() == src:
         cache = net_g.engine().encode_source(source.float())
-        kp_s = motion_estimator.estimate_kp(source)
-    else:
-        net_g.engine()
-        cache = SourceCache({s: torch.empty(sh, device=source.device, dtype=torch.float32) for s, sh in shapes.items()}, 1)
-        kp_s = {"value": torch.empty((1, 15, 2), device=source.device), "jacobian": torch.empty((1, 15, 2, 2), device=source.device)}
-    flat = torch.cat([cache.feats[s].reshape(-1) for s in (32, 64, 128, 256)] + [kp_s["value"].reshape(-1), kp_s["jacobian"].reshape(-1)])
-    dist.broadcast(flat, src=src)
-    if rank != src:
-        off = 0
-        for s in (32, 64, 128, 256):
-            n = cache.feats[s].numel()
-            cache.feats[s] = flat[off:off + n].view(shapes[s]).clone()
-            off += n
-        kp_s["value"] = flat[off:off + 30].view(1, 15, 2).clone()
-        kp_s["jacobian"] = flat[off + 30:off + 90].view(1, 15, 2, 2).clone()
-    return cache, kp_s
+        flat = pack_source_cache(cache, motion_estimator.engine().estimate_kp(source.float()))
+    return unpack_source_cache(broadcast_flat(flat, source.device, src))
 
 
 @torch.no_grad()

@@ -1,0 +1,166 @@
+"""CPU-side tests: the drop-in boundary (registry names, constructor kwargs, checkpoint key
+layout, yaml loader, image conversion), the relative-keypoint transfer of the driver, frame
+sharding, and that libsmx.so loads and exports every symbol include/smx.h declares.  No GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from tests.util import golden, manifest, weights, HERE
+from synergize_motion_appearance_amd.synth import synth_input
+
+REPO = os.path.dirname(HERE)
+
+
+def _cfg():
+    from basicsr.utils.options import ordered_yaml
+    return yaml.load(open(os.path.join(REPO, "options/test.yml")), Loader=ordered_yaml()[0])
+
+
+def test_registry_semantics():
+    from basicsr.utils.registry import Registry, ARCH_REGISTRY
+    r = Registry("t")
+
+    @r.register()
+    class A:  # noqa
+        pass
+
+    def fn():
+        pass
+    r.register(fn)
+    assert r.get("A") is A and r.get("fn") is fn and "A" in r and set(r.keys()) == {"A", "fn"}
+    with pytest.raises(KeyError):
+        r.get("missing")
+    with pytest.raises(AssertionError):
+        r.register(fn)
+    import basicsr.archs  # noqa: F401  (importing the archs package registers the classes, as in the reference)
+    for name in ("AppMotionCompFormer", "Motion_Estimator_keypoint_aware"):
+        assert name in ARCH_REGISTRY
+
+
+def test_build_network_and_checkpoint_contract():
+    """every yml key is a constructor kwarg; state_dict names/shapes == the reference's (strict load)."""
+    from basicsr.archs import build_network
+    cfg = _cfg()
+    from collections import OrderedDict
+    assert isinstance(cfg, OrderedDict) and list(cfg["network_g"].keys())[0] == "type"
+    opt = cfg["network_g"]
+    net_g = build_network(opt)
+    assert opt["type"] == "AppMotionCompFormer"          # build_network deep-copies, does not pop from the caller's dict
+    me = build_network(cfg["network_motion_estimator"])
+    for net, key in ((net_g, "network_g"), (me, "network_motion_estimator")):
+        sd = net.state_dict()
+        ref = {k: tuple(s) for k, s in manifest()[key]}
+        assert set(sd) == set(ref)
+        assert all(tuple(sd[k].shape) == ref[k] for k in ref)
+        net.load_state_dict(weights(key), strict=True)
+        bad = dict(weights(key))
+        bad.pop(next(iter(bad)))
+        with pytest.raises(RuntimeError):
+            net.load_state_dict(bad, strict=True)
+    assert sum(v.numel() for v in net_g.state_dict().values()) == 30118854
+    assert sum(v.numel() for v in me.state_dict().values()) == 52071543
+    # 'module.'-prefixed checkpoints are stripped by the caller (demo.py:64-70); num_batches_tracked stays int64
+    assert me.state_dict()["kp_detector.predictor.encoder.down_blocks.0.norm.num_batches_tracked"].dtype == torch.int64
+    with pytest.raises(KeyError):
+        build_network({"type": "NoSuchArch"})
+    with pytest.raises(NotImplementedError):
+        build_network(dict(cfg["network_g"], split=2))
+
+
+def test_no_cpu_fallback():
+    """the product path must fail loudly without the device -- never route through a CPU implementation."""
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.lib import SmxError
+    from synergize_motion_appearance_amd import ops
+    cfg = _cfg()
+    me = build_network(cfg["network_motion_estimator"])
+    with pytest.raises(SmxError):
+        me.estimate_kp(torch.zeros(1, 3, 256, 256))
+    net_g = build_network(cfg["network_g"])
+    with pytest.raises(SmxError):
+        net_g(torch.zeros(1, 3, 256, 256), {"deformation": torch.zeros(1, 64, 64, 2), "occlusion_map": torch.zeros(1, 1, 64, 64),
+                                            "driving_kp_heatmap": torch.zeros(1, 15, 64, 64)}, w=1, inference=True)
+    with pytest.raises(NotImplementedError):
+        net_g(torch.zeros(1, 3, 256, 256), {}, w=1, inference=False)
+    with pytest.raises(SmxError):
+        ops.warp(torch.zeros(1, 32, 32, 64), torch.zeros(1, 64, 64, 2))
+    src = open(os.path.join(REPO, "synergize_motion_appearance_amd", "ops.py")).read() + \
+        open(os.path.join(REPO, "synergize_motion_appearance_amd", "engine_netg.py")).read() + \
+        open(os.path.join(REPO, "synergize_motion_appearance_amd", "engine_motion.py")).read()
+    assert "oracle" not in src and "F.conv2d" not in src and "grid_sample" not in src
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from synergize_motion_appearance_amd import lib as L
+    assert os.path.exists(L.LIB_PATH), "run __graft_entry__.build() first"
+    so = ctypes.CDLL(L.LIB_PATH)                        # loads without a GPU
+    header = open(os.path.join(REPO, "include", "smx.h")).read()
+    declared = set(re.findall(r"\b(smx_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    for name in declared:
+        assert getattr(so, name) is not None
+    so.smx_version.restype = ctypes.c_char_p
+    assert b"gfx950" in so.smx_version()
+    # struct mirror has the same size as the C struct would (pointer/int64 alignment sanity)
+    assert ctypes.sizeof(L.GemmDesc) % 8 == 0
+
+
+def test_img_util_matches_reference():
+    from basicsr.utils import img2tensor, tensor2img
+    t = synth_input("tensor2img", (3, 64, 64)) * 0.8
+    assert np.array_equal(tensor2img([t[None]], rgb2bgr=False, min_max=(-1, 1)), golden("tensor2img.npz")["img"])
+    img = (np.random.RandomState(0).rand(8, 9, 3) * 255).astype(np.float32)
+    x = img2tensor(img, bgr2rgb=True, float32=True)
+    assert x.shape == (3, 8, 9) and torch.equal(x[0], torch.from_numpy(img[:, :, 2]))
+    back = tensor2img(x / 255.0, rgb2bgr=True, min_max=(0, 1))
+    assert np.array_equal(back, img.round().astype(np.uint8))
+    with pytest.raises(TypeError):
+        tensor2img(np.zeros((3, 4, 4)))
+
+
+def test_driver_normalize_kp_vs_reference():
+    from synergize_motion_appearance_amd.driver import normalize_kp, adapt_scale
+    g, gn = golden("kp.npz"), golden("normalize_kp.npz")
+    kp = lambda v, j: {"value": torch.from_numpy(v), "jacobian": torch.from_numpy(j)}
+    kp_s = kp(g["src_value"], g["src_jacobian"])
+    kp_0 = kp(g["drv_value"][0:1], g["drv_jacobian"][0:1])
+    kp_3 = kp(g["drv_value"][3:4], g["drv_jacobian"][3:4])
+    for rel in (0, 1):
+        for ad in (0, 1):
+            r = normalize_kp(kp_s, kp_3, kp_0, bool(ad), bool(rel), bool(rel))
+            assert np.abs(r["value"].numpy() - gn[f"value_r{rel}a{ad}"]).max() < 1e-6
+            assert np.abs(r["jacobian"].numpy() - gn[f"jacobian_r{rel}a{ad}"]).max() < 1e-5
+    # the hull ratio is frame-invariant: passing it precomputed gives the same result, batched
+    s = adapt_scale(kp_s, kp_0)
+    kp_b = kp(g["drv_value"], g["drv_jacobian"])
+    rb = normalize_kp(kp_s, kp_b, kp_0, True, True, True, scale=s)
+    r3 = normalize_kp(kp_s, kp_3, kp_0, True, True, True)
+    assert torch.allclose(rb["value"][3:4], r3["value"], atol=1e-7) and torch.allclose(rb["jacobian"][3:4], r3["jacobian"], atol=1e-6)
+
+
+def test_shard_frames_partitions_exactly():
+    from synergize_motion_appearance_amd.driver import shard_frames
+    for n, w in ((300, 8), (300, 1), (7, 8), (2400, 8), (0, 4), (301, 2)):
+        spans = [shard_frames(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert [shard_frames(300, r, 8)[1] - shard_frames(300, r, 8)[0] for r in range(8)] == [38, 38, 38, 38, 37, 37, 37, 37]
+
+
+def test_source_cache_pack_roundtrip():
+    from synergize_motion_appearance_amd import driver
+    from synergize_motion_appearance_amd.engine_netg import SourceCache
+    feats = {s: synth_input(f"cache{s}", sh) for s, sh in driver.CACHE_SHAPES.items()}
+    kp = {"value": synth_input("cv", (1, 15, 2)), "jacobian": synth_input("cj", (1, 15, 2, 2))}
+    flat = driver.pack_source_cache(SourceCache(feats, 1), kp)
+    assert flat.numel() == driver.cache_numel() == 7077888 + 90
+    c2, kp2 = driver.unpack_source_cache(flat)
+    assert all(torch.equal(c2.feats[s], feats[s]) for s in feats)
+    assert torch.equal(kp2["value"], kp["value"]) and torch.equal(kp2["jacobian"], kp["jacobian"])
