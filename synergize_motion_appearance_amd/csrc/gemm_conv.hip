@@ -14,6 +14,7 @@
 // Tile configs (256 threads = 4 waves): 128x128, 128x64, 128x32, 64x128, 64x64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "smx.h"
 #include "smx_common.h"
 
@@ -33,6 +34,7 @@ struct GP {
   int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
   int act; float alpha; int bias_per_row; int d2s_p, d2s_c;
   int tiles_n; int is1x1;
+  int xcd_swizzle;
   int ksplit; float* ws;            // split-K: blockIdx.z owns a K range, raw partials -> ws[z][M][N]
 };
 
@@ -62,7 +64,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  // XCD-aware tile order: the dispatcher puts block b on XCD b%8 (each XCD has a private L2).
+  // Give every XCD a CONTIGUOUS range of logical tiles (tile_n fastest, then tile_m), so the
+  // N-tiles of one M-tile and the 3x3 halos of neighbouring M-tiles hit the same L2 instead of
+  // being fetched over the fabric by 4-8 different XCDs.
+  int logical = blockIdx.x;
+  if (p.xcd_swizzle) {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
   const int g = blockIdx.y, g0 = g / p.nb1, g1 = g - g0 * p.nb1;
   const float* __restrict__ A = p.a + g0 * p.a_bs0 + g1 * p.a_bs1;
   const float* __restrict__ Bt = p.bt + g0 * p.bt_bs0 + g1 * p.bt_bs1;
@@ -316,6 +327,7 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up2 = d->up2;
   p.act = d->act; p.alpha = d->alpha; p.bias_per_row = d->bias_per_row; p.d2s_p = d->d2s_p; p.d2s_c = d->d2s_c;
   p.tiles_n = 1;
+  p.xcd_swizzle = getenv("SMX_NO_XCD_SWIZZLE") ? 0 : 1;
   p.ksplit = d->ksplit > 1 ? d->ksplit : 1; p.ws = d->ws;
   if (p.ksplit > 1 && (!d->ws || nb != 1 || d->d2s_p || p.ksplit > (d->K + BK - 1) / BK)) return SMX_EINVAL;
   p.is1x1 = (d->kh == 1 && d->kw == 1 && d->stride == 1 && !d->up2 && d->pad_t == 0 && d->pad_l == 0 &&
