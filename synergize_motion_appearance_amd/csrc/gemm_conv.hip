@@ -239,32 +239,72 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
   }
   float* __restrict__ C = p.c + g0 * p.c_bs0 + g1 * p.c_bs1;
   const float* __restrict__ R = p.res ? p.res + g0 * p.res_bs0 + g1 * p.res_bs1 : nullptr;
+  const int mrow0 = tile_m * BM + wm * WTM + 4 * (lane >> 5);
+  if (!p.d2s_p) {
+    // plain store.  Two phases so that every residual / row-bias load of the tile is in flight
+    // before the first use (one s_waitcnt per tile column instead of one per element).
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = tile_n * BN + wn * WTN + j * 32 + (lane & 31);
+      const bool nok = n < p.N;
+      const float bn = (nok && p.bias && !p.bias_per_row) ? p.bias[n] : 0.f;
+      float rv[TM][16];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          float t = 0.f;
+          if (nok && m < p.M) {
+            if (R) t = R[(long long)m * p.ldres + n];
+          }
+          rv[i][r] = t;
+        }
+      float rb[TM][16];
+      if (p.bias && p.bias_per_row) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+            rb[i][r] = m < p.M ? p.bias[m] : 0.f;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rb[i][r] = bn;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          const float v = apply_act(p.alpha * acc[i][j][r] + rb[i][r], p.act) + rv[i][r];
+          if (nok && m < p.M) C[(long long)m * p.ldc + n] = v;
+        }
+    }
+    return;
+  }
+  // depth-to-space store (un-patchify): n = (p1*p+p2)*dc + c
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = tile_n * BN + wn * WTN + j * 32 + (lane & 31);
     if (n >= p.N) continue;
-    const float bn = (p.bias && !p.bias_per_row) ? p.bias[n] : 0.f;
-    int dq = 0, dcn = n;
-    if (p.d2s_p) { dq = n / p.d2s_c; dcn = n - dq * p.d2s_c; }
+    const float bn = p.bias ? p.bias[n] : 0.f;
+    const int dq = n / p.d2s_c, dcn = n - dq * p.d2s_c;
+    const int p1 = dq / p.d2s_p, p2 = dq - p1 * p.d2s_p;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = tile_m * BM + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
         if (m >= p.M) continue;
-        float v = p.alpha * acc[i][j][r] + bn;
-        if (p.bias && p.bias_per_row) v += p.bias[m];
-        v = apply_act(v, p.act);
-        long long off;
-        if (p.d2s_p) {
-          int img = m / HoWo, rem = m - img * HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-          int p1 = dq / p.d2s_p, p2 = dq - p1 * p.d2s_p;
-          off = (((long long)img * (p.Ho * p.d2s_p) + oy * p.d2s_p + p1) * (p.Wo * p.d2s_p) + ox * p.d2s_p + p2) * p.ldc + dcn;
-        } else {
-          off = (long long)m * p.ldc + n;
-        }
-        if (R) v += R[p.d2s_p ? off / p.ldc * p.ldres + dcn : (long long)m * p.ldres + n];
-        C[off] = v;
+        float v = apply_act(p.alpha * acc[i][j][r] + bn, p.act);
+        const int img = m / HoWo, rem = m - img * HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const long long pix = ((long long)img * (p.Ho * p.d2s_p) + oy * p.d2s_p + p1) * (p.Wo * p.d2s_p) + ox * p.d2s_p + p2;
+        if (R) v += R[pix * p.ldres + dcn];
+        C[pix * p.ldc + dcn] = v;
       }
     }
   }
