@@ -150,9 +150,11 @@ int smx_sparse_motion_f32(const float* src, int src_batch, const float* kpd_valu
 
 /* A6b: softmax over the K+1 mask logits and deformation = sum_k mask_k * T_k
  * (archs/dense_motion_arch.py:134-140). mask_logits NHWC [B][H][W][ldm]; deformation [B][H][W][2];
- * mask_out NHWC [B][H][W][K+1] or NULL. */
+ * mask_out NHWC [B][H][W][K+1] or NULL.  occ_out != NULL: channel K1 of the logits buffer holds the
+ * occlusion logit (mask and occlusion heads run as one stacked 7x7 conv) and
+ * occ_out[B][H][W] = sigmoid(logit)  (dense_motion_arch.py:158). */
 int smx_mask_deformation_f32(const float* mask_logits, int ldm, const float* sparse, float* deformation,
-                             float* mask_out, int B, int H, int W, int K1, void* stream);
+                             float* mask_out, float* occ_out, int B, int H, int W, int K1, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * small fused elementwise stages of AppMotionCompFormer.forward

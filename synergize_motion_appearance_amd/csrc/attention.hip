@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
     float4 t = *reinterpret_cast<const float4*>(Q + kk * 8 + hh * 4);
-    qf[kk] = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+    const float sc = p.scale * 1.44269504088896340736f;      // scores in log2 units: softmax via v_exp_f32 (exp2)
+    qf[kk] = make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc);
   }
   f32x16 oacc[DT];
 #pragma unroll
@@ -119,10 +120,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m, tmax);
     const bool dead = (m_new == -INFINITY);                 // every key so far masked
-    const float alpha = dead ? 1.f : expf(m - m_new);
+    const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
     float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = dead ? 0.f : expf(s[r] - m_new); psum += s[r]; }
+    for (int r = 0; r < 16; ++r) { s[r] = dead ? 0.f : __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
     psum += __shfl_xor(psum, 32, 64);
     l = l * alpha + psum; m = m_new;
 #pragma unroll
@@ -153,51 +154,71 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
     }
 }
 
-// d_head = 4: one query per lane; K/V chunk of 256 keys broadcast from LDS
+// d_head = 4: one query per lane, 64 queries per block; the block's 4 waves split the S keys
+// (wave w owns keys [w*S/4, (w+1)*S/4)), K/V broadcast from LDS, 8 keys per online-softmax step,
+// and the four partial (m, l, acc) states are merged through LDS at the end.
 __global__ __launch_bounds__(256) void attn_valu4_kernel(AP p) {
-  __shared__ float4 Ks[256];
-  __shared__ float4 Vs[256];
-  __shared__ uint8_t Ms[256];
+  extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+  float4* Ks = smem4;                       // [S]
+  float4* Vs = smem4 + p.S;                 // [S]
+  uint8_t* Ms = reinterpret_cast<uint8_t*>(smem4 + 2 * p.S);   // [S]
+  float* part = reinterpret_cast<float*>(Ms + p.S);             // [4][64][6]
   const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
-  const int qrow = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qrow = blockIdx.x * 64 + lane;
   float4 q = *reinterpret_cast<const float4*>(p.q + b * p.q_bs + (long long)qrow * p.ldq + h * 4);
-  q = make_float4(q.x * p.scale, q.y * p.scale, q.z * p.scale, q.w * p.scale);
+  { const float sc = p.scale * 1.44269504088896340736f; q = make_float4(q.x * sc, q.y * sc, q.z * sc, q.w * sc); }
   const float* K = p.k + b * p.k_bs + h * 4;
   const float* V = p.v + b * p.v_bs + h * 4;
   const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
+  for (int i = threadIdx.x; i < p.S; i += 256) {
+    Ks[i] = *reinterpret_cast<const float4*>(K + (long long)i * p.ldk);
+    Vs[i] = *reinterpret_cast<const float4*>(V + (long long)i * p.ldv);
+    Ms[i] = M ? M[i] : 0;
+  }
+  __syncthreads();
   float m = -INFINITY, l = 0.f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int key0 = 0; key0 < p.S; key0 += 256) {
-    __syncthreads();
-    Ks[threadIdx.x] = *reinterpret_cast<const float4*>(K + (long long)(key0 + threadIdx.x) * p.ldk);
-    Vs[threadIdx.x] = *reinterpret_cast<const float4*>(V + (long long)(key0 + threadIdx.x) * p.ldv);
-    Ms[threadIdx.x] = M ? M[key0 + threadIdx.x] : 0;
-    __syncthreads();
-    for (int g = 0; g < 256; g += 8) {
-      float s[8]; float tmax = -INFINITY;
+  const int per = p.S >> 2, g0 = wave * per;
+  for (int g = g0; g < g0 + per; g += 8) {
+    float s[8]; float tmax = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 kk = Ks[g + i];
-        float t = q.x * kk.x + q.y * kk.y + q.z * kk.z + q.w * kk.w;
-        if (Ms[g + i]) t = -INFINITY;
-        s[i] = t; tmax = fmaxf(tmax, t);
-      }
-      const float m_new = fmaxf(m, tmax);
-      if (m_new == -INFINITY) continue;
-      const float alpha = expf(m - m_new);
-      float4 a2 = make_float4(acc.x * alpha, acc.y * alpha, acc.z * alpha, acc.w * alpha);
-      float ps = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float pe = expf(s[i] - m_new);
-        const float4 vv = Vs[g + i];
-        ps += pe; a2.x += pe * vv.x; a2.y += pe * vv.y; a2.z += pe * vv.z; a2.w += pe * vv.w;
-      }
-      acc = a2; l = l * alpha + ps; m = m_new;
+    for (int i = 0; i < 8; ++i) {
+      const float4 kk = Ks[g + i];
+      float t = q.x * kk.x + q.y * kk.y + q.z * kk.z + q.w * kk.w;
+      if (Ms[g + i]) t = -INFINITY;
+      s[i] = t; tmax = fmaxf(tmax, t);
     }
+    const float m_new = fmaxf(m, tmax);
+    if (m_new == -INFINITY) continue;
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float4 a2 = make_float4(acc.x * alpha, acc.y * alpha, acc.z * alpha, acc.w * alpha);
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float pe = __builtin_amdgcn_exp2f(s[i] - m_new);
+      const float4 vv = Vs[g + i];
+      ps += pe; a2.x += pe * vv.x; a2.y += pe * vv.y; a2.z += pe * vv.z; a2.w += pe * vv.w;
+    }
+    acc = a2; l = l * alpha + ps; m = m_new;
   }
-  float4 o = make_float4(acc.x / l, acc.y / l, acc.z / l, acc.w / l);   // l == 0 -> NaN like the reference
-  *reinterpret_cast<float4*>(p.o + b * p.o_bs + (long long)qrow * p.ldo + h * 4) = o;
+  float* pp = part + (wave * 64 + lane) * 6;
+  pp[0] = m; pp[1] = l; pp[2] = acc.x; pp[3] = acc.y; pp[4] = acc.z; pp[5] = acc.w;
+  __syncthreads();
+  if (wave == 0) {
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, part[(w * 64 + lane) * 6]);
+    float ll = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* q6 = part + (w * 64 + lane) * 6;
+      const float f = (q6[0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(q6[0] - mm);
+      ll += q6[1] * f; a.x += q6[2] * f; a.y += q6[3] * f; a.z += q6[4] * f; a.w += q6[5] * f;
+    }
+    // ll == 0 (every key masked) -> 0/0 = NaN like the reference
+    *reinterpret_cast<float4*>(p.o + b * p.o_bs + (long long)qrow * p.ldo + h * 4) = make_float4(a.x / ll, a.y / ll, a.z / ll, a.w / ll);
+  }
 }
 
 }  // namespace
@@ -211,8 +232,9 @@ extern "C" int smx_attention_f32(const float* q, int ldq, int64_t q_bs, const fl
   AP p{q, k, v, o, key_mask, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo, H, L, S, scale};
   hipStream_t st = (hipStream_t)stream;
   if (dh == 4) {
-    if (L % 256 || S % 256) return SMX_EINVAL;
-    hipLaunchKernelGGL(attn_valu4_kernel, dim3(L / 256, B * H), dim3(256), 0, st, p);
+    if (L % 64 || S % 32 || S > 2048) return SMX_EINVAL;
+    const size_t lds = (size_t)S * 33 + 4 * 64 * 6 * sizeof(float);
+    hipLaunchKernelGGL(attn_valu4_kernel, dim3(L / 64, B * H), dim3(256), lds, st, p);
   } else if (dh == 32 || dh == 64) {
     if (L % 128 || S % 32) return SMX_EINVAL;
     if (dh == 32) hipLaunchKernelGGL(attn_mfma_kernel<32>, dim3(L / 128, B * H), dim3(256), 0, st, p);

@@ -34,7 +34,7 @@ struct GP {
   int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
   int act; float alpha; int bias_per_row; int d2s_p, d2s_c;
   int tiles_n; int is1x1;
-  int xcd_swizzle;
+  int xcd_swizzle; int variant;
   int ksplit; float* ws;            // split-K: blockIdx.z owns a K range, raw partials -> ws[z][M][N]
 };
 
@@ -191,12 +191,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nslices = s_end - s_begin;
-  if (nslices > 0) { load_slice(s_begin * BK); store_slice(0); }
-  __syncthreads();
   const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
-  for (int s = 0; s < nslices; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nslices) load_slice((s_begin + s + 1) * BK);
+  const bool early = (p.variant & 1) != 0, prio = (p.variant & 2) != 0;
+  auto compute = [&](int buf) {
     const float* as = As + buf * BM * LDS_LD + (wm * WTM) * LDS_LD + frag_off;
     const float* bs = Bs + buf * BN * LDS_LD + (wn * WTN) * LDS_LD + frag_off;
 #pragma unroll
@@ -206,6 +203,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kk * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_LD + kk * 8);
+      if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -215,9 +213,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
+      if (prio) __builtin_amdgcn_s_setprio(0);
     }
-    if (s + 1 < nslices) store_slice(buf ^ 1);
+  };
+  if (!early) {
+    if (nslices > 0) { load_slice(s_begin * BK); store_slice(0); }
     __syncthreads();
+    for (int s = 0; s < nslices; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nslices) load_slice((s_begin + s + 1) * BK);
+      compute(buf);
+      if (s + 1 < nslices) store_slice(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // store-early: the LDS write of slice s+1 opens iteration s (its loads were issued a full
+    // iteration ago), the loads of slice s+2 follow, then the MFMAs, then the only barrier.
+    if (nslices > 0) { load_slice(s_begin * BK); store_slice(0); }
+    if (nslices > 1) load_slice((s_begin + 1) * BK);
+    __syncthreads();
+    for (int s = 0; s < nslices; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nslices) store_slice(buf ^ 1);
+      if (s + 2 < nslices) load_slice((s_begin + s + 2) * BK);
+      compute(buf);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----------------------------------------------------------------------
@@ -368,6 +389,7 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
   p.act = d->act; p.alpha = d->alpha; p.bias_per_row = d->bias_per_row; p.d2s_p = d->d2s_p; p.d2s_c = d->d2s_c;
   p.tiles_n = 1;
   p.xcd_swizzle = getenv("SMX_NO_XCD_SWIZZLE") ? 0 : 1;
+  p.variant = getenv("SMX_GEMM_VARIANT") ? atoi(getenv("SMX_GEMM_VARIANT")) : 3;
   p.ksplit = d->ksplit > 1 ? d->ksplit : 1; p.ws = d->ws;
   if (p.ksplit > 1 && (!d->ws || nb != 1 || d->d2s_p || p.ksplit > (d->K + BK - 1) / BK)) return SMX_EINVAL;
   p.is1x1 = (d->kh == 1 && d->kw == 1 && d->stride == 1 && !d->up2 && d->pad_t == 0 && d->pad_l == 0 &&

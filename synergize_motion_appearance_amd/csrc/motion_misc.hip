@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void sparse_motion_kernel(const float* __restr
 // ---- A6b: mask softmax + deformation ------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_deformation_kernel(const float* __restrict__ ml, int ldm,
                                                                const float* __restrict__ sparse, float* __restrict__ deform,
-                                                               float* __restrict__ mask_out, long long npix, int HW, int K1) {
+                                                               float* __restrict__ mask_out, long long npix, int HW, int K1,
+                                                               float* __restrict__ occ_out) {
   for (long long p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
     const int b = (int)(p / HW); const int rem = (int)(p - (long long)b * HW);
     const float* l = ml + p * ldm;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void mask_deformation_kernel(const float* __re
       if (mask_out) mask_out[p * K1 + k] = m;
     }
     *reinterpret_cast<float2*>(deform + p * 2) = make_float2(dx, dy);
+    if (occ_out) occ_out[p] = 1.f / (1.f + expf(-l[K1]));       // occlusion logit rides in channel K1
   }
 }
 
@@ -255,11 +257,11 @@ extern "C" int smx_sparse_motion_f32(const float* src, int src_batch, const floa
 }
 
 extern "C" int smx_mask_deformation_f32(const float* mask_logits, int ldm, const float* sparse, float* deformation,
-                                        float* mask_out, int B, int H, int W, int K1, void* stream) {
-  if (!mask_logits || !sparse || !deformation || B <= 0 || H <= 0 || W <= 0 || K1 <= 0 || ldm < K1) return SMX_EINVAL;
+                                        float* mask_out, float* occ_out, int B, int H, int W, int K1, void* stream) {
+  if (!mask_logits || !sparse || !deformation || B <= 0 || H <= 0 || W <= 0 || K1 <= 0 || ldm < K1 + (occ_out ? 1 : 0)) return SMX_EINVAL;
   const long long npix = (long long)B * H * W;
   hipLaunchKernelGGL(mask_deformation_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, mask_logits, ldm, sparse,
-                     deformation, mask_out, npix, H * W, K1);
+                     deformation, mask_out, npix, H * W, K1, occ_out);
   return smx_launch_status();
 }
 

@@ -82,13 +82,19 @@ class MotionEngine:
         self.temperature = kp["temperature"]
         self.kp_hg = HourglassPlan(P, "kp_detector.predictor", kp["block_expansion"], common["num_channels"],
                                    kp["num_blocks"], kp["max_features"])
-        self.kp_conv = Conv.from_torch(P["kp_detector.kp.weight"], P["kp_detector.kp.bias"])
-        self.jac_conv = Conv.from_torch(P["kp_detector.jacobian.weight"], P["kp_detector.jacobian.bias"])
+        # kp (15) and jacobian (60) heads share their input and geometry (7x7 valid): one conv with
+        # N = 60 + 15 + 1 pad -> [jac | kp | 0]; 76 keeps the float4 reads of the jacobian maps aligned
+        kpc = Conv.from_torch(P["kp_detector.kp.weight"], P["kp_detector.kp.bias"])
+        jc = Conv.from_torch(P["kp_detector.jacobian.weight"], P["kp_detector.jacobian.bias"])
+        zero = Conv(torch.zeros_like(kpc.w[:1]), torch.zeros_like(kpc.b[:1]), 7, 7, kpc.cin, 1)
+        self.head_conv = Conv.cat([jc, kpc, zero])
+        self.n_jac = jc.cout
         self.kp_down = P["kp_detector.down.weight"].reshape(common["num_channels"], 13, 13).contiguous()
         self.dm_hg = HourglassPlan(P, "dense_motion_network.hourglass", dense["block_expansion"],
                                    (self.num_kp + 1) * (common["num_channels"] + 1), dense["num_blocks"], dense["max_features"])
-        self.mask_conv = Conv.from_torch(P["dense_motion_network.mask.weight"], P["dense_motion_network.mask.bias"])
-        self.occ_conv = Conv.from_torch(P["dense_motion_network.occlusion.weight"], P["dense_motion_network.occlusion.bias"])
+        # mask (16) and occlusion (1) heads: one stacked 7x7 conv, N = 17
+        self.mo_conv = Conv.cat([Conv.from_torch(P["dense_motion_network.mask.weight"], P["dense_motion_network.mask.bias"]),
+                                 Conv.from_torch(P["dense_motion_network.occlusion.weight"], P["dense_motion_network.occlusion.bias"])])
         self.dm_down = P["dense_motion_network.down.weight"].reshape(common["num_channels"], 13, 13).contiguous()
         self.kp_variance = 0.01
 
@@ -98,9 +104,9 @@ class MotionEngine:
         buf, inp = self.kp_hg.alloc_input(B, 64, image_nchw.device)
         ops.antialias_down(image_nchw, self.kp_down, out=inp)
         fm = self.kp_hg.run(buf, B, 64)                       # [B,64,64,35]
-        logits = ops.conv(fm, self.kp_conv, pad=(0, 0))       # 7x7 valid -> [B,58,58,15]
-        jmaps = ops.conv(fm, self.jac_conv, pad=(0, 0))       # [B,58,58,60]
-        value, jac = ops.kp_head(logits, jmaps, self.num_kp, self.temperature)
+        heads = ops.conv(fm, self.head_conv, pad=(0, 0))      # 7x7 valid -> [B,58,58,76] = [jac 60 | kp 15 | 0]
+        value, jac = ops.kp_head(heads[..., self.n_jac:self.n_jac + self.num_kp], heads[..., :self.n_jac],
+                                 self.num_kp, self.temperature)
         return {"value": value, "jacobian": jac}
 
     # ---- A4-A6b ------------------------------------------------------------------------
@@ -115,9 +121,8 @@ class MotionEngine:
                                          kp_source["value"], kp_source["jacobian"].reshape(kp_source["value"].shape[0], -1, 4),
                                          inp, B, self.num_kp, self.kp_variance)
         pred = self.dm_hg.run(buf, B, 64)                     # [B,64,64,128]
-        mlog = ops.conv(pred, self.mask_conv)                 # 7x7 pad 3 -> [B,64,64,16]
-        deformation, mask = ops.mask_deformation(mlog, sparse, want_mask=want_aux)
-        occ = ops.conv(pred, self.occ_conv, act=ACT_SIGMOID)  # [B,64,64,1]
+        mlog = ops.conv(pred, self.mo_conv)                   # 7x7 pad 3 -> [B,64,64,17] = [mask 16 | occlusion logit]
+        deformation, mask, occ = ops.mask_deformation(mlog, sparse, want_mask=want_aux, K1=self.num_kp + 1, fused_occ=True)
         out = {"deformation": deformation, "occlusion_nhwc": occ, "heat_nhwc": heat, "sparse_motion": sparse}
         if want_aux:
             out["mask_nhwc"] = mask

@@ -158,7 +158,12 @@ class NetGEngine:
         self.bme = {n: cv("BasicMotionEncoder." + n) for n in ("convc1", "convc2", "convf1", "convf2", "conv")}
         self.ref_c1 = cv("refine.convc1")
         self.ref_h = Conv.cat([cv("refine.conv1"), cv("refine.convo1")])      # shared input -> N=256
-        self.ref_flow, self.ref_occ = cv("refine.conv2"), cv("refine.convo2")
+        # conv2 (2 <- h[:128]) and convo2 (1 <- h[128:]) as ONE block-diagonal conv 256 -> 3 writing r directly
+        f2, o2 = cv("refine.conv2"), cv("refine.convo2")
+        wz = torch.zeros((3, 9, 256), device=f2.w.device, dtype=torch.float32)
+        wz[0:2, :, :128] = f2.w.view(2, 9, 128)
+        wz[2:3, :, 128:] = o2.w.view(1, 9, 128)
+        self.ref_out = Conv(wz.reshape(3, 9 * 256).contiguous(), torch.cat([f2.b, o2.b]).contiguous(), 3, 3, 256, 3)
         self.app_in, self.app_out = {}, {}
         for s in [int(x) for x in cfg["connect_app_list"]]:
             if s == 32:
@@ -242,10 +247,7 @@ class NetGEngine:
             wf = ops.resize(wf, 64, 64)
         ops.conv(wf, self.ref_c1, out=inp[..., 128:], act=ACT_RELU)
         h = ops.conv(inp, self.ref_h, act=ACT_RELU)                           # [B,64,64,256] = [conv1 | convo1]
-        r = torch.empty((B, 64, 64, 3), device=q.device, dtype=torch.float32)
-        ops.conv(h[..., :128], self.ref_flow, out=r[..., 0:2])
-        ops.conv(h[..., 128:], self.ref_occ, out=r[..., 2:3])
-        return r
+        return ops.conv(h, self.ref_out)                                      # [B,64,64,3] = [dflow(2) | docc(1)]
 
     # ---- A10 ------------------------------------------------------------------------------
     def _app_comp(self, feat, m_com, s, out=None):

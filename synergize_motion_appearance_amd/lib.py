@@ -51,7 +51,7 @@ SIGNATURES = {
     "smx_antialias_down_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_kp_head_f32": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
     "smx_sparse_motion_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
-    "smx_mask_deformation_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smx_mask_deformation_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smx_flow_to_residual_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "smx_flow_occ_update_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "smx_motion_ignore_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

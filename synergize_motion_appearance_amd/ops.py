@@ -275,14 +275,18 @@ def sparse_motion(src64, kpd_value, kpd_jac, kps_value, kps_jac, hg_in, B, K=15,
     return sparse, heat
 
 
-def mask_deformation(mask_logits, sparse, want_mask=False):
-    B, H, W, K1 = mask_logits.shape
+def mask_deformation(mask_logits, sparse, want_mask=False, K1=None, fused_occ=False):
+    """mask_logits [B,H,W,>=K1]; fused_occ: channel K1 is the occlusion logit -> also returns sigmoid."""
+    B, H, W, Cl = mask_logits.shape
+    K1 = Cl if K1 is None else K1
     mp, ldm = _pix(mask_logits, "mask logits")
     deform = torch.empty((B, H, W, 2), device=mask_logits.device, dtype=torch.float32)
     mask = torch.empty((B, H, W, K1), device=mask_logits.device, dtype=torch.float32) if want_mask else None
+    occ = torch.empty((B, H, W), device=mask_logits.device, dtype=torch.float32) if fused_occ else None
     L.check(L.load().smx_mask_deformation_f32(mp, ldm, sparse.data_ptr(), deform.data_ptr(),
-                                              None if mask is None else mask.data_ptr(), B, H, W, K1, _stream()), "mask_deformation")
-    return deform, mask
+                                              None if mask is None else mask.data_ptr(),
+                                              None if occ is None else occ.data_ptr(), B, H, W, K1, _stream()), "mask_deformation")
+    return deform, mask, occ
 
 
 def flow_to_residual(flow):

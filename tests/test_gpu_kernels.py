@@ -286,6 +286,9 @@ def test_kp_head(ops):
     jac = (heat.unsqueeze(2) * jm.view(B, K, 4, 58, 58)).view(B, K, 4, -1).sum(-1).view(B, K, 2, 2)
     v, j = ops.kp_head(nhwc(logits), nhwc(jm), K, 0.1)
     assert maxabs(v.cpu(), value) < 2e-6 and maxabs(j.cpu(), jac) < 5e-6
+    both = nhwc(torch.cat([jm, logits, torch.zeros(B, 1, 58, 58)], 1))              # stacked [jac 60 | kp 15 | pad] heads
+    v, j = ops.kp_head(both[..., 60:75], both[..., :60], K, 0.1)
+    assert maxabs(v.cpu(), value) < 2e-6 and maxabs(j.cpu(), jac) < 5e-6
 
 
 def test_sparse_motion_and_mask_deformation(ops):
@@ -314,8 +317,11 @@ def test_sparse_motion_and_mask_deformation(ops):
     ml = rnd("ml", (B, 16, 64, 64)) * 2
     mask = torch.softmax(ml, 1)
     deformation = (sparse.permute(0, 1, 4, 2, 3) * mask.unsqueeze(2)).sum(1).permute(0, 2, 3, 1)
-    d, m = ops.mask_deformation(nhwc(ml), sp, want_mask=True)
+    d, m, _ = ops.mask_deformation(nhwc(ml), sp, want_mask=True)
     assert maxabs(d.cpu(), deformation) < 2e-6 and maxabs(nchw(m), mask) < 1e-6
+    ml17 = torch.cat([ml, rnd("mlocc", (B, 1, 64, 64))], 1)                      # stacked mask + occlusion logits
+    d, _, occ = ops.mask_deformation(nhwc(ml17), sp, K1=16, fused_occ=True)
+    assert maxabs(d.cpu(), deformation) < 2e-6 and maxabs(occ.cpu(), torch.sigmoid(ml17[:, 16])) < 1e-6
 
 
 def test_flow_stage_kernels(ops):
