@@ -91,13 +91,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the HIP path)"
+    if os.environ.get("SMX_BENCH_ONE_DEVICE"):          # test knob: exercise the N>1 control flow on a 1-GPU box
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL on ROCm
+        backend = os.environ.get("SMX_BENCH_BACKEND", "nccl")                          # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from synergize_motion_appearance_amd import ops, driver
     from synergize_motion_appearance_amd.synth import synth_clip

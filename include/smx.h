@@ -79,6 +79,16 @@ typedef struct smx_gemm_desc {
 
 int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream);
 
+/* Fused Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 convolutions (same call sites as above for
+ * the eligible layers: ResBlock / Upsample / SFT / FFN / RefineFlow 3x3 convs): 2.25x fewer MFMA
+ * passes, fp32, input + output transforms fused (nothing transformed touches HBM).
+ * x NHWC [B][H][W][lda] (or [B][H/2][W/2][lda] with up2: virtual nearest x2 upsampling),
+ * u_packed = G g G^T in fragment order [16][ceil(Cout/32)][Cin/8][64][4] (host: ops.Conv.winograd_u),
+ * y NHWC [B][H][W][ldc]; act/bias/res as in smx_gemm_conv_f32.  H%8==0, W%16==0, Cin%32==0. */
+int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
+                             const float* res, int ldres, float* y, int ldc, int B, int H, int W,
+                             int Cin, int Cout, int up2, int act, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * GroupNorm(32 groups, eps) [+ swish] on NHWC.   normalize/swish archs/vqgan_arch.py:14-20.
  * Two launches inside: per-(b,chunk,c) partial moments -> per-(b,c) scale/shift -> apply.

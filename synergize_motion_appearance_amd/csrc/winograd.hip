@@ -1,0 +1,210 @@
+// Fused Winograd F(2x2,3x3) convolution for gfx950 (fp32, v_mfma_f32_32x32x2_f32).
+//
+// 3x3 / stride 1 / pad 1 convolutions are ~85% of the path's GEMM flops.
+// Y = A^T [ (G g G^T) . (B^T d B) ] A needs 16 multiplies per 2x2 output tile and channel instead
+// of 36: 2.25x fewer MFMA passes than the direct implicit GEMM, at fp32 accuracy (transform
+// coefficients are 0, +-1, +-1/2).  Everything is fused -- no transformed tensor touches HBM:
+//
+//   * a block owns 32 output tiles (4x8 tiles = 8x16 output pixels of one image) x 64 output
+//     channels and ALL 16 Winograd frequencies; 8 waves = 4 frequency rows i x 2 N-halves;
+//   * per 32-channel slice the raw 10x18-pixel input region is staged ONCE, coalesced, into LDS
+//     (double buffered, one barrier per slice = 64 MFMAs per wave per barrier);
+//   * the input transform is wave-private and register-resident: lane l owns tile (l&31) and
+//     channels 4*(l>>5)+0..3 of an 8-channel step -- exactly its MFMA A fragment -- reads the two
+//     patch rows its frequency row needs (B^T row i has two non-zeros) with ds_read_b128 and
+//     forms V[i][0..3] with 8 float4 add/subs; no transpose, no second LDS trip;
+//   * U = G g G^T is precomputed at weight-pack time and stored fragment-ordered
+//     ([f][n/32][c/8][lane][4]), so a wave's B fragment is one fully coalesced 1 KiB load;
+//   * epilogue: Z_i = M_i. A (in registers), cross-frequency-row sum through LDS, then bias /
+//     activation / residual and coalesced NHWC stores.
+// Optional virtual nearest-x2 upsampling of the input (Upsample blocks) is folded into the region
+// loader.  Replaces the same reference call sites as smx_gemm_conv_f32 for eligible layers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "smx.h"
+#include "smx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int RH = 10, RW = 18, RPIX = RH * RW;     // staged input region (pixels)
+constexpr int RLD = 36;                             // floats per region pixel in LDS (32 + 4 pad)
+constexpr int NTHR = 512;
+
+struct WP {
+  const float* x; const float* u; const float* bias; const float* res; float* y;
+  int lda, ldc, ldres;
+  int B, H, W, Cin, Cout, up2, act;
+  int tiles_y, tiles_x;          // blocks per image along y / x
+  int n32;                       // ceil(Cout/32) (U is packed for n32*32 rows)
+};
+
+__device__ __forceinline__ float w_act(float v, int act) {
+  switch (act) {
+    case SMX_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SMX_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
+    case SMX_ACT_SWISH: return v / (1.f + expf(-v));
+    case SMX_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case SMX_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+__global__ __launch_bounds__(NTHR, 4) void winograd_kernel(WP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2][RPIX][RLD] (reused by the epilogue)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = wave >> 1, nh = wave & 1;                          // frequency row, N half
+  const int hh = lane >> 5, t = lane & 31, tr = t >> 3, tc = t & 7;
+  // block -> (image, tile-block y, tile-block x), N block
+  int bid = blockIdx.x;
+  const int bx = bid % p.tiles_x; bid /= p.tiles_x;
+  const int by = bid % p.tiles_y; const int img = bid / p.tiles_y;
+  const int nblk = blockIdx.y;
+  const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
+  const float* __restrict__ X = p.x + (long long)img * Hs * Ws * p.lda;
+
+  // ---- region staging: RPIX x 8 float4 per 32-channel slice, NTHR threads -> 3 items max ----
+  constexpr int NIT = (RPIX * 8 + NTHR - 1) / NTHR;
+  int goff[NIT]; int loff[NIT]; bool gok[NIT], lok[NIT];     // element offsets fit 32 bits (checked on the host)
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int item = tid + NTHR * k;
+    lok[k] = item < RPIX * 8;
+    const int px = item >> 3, c4 = item & 7;
+    const int ry = px / RW, rx = px - ry * RW;
+    int iy = by * 8 - 1 + ry, ix = bx * 16 - 1 + rx;
+    gok[k] = lok[k] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    if (p.up2) { iy >>= 1; ix >>= 1; }
+    goff[k] = (iy * Ws + ix) * p.lda + c4 * 4;
+    loff[k] = px * RLD + c4 * 4;
+  }
+  float4 stage[NIT];
+  auto load_region = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gok[k]) v = *reinterpret_cast<const float4*>(X + goff[k] + c0);
+      stage[k] = v;
+    }
+  };
+  auto store_region = [&](int buf) {
+    float* rb = smem + buf * RPIX * RLD;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) if (lok[k]) *reinterpret_cast<float4*>(rb + loff[k]) = stage[k];
+  };
+
+  // which two patch rows frequency row fi needs: B^T rows (0:[d0-d2] 1:[d1+d2] 2:[d2-d1] 3:[d1-d3])
+  const int ra = (fi == 0) ? 0 : ((fi == 2) ? 2 : 1);
+  const int rb_ = (fi == 0) ? 2 : ((fi == 1) ? 2 : ((fi == 2) ? 1 : 3));
+  const bool plus = (fi == 1);
+  const int pa = ((2 * tr + ra) * RW + 2 * tc) * RLD + hh * 4;      // patch row a, col 0, this lane's k chunk
+  const int pb = ((2 * tr + rb_) * RW + 2 * tc) * RLD + hh * 4;
+
+  // U fragments: [f][n32][Cin/8][64 lanes][4]
+  const int nt = nblk * 2 + nh;                                     // 32-wide N tile of this wave
+  const bool n_live = nt < p.n32;
+  const int cs8 = p.Cin >> 3;
+  const float* __restrict__ U = p.u + (((long long)(fi * 4) * p.n32 + nt) * cs8) * 256 + lane * 4;
+  const long long ufs = (long long)p.n32 * cs8 * 256;              // stride between frequencies
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int nsl = p.Cin >> 5;
+  load_region(0); store_region(0);
+  __syncthreads();
+  for (int s = 0; s < nsl; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsl) load_region((s + 1) * 32);
+    const float* rb = smem + buf * RPIX * RLD;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      // this step's U fragments: one coalesced 1 KiB load per frequency, issued before the LDS
+      // reads + transform so its latency overlaps them (other resident waves cover the rest)
+      const int step = s * 4 + sub;
+      float4 ucur[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ucur[j] = n_live ? *reinterpret_cast<const float4*>(U + j * ufs + (long long)step * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // input transform for frequency row fi, this lane's (tile, 4 channels)
+      float4 tt[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + sub * 8);
+        const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + sub * 8);
+        tt[b] = plus ? f4add(da, db) : f4sub(da, db);
+      }
+      float4 v[4];
+      v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ucur[j].x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ucur[j].y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ucur[j].z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ucur[j].w, acc[j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsl) store_region(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: Y = A^T M A.  In-register: Z_i[q] = sum_j M[i][j] A[j][q] ------------------
+  //   A^T = [[1,1,1,0],[0,1,-1,-1]]  =>  Z[0] = M0+M1+M2 ;  Z[1] = M1-M2-M3
+  // Cross-row: Y[0][q] = Z_0+Z_1+Z_2 ; Y[1][q] = Z_1-Z_2-Z_3  (via LDS zb[4][32 tiles][64 n])
+  float* zb = smem;
+  float* __restrict__ Yp = p.y;
+  const float* __restrict__ Rp = p.res;
+  for (int q = 0; q < 2; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;              // tile index within the block
+      const float z = q == 0 ? (acc[0][r] + acc[1][r] + acc[2][r]) : (acc[1][r] - acc[2][r] - acc[3][r]);
+      zb[(fi * 32 + row) * 64 + nh * 32 + t] = z;
+    }
+    __syncthreads();
+    // 32 tiles x 64 n = 2048 pairs / 512 threads
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pair = tid + NTHR * k;
+      const int tile = pair >> 6, nl = pair & 63;
+      const int n = nblk * 64 + nl;
+      if (n >= p.Cout) continue;
+      const float z0 = zb[(0 * 32 + tile) * 64 + nl], z1 = zb[(1 * 32 + tile) * 64 + nl];
+      const float z2 = zb[(2 * 32 + tile) * 64 + nl], z3 = zb[(3 * 32 + tile) * 64 + nl];
+      const float bn = p.bias ? p.bias[n] : 0.f;
+      const int oy = by * 8 + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7) + q;
+      const long long pix0 = ((long long)img * p.H + oy) * p.W + ox;
+      float y0 = w_act(z0 + z1 + z2 + bn, p.act), y1 = w_act(z1 - z2 - z3 + bn, p.act);
+      if (Rp) { y0 += Rp[pix0 * p.ldres + n]; y1 += Rp[(pix0 + p.W) * p.ldres + n]; }
+      Yp[pix0 * p.ldc + n] = y0;
+      Yp[(pix0 + p.W) * p.ldc + n] = y1;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
+                                        const float* res, int ldres, float* y, int ldc, int B, int H, int W,
+                                        int Cin, int Cout, int up2, int act, void* stream) {
+  if (!x || !u_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0) return SMX_EINVAL;
+  if (H % 8 != 0 || W % 16 != 0 || Cin % 32 != 0 || lda % 4 != 0 || lda < Cin || ldc < Cout) return SMX_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)u_packed & 15) || (res && ldres < Cout)) return SMX_EINVAL;
+  WP p;
+  p.x = x; p.u = u_packed; p.bias = bias; p.res = res; p.y = y; p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
+  p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32;
+  const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
+  if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
+  const size_t lds = (size_t)2 * RPIX * RLD * sizeof(float);       // 51,840 B (>= epilogue's 32 KiB)
+  hipLaunchKernelGGL(winograd_kernel, dim3((unsigned)blocks, (Cout + 63) / 64), dim3(NTHR), lds, (hipStream_t)stream, p);
+  return smx_launch_status();
+}

@@ -74,12 +74,32 @@ def _pix(t, name="tensor"):
     return t.data_ptr(), int(ld)
 
 
+import os as _os
+
+WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
+
+
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
+        self._u = None
+
+    def winograd_u(self):
+        """U = G g G^T for F(2x2,3x3), fragment-ordered [16][ceil(Cout/32)][Cin/8][64 lanes][4]
+        (lane l <-> row n = 32*nt + (l&31), channels 8s + 4*(l>>5) + 0..3); built once per layer."""
+        if self._u is None:
+            g = self.w.view(self.cout, 3, 3, self.cin).double()
+            G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=g.device)
+            U = torch.einsum("ia,nabc,jb->ijnc", G, g, G).float()                     # [4,4,Cout,Cin]
+            n32 = (self.cout + 31) // 32
+            Up = torch.zeros((16, n32 * 32, self.cin), device=g.device, dtype=torch.float32)
+            Up[:, :self.cout] = U.reshape(16, self.cout, self.cin)
+            Up = Up.view(16, n32, 32, self.cin // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
+            self._u = Up.view(-1)
+        return self._u
 
     @staticmethod
     def from_torch(weight, bias):
@@ -133,6 +153,15 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     a_ptr, lda = _pix(x, "conv input")
     c_ptr, ldc = _pix(out, "conv output")
     r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
+    if (WINOGRAD and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s
+            and (Ho, Wo) == (He, We) and Cin % 32 == 0 and cv.cout >= 32 and He % 8 == 0 and We % 16 == 0
+            and lda % 4 == 0 and a_ptr % 16 == 0):
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3,
+                "wino": 1} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
+                       None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,
+                       int(up2), act, _stream()), "smx_winograd_conv3x3_f32")
+        return out
     M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
     ksplit, ws = 1, None
     if not d2s and K >= 1024:

@@ -91,6 +91,36 @@ def test_conv(ops, case):
     assert maxabs(nchw(y), ref) < 2e-5, tag
 
 
+WINO_CASES = [(2, 64, 64, 32, False, 0, False), (1, 128, 128, 64, False, 3, True), (2, 256, 512, 32, False, 4, False),
+              (1, 128, 64, 64, False, 0, True), (2, 64, 64, 16, True, 0, False), (1, 160, 126, 32, False, 1, False),
+              (1, 128, 96, 32, False, 1, False), (3, 32, 32, 32, False, 2, True), (1, 64, 64, 256, False, 0, True)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_H{c[3]}_up{int(c[4])}_act{c[5]}_res{int(c[6])}" for c in WINO_CASES])
+def test_winograd_conv3x3(ops, case):
+    """fused Winograd F(2x2,3x3) == F.conv2d (3x3, s1, p1); also through channel-slice operands."""
+    B, Cin, Cout, H, up2, act, with_res = case
+    x = rnd(f"wx{case}", (B, Cin, H, H))
+    w = rnd(f"ww{case}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd(f"wb{case}", (Cout,), 0.1)
+    xe = F.interpolate(x, scale_factor=2.0, mode="nearest") if up2 else x
+    ref = F.conv2d(xe, w, b, padding=1)
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: O.swish, 4: F.gelu}[act](ref)
+    r = rnd(f"wr{case}", tuple(ref.shape)) if with_res else None
+    if with_res:
+        ref = ref + r
+    assert ops.WINOGRAD
+    xin = torch.zeros((B, H, H, Cin + 32), device="cuda")
+    xin[..., 32:] = nhwc(x)
+    out = torch.full((B, ref.shape[2], ref.shape[3], Cout + 8), 5.0, device="cuda")
+    ops.conv(xin[..., 32:], ops.Conv.from_torch(w.cuda(), b.cuda()), out=out[..., 4:4 + Cout], up2=up2, act=act,
+             res=None if r is None else nhwc(r))
+    assert maxabs(nchw(out[..., 4:4 + Cout]), ref) < 5e-5
+    assert float(out[..., :4].min()) == 5.0 and float(out[..., 4 + Cout:].max()) == 5.0
+    direct = ops.conv(xin[..., 32:], ops.Conv.from_torch(w.cuda(), b.cuda()), up2=up2, act=act, res=None if r is None else nhwc(r), tile=5)
+    assert maxabs(nchw(direct), ref) < 3e-5
+
+
 def test_conv_residual_and_slices(ops):
     """output into a channel slice of a concat buffer, input from a slice, fused residual."""
     x = rnd("sx", (2, 96, 32, 32))
