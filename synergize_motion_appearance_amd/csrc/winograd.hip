@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include "smx.h"
 #include "smx_common.h"
 
@@ -29,9 +30,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int RH = 10, RW = 18, RPIX = RH * RW;     // staged input region (pixels)
+constexpr int RH = 10, RW = 18;                     // staged input region (pixels)
+constexpr int RPMAX = 19, RPIX = RH * RPMAX;              // LDS row pitch 19 px: with the chunk swizzle below every
+                                                    // ds_read_b128 16-lane group hits 16 distinct 4-bank slots
 constexpr int RLD = 36;                             // floats per region pixel in LDS (32 + 4 pad)
-constexpr int NTHR = 512;
 
 struct WP {
   const float* x; const float* u; const float* bias; const float* res; float* y;
@@ -55,11 +57,21 @@ __device__ __forceinline__ float w_act(float v, int act) {
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-__global__ __launch_bounds__(NTHR, 4) void winograd_kernel(WP p) {
+// NW = 32-wide N tiles per block (waves = 4 frequency rows x NW).  NW=1: 4 waves, <=168 VGPRs, 3 blocks/CU;
+// NW=2: 8 waves, <=128 VGPRs, 2 blocks/CU.
+template <bool SWZ, int NW>
+__global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP p) {
+  constexpr int RP = SWZ ? 19 : 18;
+  constexpr int NTHR = 256 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [2][RPIX][RLD] (reused by the epilogue)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fi = wave >> 1, nh = wave & 1;                          // frequency row, N half
-  const int hh = lane >> 5, t = lane & 31, tr = t >> 3, tc = t & 7;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform -> SGPR addressing below
+  const int fi = wave / NW, nh = wave % NW;                         // frequency row, N tile within the block
+  // lane -> tile map chosen so that each hardware ds_read_b128 lane group ({0-3,12-15,20-27},
+  // {4-11,16-19,28-31}) holds two complete tile rows: tile = 16*parity(q) + 4*(q>>1) + (t&3), q = t>>2
+  const int hh = lane >> 5, t = lane & 31;
+  const int tile_of_lane = SWZ ? 16 * (__popc((unsigned)(t >> 2)) & 1) + 4 * (t >> 3) + (t & 3) : t;
+  const int tr = tile_of_lane >> 3, tc = tile_of_lane & 7;
   // block -> (image, tile-block y, tile-block x), N block
   int bid = blockIdx.x;
   const int bx = bid % p.tiles_x; bid /= p.tiles_x;
@@ -69,19 +81,19 @@ __global__ __launch_bounds__(NTHR, 4) void winograd_kernel(WP p) {
   const float* __restrict__ X = p.x + (long long)img * Hs * Ws * p.lda;
 
   // ---- region staging: RPIX x 8 float4 per 32-channel slice, NTHR threads -> 3 items max ----
-  constexpr int NIT = (RPIX * 8 + NTHR - 1) / NTHR;
+  constexpr int NIT = (RH * RW * 8 + NTHR - 1) / NTHR;
   int goff[NIT]; int loff[NIT]; bool gok[NIT], lok[NIT];     // element offsets fit 32 bits (checked on the host)
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
     const int item = tid + NTHR * k;
-    lok[k] = item < RPIX * 8;
+    lok[k] = item < RH * RW * 8;
     const int px = item >> 3, c4 = item & 7;
     const int ry = px / RW, rx = px - ry * RW;
     int iy = by * 8 - 1 + ry, ix = bx * 16 - 1 + rx;
     gok[k] = lok[k] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     if (p.up2) { iy >>= 1; ix >>= 1; }
     goff[k] = (iy * Ws + ix) * p.lda + c4 * 4;
-    loff[k] = px * RLD + c4 * 4;
+    loff[k] = (ry * RP + rx) * RLD + ((SWZ ? (c4 ^ ((rx >> 1) & 1)) : c4) * 4);      // XOR swizzle of the 16-B chunk
   }
   float4 stage[NIT];
   auto load_region = [&](int c0) {
@@ -102,15 +114,18 @@ __global__ __launch_bounds__(NTHR, 4) void winograd_kernel(WP p) {
   const int ra = (fi == 0) ? 0 : ((fi == 2) ? 2 : 1);
   const int rb_ = (fi == 0) ? 2 : ((fi == 1) ? 2 : ((fi == 2) ? 1 : 3));
   const bool plus = (fi == 1);
-  const int pa = ((2 * tr + ra) * RW + 2 * tc) * RLD + hh * 4;      // patch row a, col 0, this lane's k chunk
-  const int pb = ((2 * tr + rb_) * RW + 2 * tc) * RLD + hh * 4;
+  const int pa = ((2 * tr + ra) * RP + 2 * tc) * RLD;               // patch row a, col 0 (chunk added per read)
+  const int pb = ((2 * tr + rb_) * RP + 2 * tc) * RLD;
+  const int par = SWZ ? (tc & 1) : 0;                                           // swizzle parity of patch columns 0,1 (2,3: flipped)
 
-  // U fragments: [f][n32][Cin/8][64 lanes][4]
-  const int nt = nblk * 2 + nh;                                     // 32-wide N tile of this wave
-  const bool n_live = nt < p.n32;
+  // U fragments: [f][n32][Cin/8][64 lanes][4] (+ one padded step at the end so the 2-unit prefetch
+  // never needs a predicate); wave-uniform bases (SGPR) + lane*16 B
+  const int nt = nblk * NW + nh;                                    // 32-wide N tile of this wave
   const int cs8 = p.Cin >> 3;
-  const float* __restrict__ U = p.u + (((long long)(fi * 4) * p.n32 + nt) * cs8) * 256 + lane * 4;
-  const long long ufs = (long long)p.n32 * cs8 * 256;              // stride between frequencies
+  const int nt_c = nt < p.n32 ? nt : p.n32 - 1;                     // dead N tile (NW=2 only): read a live one, never stored
+  const float* __restrict__ U = p.u + (((long long)(fi * 4) * p.n32 + nt_c) * cs8) * 256;
+  const int ufs = p.n32 * cs8 * 256;                               // stride between frequencies (floats)
+  const int lane4 = lane * 4;
 
   f32x16 acc[4];
 #pragma unroll
@@ -119,36 +134,43 @@ __global__ __launch_bounds__(NTHR, 4) void winograd_kernel(WP p) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int nsl = p.Cin >> 5;
+  const float sgn = plus ? 1.f : -1.f;
   load_region(0); store_region(0);
+  // U ring: slot j holds the fragment of the unit with frequency j; prefetch distance = 2 units
+  // (= 8 MFMAs of this wave, ~4x that in wall time with 4 waves per SIMD) hides the L2 latency.
+  float4 ur[4];
+  auto uload = [&](int unit) -> float4 {
+    return *reinterpret_cast<const float4*>(U + ((unit & 3) * ufs + (unit >> 2) * 256) + lane4);
+  };
+  ur[0] = uload(0); ur[1] = uload(1);
   __syncthreads();
   for (int s = 0; s < nsl; ++s) {
     const int buf = s & 1;
     if (s + 1 < nsl) load_region((s + 1) * 32);
     const float* rb = smem + buf * RPIX * RLD;
-#pragma unroll
+#pragma unroll 1
     for (int sub = 0; sub < 4; ++sub) {
-      // this step's U fragments: one coalesced 1 KiB load per frequency, issued before the LDS
-      // reads + transform so its latency overlaps them (other resident waves cover the rest)
-      const int step = s * 4 + sub;
-      float4 ucur[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ucur[j] = n_live ? *reinterpret_cast<const float4*>(U + j * ufs + (long long)step * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-      // input transform for frequency row fi, this lane's (tile, 4 channels)
-      float4 tt[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + sub * 8);
-        const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + sub * 8);
-        tt[b] = plus ? f4add(da, db) : f4sub(da, db);
-      }
+      // input transform for frequency row fi, this lane's (tile, 4 channels): t_b = d[ra][b] +- d[rb][b]
       float4 v[4];
-      v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+      {
+        float4 tt[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int ch = (SWZ ? ((2 * sub + hh) ^ (par ^ (b >> 1))) : (2 * sub + hh)) * 4;
+          const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + ch);
+          const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + ch);
+          tt[b] = make_float4(fmaf(sgn, db.x, da.x), fmaf(sgn, db.y, da.y), fmaf(sgn, db.z, da.z), fmaf(sgn, db.w, da.w));
+        }
+        v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+      }
+      const int unit0 = (s * 4 + sub) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ucur[j].x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ucur[j].y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ucur[j].z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ucur[j].w, acc[j], 0, 0, 0);
+        ur[(j + 2) & 3] = uload(unit0 + j + 2);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[j].x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[j].y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[j].z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[j].w, acc[j], 0, 0, 0);
       }
     }
     if (s + 1 < nsl) store_region(buf ^ 1);
@@ -165,20 +187,22 @@ __global__ __launch_bounds__(NTHR, 4) void winograd_kernel(WP p) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;              // tile index within the block
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;               // MFMA row = lane that supplied the A row
+      const int row = SWZ ? 16 * (__popc((unsigned)(rl >> 2)) & 1) + 4 * (rl >> 3) + (rl & 3) : rl;   // -> its tile
       const float z = q == 0 ? (acc[0][r] + acc[1][r] + acc[2][r]) : (acc[1][r] - acc[2][r] - acc[3][r]);
-      zb[(fi * 32 + row) * 64 + nh * 32 + t] = z;
+      zb[(fi * 32 + row) * (32 * NW) + nh * 32 + t] = z;
     }
     __syncthreads();
-    // 32 tiles x 64 n = 2048 pairs / 512 threads
+    // 32 tiles x 32*NW n pairs / NTHR threads = 4 per thread
+    constexpr int NB = 32 * NW;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int pair = tid + NTHR * k;
-      const int tile = pair >> 6, nl = pair & 63;
-      const int n = nblk * 64 + nl;
+      const int tile = pair / NB, nl = pair % NB;
+      const int n = nblk * NB + nl;
       if (n >= p.Cout) continue;
-      const float z0 = zb[(0 * 32 + tile) * 64 + nl], z1 = zb[(1 * 32 + tile) * 64 + nl];
-      const float z2 = zb[(2 * 32 + tile) * 64 + nl], z3 = zb[(3 * 32 + tile) * 64 + nl];
+      const float z0 = zb[(0 * 32 + tile) * NB + nl], z1 = zb[(1 * 32 + tile) * NB + nl];
+      const float z2 = zb[(2 * 32 + tile) * NB + nl], z3 = zb[(3 * 32 + tile) * NB + nl];
       const float bn = p.bias ? p.bias[n] : 0.f;
       const int oy = by * 8 + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7) + q;
       const long long pix0 = ((long long)img * p.H + oy) * p.W + ox;
@@ -204,7 +228,22 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32;
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
-  const size_t lds = (size_t)2 * RPIX * RLD * sizeof(float);       // 51,840 B (>= epilogue's 32 KiB)
-  hipLaunchKernelGGL(winograd_kernel, dim3((unsigned)blocks, (Cout + 63) / 64), dim3(NTHR), lds, (hipStream_t)stream, p);
+  if (16LL * ((Cout + 31) / 32) * (Cin / 8) * 256 > 2147483647LL) return SMX_EINVAL;
+  const size_t lds = (size_t)2 * RPIX * RLD * sizeof(float);       // 54,720 B (>= the epilogue 32 KiB)
+  // measured (profiles/r01_e_winograd_variants.txt): 8-wave blocks (N=64) win once there are >= 1024 of
+  // them, 4-wave blocks (N=32, 3 per CU) otherwise; the conflict-free LDS swizzle is neutral (LDS is
+  // not the limiter) and stays off by default.
+  const int swz = getenv("SMX_WINO_SWZ") ? atoi(getenv("SMX_WINO_SWZ")) : 0;
+  const int nw = getenv("SMX_WINO_NW") ? atoi(getenv("SMX_WINO_NW")) : ((Cout % 64 == 0 && blocks * (Cout / 64) >= 1024) ? 2 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (nw == 2) {
+    dim3 grid((unsigned)blocks, (Cout + 63) / 64);
+    if (swz) hipLaunchKernelGGL((winograd_kernel<true, 2>), grid, dim3(512), lds, st, p);
+    else hipLaunchKernelGGL((winograd_kernel<false, 2>), grid, dim3(512), lds, st, p);
+  } else {
+    dim3 grid((unsigned)blocks, (Cout + 31) / 32);
+    if (swz) hipLaunchKernelGGL((winograd_kernel<true, 1>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((winograd_kernel<false, 1>), grid, dim3(256), lds, st, p);
+  }
   return smx_launch_status();
 }
