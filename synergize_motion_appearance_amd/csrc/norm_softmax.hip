@@ -42,27 +42,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   }
 }
 
-// pass 2 -- per (b): reduce chunks (double), per-group mean/rstd -> per-channel scale/shift
-__global__ void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ ss, int HW, int C,
-                                   int groups, int nch, float eps) {
-  extern __shared__ double dred[];                     // [C][2]
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double s = 0.0, q = 0.0;
-    const float* pp = part + ((long long)b * nch * C + c) * 2;
-    for (int t = 0; t < nch; ++t) { s += pp[(long long)t * C * 2]; q += pp[(long long)t * C * 2 + 1]; }
-    dred[2 * c] = s; dred[2 * c + 1] = q;
+// pass 2 -- one wave per (b, group): reduce the chunk partials in double with a wavefront
+// shuffle tree, mean/rstd -> per-channel scale/shift
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ ss, int HW, int C,
+                                                         int groups, int nch, float eps) {
+  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+  const int cpg = C / groups, items = nch * cpg;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < items; i += 64) {
+    const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
+    const float* pp = part + (((long long)b * nch + chunk) * C + c) * 2;
+    s += pp[0]; q += pp[1];
   }
-  __syncthreads();
-  const int cpg = C / groups;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    double s = 0.0, q = 0.0;
-    for (int j = 0; j < cpg; ++j) { s += dred[2 * (g * cpg + j)]; q += dred[2 * (g * cpg + j) + 1]; }
-    const double n = (double)HW * cpg, mean = s / n;
-    double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  const double n = (double)HW * cpg, mean = s / n;
+  double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int j = threadIdx.x; j < cpg; j += 64) {
+    const int c = g * cpg + j;
     const float sc = rstd * gamma[c];
     ss[((long long)b * C + c) * 2] = sc;
     ss[((long long)b * C + c) * 2 + 1] = beta[c] - (float)mean * sc;
@@ -176,8 +175,7 @@ extern "C" int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float
   float* part = ws; float* ss = ws + (int64_t)B * nch * C * 2;
   const int rows = 256 / (C / 4);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, part, HW, C, ppc, nch);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(C < 64 ? 64 : (C > 256 ? 256 : C)), (size_t)C * 2 * sizeof(double), st,
-                     part, gamma, beta, ss, HW, C, groups, nch, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, gamma, beta, ss, HW, C, groups, nch, eps);
   const long long total4 = (long long)B * HW * (C / 4);
   int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, ss, total4, HW, C, swish);

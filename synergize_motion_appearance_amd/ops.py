@@ -154,10 +154,10 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     c_ptr, ldc = _pix(out, "conv output")
     r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
     if (WINOGRAD and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s
-            and (Ho, Wo) == (He, We) and Cin % 32 == 0 and cv.cout >= 32 and He % 8 == 0 and We % 16 == 0
+            and (Ho, Wo) == (He, We) and Cin % 32 == 0 and He % 8 == 0 and We % 16 == 0
             and lda % 4 == 0 and a_ptr % 16 == 0):
-        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3,
-                "wino": 1} if _PROFILE is not None else None
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * Ho * Wo * cv.cout * 4 * Cin,
+                "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1} if _PROFILE is not None else None
         L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                        None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,
                        int(up2), act, _stream()), "smx_winograd_conv3x3_f32")
