@@ -144,34 +144,40 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   };
   ur[0] = uload(0); ur[1] = uload(1);
   __syncthreads();
+  // input transform of 8-channel step `sub` for frequency row fi, this lane's (tile, 4 channels):
+  // t_b = d[ra][b] +- d[rb][b];  V[i][0..3] = t0-t2, t1+t2, t2-t1, t1-t3
+  auto transform = [&](const float* rb, int sub, float4 (&v)[4]) {
+    float4 tt[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ch = (SWZ ? ((2 * sub + hh) ^ (par ^ (b >> 1))) : (2 * sub + hh)) * 4;
+      const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + ch);
+      const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + ch);
+      tt[b] = make_float4(fmaf(sgn, db.x, da.x), fmaf(sgn, db.y, da.y), fmaf(sgn, db.z, da.z), fmaf(sgn, db.w, da.w));
+    }
+    v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+  };
+  auto mfma16 = [&](const float4 (&v)[4], int unit0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ur[(j + 2) & 3] = uload(unit0 + j + 2);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[j].x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[j].y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[j].z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[j].w, acc[j], 0, 0, 0);
+    }
+  };
   for (int s = 0; s < nsl; ++s) {
     const int buf = s & 1;
     if (s + 1 < nsl) load_region((s + 1) * 32);
     const float* rb = smem + buf * RPIX * RLD;
+    // (a hand-unrolled variant that put the transform of step sub+1 in the same basic block as the
+    //  MFMAs of step sub measured 15-20% SLOWER under hipcc's scheduling -- kept simple.)
 #pragma unroll 1
     for (int sub = 0; sub < 4; ++sub) {
-      // input transform for frequency row fi, this lane's (tile, 4 channels): t_b = d[ra][b] +- d[rb][b]
       float4 v[4];
-      {
-        float4 tt[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int ch = (SWZ ? ((2 * sub + hh) ^ (par ^ (b >> 1))) : (2 * sub + hh)) * 4;
-          const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + ch);
-          const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + ch);
-          tt[b] = make_float4(fmaf(sgn, db.x, da.x), fmaf(sgn, db.y, da.y), fmaf(sgn, db.z, da.z), fmaf(sgn, db.w, da.w));
-        }
-        v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
-      }
-      const int unit0 = (s * 4 + sub) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ur[(j + 2) & 3] = uload(unit0 + j + 2);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[j].x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[j].y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[j].z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[j].w, acc[j], 0, 0, 0);
-      }
+      transform(rb, sub, v);
+      mfma16(v, (s * 4 + sub) * 4);
     }
     if (s + 1 < nsl) store_region(buf ^ 1);
     __syncthreads();
