@@ -8,6 +8,7 @@
 // with a wavefront shuffle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "smx.h"
 #include "smx_common.h"
 
@@ -22,63 +23,124 @@ __device__ __forceinline__ void ac_src(int o, int in, int out, int& i0, int& i1,
   l1 = fminf(fmaxf(real - i0, 0.f), 1.f); l0 = 1.f - l1;
 }
 
-template <int LPP>  // lanes per pixel = C/4 (power of two, <= 64)
+// LPP = lanes per pixel = C/4 (power of two, <= 64); PPT = pixels per thread.  A wave's life is a
+// dependent chain (flow taps -> shuffle -> 4 feature taps -> store), so one pixel per thread is
+// latency-bound (measured 3.6 TB/s at s=256); PPT independent pixels per thread put 4*PPT
+// feature loads in flight per lane.
+template <int LPP, int PPT>
 __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ feat, long long feat_bs,
                                                    const float* __restrict__ flow, const float* __restrict__ occ,
                                                    float* __restrict__ out, long long npix, int H, int W, int C,
-                                                   int Hf, int Wf) {
-  const long long gt = blockIdx.x * 256LL + threadIdx.x;
-  const long long pix = gt / LPP; const int sub = (int)(gt % LPP);
-  const bool live = pix < npix;
-  const long long pp = live ? pix : npix - 1;
-  const int HW = H * W; const int b = (int)(pp / HW); const int rem = (int)(pp - (long long)b * HW);
-  const int y = rem / W, x = rem - y * W;
-  float gx = 0.f, gy = 0.f, oc = 1.f;
-  if (sub == 0) {
+                                                   int Hf, int Wf, int chunks_per_img, int nframes) {
+  constexpr int PPB = 256 / LPP;                                     // pixels per block per pass
+  const int sub = threadIdx.x % LPP;
+  const int HW = H * W;
+  // Block order: each XCD (block b -> XCD b%8, private 4 MiB L2) gets a contiguous range of logical
+  // chunks, ordered (spatial chunk, frame) with the FRAME fastest: the B frames that warp the same
+  // broadcast source region run back to back on one L2, so the source features are fetched over
+  // the fabric once per region instead of once per frame (the source map alone is 4x an L2).
+  // (all pixel indices are 32-bit: 64-bit integer division is a ~150-instruction software routine)
+  int logical = blockIdx.x;
+  if (chunks_per_img > 0) {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int region = lin / nframes, fr = lin - region * nframes;
+    logical = fr * chunks_per_img + region;
+  }
+  const int pix0 = logical * PPB * PPT + threadIdx.x / LPP;
+  float gx[PPT], gy[PPT], oc[PPT]; int bb[PPT]; bool live[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int pix = pix0 + i * PPB;
+    live[i] = pix < (int)npix;
+    const int pp = live[i] ? pix : (int)npix - 1;
+    const int b = pp / HW; const int rem = pp - b * HW;
+    const int y = rem / W, x = rem - y * W;
+    bb[i] = b;
+    float fxv = 0.f, fyv = 0.f, ov = 1.f;
     const float* fb = flow + (long long)b * Hf * Wf * 2;
+    const float* ob = occ ? occ + (long long)b * Hf * Wf : nullptr;
     if (Hf == H && Wf == W) {
-      gx = fb[(y * Wf + x) * 2]; gy = fb[(y * Wf + x) * 2 + 1];
-      if (occ) oc = occ[(long long)b * Hf * Wf + y * Wf + x];
-    } else {
+      if (sub == 0) {
+        fxv = fb[(y * Wf + x) * 2]; fyv = fb[(y * Wf + x) * 2 + 1];
+        if (ob) ov = ob[y * Wf + x];
+      }
+    } else if (LPP >= 16) {
+      // lane-parallel flow / occlusion resize: lanes 0-3 of the pixel group fetch the 4 taps of
+      // flow.x, 4-7 of flow.y, 8-11 of the occlusion -- ONE load instruction for the 12 values
+      // instead of 12 serial scalar loads on one lane -- then a 4-lane shuffle reduction.
+      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+      ac_src(y, Hf, H, y0, y1, ly0, ly1); ac_src(x, Wf, W, x0, x1, lx0, lx1);
+      const int tapi = sub & 3, what = sub >> 2;                     // tap (00,01,10,11), quantity (fx, fy, occ)
+      const int ty_ = (tapi >> 1) ? y1 : y0, tx_ = (tapi & 1) ? x1 : x0;
+      const float wt = ((tapi >> 1) ? ly1 : ly0) * ((tapi & 1) ? lx1 : lx0);
+      float val = 0.f;
+      if (what < 2) val = fb[(ty_ * Wf + tx_) * 2 + what];
+      else if (what == 2 && ob) val = ob[ty_ * Wf + tx_];
+      // ATen's association: ly0*(lx0*v00 + lx1*v01) + ly1*(lx0*v10 + lx1*v11)
+      float part = ((tapi & 1) ? lx1 : lx0) * val;
+      part += __shfl_xor(part, 1, 64);                               // row sums (lx0*v_0 + lx1*v_1)
+      part *= (tapi >> 1) ? ly1 : ly0;
+      part += __shfl_xor(part, 2, 64);
+      (void)wt;
+      fxv = part;                                                    // lanes 0-3: gx, 4-7: gy, 8-11: occ
+    } else if (sub == 0) {
       int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
       ac_src(y, Hf, H, y0, y1, ly0, ly1); ac_src(x, Wf, W, x0, x1, lx0, lx1);
       const float2 f00 = *reinterpret_cast<const float2*>(fb + (y0 * Wf + x0) * 2);
       const float2 f01 = *reinterpret_cast<const float2*>(fb + (y0 * Wf + x1) * 2);
       const float2 f10 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x0) * 2);
       const float2 f11 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x1) * 2);
-      gx = ly0 * (lx0 * f00.x + lx1 * f01.x) + ly1 * (lx0 * f10.x + lx1 * f11.x);
-      gy = ly0 * (lx0 * f00.y + lx1 * f01.y) + ly1 * (lx0 * f10.y + lx1 * f11.y);
-      if (occ) {
-        const float* ob = occ + (long long)b * Hf * Wf;
-        oc = ly0 * (lx0 * ob[y0 * Wf + x0] + lx1 * ob[y0 * Wf + x1]) + ly1 * (lx0 * ob[y1 * Wf + x0] + lx1 * ob[y1 * Wf + x1]);
+      fxv = ly0 * (lx0 * f00.x + lx1 * f01.x) + ly1 * (lx0 * f10.x + lx1 * f11.x);
+      fyv = ly0 * (lx0 * f00.y + lx1 * f01.y) + ly1 * (lx0 * f10.y + lx1 * f11.y);
+      if (ob) ov = ly0 * (lx0 * ob[y0 * Wf + x0] + lx1 * ob[y0 * Wf + x1]) + ly1 * (lx0 * ob[y1 * Wf + x0] + lx1 * ob[y1 * Wf + x1]);
+    }
+    gx[i] = fxv; gy[i] = fyv; oc[i] = ov;
+  }
+  {
+    const int src = (threadIdx.x & 63) & ~(LPP - 1);
+    const bool par = LPP >= 16 && !(Hf == H && Wf == W);
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      if (par) {
+        const float g0 = __shfl(gx[i], src, 64), g1 = __shfl(gx[i], src + 4, 64), g2 = __shfl(gx[i], src + 8, 64);
+        gx[i] = g0; gy[i] = g1; oc[i] = occ ? g2 : 1.f;
+      } else if (LPP > 1) {
+        gx[i] = __shfl(gx[i], src, 64); gy[i] = __shfl(gy[i], src, 64); oc[i] = __shfl(oc[i], src, 64);
       }
     }
   }
-  if (LPP > 1) {
-    const int src = (threadIdx.x & 63) & ~(LPP - 1);
-    gx = __shfl(gx, src, 64); gy = __shfl(gy, src, 64); oc = __shfl(oc, src, 64);
-  }
-  if (!live) return;
-  // grid_sample, bilinear, zeros padding, align_corners=True
-  const float ix = ((gx + 1.f) / 2.f) * (W - 1), iy = ((gy + 1.f) / 2.f) * (H - 1);
-  const float fx = floorf(ix), fy = floorf(iy);
-  const int x0 = (int)fx, y0 = (int)fy;
-  const float tx = ix - fx, ty = iy - fy;
-  const float wnw = (1.f - tx) * (1.f - ty), wne = tx * (1.f - ty), wsw = (1.f - tx) * ty, wse = tx * ty;
-  const float* fbase = feat + (long long)b * feat_bs + sub * 4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto tap = [&](int yy, int xx, float w) {
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const float4 v = *reinterpret_cast<const float4*>(fbase + ((long long)yy * W + xx) * C);
-      acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+  // grid_sample, bilinear, zeros padding, align_corners=True: issue all 4*PPT taps, then blend
+  float4 v[PPT][4]; float w[PPT][4];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const float ix = ((gx[i] + 1.f) / 2.f) * (W - 1), iy = ((gy[i] + 1.f) / 2.f) * (H - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float tx = ix - fx, ty = iy - fy;
+    // NaN / huge coordinates: every comparison fails and all taps are skipped (zeros), as in ATen
+    const bool sane = ix > -2.f && ix < (float)W + 1.f && iy > -2.f && iy < (float)H + 1.f;
+    const int x0 = sane ? (int)fx : -4, y0 = sane ? (int)fy : -4;
+    w[i][0] = (1.f - tx) * (1.f - ty); w[i][1] = tx * (1.f - ty); w[i][2] = (1.f - tx) * ty; w[i][3] = tx * ty;
+    const float* fbase = feat + (long long)bb[i] * feat_bs + sub * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+      v[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live[i] && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        v[i][k] = *reinterpret_cast<const float4*>(fbase + ((long long)yy * W + xx) * C);
     }
-  };
-  // NaN / huge coordinates: the comparisons below fail and every tap is skipped (zeros), as in ATen
-  if (ix > -2.f && ix < (float)W + 1.f && iy > -2.f && iy < (float)H + 1.f) {
-    tap(y0, x0, wnw); tap(y0, x0 + 1, wne); tap(y0 + 1, x0, wsw); tap(y0 + 1, x0 + 1, wse);
   }
-  if (occ) { acc.x *= oc; acc.y *= oc; acc.z *= oc; acc.w *= oc; }
-  *reinterpret_cast<float4*>(out + pix * C + sub * 4) = acc;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    if (!live[i]) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc.x += v[i][k].x * w[i][k]; acc.y += v[i][k].y * w[i][k]; acc.z += v[i][k].z * w[i][k]; acc.w += v[i][k].w * w[i][k];
+    }
+    if (occ) { acc.x *= oc[i]; acc.y *= oc[i]; acc.z *= oc[i]; acc.w *= oc[i]; }
+    *reinterpret_cast<float4*>(out + (long long)(pix0 + i * PPB) * C + sub * 4) = acc;
+  }
 }
 
 __global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
@@ -138,9 +200,16 @@ extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float*
   const int lpp = C / 4;
   if (C % 4 != 0 || lpp < 1 || lpp > 64 || (lpp & (lpp - 1)) != 0) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const long long npix = (long long)B * H * W; const long long feat_bs = feat_batch == 1 ? 0 : (long long)H * W * C;
-  dim3 grid(smx_cdiv(npix * lpp, 256)), block(256);
-#define SMX_WARP(L) hipLaunchKernelGGL(warp_kernel<L>, grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf)
+  const long long npix = (long long)B * H * W;
+  if (npix * lpp > 2147483647LL) return SMX_EINVAL;
+  const long long feat_bs = feat_batch == 1 ? 0 : (long long)H * W * C;
+  // 4 pixels per thread once the launch is large (>= 8M lanes); small launches keep 1 for parallelism
+  const int ppt = (npix * lpp >= (8LL << 20)) ? 4 : 1;
+  dim3 grid(smx_cdiv(npix * lpp, 256 * ppt)), block(256);
+  const int chunk = 256 / lpp * ppt;                                // pixels per block
+  int cpi = ((H * W) % chunk == 0 && !getenv("SMX_WARP_NO_REORDER")) ? (H * W) / chunk : 0;
+#define SMX_WARP(L) do { if (ppt == 4) hipLaunchKernelGGL((warp_kernel<L, 4>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); \
+                         else hipLaunchKernelGGL((warp_kernel<L, 1>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); } while (0)
   switch (lpp) {
     case 1: SMX_WARP(1); break; case 2: SMX_WARP(2); break; case 4: SMX_WARP(4); break; case 8: SMX_WARP(8); break;
     case 16: SMX_WARP(16); break; case 32: SMX_WARP(32); break; default: SMX_WARP(64); break;
