@@ -7,8 +7,8 @@ A "step" is one pass of the per-frame hot path (keypoints -> relative-kp transfe
 motion -> warp / codebook compensation / decoder -> uint8 frames) over one batch of B
 synthetic 256x256 driving frames already resident in HBM; the source encoding is the
 frame-invariant cache (computed before the timed region, like the reference's weights).
-Workload = BASELINE.json configs[1]: 1 source + 300-frame driving clip, fp32 -> 15 steps
-of B=20 frames by default.  N>1: every rank owns its own contiguous block of frames (weak
+Workload = BASELINE.json configs[1]: 1 source + 300-frame driving clip, fp32 -> 10 steps
+of B=30 frames by default.  N>1: every rank owns its own contiguous block of frames (weak
 scaling: per-GPU work fixed), the source cache is broadcast once over RCCL inside the
 timed region; no other collective is on the data path.
 
@@ -77,9 +77,9 @@ def cpu_baseline(Pg, Pm, src, drv, budget_s=12.0, max_frames=12, threads=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=15)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=20, help="driving frames per step (frames in flight)")
+    ap.add_argument("--batch", type=int, default=30, help="driving frames per step (frames in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")

@@ -287,6 +287,44 @@ def test_warp_four_scales(ops, C, s):
     assert maxabs(nchw(y2), O.deform_input(feat.repeat(B, 1, 1, 1), flow)) < tol
 
 
+@pytest.mark.parametrize("C,s", [(64, 512), (128, 256), (128, 128), (256, 64)])
+def test_warp_config4_512_kernel_level(ops, C, s):
+    """BASELINE.json configs[3] (512x512: 4x flow + warp grid).  The reference itself raises at 512
+    (SURVEY.md section 8d), so parity is kernel-level: A7 with a 128x128 flow against the ATen semantics."""
+    B = 2
+    feat = F.interpolate(rnd(f"w5f{s}", (1, C, 8, 8)), size=(s, s), mode="bicubic", align_corners=True)
+    flow = O.make_coordinate_grid(128, 128, torch.float32)[None] + 0.2 * F.interpolate(
+        rnd(f"w5fl{s}", (B, 2, 6, 6)), size=(128, 128), mode="bicubic", align_corners=True).permute(0, 2, 3, 1)
+    occ = torch.sigmoid(rnd(f"w5o{s}", (B, 1, 128, 128)))
+    ref = O.occlude_input(O.deform_input(feat.repeat(B, 1, 1, 1), flow), occ)
+    y = ops.warp(nhwc(feat), flow.cuda(), occ.view(B, 128, 128).cuda())
+    assert maxabs(nchw(y), ref) < (5e-4 if s >= 256 else 5e-5)
+
+
+def test_sparse_motion_config4_128_grid(ops):
+    """configs[3]: A4-A6b stage on a 128x128 grid (512x512 input, scale 0.25)."""
+    from synergize_motion_appearance_amd.synth import synth_keypoints
+    B, K, G = 1, 15, 128
+    kps, kpd = synth_keypoints(B, seed=3)
+    src = F.interpolate(rnd("sm5_src", (1, 3, 16, 16)), size=(G, G), mode="bicubic", align_corners=True)
+    ident = O.make_coordinate_grid(G, G, torch.float32).view(1, 1, G, G, 2)
+    cg = ident - kpd["value"].view(B, K, 1, 1, 2)
+    jac = torch.matmul(kps["jacobian"], torch.inverse(kpd["jacobian"])).unsqueeze(-3).unsqueeze(-3)
+    d2s = torch.matmul(jac, cg.unsqueeze(-1)).squeeze(-1) + kps["value"].view(B, K, 1, 1, 2)
+    sparse = torch.cat([ident.repeat(B, 1, 1, 1, 1), d2s], 1)
+    deformed = F.grid_sample(src.repeat(K + 1, 1, 1, 1), sparse.view(K + 1, G, G, 2), align_corners=False).view(B, K + 1, 3, G, G)
+    heat = O.kp2gaussian(kpd["value"], G, G) - O.kp2gaussian(kps["value"], G, G)
+    hg = torch.empty((B, G, G, 64), device="cuda")
+    sp, dh = ops.sparse_motion(nhwc(src), kpd["value"].cuda(), kpd["jacobian"].reshape(B, K, 4).cuda(),
+                               kps["value"].cuda(), kps["jacobian"].reshape(B, K, 4).cuda(), hg, B, K)
+    got = hg.cpu().view(B, G, G, 16, 4).permute(0, 3, 4, 1, 2)
+    assert maxabs(sp.cpu(), sparse) < 2e-6 and maxabs(got[:, 1:, 0], heat) < 1e-6 and maxabs(got[:, :, 1:4], deformed) < 1e-4
+    ml = rnd("ml5", (B, 16, G, G))
+    d, _, _ = ops.mask_deformation(nhwc(ml), sp)
+    ref = (sparse.permute(0, 1, 4, 2, 3) * torch.softmax(ml, 1).unsqueeze(2)).sum(1).permute(0, 2, 3, 1)
+    assert maxabs(d.cpu(), ref) < 2e-6
+
+
 def test_resize_avgpool_antialias(ops):
     x = rnd("rs", (2, 15, 64, 64))
     assert maxabs(nchw(ops.resize(nhwc(x), 32, 32)), O.resize_ac(x, (32, 32))) < 1e-6
