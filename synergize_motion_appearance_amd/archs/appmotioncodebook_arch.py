@@ -8,6 +8,17 @@ from ..manifest import netg_manifest
 from .. import ops
 from ..registry import ARCH_REGISTRY
 from ._base import HipArch
+from ..paramtree import ParamNode
+
+
+class _GeneratorNode(ParamNode):
+    """`net_g.generator(x)` -- the decoder alone, as the reference's model.test() calls it
+    (models/appmotioncomp_model.py:453); still owns the generator.blocks.* parameters."""
+
+    @torch.no_grad()
+    def forward(self, x):
+        owner = self.__dict__["_owner"][0]
+        return ops.nhwc_to_nchw(owner.engine().generator_only(ops.nchw_to_nhwc(x.float())))
 
 
 @ARCH_REGISTRY.register()
@@ -37,6 +48,8 @@ class AppMotionCompFormer(HipArch):
                                        dim_embd_motion, n_layers_motion, dim_embd_app, n_layers_app, split, num_kp,
                                        tuple(connect_list), tuple(connect_app_list)))
         self.beta = beta
+        self._modules["generator"].__class__ = _GeneratorNode
+        self._modules["generator"].__dict__["_owner"] = (self,)        # plain attribute: no module cycle
         if ae_path is not None:
             self.load_state_dict(torch.load(ae_path, map_location='cpu')['params_ema'])
         self.full_outputs = True      # return every key of the reference's out_dict (NCHW copies)
@@ -58,6 +71,11 @@ class AppMotionCompFormer(HipArch):
         c = self.engine().encode_source(x.float())
         self._src_key, self._src_cache = key, c
         return c
+
+    @torch.no_grad()
+    def encode_driving(self, x):
+        """{'256','128','64','32'} -> NCHW encoder taps (appmotioncodebook_arch.py:364-371)."""
+        return {k: ops.nhwc_to_nchw(v) for k, v in self.engine().encode_driving(x.float()).items()}
 
     @torch.no_grad()
     def forward(self, x, dense_motion, w=1, inference=False, vis_app_before_comp=False, gt=None,

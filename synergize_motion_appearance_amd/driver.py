@@ -106,15 +106,19 @@ def broadcast_source_cache(net_g, motion_estimator, source, src=0):
 
 @torch.no_grad()
 def animate_batched(source, driving, net_g, motion_estimator, relative=True, adapt_movement_scale=True,
-                    batch=8, kp_source=None, kp_driving_initial=None, source_cache=None, want="uint8"):
+                    batch=8, kp_source=None, kp_driving_initial=None, source_cache=None, want="uint8", anchor_idx=0):
     """source [3,H,W] / [1,3,H,W], driving [N,3,H,W] device tensors in [-1,1].
-    -> uint8 frames [N,H,W,3] (want='uint8'), fp32 NCHW [N,3,H,W] ('float'), or both ('both')."""
+    -> uint8 frames [N,H,W,3] (want='uint8'), fp32 NCHW [N,3,H,W] ('float'), or both ('both').
+    anchor_idx: the frame whose keypoints are `kp_driving_initial`.  The reference's dataset path
+    (models/appmotioncomp_model.py:675-683) animates forward from the anchor and backward from it
+    and splices the two lists; both runs use kp(driving[anchor]) as the initial keypoints and frames
+    are otherwise independent, so that equals ONE pass over all frames with this anchor."""
     src = source if source.dim() == 4 else source.unsqueeze(0)
     eng_g, eng_m = net_g.engine(), motion_estimator.engine()
     if kp_source is None:
         kp_source = eng_m.estimate_kp(src.float())
     if kp_driving_initial is None and (relative or adapt_movement_scale):
-        kp_driving_initial = eng_m.estimate_kp(driving[0:1].float())
+        kp_driving_initial = eng_m.estimate_kp(driving[anchor_idx:anchor_idx + 1].float())
     scale = adapt_scale(kp_source, kp_driving_initial) if adapt_movement_scale else None
     cache = eng_g.encode_source(src.float()) if source_cache is None else source_cache
     src64 = eng_m.source_down(src.float())

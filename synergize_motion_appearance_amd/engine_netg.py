@@ -220,6 +220,25 @@ class NetGEngine:
         feats[32] = x
         return SourceCache(feats, x_nchw.shape[0])
 
+    def encode_driving(self, x_nchw):
+        """taps after encoder blocks 2, 5, 8, 11 keyed by size (appmotioncodebook_arch.py:364-371), NHWC."""
+        x = ops.nchw_to_nhwc(x_nchw)
+        out = {}
+        for i, (kind, blk) in enumerate(zip(self.enc_kinds, self.enc)):
+            x = self._run(kind, blk, x)
+            if i in (2, 5, 8, 11):
+                out[str(x.shape[1])] = x
+            if i == 11:
+                break
+        return out
+
+    def generator_only(self, x_nhwc):
+        """Generator.forward without fusion (vqgan_arch.py:344-348): lq_recon = generator(lq_feat)."""
+        x = x_nhwc
+        for kind, blk in zip(self.gen_kinds, self.gen):
+            x = self._run(kind, blk, x)
+        return x
+
     # ---- A9 -------------------------------------------------------------------------------
     def _motion_comp(self, flow_res, mq, warp0, s):
         B = flow_res.shape[0]

@@ -126,6 +126,13 @@ def main():
                 d[f"{key}_{i}"] = sub(t)
         np.savez_compressed(os.path.join(HERE, "netg.npz"), **d)
 
+        # ---- animate.py / model.test() side entries: encode_driving + generator on lq_feat ----------
+        #      (models/appmotioncomp_model.py:450-454)
+        ed = net_g.encode_driving(drv[2:3])
+        aux = {f"enc_{k}": np32(v[:, ::8, ::4, ::4]) for k, v in ed.items()}
+        aux["lq_recon"] = np32(net_g.generator(o["lq_feat"]))
+        np.savez_compressed(os.path.join(HERE, "aux_entries.npz"), **aux)
+
         # ---- synthetic-keypoint mode: out-of-frame flow, zero padding, motion_ignore ------
         kps, kpd = synth_keypoints(2, seed=7)
         dms = me.estimate_motion_w_kp(kp_source=kps, kp_driving=kpd, source_image=src[None].repeat(2, 1, 1, 1))

@@ -164,3 +164,33 @@ def test_full_size_properties(nets):
     assert maxabs(w.cpu(), feat.expand(B, -1, -1, -1).cpu()) < 5e-4
     z = ops.warp(feat, ident + 5.0)                                      # everything out of frame -> zeros
     assert float(z.abs().max()) == 0.0
+
+
+def test_model_test_side_entries_vs_reference(nets):
+    """encode_driving / generator(lq_feat) as called by the reference's model.test()
+    (models/appmotioncomp_model.py:450-454)."""
+    net_g, _ = nets
+    _, drv = clip()
+    g, gn = golden("aux_entries.npz"), golden("netg.npz")
+    ed = net_g.encode_driving(drv[2:3].cuda())
+    assert sorted(ed) == ["128", "256", "32", "64"]
+    for k, v in ed.items():
+        assert maxabs(v.cpu()[:, ::8, ::4, ::4], g[f"enc_{k}"]) < 5e-4, k
+    rec = net_g.generator(torch.from_numpy(gn["lq_feat"]).cuda())
+    assert maxabs(rec.cpu(), g["lq_recon"]) < 1e-3
+    assert len(net_g.state_dict()) == 472                      # the callable node still owns its parameters
+
+
+def test_anchor_animation_equals_forward_backward_splice(nets):
+    """generate_video_image semantics (models/appmotioncomp_model.py:675-683): backward[::-1] + forward[1:]
+    from the anchor frame == one batched pass with kp_driving_initial taken at the anchor."""
+    from synergize_motion_appearance_amd.driver import animate_batched
+    net_g, me = nets
+    src, drv = clip()
+    d, a = drv.cuda(), 3
+    fwd = animate_batched(src.cuda(), d[a:], net_g, me, True, True, batch=5)
+    bwd = animate_batched(src.cuda(), d[:a + 1].flip(0), net_g, me, True, True, batch=5)
+    splice = torch.cat([bwd.flip(0), fwd[1:]])
+    one = animate_batched(src.cuda(), d, net_g, me, True, True, batch=4, anchor_idx=a)
+    assert splice.shape == one.shape
+    assert int((splice.int() - one.int()).abs().max()) <= 1

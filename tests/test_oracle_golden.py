@@ -140,3 +140,17 @@ def test_vector_quantizer():
 def test_tensor2img():
     t = synth_input("tensor2img", (3, 64, 64)) * 0.8
     assert np.array_equal(O.tensor2img(t[None]), golden("tensor2img.npz")["img"])
+
+
+def test_encode_driving_and_generator_entries():
+    """side entries used by the reference's model.test() (models/appmotioncomp_model.py:450-454)."""
+    Pg = weights("network_g")
+    _, drv = clip()
+    g, gn = golden("aux_entries.npz"), golden("netg.npz")
+    with torch.no_grad():
+        ed = O.encode_driving(Pg, drv[2:3])
+        rec = O.generator(Pg, torch.from_numpy(gn["lq_feat"]))
+    assert sorted(ed) == ["128", "256", "32", "64"]
+    for k, v in ed.items():
+        assert maxabs(v[:, ::8, ::4, ::4], g[f"enc_{k}"]) < 1e-4, k
+    assert maxabs(rec, g["lq_recon"]) < 2e-4
