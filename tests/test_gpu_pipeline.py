@@ -194,3 +194,24 @@ def test_anchor_animation_equals_forward_backward_splice(nets):
     one = animate_batched(src.cuda(), d, net_g, me, True, True, batch=4, anchor_idx=a)
     assert splice.shape == one.shape
     assert int((splice.int() - one.int()).abs().max()) <= 1
+
+
+def test_batch_of_distinct_sources(nets):
+    """configs[2]-style batches: every sample has its OWN source image (x batch == dense_motion batch);
+    equals per-sample calls, and sample 0 equals the reference fixture."""
+    from synergize_motion_appearance_amd.synth import synth_clip
+    net_g, me = nets
+    src0, drv = clip()
+    src1, _ = synth_clip(1, seed=77)
+    srcs = torch.stack([src0, src1]).cuda()
+    kp_s = me.estimate_kp(srcs)
+    kp_d = me.estimate_kp(drv[[2, 5]].cuda())
+    dm = me.estimate_motion_w_kp(kp_source=kp_s, kp_driving=kp_d, source_image=srcs)
+    both = net_g(srcs, dm, w=1, inference=True)["out"].cpu()
+    for i in range(2):
+        kps_i = {k: v[i:i + 1].contiguous() for k, v in kp_s.items()}
+        kpd_i = {k: v[i:i + 1].contiguous() for k, v in kp_d.items()}
+        dmi = me.estimate_motion_w_kp(kp_source=kps_i, kp_driving=kpd_i, source_image=srcs[i:i + 1].contiguous())
+        one = net_g(srcs[i:i + 1].contiguous(), dmi, w=1, inference=True)["out"].cpu()
+        assert maxabs(both[i:i + 1], one) < 3e-4, i
+    assert maxabs(both[0:1], golden("netg.npz")["out"]) < 1e-3
