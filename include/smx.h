@@ -87,7 +87,10 @@ int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream);
  * y NHWC [B][H][W][ldc]; act/bias/res as in smx_gemm_conv_f32.  H%8==0, W%16==0, Cin%32==0. */
 int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
                              const float* res, int ldres, float* y, int ldc, int B, int H, int W,
-                             int Cin, int Cout, int up2, int act, void* stream);
+                             int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish, void* stream);
+/* in_ss != NULL: the GroupNorm(+swish, if in_swish) that precedes the conv in ResBlock
+ * (archs/vqgan_arch.py:183-188) is applied by the region loader: x*in_ss[b][c][0] + in_ss[b][c][1],
+ * with in_ss from smx_groupnorm_stats_f32 -- the separate normalise read+write pass disappears. */
 
 /* ---------------------------------------------------------------------------------------
  * GroupNorm(32 groups, eps) [+ swish] on NHWC.   normalize/swish archs/vqgan_arch.py:14-20.
@@ -98,6 +101,13 @@ int64_t smx_groupnorm_ws_floats(int B, int HW, int C);
 int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float* gamma, const float* beta,
                                  float* y, int ldy, int B, int HW, int C, int groups, float eps,
                                  int swish, float* ws, void* stream);
+
+/* the two halves of the above: per-(b,c) {scale, shift} = {rstd*gamma, beta - mean*rstd*gamma} into
+ * ss[B][C][2] (ws: B*nchunks*C*2 floats, smx_groupnorm_ws_floats is enough), and the apply pass */
+int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float* ss,
+                            int B, int HW, int C, int groups, float eps, float* ws, void* stream);
+int smx_groupnorm_apply_f32(const float* x, int ldx, const float* ss, float* y, int ldy, int B, int HW, int C,
+                            int swish, void* stream);
 
 /* LayerNorm over E (eps) on tokens [T][E]; also writes y_pos = LN(x) + pos[t % npos] when
  * y_pos != NULL.  TransformerLayer.norm1/2/3 + with_pos_embed (appmotioncodebook_arch.py:97-119). */

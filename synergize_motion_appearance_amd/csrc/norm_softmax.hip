@@ -182,6 +182,28 @@ extern "C" int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float
   return smx_launch_status();
 }
 
+extern "C" int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float* ss,
+                                       int B, int HW, int C, int groups, float eps, float* ws, void* stream) {
+  if (!x || !ss || !gamma || !beta || !ws || B <= 0 || HW <= 0) return SMX_EINVAL;
+  if (C < 4 || C > 1024 || (C & (C - 1)) != 0 || C % groups != 0 || ldx % 4 != 0 || ldx < C) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
+  const int nch = (HW + ppc - 1) / ppc;
+  const int rows = 256 / (C / 4);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, ws, HW, C, ppc, nch);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, ws, gamma, beta, ss, HW, C, groups, nch, eps);
+  return smx_launch_status();
+}
+
+extern "C" int smx_groupnorm_apply_f32(const float* x, int ldx, const float* ss, float* y, int ldy, int B, int HW, int C,
+                                       int swish, void* stream) {
+  if (!x || !ss || !y || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < C || ldy < C) return SMX_EINVAL;
+  const long long total4 = (long long)B * HW * (C / 4);
+  int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, ss, total4, HW, C, swish);
+  return smx_launch_status();
+}
+
 extern "C" int smx_layernorm_pos_f32(const float* x, const float* gamma, const float* beta, const float* pos,
                                      float* y, float* y_pos, int T, int E, int npos, float eps, void* stream) {
   if (!x || !y || !gamma || !beta || T <= 0 || E <= 0 || E > 512 || (y_pos && (!pos || npos <= 0))) return SMX_EINVAL;

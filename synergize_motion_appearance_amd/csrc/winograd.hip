@@ -37,6 +37,7 @@ constexpr int RLD = 36;                             // floats per region pixel i
 
 struct WP {
   const float* x; const float* u; const float* bias; const float* res; float* y;
+  const float* in_ss; int in_swish;   // fused GroupNorm apply on the loaded input: x*ss[b][c][0]+ss[b][c][1] (+swish)
   int lda, ldc, ldres;
   int B, H, W, Cin, Cout, up2, act;
   int tiles_y, tiles_x;          // blocks per image along y / x
@@ -100,7 +101,24 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gok[k]) v = *reinterpret_cast<const float4*>(X + goff[k] + c0);
+      if (gok[k]) {
+        v = *reinterpret_cast<const float4*>(X + goff[k] + c0);
+        if (p.in_ss) {
+          // GroupNorm(+swish) of the producer folded into the loader: each input element is normalised
+          // once per staged region instead of in a separate read+write pass; padding stays exactly 0
+          const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + ((tid + NTHR * k) & 7) * 4) * 2;
+          const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+          v = make_float4(fmaf(v.x, s0.x, s0.y), fmaf(v.y, s0.z, s0.w), fmaf(v.z, s1.x, s1.y), fmaf(v.w, s1.z, s1.w));
+          if (p.in_swish) {
+            // swish = v * rcp(1 + 2^(-v*log2e)): v_exp_f32 + v_rcp_f32 (1 ulp each) keep the loader light
+            constexpr float L2E = 1.44269504088896340736f;
+            v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
+            v.y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.y));
+            v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
+            v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
+          }
+        }
+      }
       stage[k] = v;
     }
   };
@@ -250,12 +268,15 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
 
 extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
                                         const float* res, int ldres, float* y, int ldc, int B, int H, int W,
-                                        int Cin, int Cout, int up2, int act, void* stream) {
+                                        int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
+                                        void* stream) {
   if (!x || !u_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0) return SMX_EINVAL;
+  if (in_ss && (((uintptr_t)in_ss) & 15)) return SMX_EINVAL;
   if (H % 8 != 0 || W % 16 != 0 || Cin % 32 != 0 || lda % 4 != 0 || lda < Cin || ldc < Cout) return SMX_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)u_packed & 15) || (res && ldres < Cout)) return SMX_EINVAL;
   WP p;
   p.x = x; p.u = u_packed; p.bias = bias; p.res = res; p.y = y; p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0;
+  p.in_ss = in_ss; p.in_swish = in_swish;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
   p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32;
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;

@@ -36,11 +36,11 @@ class _Res:
 
     def __call__(self, x, out=None):
         """ResBlock.forward archs/vqgan_arch.py:180-191."""
-        h = ops.groupnorm(x, *self.n1, swish=True)
-        h = ops.conv(h, self.c1)
-        h = ops.groupnorm(h, *self.n2, swish=True)
+        # GN statistics are their own (read-only) pass; the normalise + swish is applied by the
+        # consuming conv's region loader, so no normalised copy of the activation is ever written
+        h = ops.conv(x, self.c1, in_ss=ops.groupnorm_stats(x, *self.n1), in_swish=True)
         skip = x if self.sc is None else ops.conv(x, self.sc)
-        return ops.conv(h, self.c2, out=out, res=skip)
+        return ops.conv(h, self.c2, out=out, res=skip, in_ss=ops.groupnorm_stats(h, *self.n2), in_swish=True)
 
 
 class _Attn:
@@ -209,14 +209,30 @@ class NetGEngine:
             return ops.groupnorm(x, blk[0], blk[1], swish=False)
         raise ValueError(kind)
 
+    def _run_seq(self, kinds, blocks, x, hook=None):
+        """run a block list; a trailing [gn, conv] pair (blocks 17, 18) is fused: GN folded into the conv loader."""
+        i = 0
+        while i < len(kinds):
+            if kinds[i] == "gn" and i + 1 < len(kinds) and kinds[i + 1] == "conv":
+                x = ops.conv(x, blocks[i + 1], in_ss=ops.groupnorm_stats(x, blocks[i][0], blocks[i][1]), in_swish=False)
+                i += 2
+            else:
+                x = self._run(kinds[i], blocks[i], x)
+                i += 1
+            if hook is not None:
+                x = hook(i - 1, x)
+        return x
+
     # ---- A8 encoder: frame-invariant -------------------------------------------------------
     def encode_source(self, x_nchw):
         x = ops.nchw_to_nhwc(x_nchw)
         feats = {}
-        for i, (kind, blk) in enumerate(zip(self.enc_kinds, self.enc)):
-            x = self._run(kind, blk, x)
+
+        def tap(i, t):
             if i in self.taps_after:
-                feats[self.taps_after[i]] = x
+                feats[self.taps_after[i]] = t
+            return t
+        x = self._run_seq(self.enc_kinds, self.enc, x, tap)
         feats[32] = x
         return SourceCache(feats, x_nchw.shape[0])
 
@@ -234,10 +250,7 @@ class NetGEngine:
 
     def generator_only(self, x_nhwc):
         """Generator.forward without fusion (vqgan_arch.py:344-348): lq_recon = generator(lq_feat)."""
-        x = x_nhwc
-        for kind, blk in zip(self.gen_kinds, self.gen):
-            x = self._run(kind, blk, x)
-        return x
+        return self._run_seq(self.gen_kinds, self.gen, x_nhwc)
 
     # ---- A9 -------------------------------------------------------------------------------
     def _motion_comp(self, flow_res, mq, warp0, s):
@@ -325,11 +338,11 @@ class NetGEngine:
         st["kp_feat"] = ops.conv(ops.resize(heat_nhwc, 32, 32), self.kp_enc, act=ACT_RELU)
         x = self._one_scale(st, cache.feats[32], 32, True)
         st["lq"] = x
-        for i, (kind, blk) in enumerate(zip(self.gen_kinds, self.gen)):
-            x = self._run(kind, blk, x)
+        def fuse(i, t):
             if i in self.fuse_after and w > 0:
                 s = self.fuse_after[i]
                 ew = self._one_scale(st, cache.feats[s], s, False)
-                x = self._fuse(s, ew, x, w)
-        st["out"] = x
+                t = self._fuse(s, ew, t, w)
+            return t
+        st["out"] = self._run_seq(self.gen_kinds, self.gen, x, fuse)
         return st

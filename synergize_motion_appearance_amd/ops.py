@@ -131,7 +131,7 @@ def gemm_raw(**kw):
 
 
 def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None,
-         d2s=None, tile=0):
+         d2s=None, tile=0, in_ss=None, in_swish=False):
     """y = act(conv(x) + bias) [+ res].  x [B,H,W,Cin] (slice ok) -> out [B,Ho,Wo,Cout] (slice ok).
     pad: (top, left) (default (kh//2, kw//2)); out_hw for asymmetric pads / strides.
     d2s=(p, C): un-patchify store, out is [B,Ho*p,Wo*p,C]."""
@@ -160,8 +160,12 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
                 "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1} if _PROFILE is not None else None
         L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                        None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,
-                       int(up2), act, _stream()), "smx_winograd_conv3x3_f32")
+                       int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish), _stream()),
+                "smx_winograd_conv3x3_f32")
         return out
+    if in_ss is not None:      # layer not eligible for the fused loader: normalise in its own pass, then convolve
+        x = groupnorm_apply(x, in_ss, in_swish)
+        a_ptr, lda = _pix(x, "conv input")
     M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
     ksplit, ws = 1, None
     if not d2s and K >= 1024:
@@ -205,6 +209,29 @@ def groupnorm(x, gamma, beta, swish=True, out=None, groups=32, eps=1e-6):
     ws = torch.empty(int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)), device=x.device, dtype=torch.float32)
     L.check(_timed("groupnorm", {"bytes": 8.0 * B * H * W * Cc}, lib.smx_groupnorm_swish_nhwc_f32, xp, ldx, _dev(gamma).data_ptr(),
                    _dev(beta).data_ptr(), yp, ldy, B, H * W, Cc, groups, eps, int(swish), ws.data_ptr(), _stream()), "groupnorm")
+    return out
+
+
+def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
+    """per-(b,c) {scale, shift} of GroupNorm for x [B,H,W,C] -> ss [B,C,2] (consumed by conv(in_ss=...))."""
+    B, H, W, Cc = x.shape
+    xp, ldx = _pix(x, "groupnorm input")
+    lib = L.load()
+    ws = torch.empty(int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)), device=x.device, dtype=torch.float32)
+    ss = torch.empty((B, Cc, 2), device=x.device, dtype=torch.float32)
+    L.check(_timed("groupnorm", {"bytes": 4.0 * B * H * W * Cc}, lib.smx_groupnorm_stats_f32, xp, ldx, _dev(gamma).data_ptr(),
+                   _dev(beta).data_ptr(), ss.data_ptr(), B, H * W, Cc, groups, eps, ws.data_ptr(), _stream()), "groupnorm_stats")
+    return ss
+
+
+def groupnorm_apply(x, ss, swish=True, out=None):
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+    xp, ldx = _pix(x, "groupnorm input")
+    yp, ldy = _pix(out, "groupnorm output")
+    L.check(_timed("groupnorm", {"bytes": 8.0 * B * H * W * Cc}, L.load().smx_groupnorm_apply_f32, xp, ldx, ss.data_ptr(), yp, ldy,
+                   B, H * W, Cc, int(swish), _stream()), "groupnorm_apply")
     return out
 
 

@@ -121,6 +121,23 @@ def test_winograd_conv3x3(ops, case):
     assert maxabs(nchw(direct), ref) < 3e-5
 
 
+def test_winograd_fused_groupnorm_loader(ops):
+    """GN(32, eps 1e-6) + swish folded into the Winograd region loader == group_norm -> swish -> conv2d."""
+    for (B, C, Co, H, sw) in ((2, 64, 64, 32, True), (1, 128, 64, 64, True), (2, 256, 128, 16, False), (1, 32, 32, 32, True)):
+        x = rnd(f"gx{C}{H}", (B, C, H, H)) * 1.5 + 0.2
+        g, bt = 1 + 0.1 * rnd(f"gg{C}", (C,)), 0.1 * rnd(f"gb{C}", (C,))
+        w = rnd(f"gw{C}{Co}", (Co, C, 3, 3), 1.0 / math.sqrt(9 * C))
+        b = rnd(f"gbb{Co}", (Co,), 0.1)
+        hn = F.group_norm(x, 32, g, bt, 1e-6)
+        ref = F.conv2d(O.swish(hn) if sw else hn, w, b, padding=1)
+        xin = nhwc(x)
+        ss = ops.groupnorm_stats(xin, g.cuda(), bt.cuda())
+        y = ops.conv(xin, ops.Conv.from_torch(w.cuda(), b.cuda()), in_ss=ss, in_swish=sw)
+        assert maxabs(nchw(y), ref) < 5e-5
+        y2 = ops.conv(xin, ops.Conv.from_torch(w.cuda(), b.cuda()), in_ss=ss, in_swish=sw, tile=5)   # non-fused fallback path
+        assert maxabs(nchw(y2), ref) < 5e-5
+
+
 def test_conv_residual_and_slices(ops):
     """output into a channel slice of a concat buffer, input from a slice, fused residual."""
     x = rnd("sx", (2, 96, 32, 32))
