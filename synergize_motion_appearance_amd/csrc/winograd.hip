@@ -97,35 +97,39 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     loff[k] = (ry * RP + rx) * RLD + ((SWZ ? (c4 ^ ((rx >> 1) & 1)) : c4) * 4);      // XOR swizzle of the 16-B chunk
   }
   float4 stage[NIT];
+  // load_region only ISSUES the global loads (consumed a whole slice of MFMAs later);
+  // store_region applies the fused GroupNorm(+swish) and writes LDS.
   auto load_region = [&](int c0) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gok[k]) {
-        v = *reinterpret_cast<const float4*>(X + goff[k] + c0);
-        if (p.in_ss) {
-          // GroupNorm(+swish) of the producer folded into the loader: each input element is normalised
-          // once per staged region instead of in a separate read+write pass; padding stays exactly 0
-          const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + ((tid + NTHR * k) & 7) * 4) * 2;
-          const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-          v = make_float4(fmaf(v.x, s0.x, s0.y), fmaf(v.y, s0.z, s0.w), fmaf(v.z, s1.x, s1.y), fmaf(v.w, s1.z, s1.w));
-          if (p.in_swish) {
-            // swish = v * rcp(1 + 2^(-v*log2e)): v_exp_f32 + v_rcp_f32 (1 ulp each) keep the loader light
-            constexpr float L2E = 1.44269504088896340736f;
-            v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
-            v.y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.y));
-            v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
-            v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
-          }
-        }
-      }
+      if (gok[k]) v = *reinterpret_cast<const float4*>(X + goff[k] + c0);
       stage[k] = v;
     }
   };
-  auto store_region = [&](int buf) {
+  auto store_region = [&](int buf, int c0) {
     float* rb = smem + buf * RPIX * RLD;
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) if (lok[k]) *reinterpret_cast<float4*>(rb + loff[k]) = stage[k];
+    for (int k = 0; k < NIT; ++k) {
+      if (!lok[k]) continue;
+      float4 v = stage[k];
+      if (p.in_ss && gok[k]) {
+        // GroupNorm(+swish) of the producer folded into the loader: each input element is normalised
+        // once per staged region instead of in a separate read+write pass; padding stays exactly 0
+        const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + ((tid + NTHR * k) & 7) * 4) * 2;
+        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+        v = make_float4(fmaf(v.x, s0.x, s0.y), fmaf(v.y, s0.z, s0.w), fmaf(v.z, s1.x, s1.y), fmaf(v.w, s1.z, s1.w));
+        if (p.in_swish) {
+          // swish = v * rcp(1 + 2^(-v*log2e)): v_exp_f32 + v_rcp_f32 (1 ulp each) keep the loader light
+          constexpr float L2E = 1.44269504088896340736f;
+          v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
+          v.y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.y));
+          v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
+          v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
+        }
+      }
+      *reinterpret_cast<float4*>(rb + loff[k]) = v;
+    }
   };
 
   // which two patch rows frequency row fi needs: B^T rows (0:[d0-d2] 1:[d1+d2] 2:[d2-d1] 3:[d1-d3])
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
 
   const int nsl = p.Cin >> 5;
   const float sgn = plus ? 1.f : -1.f;
-  load_region(0); store_region(0);
+  load_region(0); store_region(0, 0);
   // U ring: slot j holds the fragment of the unit with frequency j; prefetch distance = 2 units
   // (= 8 MFMAs of this wave, ~4x that in wall time with 4 waves per SIMD) hides the L2 latency.
   float4 ur[4];
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
       transform(rb, sub, v);
       mfma16(v, (s * 4 + sub) * 4);
     }
-    if (!(ABL & 4) && s + 1 < nsl) store_region(buf ^ 1);
+    if (!(ABL & 4) && s + 1 < nsl) store_region(buf ^ 1, (s + 1) * 32);
     __syncthreads();
   }
   if (ABL & 16) { if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 123.456f) p.y[0] = 1.f; return; }
