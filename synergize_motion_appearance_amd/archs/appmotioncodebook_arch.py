@@ -70,6 +70,7 @@ class AppMotionCompFormer(HipArch):
             return self._src_cache
         c = self.engine().encode_source(x.float())
         self._src_key, self._src_cache = key, c
+        self._src_ref = x            # keep the tensor alive: its address cannot be recycled while the key is cached
         return c
 
     @torch.no_grad()

@@ -47,6 +47,7 @@ class Motion_Estimator_keypoint_aware(HipArch):
         if key != self._src_key:
             self._src64 = self.engine().source_down(source_image.float())
             self._src_key = key
+            self._src_ref = source_image      # keep alive so the address cannot be recycled under the cached key
         return self._src64
 
     @torch.no_grad()
