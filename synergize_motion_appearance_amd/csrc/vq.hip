@@ -21,11 +21,12 @@ template <int D>
 __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                  int64_t* __restrict__ idx_out, float* __restrict__ zq,
                                                  float* __restrict__ dmin_out, float* __restrict__ sqerr, int N, int Ks) {
-  constexpr int LD = D + 4, KS = D / 8;
+  constexpr int LD = D + 4, KS = D / 8, CT = 64;     // 64 codes staged per barrier pair (two 32-wide MFMA tiles)
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* cs = sm;                       // [32][LD] code tile
-  float* ee = sm + 32 * LD;             // [32] code norms
-  float* zzs = ee + 32;                 // [4][32] token norms per wave
+  float* cs = sm;                       // [CT][LD] code tile
+  float* ee = sm + CT * LD;             // [Ks rounded up to CT] all code norms, computed once per block
+  const int ks_pad = (Ks + CT - 1) / CT * CT;
+  float* zzs = ee + ks_pad;             // [4][32] token norms per wave
   int* bis = reinterpret_cast<int*>(zzs + 128);   // [4][32] best index per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * 128 + wave * 32;
@@ -41,6 +42,16 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
   }
   zz += __shfl_xor(zz, 32, 64);
   if (lane < 32) zzs[wave * 32 + lane] = zz;
+  // all code norms once per block (Ks*D MACs: <1% of the block's 128*Ks*D): 8 lanes per code
+  for (int c0 = 0; c0 < ks_pad; c0 += 32) {
+    const int code = c0 + (threadIdx.x >> 3), part = threadIdx.x & 7; float s = 0.f;
+    if (code < Ks) {
+      const float* cp = cb + (long long)code * D;
+      for (int c = part * 4; c < D; c += 32) { const float4 v = *reinterpret_cast<const float4*>(cp + c); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (part == 0) ee[code] = s;
+  }
   __syncthreads();
   float zzr[16];
 #pragma unroll
@@ -50,43 +61,38 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
 #pragma unroll
   for (int r = 0; r < 16; ++r) { bestd[r] = INFINITY; besti[r] = 0; }
 
-  const int ntiles = (Ks + 31) / 32;
+  const int ntiles = ks_pad / CT;
   for (int t = 0; t < ntiles; ++t) {
     __syncthreads();                    // previous tile fully consumed
-    // stage 32 codes x D
-    for (int i = threadIdx.x; i < 32 * (D / 4); i += 256) {
-      const int r = i / (D / 4), c4 = i % (D / 4); const int code = t * 32 + r;
+    for (int i = threadIdx.x; i < CT * (D / 4); i += 256) {
+      const int r = i / (D / 4), c4 = i % (D / 4); const int code = t * CT + r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (code < Ks) v = *reinterpret_cast<const float4*>(cb + (long long)code * D + c4 * 4);
       *reinterpret_cast<float4*>(cs + r * LD + c4 * 4) = v;
     }
     __syncthreads();
-    {   // code norms: 8 threads per code
-      const int r = threadIdx.x >> 3, part = threadIdx.x & 7; float s = 0.f;
-      for (int c = part; c < D; c += 8) { const float v = cs[r * LD + c]; s += v * v; }
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-      if (part == 0) ee[r] = s;
-    }
-    __syncthreads();
-    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* bp = cs + (lane & 31) * LD + (lane >> 5) * 4;
+    for (int h2 = 0; h2 < 2; ++h2) {
+      f32x16 acc;
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const float4 bf = *reinterpret_cast<const float4*>(bp + kk * 8);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf.w, acc, 0, 0, 0);
-    }
-    const int code = t * 32 + (lane & 31);
-    const float e2 = ee[lane & 31];
-    if (code < Ks) {
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* bp = cs + (h2 * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float d = (zzr[r] + e2) - 2.f * acc[r];
-        if (d < bestd[r]) { bestd[r] = d; besti[r] = code; }
+      for (int kk = 0; kk < KS; ++kk) {
+        const float4 bf = *reinterpret_cast<const float4*>(bp + kk * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf.w, acc, 0, 0, 0);
+      }
+      const int code = t * CT + h2 * 32 + (lane & 31);
+      if (code < Ks) {
+        const float e2 = ee[code];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = (zzr[r] + e2) - 2.f * acc[r];
+          if (d < bestd[r]) { bestd[r] = d; besti[r] = code; }
+        }
       }
     }
   }
@@ -130,7 +136,8 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
 
 template <int D>
 int launch_vq(const float* z, const float* cb, int64_t* idx, float* zq, float* dmin, float* sqerr, int N, int Ks, hipStream_t st) {
-  const size_t lds = (size_t)(32 * (D + 4) + 32 + 128 + 128) * sizeof(float);
+  const size_t lds = (size_t)(64 * (D + 4) + (Ks + 63) / 64 * 64 + 128 + 128) * sizeof(float);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vq_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(vq_kernel<D>, dim3(smx_cdiv(N, 128)), dim3(256), lds, st, z, cb, idx, zq, dmin, sqerr, N, Ks);
   return smx_launch_status();
 }
