@@ -159,6 +159,14 @@ int smx_antialias_down_f32(const float* img_nchw, const float* w, float* out, in
 int smx_kp_head_f32(const float* logits, int ldl, const float* jmaps, int ldj, float* value, float* jac,
                     int B, int H, int W, int K, float temperature, void* stream);
 
+/* A0: normalize_kp (demo.py:24-44) for B driving frames against ONE source / initial frame:
+ * value = (kp_d - kp_d0)*scale + kp_s ; jac = J_d inv(J_d0) J_s  (rel_move / rel_jac as in the reference's
+ * use_relative_movement / use_relative_jacobian; scale = sqrt(hull(kp_s)/hull(kp_d0)) from the host, 1 if off).
+ * kpd_* [B][K][2|4]; kp0_*, kps_* [K][2|4]. */
+int smx_normalize_kp_f32(const float* kpd_value, const float* kpd_jac, const float* kp0_value, const float* kp0_jac,
+                         const float* kps_value, const float* kps_jac, float* out_value, float* out_jac,
+                         int B, int K, float scale, int rel_move, int rel_jac, void* stream);
+
 /* A4-A6: heatmaps + sparse motions + 16 sparse warps fused (archs/dense_motion_arch.py:65-116).
  * src NHWC [Bs][H][W][3] (Bs = 1 broadcasts); kp value [B][K][2], jacobian [B][K][4].
  * hg_in: NHWC [B][H][W][ldh], channel 4k+0 = heatmap_k (k=0 background = 0), 4k+1..3 = deformed rgb.

@@ -128,6 +128,33 @@ __global__ __launch_bounds__(256) void mask_deformation_kernel(const float* __re
   }
 }
 
+// ---- A0: relative keypoint transfer (demo.py:24-44), one thread per (frame, keypoint) ------------
+__global__ void normalize_kp_kernel(const float* __restrict__ dv, const float* __restrict__ dj, const float* __restrict__ iv,
+                                    const float* __restrict__ ij, const float* __restrict__ sv, const float* __restrict__ sj,
+                                    float* __restrict__ ov, float* __restrict__ oj, int B, int K, float scale,
+                                    int rel_move, int rel_jac) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * K) return;
+  const int k = t % K;
+  float vx = dv[t * 2], vy = dv[t * 2 + 1];
+  float j0 = dj[t * 4], j1 = dj[t * 4 + 1], j2 = dj[t * 4 + 2], j3 = dj[t * 4 + 3];
+  if (rel_move) {
+    vx = (vx - iv[k * 2]) * scale + sv[k * 2];
+    vy = (vy - iv[k * 2 + 1]) * scale + sv[k * 2 + 1];
+    if (rel_jac) {
+      // jac = J_d . inv(J_d0) . J_s   (closed-form 2x2 inverse)
+      const float a = ij[k * 4], b = ij[k * 4 + 1], c = ij[k * 4 + 2], d = ij[k * 4 + 3];
+      const float det = a * d - b * c;
+      const float i0 = d / det, i1 = -b / det, i2 = -c / det, i3 = a / det;
+      const float m0 = j0 * i0 + j1 * i2, m1 = j0 * i1 + j1 * i3, m2 = j2 * i0 + j3 * i2, m3 = j2 * i1 + j3 * i3;
+      const float s0 = sj[k * 4], s1 = sj[k * 4 + 1], s2 = sj[k * 4 + 2], s3 = sj[k * 4 + 3];
+      j0 = m0 * s0 + m1 * s2; j1 = m0 * s1 + m1 * s3; j2 = m2 * s0 + m3 * s2; j3 = m2 * s1 + m3 * s3;
+    }
+  }
+  ov[t * 2] = vx; ov[t * 2 + 1] = vy;
+  oj[t * 4] = j0; oj[t * 4 + 1] = j1; oj[t * 4 + 2] = j2; oj[t * 4 + 3] = j3;
+}
+
 // ---- compensation-loop elementwise stages -------------------------------------------------
 __global__ void flow_to_residual_kernel(const float* __restrict__ flow, float* __restrict__ res, long long npix, int H, int W) {
   for (long long p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
@@ -239,6 +266,16 @@ extern "C" int smx_kp_head_f32(const float* logits, int ldl, const float* jmaps,
   if (!logits || !value || B <= 0 || H <= 1 || W <= 1 || K <= 0 || ldl < K || temperature <= 0.f) return SMX_EINVAL;
   if (jmaps && (!jac || ldj < 4 * K || ldj % 4 != 0)) return SMX_EINVAL;
   hipLaunchKernelGGL(kp_head_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, logits, ldl, jmaps, ldj, value, jac, H, W, K, temperature);
+  return smx_launch_status();
+}
+
+extern "C" int smx_normalize_kp_f32(const float* kpd_value, const float* kpd_jac, const float* kp0_value, const float* kp0_jac,
+                                    const float* kps_value, const float* kps_jac, float* out_value, float* out_jac,
+                                    int B, int K, float scale, int rel_move, int rel_jac, void* stream) {
+  if (!kpd_value || !kpd_jac || !out_value || !out_jac || B <= 0 || K <= 0) return SMX_EINVAL;
+  if (rel_move && (!kp0_value || !kps_value || (rel_jac && (!kp0_jac || !kps_jac)))) return SMX_EINVAL;
+  hipLaunchKernelGGL(normalize_kp_kernel, dim3(smx_cdiv((long long)B * K, 128)), dim3(128), 0, (hipStream_t)stream, kpd_value, kpd_jac,
+                     kp0_value, kp0_jac, kps_value, kps_jac, out_value, out_jac, B, K, scale, rel_move, rel_jac);
   return smx_launch_status();
 }
 

@@ -33,6 +33,9 @@ def normalize_kp(kp_source, kp_driving, kp_driving_initial, adapt_movement_scale
         s = adapt_scale(kp_source, kp_driving_initial) if scale is None else scale
     else:
         s = 1
+    if use_relative_movement and kp_driving["value"].is_cuda and kp_source["value"].shape[0] == 1:
+        # device tensors: one small HIP kernel for the whole batch (no ATen matmul / inverse on the path)
+        return ops.normalize_kp(kp_driving, kp_driving_initial, kp_source, s, True, use_relative_jacobian)
     kp_new = {k: v for k, v in kp_driving.items()}
     if use_relative_movement:
         kp_new["value"] = (kp_driving["value"] - kp_driving_initial["value"]) * s + kp_source["value"]

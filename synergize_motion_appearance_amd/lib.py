@@ -53,6 +53,7 @@ SIGNATURES = {
     "smx_avgpool2_nhwc_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "smx_antialias_down_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_kp_head_f32": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "smx_normalize_kp_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _p]),
     "smx_sparse_motion_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
     "smx_mask_deformation_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smx_flow_to_residual_f32": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -316,6 +316,18 @@ def kp_head(logits, jmaps, K, temperature):
     return value, jac
 
 
+def normalize_kp(kp_d, kp_0, kp_s, scale, rel_move, rel_jac):
+    """device version of demo.py:24-44 for a batch of driving keypoints against one source / initial frame."""
+    v, j = _dev(kp_d["value"]).contiguous(), _dev(kp_d["jacobian"]).contiguous()
+    B, K = v.shape[0], v.shape[1]
+    ov, oj = torch.empty_like(v), torch.empty_like(j)
+    ptr = lambda d, k: None if d is None else _dev(d[k]).contiguous().data_ptr()
+    L.check(L.load().smx_normalize_kp_f32(v.data_ptr(), j.data_ptr(), ptr(kp_0, "value"), ptr(kp_0, "jacobian"), ptr(kp_s, "value"),
+                                          ptr(kp_s, "jacobian"), ov.data_ptr(), oj.data_ptr(), B, K, float(scale), int(rel_move),
+                                          int(rel_jac), _stream()), "normalize_kp")
+    return {"value": ov, "jacobian": oj}
+
+
 def sparse_motion(src64, kpd_value, kpd_jac, kps_value, kps_jac, hg_in, B, K=15, var=0.01):
     """-> (sparse [B,K+1,H,W,2], drv_heat [B,H,W,K]); hg_in slice [B,H,W,4(K+1)] is written."""
     Bs, H, W, _ = src64.shape

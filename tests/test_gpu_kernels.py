@@ -376,6 +376,22 @@ def test_kp_head(ops):
     assert maxabs(v.cpu(), value) < 2e-6 and maxabs(j.cpu(), jac) < 5e-6
 
 
+def test_normalize_kp_kernel_vs_reference(ops):
+    """A0 on the device against the reference fixture (4 flag combinations of demo.normalize_kp)."""
+    from synergize_motion_appearance_amd.driver import normalize_kp
+    g, gn = golden("kp.npz"), golden("normalize_kp.npz")
+    kp = lambda v, j: {"value": torch.from_numpy(v).cuda(), "jacobian": torch.from_numpy(j).cuda()}
+    kp_s, kp_0, kp_3 = kp(g["src_value"], g["src_jacobian"]), kp(g["drv_value"][0:1], g["drv_jacobian"][0:1]), kp(g["drv_value"][3:4], g["drv_jacobian"][3:4])
+    for rel in (0, 1):
+        for ad in (0, 1):
+            r = normalize_kp(kp_s, kp_3, kp_0, bool(ad), bool(rel), bool(rel))
+            assert maxabs(r["value"].cpu(), gn[f"value_r{rel}a{ad}"]) < 1e-6
+            assert maxabs(r["jacobian"].cpu(), gn[f"jacobian_r{rel}a{ad}"]) < 1e-5
+    kp_all = kp(g["drv_value"], g["drv_jacobian"])                       # batched == per-frame
+    rb = normalize_kp(kp_s, kp_all, kp_0, True, True, True)
+    assert maxabs(rb["value"][3:4].cpu(), gn["value_r1a1"]) < 1e-6 and maxabs(rb["jacobian"][3:4].cpu(), gn["jacobian_r1a1"]) < 1e-5
+
+
 def test_sparse_motion_and_mask_deformation(ops):
     from synergize_motion_appearance_amd.synth import synth_keypoints
     B, K = 2, 15
