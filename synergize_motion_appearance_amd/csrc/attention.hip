@@ -234,11 +234,11 @@ extern "C" int smx_attention_f32(const float* q, int ldq, int64_t q_bs, const fl
   if (dh == 4) {
     if (L % 64 || S % 32 || S > 2048) return SMX_EINVAL;
     const size_t lds = (size_t)S * 33 + 4 * 64 * 6 * sizeof(float);
-    hipLaunchKernelGGL(attn_valu4_kernel, dim3(L / 64, B * H), dim3(256), lds, st, p);
+    SMX_LAUNCH(attn_valu4_kernel, dim3(L / 64, B * H), dim3(256), lds, st, p);
   } else if (dh == 32 || dh == 64) {
     if (L % 128 || S % 32) return SMX_EINVAL;
-    if (dh == 32) hipLaunchKernelGGL(attn_mfma_kernel<32>, dim3(L / 128, B * H), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(attn_mfma_kernel<64>, dim3(L / 128, B * H), dim3(256), 0, st, p);
+    if (dh == 32) SMX_LAUNCH(attn_mfma_kernel<32>, dim3(L / 128, B * H), dim3(256), 0, st, p);
+    else SMX_LAUNCH(attn_mfma_kernel<64>, dim3(L / 128, B * H), dim3(256), 0, st, p);
   } else {
     return SMX_EINVAL;
   }

@@ -354,15 +354,15 @@ int launch_cfg(const GP& p, int nb, bool vec, hipStream_t st) {
   if (vec) {
     auto k = gemm_conv_kernel<BM, BN, WGM, WGN, true>;
     if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, block, lds, st, q);
+    SMX_LAUNCH(k, grid, block, lds, st, q);
   } else {
     auto k = gemm_conv_kernel<BM, BN, WGM, WGN, false>;
     if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, block, lds, st, q);
+    SMX_LAUNCH(k, grid, block, lds, st, q);
   }
   if (p.ksplit > 1) {
     int blocks = (int)(((long long)p.M * p.N + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, q);
+    SMX_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, q);
   }
   return smx_launch_status();
 }

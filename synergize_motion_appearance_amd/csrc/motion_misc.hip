@@ -265,7 +265,7 @@ extern "C" int smx_kp_head_f32(const float* logits, int ldl, const float* jmaps,
                                int B, int H, int W, int K, float temperature, void* stream) {
   if (!logits || !value || B <= 0 || H <= 1 || W <= 1 || K <= 0 || ldl < K || temperature <= 0.f) return SMX_EINVAL;
   if (jmaps && (!jac || ldj < 4 * K || ldj % 4 != 0)) return SMX_EINVAL;
-  hipLaunchKernelGGL(kp_head_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, logits, ldl, jmaps, ldj, value, jac, H, W, K, temperature);
+  SMX_LAUNCH(kp_head_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, logits, ldl, jmaps, ldj, value, jac, H, W, K, temperature);
   return smx_launch_status();
 }
 
@@ -274,7 +274,7 @@ extern "C" int smx_normalize_kp_f32(const float* kpd_value, const float* kpd_jac
                                     int B, int K, float scale, int rel_move, int rel_jac, void* stream) {
   if (!kpd_value || !kpd_jac || !out_value || !out_jac || B <= 0 || K <= 0) return SMX_EINVAL;
   if (rel_move && (!kp0_value || !kps_value || (rel_jac && (!kp0_jac || !kps_jac)))) return SMX_EINVAL;
-  hipLaunchKernelGGL(normalize_kp_kernel, dim3(smx_cdiv((long long)B * K, 128)), dim3(128), 0, (hipStream_t)stream, kpd_value, kpd_jac,
+  SMX_LAUNCH(normalize_kp_kernel, dim3(smx_cdiv((long long)B * K, 128)), dim3(128), 0, (hipStream_t)stream, kpd_value, kpd_jac,
                      kp0_value, kp0_jac, kps_value, kps_jac, out_value, out_jac, B, K, scale, rel_move, rel_jac);
   return smx_launch_status();
 }
@@ -287,7 +287,7 @@ extern "C" int smx_sparse_motion_f32(const float* src, int src_batch, const floa
   if (B <= 0 || H <= 1 || W <= 1 || K <= 0 || ldh < 4 * (K + 1) || ldh % 4 != 0) return SMX_EINVAL;
   if ((src_batch != 1 && src_batch != B) || (kps_batch != 1 && kps_batch != B)) return SMX_EINVAL;
   const long long total = (long long)B * H * W * (K + 1);
-  hipLaunchKernelGGL(sparse_motion_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+  SMX_LAUNCH(sparse_motion_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
                      src_batch == 1 ? 0LL : (long long)H * W * 3, kpd_value, kpd_jac, kps_value, kps_jac,
                      kps_batch == 1 ? 0 : 1, hg_in, ldh, sparse, drv_heat, total, H, W, K, kp_variance);
   return smx_launch_status();
@@ -297,7 +297,7 @@ extern "C" int smx_mask_deformation_f32(const float* mask_logits, int ldm, const
                                         float* mask_out, float* occ_out, int B, int H, int W, int K1, void* stream) {
   if (!mask_logits || !sparse || !deformation || B <= 0 || H <= 0 || W <= 0 || K1 <= 0 || ldm < K1 + (occ_out ? 1 : 0)) return SMX_EINVAL;
   const long long npix = (long long)B * H * W;
-  hipLaunchKernelGGL(mask_deformation_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, mask_logits, ldm, sparse,
+  SMX_LAUNCH(mask_deformation_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, mask_logits, ldm, sparse,
                      deformation, mask_out, npix, H * W, K1, occ_out);
   return smx_launch_status();
 }
@@ -305,7 +305,7 @@ extern "C" int smx_mask_deformation_f32(const float* mask_logits, int ldm, const
 extern "C" int smx_flow_to_residual_f32(const float* flow, float* res, int B, int H, int W, void* stream) {
   if (!flow || !res || B <= 0 || H <= 1 || W <= 1) return SMX_EINVAL;
   const long long npix = (long long)B * H * W;
-  hipLaunchKernelGGL(flow_to_residual_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, flow, res, npix, H, W);
+  SMX_LAUNCH(flow_to_residual_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, flow, res, npix, H, W);
   return smx_launch_status();
 }
 
@@ -313,7 +313,7 @@ extern "C" int smx_flow_occ_update_f32(const float* flow, const float* r, const 
                                        float* res_norm, float* occ_out, int B, int H, int W, void* stream) {
   if (!flow || !r || !occ_prev || !m_com || !res_norm || !occ_out || B <= 0 || H <= 1 || W <= 1) return SMX_EINVAL;
   const long long npix = (long long)B * H * W;
-  hipLaunchKernelGGL(flow_occ_update_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, flow, r, occ_prev, m_com,
+  SMX_LAUNCH(flow_occ_update_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, flow, r, occ_prev, m_com,
                      res_norm, occ_out, npix, ((float)H - 1.f) / 2.f);
   return smx_launch_status();
 }
@@ -321,47 +321,47 @@ extern "C" int smx_flow_occ_update_f32(const float* flow, const float* r, const 
 extern "C" int smx_motion_ignore_f32(const float* flow, uint8_t* ignore, int B, int Hf, int Wf, int Ht, int Wt, void* stream) {
   if (!flow || !ignore || B <= 0 || Hf <= 0 || Wf <= 0 || Ht <= 0 || Wt <= 0) return SMX_EINVAL;
   const long long total = (long long)B * Ht * Wt;
-  hipLaunchKernelGGL(motion_ignore_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, flow, ignore, total, Hf, Wf, Ht, Wt);
+  SMX_LAUNCH(motion_ignore_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, flow, ignore, total, Hf, Wf, Ht, Wt);
   return smx_launch_status();
 }
 
 extern "C" int smx_sft_combine_f32(const float* dec, const float* scale, const float* shift, float* out, float w,
                                    int64_t n, void* stream) {
   if (!dec || !scale || !shift || !out || n <= 0 || n % 4 != 0) return SMX_EINVAL;
-  hipLaunchKernelGGL(sft_combine_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dec,
+  SMX_LAUNCH(sft_combine_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dec,
                      (const float4*)scale, (const float4*)shift, (float4*)out, w, (long long)(n / 4));
   return smx_launch_status();
 }
 
 extern "C" int smx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream) {
   if (!a || !b || !y || n <= 0) return SMX_EINVAL;
-  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n);
+  SMX_LAUNCH(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n);
   return smx_launch_status();
 }
 
 extern "C" int smx_copy_slice_f32(const float* x, int ldx, float* y, int ldy, int64_t P, int C, void* stream) {
   if (!x || !y || P <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
   const long long total = (long long)P * C;
-  hipLaunchKernelGGL(copy_slice_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, C);
+  SMX_LAUNCH(copy_slice_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, C);
   return smx_launch_status();
 }
 
 extern "C" int smx_nchw_to_nhwc_f32(const float* x, float* y, int ldy, int B, int C, int H, int W, void* stream) {
   if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldy < C) return SMX_EINVAL;
   const long long total = (long long)B * C * H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, ldy, total, C, H * W);
+  SMX_LAUNCH(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, ldy, total, C, H * W);
   return smx_launch_status();
 }
 
 extern "C" int smx_nhwc_to_nchw_f32(const float* x, int ldx, float* y, int B, int C, int H, int W, void* stream) {
   if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldx < C || B > 65535) return SMX_EINVAL;
   const int HW = H * W;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(smx_cdiv(HW, 32), smx_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, C, HW);
+  SMX_LAUNCH(nhwc_to_nchw_kernel, dim3(smx_cdiv(HW, 32), smx_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, C, HW);
   return smx_launch_status();
 }
 
 extern "C" int smx_to_uint8_f32(const float* x, uint8_t* y, int64_t n, float lo, float hi, void* stream) {
   if (!x || !y || n <= 0 || !(hi > lo)) return SMX_EINVAL;
-  hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, lo, hi);
+  SMX_LAUNCH(to_uint8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, lo, hi);
   return smx_launch_status();
 }

@@ -174,11 +174,11 @@ extern "C" int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float
   const int nch = (HW + ppc - 1) / ppc;
   float* part = ws; float* ss = ws + (int64_t)B * nch * C * 2;
   const int rows = 256 / (C / 4);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, part, HW, C, ppc, nch);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, gamma, beta, ss, HW, C, groups, nch, eps);
+  SMX_LAUNCH(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, part, HW, C, ppc, nch);
+  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, gamma, beta, ss, HW, C, groups, nch, eps);
   const long long total4 = (long long)B * HW * (C / 4);
   int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, ss, total4, HW, C, swish);
+  SMX_LAUNCH(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, ss, total4, HW, C, swish);
   return smx_launch_status();
 }
 
@@ -190,8 +190,8 @@ extern "C" int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gam
   int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
   const int nch = (HW + ppc - 1) / ppc;
   const int rows = 256 / (C / 4);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, ws, HW, C, ppc, nch);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, ws, gamma, beta, ss, HW, C, groups, nch, eps);
+  SMX_LAUNCH(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, ws, HW, C, ppc, nch);
+  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, ws, gamma, beta, ss, HW, C, groups, nch, eps);
   return smx_launch_status();
 }
 
@@ -200,7 +200,7 @@ extern "C" int smx_groupnorm_apply_f32(const float* x, int ldx, const float* ss,
   if (!x || !ss || !y || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < C || ldy < C) return SMX_EINVAL;
   const long long total4 = (long long)B * HW * (C / 4);
   int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, ss, total4, HW, C, swish);
+  SMX_LAUNCH(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, ss, total4, HW, C, swish);
   return smx_launch_status();
 }
 
@@ -209,9 +209,9 @@ extern "C" int smx_layernorm_pos_f32(const float* x, const float* gamma, const f
   if (!x || !y || !gamma || !beta || T <= 0 || E <= 0 || E > 512 || (y_pos && (!pos || npos <= 0))) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(smx_cdiv(T, 4)), block(256);
-  if (E <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
-  else if (E <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
+  if (E <= 64) SMX_LAUNCH(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
+  else if (E <= 256) SMX_LAUNCH(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
+  else SMX_LAUNCH(layernorm_kernel<8>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
   return smx_launch_status();
 }
 
@@ -220,8 +220,8 @@ extern "C" int smx_softmax_rows_f32(float* s, int ld, int R, int S, float scale,
   if (!s || R <= 0 || S <= 0 || S > 1024 || ld < S || (mask && rows_per_mask <= 0)) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(smx_cdiv(R, 4)), block(256);
-  if (S <= 256) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
-  else if (S <= 512) hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
-  else hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  if (S <= 256) SMX_LAUNCH(softmax_rows_kernel<4>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else if (S <= 512) SMX_LAUNCH(softmax_rows_kernel<8>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else SMX_LAUNCH(softmax_rows_kernel<16>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
   return smx_launch_status();
 }

@@ -1,6 +1,8 @@
 // shared host-side helpers for the libsmx translation units
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "smx.h"
 
 #define SMX_HIP(expr)                                  \
@@ -9,8 +11,25 @@
     if (_e != hipSuccess) return SMX_ELAUNCH;          \
   } while (0)
 
+// hipGetLastError() is per-thread and sticky across ALL runtime calls, including the host
+// framework's own (a benign hipErrorNotReady / invalid-pointer probe left behind by the caller
+// must not be reported as our launch failing): clear it right before the launch, read it after.
+static inline void smx_clear_stale_error() {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess && getenv("SMX_DEBUG_STALE")) fprintf(stderr, "[libsmx] cleared stale caller error: %s\n", hipGetErrorString(e));
+}
+
+#define SMX_LAUNCH(...)               \
+  do {                                \
+    smx_clear_stale_error();          \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 static inline int smx_launch_status() {
-  return hipGetLastError() == hipSuccess ? SMX_OK : SMX_ELAUNCH;
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return SMX_OK;
+  fprintf(stderr, "[libsmx] kernel launch failed: %s\n", hipGetErrorString(e));
+  return SMX_ELAUNCH;
 }
 
 static inline int smx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

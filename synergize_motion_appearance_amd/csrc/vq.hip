@@ -138,7 +138,7 @@ template <int D>
 int launch_vq(const float* z, const float* cb, int64_t* idx, float* zq, float* dmin, float* sqerr, int N, int Ks, hipStream_t st) {
   const size_t lds = (size_t)(64 * (D + 4) + (Ks + 63) / 64 * 64 + 128 + 128) * sizeof(float);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vq_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(vq_kernel<D>, dim3(smx_cdiv(N, 128)), dim3(256), lds, st, z, cb, idx, zq, dmin, sqerr, N, Ks);
+  SMX_LAUNCH(vq_kernel<D>, dim3(smx_cdiv(N, 128)), dim3(256), lds, st, z, cb, idx, zq, dmin, sqerr, N, Ks);
   return smx_launch_status();
 }
 

@@ -208,8 +208,8 @@ extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float*
   dim3 grid(smx_cdiv(npix * lpp, 256 * ppt)), block(256);
   const int chunk = 256 / lpp * ppt;                                // pixels per block
   int cpi = ((H * W) % chunk == 0 && !getenv("SMX_WARP_NO_REORDER")) ? (H * W) / chunk : 0;
-#define SMX_WARP(L) do { if (ppt == 4) hipLaunchKernelGGL((warp_kernel<L, 4>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); \
-                         else hipLaunchKernelGGL((warp_kernel<L, 1>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); } while (0)
+#define SMX_WARP(L) do { if (ppt == 4) SMX_LAUNCH((warp_kernel<L, 4>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); \
+                         else SMX_LAUNCH((warp_kernel<L, 1>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); } while (0)
   switch (lpp) {
     case 1: SMX_WARP(1); break; case 2: SMX_WARP(2); break; case 4: SMX_WARP(4); break; case 8: SMX_WARP(8); break;
     case 16: SMX_WARP(16); break; case 32: SMX_WARP(32); break; default: SMX_WARP(64); break;
@@ -222,14 +222,14 @@ extern "C" int smx_resize_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y
                                                int Hout, int Wout, int C, void* stream) {
   if (!x || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
   const long long total = (long long)B * Hout * Wout * C;
-  hipLaunchKernelGGL(resize_ac_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, Hin, Win, Hout, Wout, C);
+  SMX_LAUNCH(resize_ac_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, Hin, Win, Hout, Wout, C);
   return smx_launch_status();
 }
 
 extern "C" int smx_avgpool2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int B, int Hin, int Win, int C, void* stream) {
   if (!x || !y || B <= 0 || Hin < 2 || Win < 2 || (Hin & 1) || (Win & 1) || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
   const long long total = (long long)B * (Hin / 2) * (Win / 2) * C;
-  hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, Hin, Win, C);
+  SMX_LAUNCH(avgpool2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, Hin, Win, C);
   return smx_launch_status();
 }
 
@@ -237,6 +237,6 @@ extern "C" int smx_antialias_down_f32(const float* img_nchw, const float* w, flo
                                       int H, int W, int K, int step, void* stream) {
   if (!img_nchw || !w || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || !(K & 1) || step <= 0 || ldo < C) return SMX_EINVAL;
   const long long total = (long long)B * ((H + step - 1) / step) * ((W + step - 1) / step) * C;
-  hipLaunchKernelGGL(antialias_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img_nchw, w, out, ldo, total, C, H, W, K, step);
+  SMX_LAUNCH(antialias_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img_nchw, w, out, ldo, total, C, H, W, K, step);
   return smx_launch_status();
 }

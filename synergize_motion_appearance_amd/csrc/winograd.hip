@@ -297,22 +297,22 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   if (abl && nw == 2) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
     switch (abl) {
-      case 2: hipLaunchKernelGGL((winograd_kernel<false, 2, 2>), grid, dim3(512), lds, st, p); break;
-      case 4: hipLaunchKernelGGL((winograd_kernel<false, 2, 4>), grid, dim3(512), lds, st, p); break;
-      case 6: hipLaunchKernelGGL((winograd_kernel<false, 2, 6>), grid, dim3(512), lds, st, p); break;
-      case 16: hipLaunchKernelGGL((winograd_kernel<false, 2, 16>), grid, dim3(512), lds, st, p); break;
-      default: hipLaunchKernelGGL((winograd_kernel<false, 2, 22>), grid, dim3(512), lds, st, p); break;
+      case 2: SMX_LAUNCH((winograd_kernel<false, 2, 2>), grid, dim3(512), lds, st, p); break;
+      case 4: SMX_LAUNCH((winograd_kernel<false, 2, 4>), grid, dim3(512), lds, st, p); break;
+      case 6: SMX_LAUNCH((winograd_kernel<false, 2, 6>), grid, dim3(512), lds, st, p); break;
+      case 16: SMX_LAUNCH((winograd_kernel<false, 2, 16>), grid, dim3(512), lds, st, p); break;
+      default: SMX_LAUNCH((winograd_kernel<false, 2, 22>), grid, dim3(512), lds, st, p); break;
     }
     return smx_launch_status();
   }
   if (nw == 2) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
-    if (swz) hipLaunchKernelGGL((winograd_kernel<true, 2>), grid, dim3(512), lds, st, p);
-    else hipLaunchKernelGGL((winograd_kernel<false, 2>), grid, dim3(512), lds, st, p);
+    if (swz) SMX_LAUNCH((winograd_kernel<true, 2>), grid, dim3(512), lds, st, p);
+    else SMX_LAUNCH((winograd_kernel<false, 2>), grid, dim3(512), lds, st, p);
   } else {
     dim3 grid((unsigned)blocks, (Cout + 31) / 32);
-    if (swz) hipLaunchKernelGGL((winograd_kernel<true, 1>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((winograd_kernel<false, 1>), grid, dim3(256), lds, st, p);
+    if (swz) SMX_LAUNCH((winograd_kernel<true, 1>), grid, dim3(256), lds, st, p);
+    else SMX_LAUNCH((winograd_kernel<false, 1>), grid, dim3(256), lds, st, p);
   }
   return smx_launch_status();
 }

@@ -83,6 +83,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SmxError(f"{LIB_PATH} not found: build it with `python -m synergize_motion_appearance_amd.build` "
                        "(__graft_entry__.build()). There is no CPU fallback for the HIP path.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the one
+    # already resident when libsmx.so (NEEDED libamdhip64.so.7) is dlopen'ed, otherwise the system
+    # runtime is pulled in first, torch then shares it with its bundled HSA and no device is found.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

@@ -215,3 +215,16 @@ def test_batch_of_distinct_sources(nets):
         one = net_g(srcs[i:i + 1].contiguous(), dmi, w=1, inference=True)["out"].cpu()
         assert maxabs(both[i:i + 1], one) < 3e-4, i
     assert maxabs(both[0:1], golden("netg.npz")["out"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_graft_entry_build_then_smoke_in_a_fresh_process():
+    """build() followed by smoke() in ONE fresh interpreter (the driver's order): libsmx must bind
+    to the HIP runtime torch brings, whichever of the two is touched first."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "__graft_entry__.py"), "--smoke"], capture_output=True,
+                       text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "smoke: one 256x256 frame" in r.stdout
