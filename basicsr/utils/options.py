@@ -1,1 +1,1 @@
-from synergize_motion_appearance_amd.options import ordered_yaml  # noqa: F401
+from synergize_motion_appearance_amd.options import ordered_yaml, parse, dict2str  # noqa: F401

@@ -109,7 +109,7 @@ def broadcast_source_cache(net_g, motion_estimator, source, src=0):
 
 @torch.no_grad()
 def animate_batched(source, driving, net_g, motion_estimator, relative=True, adapt_movement_scale=True,
-                    batch=8, kp_source=None, kp_driving_initial=None, source_cache=None, want="uint8", anchor_idx=0):
+                    batch=8, kp_source=None, kp_driving_initial=None, source_cache=None, want="uint8", anchor_idx=0, w=1.0):
     """source [3,H,W] / [1,3,H,W], driving [N,3,H,W] device tensors in [-1,1].
     -> uint8 frames [N,H,W,3] (want='uint8'), fp32 NCHW [N,3,H,W] ('float'), or both ('both').
     anchor_idx: the frame whose keypoints are `kp_driving_initial`.  The reference's dataset path
@@ -131,7 +131,7 @@ def animate_batched(source, driving, net_g, motion_estimator, relative=True, ada
         kp_d = eng_m.estimate_kp(frames)
         kp_n = normalize_kp(kp_source, kp_d, kp_driving_initial, adapt_movement_scale, relative, relative, scale)
         dm = eng_m.dense_motion(src64, kp_n, kp_source)
-        st = eng_g.forward(cache, dm["deformation"], dm["occlusion_nhwc"].view(-1, 64, 64), dm["heat_nhwc"], 1.0)
+        st = eng_g.forward(cache, dm["deformation"], dm["occlusion_nhwc"].view(-1, 64, 64), dm["heat_nhwc"], float(w))
         if want in ("uint8", "both"):
             u8.append(ops.to_uint8(st["out"], -1.0, 1.0))
         if want in ("float", "both"):

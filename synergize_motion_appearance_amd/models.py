@@ -1,0 +1,231 @@
+"""MODEL-level entry of the animation path: `build_model(opt)` and
+the inference surface of `AppMotionCompModel` -- `feed_data`, `test`, `make_animation`,
+`generate_video_image`, `load_network` -- as `basicsr/animate.py:73-78` and `basicsr/test.py:75-80`
+drive them (reference `basicsr/models/__init__.py:19-30`, `sr_model.py:17-31`,
+`base_model.py:17-22, 236-262`, `appmotioncomp_model.py:110-114, 437-456, 607-756`).
+
+Same names, argument meaning and return types (BGR uint8 HWC arrays, the same files at the same
+relative paths); the per-frame loop inside is the batched HIP path of `driver.animate_batched`:
+one keypoint / dense-motion / generator launch sequence per `val.batch` frames, the source
+encoded once per video.  Training members (`optimize_parameters`, losses, EMA, schedulers) are
+row N2 and raise."""
+from collections import OrderedDict
+from copy import deepcopy
+from os import path as osp
+
+import numpy as np
+import torch
+
+from . import driver, ops
+from .archs import build_network
+from .img_util import imwrite, mimsave, tensor2img
+from .registry import MODEL_REGISTRY
+
+__all__ = ["build_model", "AppMotionCompModel", "calculate_psnr", "calculate_l1", "calculate_ssim"]
+
+
+def build_model(opt):
+    """reference `basicsr/models/__init__.py:19-30`: deep copy, `opt['model_type']` -> class(opt)."""
+    opt = deepcopy(opt)
+    return MODEL_REGISTRY.get(opt["model_type"])(opt)
+
+
+# ---- the three array metrics of `val.metrics` that need no external network ----------------------
+def _crop(img, crop_border):
+    return img if crop_border == 0 else img[crop_border:-crop_border, crop_border:-crop_border, ...]
+
+
+def calculate_psnr(img1, img2, crop_border=0, test_y_channel=False, **_):
+    """`basicsr/metrics/psnr_ssim.py` calculate_psnr on uint8/[0,255] HWC arrays."""
+    if test_y_channel:
+        raise NotImplementedError("test_y_channel needs the reference's bgr2ycbcr tables; the shipped yml uses false")
+    a, b = _crop(np.asarray(img1, np.float64), crop_border), _crop(np.asarray(img2, np.float64), crop_border)
+    mse = np.mean((a - b) ** 2)
+    return float("inf") if mse == 0 else float(20.0 * np.log10(255.0 / np.sqrt(mse)))
+
+
+def calculate_l1(img1, img2, crop_border=0, **_):
+    a, b = _crop(np.asarray(img1, np.float64), crop_border), _crop(np.asarray(img2, np.float64), crop_border)
+    return float(np.mean(np.abs(a - b)))
+
+
+def calculate_ssim(img1, img2, crop_border=0, test_y_channel=False, **_):
+    """SSIM with the 11x11 sigma-1.5 Gaussian window, 'valid' region, averaged over channels."""
+    if test_y_channel:
+        raise NotImplementedError("test_y_channel needs the reference's bgr2ycbcr tables")
+    from scipy.signal import convolve2d
+    a, b = _crop(np.asarray(img1, np.float64), crop_border), _crop(np.asarray(img2, np.float64), crop_border)
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    g /= g.sum()
+    win = np.outer(g, g)
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+
+    def one(x, y):
+        f = lambda z: convolve2d(z, win, mode="valid")   # noqa: E731
+        mx, my = f(x), f(y)
+        sxx, syy, sxy = f(x * x) - mx * mx, f(y * y) - my * my, f(x * y) - mx * my
+        return float((((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sxx + syy + c2))).mean())
+    if a.ndim == 2:
+        return one(a, b)
+    return float(np.mean([one(a[..., i], b[..., i]) for i in range(a.shape[2])]))
+
+
+_ARRAY_METRICS = {"calculate_psnr": calculate_psnr, "calculate_l1": calculate_l1, "calculate_ssim": calculate_ssim}
+
+
+@MODEL_REGISTRY.register()
+class AppMotionCompModel:
+    """Inference half of the reference model class (`appmotioncomp_model.py:108`)."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        if opt.get("num_gpu", 1) == 0:
+            raise RuntimeError("the MI355X-native path has no CPU mode (num_gpu: 0)")
+        self.device = torch.device("cuda")
+        self.is_train = opt.get("is_train", False)
+        if self.is_train:
+            raise NotImplementedError("training (optimize_parameters, losses, EMA) is SURVEY row N2, not built")
+        self.net_g = build_network(opt["network_g"]).to(self.device).eval()
+        path = opt.get("path", {})
+        if path.get("pretrain_network_g") is not None:
+            self.load_network(self.net_g, path["pretrain_network_g"], path.get("strict_load_g", True),
+                              path.get("param_key_g", "params"))
+        self.motion_estimator = None
+        self.metric_results = {}
+
+    # -- base_model.py:236-262 ------------------------------------------------------------------------
+    def load_network(self, net, load_path, strict=True, param_key="params"):
+        load_net = torch.load(load_path, map_location="cpu")
+        if param_key is not None:
+            if param_key not in load_net and "params" in load_net:
+                param_key = "params"
+            load_net = load_net[param_key]
+        load_net = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in load_net.items())
+        net.load_state_dict(load_net, strict=strict)
+
+    def _ensure_motion_estimator(self):
+        """appmotioncomp_model.py:658-668 (built, and its checkpoint loaded, at validation time)."""
+        if self.motion_estimator is None:
+            if self.opt.get("network_motion_estimator") is None:
+                raise KeyError("opt['network_motion_estimator'] is required by the animation path")
+            me = build_network(self.opt["network_motion_estimator"]).to(self.device).eval()
+            path = self.opt.get("path", {})
+            if path.get("pretrain_network_motion_estimator") is not None:
+                self.load_network(me, path["pretrain_network_motion_estimator"],
+                                  path.get("strict_load_motion_estimator", True), path.get("param_key_m", "params"))
+            self.motion_estimator = me
+        return self.motion_estimator
+
+    # -- appmotioncomp_model.py:110-114, 437-456 --------------------------------------------------------
+    def feed_data(self, data):
+        self.gt = data["driving"].to(self.device)
+        self.source = data["source"].to(self.device)
+        self.b = self.gt.shape[0]
+
+    @torch.no_grad()
+    def test(self):
+        me = self._ensure_motion_estimator()
+        self.dense_motion = me(self.gt, self.source)
+        self.out_dict = self.net_g(self.source, self.dense_motion, w=self.opt.get("val", {}).get("w", 1), inference=True)
+        self.driving_feat = self.net_g.encode_driving(self.gt)
+        self.source_feat = self.net_g.encode_driving(self.source)
+        if "lq_feat" in self.out_dict:
+            self.lq_recon = self.net_g.generator(self.out_dict["lq_feat"])
+
+    def get_current_visuals(self):
+        out = OrderedDict()
+        out["gt"], out["source"] = self.gt.detach().cpu(), self.source.detach().cpu()
+        out["result"] = self.out_dict["out"].detach().cpu()
+        return out
+
+    # -- appmotioncomp_model.py:607-639 -----------------------------------------------------------------
+    @torch.no_grad()
+    def make_animation(self, source_img, driving, cpu=False, anchor_idx=0):
+        """source [1,3,H,W]; driving: list of [1,3,H,W] (or [N,3,H,W]) in [-1,1] ->
+        (predictions, driving_imgs): lists of BGR uint8 HWC arrays, one per driving frame.
+        `driving[anchor_idx]` supplies kp_driving_initial (the reference always uses index 0 and gets
+        the effect of an anchor by reversing lists; see `generate_video_image`)."""
+        if cpu:
+            raise RuntimeError("the MI355X-native path has no CPU mode")
+        val = self.opt.get("val", {})
+        relative, adapt = val.get("relative", False), val.get("adapt_scale", False)
+        me = self._ensure_motion_estimator()
+        drv = driving if torch.is_tensor(driving) else torch.cat([d if d.dim() == 4 else d[None] for d in driving])
+        self.gt, self.source = driving, source_img.to(self.device)
+        self.b = 1
+        drv = drv.to(self.device).float()
+        out = driver.animate_batched(self.source.float(), drv, self.net_g, me, relative=relative,
+                                     adapt_movement_scale=adapt, batch=int(val.get("batch", 30)), anchor_idx=anchor_idx,
+                                     w=float(val.get("w", 1)))
+        preds = [np.ascontiguousarray(p[:, :, ::-1]) for p in out.cpu().numpy()]
+        d8 = ops.to_uint8(ops.nchw_to_nhwc(drv), -1.0, 1.0).cpu().numpy()
+        return preds, [np.ascontiguousarray(d[:, :, ::-1]) for d in d8]
+
+    # -- appmotioncomp_model.py:642-756 -----------------------------------------------------------------
+    @torch.no_grad()
+    def generate_video_image(self, dataloader, current_iter, tb_logger):
+        dataset_name = dataloader.dataset.opt["name"]
+        val = self.opt.get("val", {})
+        metrics = val.get("metrics")
+        with_metrics = metrics is not None
+        if with_metrics:
+            self.metric_results = {m: 0 for m in metrics.keys()}
+        vis_root = osp.join(self.opt["path"]["visualization"], dataset_name)
+        self.net_g.eval()
+        self._ensure_motion_estimator()
+        count_num = 0
+        for val_data in dataloader:
+            video_name, anchor_idx = val_data["video_name"], val_data["anchor_idx"]
+            driving_video = val_data["driving_video"]
+            if torch.is_tensor(anchor_idx):
+                anchor_idx = int(anchor_idx)
+            if anchor_idx is None:
+                raise TypeError("val_data['anchor_idx'] is None (the reference fails here too: "
+                                "driving_forward is unbound, appmotioncomp_model.py:679-683)")
+            # reference: make_animation(driving[a:]) ++ make_animation(driving[:a+1][::-1]) spliced as
+            # backward[::-1] + forward[1:]; both halves start at driving[a], so kp_driving_initial is
+            # kp(driving[a]) for every frame -> one pass over the frames in order with that anchor.
+            predictions, drivings = self.make_animation(val_data["source"], driving_video, anchor_idx=anchor_idx)
+            source = tensor2img([self.source.detach().cpu()], rgb2bgr=True, min_max=(-1, 1))
+            visual = []
+            for i in range(len(predictions)):
+                vis = np.concatenate((source, drivings[i], predictions[i]), axis=1)
+                visual.append(vis)
+                img_name = video_name[0] + "_" + val_data["driving_name_list"][i][0]
+                imwrite(vis, osp.join(vis_root, "visual", f"{img_name}_v.png"))
+                imwrite(predictions[i], osp.join(vis_root, "result", f"{img_name}_r.png"))
+                imwrite(source, osp.join(vis_root, "source", f"{img_name}_s.png"))
+                imwrite(drivings[i], osp.join(vis_root, "driving", f"{img_name}_d.png"))
+                if with_metrics:
+                    for name, opt_ in metrics.items():
+                        if name in ("psnr", "ssim", "l1"):
+                            o = dict(opt_)
+                            fn = _ARRAY_METRICS[o.pop("type")]
+                            self.metric_results[name] += fn(predictions[i], drivings[i], **o)
+                            count_num += 1
+            mimsave([np.ascontiguousarray(p[:, :, ::-1]) for p in predictions],
+                    osp.join(vis_root, "result_videos", f"{video_name[0]}_r.mp4"))
+            mimsave([np.ascontiguousarray(v[:, :, ::-1]) for v in visual],
+                    osp.join(vis_root, "visual_videos", f"{video_name[0]}_v.mp4"))
+        if with_metrics:
+            for metric in list(metrics.keys()):
+                if metric in ("psnr", "ssim", "l1"):
+                    # the reference divides by the count accumulated over ALL array metrics
+                    # (appmotioncomp_model.py:706-711, 722-724): kept, so the logged numbers agree
+                    self.metric_results[metric] /= max(count_num, 1)
+                    if metric == "l1":
+                        self.metric_results["l1_255"] = self.metric_results["l1"] / 255.0
+                else:
+                    # fid / lpips / face_akd / face_aed / id_similarity / pose_accuracy need networks the
+                    # reference downloads (InceptionV3, VGG, face_alignment, ArcFace, hopenet): not built
+                    self.metric_results[metric] = float("nan")
+        return self.metric_results
+
+    def validation(self, dataloader, current_iter, tb_logger, save_img=False, **kwargs):
+        raise NotImplementedError("frame-pair validation (test.py) is outside the animation path; use generate_video_image")
+
+    def optimize_parameters(self, current_iter):
+        raise NotImplementedError("training is SURVEY row N2, not built")
+
+    def save(self, epoch, current_iter):
+        raise NotImplementedError("training is SURVEY row N2, not built")

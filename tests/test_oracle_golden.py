@@ -112,6 +112,21 @@ def test_make_animation_config1():
         assert np.abs(fr_rel[t].astype(int) - g["frames_r1a1"][t].astype(int)).max() <= 1
 
 
+def test_generate_video_frames_anchor_splice_vs_reference_model_class():
+    """the oracle's literal restatement of `generate_video_image`'s anchor splice vs
+    the frames the reference's own AppMotionCompModel wrote (tests/golden/make_golden_model.py)."""
+    g = golden("model_animate.npz")
+    n, anchor, seed = int(g["n_frames"]), int(g["anchor_idx"]), int(g["seed"])
+    src, drv = clip(n, seed)
+    with torch.no_grad():
+        fr = O.generate_video_frames(weights("network_g"), weights("network_motion_estimator"), src, drv, anchor,
+                                     relative=True, adapt_movement_scale=True)
+    assert len(fr) == n
+    for t in range(n):
+        d = np.abs(fr[t].astype(int) - g["result_png"][t].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, (t, d.max(), (d > 0).mean())
+
+
 def test_warp_explicit_matches_aten():
     x = synth_input("warp_feat", (2, 16, 64, 64))
     flow = O.make_coordinate_grid(64, 64, torch.float32)[None].repeat(2, 1, 1, 1) + 0.3 * synth_input("warp_flow", (2, 64, 64, 2))
