@@ -143,6 +143,90 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
   }
 }
 
+// Row-chunk variant for the big launches (LPP >= 16, W a multiple of the block's 4*PPB pixels).
+// The per-pixel coordinate work (flow / occlusion bilinear resize, two integer divisions, the
+// align_corners index math: ~150 VALU instructions) used to be repeated by all C/4 lanes of a pixel
+// and cost more issue slots than the 16 tap loads + 4 stores it feeds (measured at s=256, B=30:
+// 236 us -> 166 us; a 4-row tall tile instead of a row chunk measured within 3 % either way).  Here a block owns 4*PPB consecutive pixels of ONE image row, so frame,
+// row and x-base are block-uniform (scalar ALU); lane j < NPW of each wave computes the sampling
+// position of the wave's j-th pixel ONCE and the pixel's lane group fetches it with three
+// wavefront shuffles.  Arithmetic and association order are those of the scalar path of warp_kernel.
+template <int LPP>
+__global__ __launch_bounds__(256) void warp_rows_kernel(const float* __restrict__ feat, long long feat_bs,
+                                                        const float* __restrict__ flow, const float* __restrict__ occ,
+                                                        float* __restrict__ out, int H, int W, int C, int Hf, int Wf,
+                                                        int chunks_per_img, int nframes) {
+  constexpr int PPT = 4, PPB = 256 / LPP, GPW = 64 / LPP, NPW = GPW * PPT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPP, g = lane / LPP;
+  // (XCD, region, frame) block order -- see warp_kernel
+  const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int region = lin / nframes, b = lin - region * nframes;
+  const int cpr = W / (PPB * PPT);
+  const int y = region / cpr, xb = (region - y * cpr) * (PPB * PPT);
+  (void)chunks_per_img;
+
+  float cix = 0.f, ciy = 0.f, coc = 1.f;
+  if (lane < NPW) {
+    const int pass = lane / GPW, gg = lane % GPW;
+    const int x = xb + pass * PPB + wave * GPW + gg;
+    const float* fb = flow + (long long)b * Hf * Wf * 2;
+    const float* ob = occ ? occ + (long long)b * Hf * Wf : nullptr;
+    float fxv, fyv, ov = 1.f;
+    if (Hf == H && Wf == W) {
+      fxv = fb[(y * Wf + x) * 2]; fyv = fb[(y * Wf + x) * 2 + 1];
+      if (ob) ov = ob[y * Wf + x];
+    } else {
+      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+      ac_src(y, Hf, H, y0, y1, ly0, ly1); ac_src(x, Wf, W, x0, x1, lx0, lx1);
+      const float2 f00 = *reinterpret_cast<const float2*>(fb + (y0 * Wf + x0) * 2);
+      const float2 f01 = *reinterpret_cast<const float2*>(fb + (y0 * Wf + x1) * 2);
+      const float2 f10 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x0) * 2);
+      const float2 f11 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x1) * 2);
+      // unfused, in ATen's association (and bit-identical to warp_kernel's lane-parallel resize)
+      auto bil = [&](float v00, float v01, float v10, float v11) {
+        return __fadd_rn(__fmul_rn(ly0, __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx1, v01))),
+                         __fmul_rn(ly1, __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx1, v11))));
+      };
+      fxv = bil(f00.x, f01.x, f10.x, f11.x);
+      fyv = bil(f00.y, f01.y, f10.y, f11.y);
+      if (ob) ov = bil(ob[y0 * Wf + x0], ob[y0 * Wf + x1], ob[y1 * Wf + x0], ob[y1 * Wf + x1]);
+    }
+    cix = ((fxv + 1.f) / 2.f) * (W - 1); ciy = ((fyv + 1.f) / 2.f) * (H - 1); coc = ov;
+  }
+  float4 v[PPT][4]; float w[PPT][4]; float oc[PPT];
+  const float* fbase = feat + (long long)b * feat_bs + sub * 4;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int src = i * GPW + g;
+    const float ix = __shfl(cix, src, 64), iy = __shfl(ciy, src, 64);
+    oc[i] = __shfl(coc, src, 64);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float tx = ix - fx, ty = iy - fy;
+    const bool sane = ix > -2.f && ix < (float)W + 1.f && iy > -2.f && iy < (float)H + 1.f;
+    const int x0 = sane ? (int)fx : -4, y0 = sane ? (int)fy : -4;
+    w[i][0] = (1.f - tx) * (1.f - ty); w[i][1] = tx * (1.f - ty); w[i][2] = (1.f - tx) * ty; w[i][3] = tx * ty;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+      v[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        v[i][k] = *reinterpret_cast<const float4*>(fbase + (yy * W + xx) * C);
+    }
+  }
+  float* ob_ = out + ((long long)b * H * W + (long long)y * W + xb + wave * GPW + g) * C + sub * 4;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc.x += v[i][k].x * w[i][k]; acc.y += v[i][k].y * w[i][k]; acc.z += v[i][k].z * w[i][k]; acc.w += v[i][k].w * w[i][k];
+    }
+    if (occ) { acc.x *= oc[i]; acc.y *= oc[i]; acc.z *= oc[i]; acc.w *= oc[i]; }
+    *reinterpret_cast<float4*>(ob_ + i * PPB * C) = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                         long long total, int Hin, int Win, int Hout, int Wout, int C) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -206,6 +290,16 @@ extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float*
   // 4 pixels per thread once the launch is large (>= 8M lanes); small launches keep 1 for parallelism
   const int ppt = (npix * lpp >= (8LL << 20)) ? 4 : 1;
   dim3 grid(smx_cdiv(npix * lpp, 256 * ppt)), block(256);
+  // whole row chunks and enough blocks: coordinates computed once per pixel (warp_rows_kernel)
+  const int rchunk = 256 / (lpp > 0 ? lpp : 1) * 4;
+  if (lpp >= 16 && W % rchunk == 0 && npix / rchunk >= 256 && (long long)H * W * C < (1LL << 31) && !getenv("SMX_WARP_OLD")) {
+    const int cpi2 = (H * W) / rchunk;
+    dim3 grid2(cpi2 * B);
+    if (lpp == 16) SMX_LAUNCH((warp_rows_kernel<16>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+    else if (lpp == 32) SMX_LAUNCH((warp_rows_kernel<32>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+    else SMX_LAUNCH((warp_rows_kernel<64>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+    return smx_launch_status();
+  }
   const int chunk = 256 / lpp * ppt;                                // pixels per block
   int cpi = ((H * W) % chunk == 0 && !getenv("SMX_WARP_NO_REORDER")) ? (H * W) / chunk : 0;
 #define SMX_WARP(L) do { if (ppt == 4) SMX_LAUNCH((warp_kernel<L, 4>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); \

@@ -304,6 +304,35 @@ def test_warp_four_scales(ops, C, s):
     assert maxabs(nchw(y2), O.deform_input(feat.repeat(B, 1, 1, 1), flow)) < tol
 
 
+@pytest.mark.parametrize("C,s,B,fs", [(64, 256, 8, 64), (128, 128, 16, 64), (256, 32, 20, 64), (128, 64, 9, 64), (64, 64, 16, 64)])
+def test_warp_row_chunk_kernel_equals_per_lane_kernel_and_oracle(ops, C, s, B, fs, monkeypatch):
+    """Large launches take `warp_rows_kernel` (coordinates once per pixel, shuffled to the pixel's lanes);
+    it must agree with the per-lane kernel -- bit for bit where no flow resize is involved, to flow-ulp
+    level otherwise (the two resize code shapes contract into different FMAs) -- with broadcast and
+    per-frame features, flow at 64x64 and at the feature size, and match the oracle."""
+    feat = F.interpolate(rnd(f"wr{s}{C}", (1, C, 8, 8)), size=(s, s), mode="bicubic", align_corners=True)
+    fs = s if (C, s) == (64, 64) else fs                     # one case with flow size == feature size (no resize)
+    flow = O.make_coordinate_grid(fs, fs, torch.float32)[None] + 0.25 * F.interpolate(
+        rnd(f"wrf{s}{C}", (B, 2, 6, 6)), size=(fs, fs), mode="bicubic", align_corners=True).permute(0, 2, 3, 1)
+    flow[0, :2, :2] = float("nan")                           # NaN coordinates: all taps skipped, as in ATen
+    flow[1, 3, 3] = 1e9
+    occ = torch.sigmoid(rnd(f"wro{s}{C}", (B, 1, fs, fs)))
+    fd, od, xs = flow.cuda().contiguous(), occ.view(B, fs, fs).cuda().contiguous(), nhwc(feat)
+    xb = nhwc(feat.repeat(B, 1, 1, 1) * torch.linspace(0.5, 1.5, B).view(B, 1, 1, 1))
+    new = [ops.warp(xs, fd, od), ops.warp(xs, fd), ops.warp(xb, fd, od)]
+    monkeypatch.setenv("SMX_WARP_OLD", "1")
+    old = [ops.warp(xs, fd, od), ops.warp(xs, fd), ops.warp(xb, fd, od)]
+    monkeypatch.delenv("SMX_WARP_OLD")
+    for a, b in zip(new, old):
+        a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
+        # two correct fp32 flow resizes differ by an ulp of the flow, amplified by (s-1)/2 x feature gradient
+        assert torch.equal(a, b) if fs == s else maxabs(a.cpu(), b.cpu()) < (3e-4 if s >= 128 else 5e-5)
+    fl = flow.clone()
+    ref = O.occlude_input(O.deform_input(feat.repeat(B, 1, 1, 1), fl), occ)
+    ok = torch.isfinite(ref)
+    assert maxabs(torch.where(ok, nchw(new[0]), torch.zeros(())), torch.where(ok, ref, torch.zeros(()))) < (3e-4 if s >= 128 else 5e-5)
+
+
 @pytest.mark.parametrize("C,s", [(64, 512), (128, 256), (128, 128), (256, 64)])
 def test_warp_config4_512_kernel_level(ops, C, s):
     """BASELINE.json configs[3] (512x512: 4x flow + warp grid).  The reference itself raises at 512
