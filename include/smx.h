@@ -195,9 +195,10 @@ int smx_flow_occ_update_f32(const float* flow, const float* r, const float* occ_
                             float* res_norm, float* occ_out, int B, int H, int W, void* stream);
 /* motion_ignore[b][n] = any(|flow32|>1) with flow bilinear-resized (ac=True) to 32x32 (:487-492) */
 int smx_motion_ignore_f32(const float* flow, uint8_t* ignore, int B, int Hf, int Wf, int Ht, int Wt, void* stream);
-/* out = dec + w*(dec*scale + shift)  (Fuse_sft_block.forward :50-51), n elements */
-int smx_sft_combine_f32(const float* dec, const float* scale, const float* shift, float* out, float w,
-                        int64_t n, void* stream);
+/* out = dec + w*(dec*scale + shift)  (Fuse_sft_block.forward :50-51); P pixels x C channels, dec may be a
+ * channel slice (row stride ld_dec floats) of the [enc|dec] concat buffer, the others are dense */
+int smx_sft_combine_f32(const float* dec, int ld_dec, const float* scale, const float* shift, float* out, float w,
+                        int64_t P, int C, void* stream);
 /* y = a + b (n elements) */
 int smx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
 /* copy a channel slice: y[.., 0:C] (ld ldy) = x[.., 0:C] (ld ldx) over P pixels */

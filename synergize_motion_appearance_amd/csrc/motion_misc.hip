@@ -208,9 +208,11 @@ __global__ void motion_ignore_kernel(const float* __restrict__ flow, uint8_t* __
 }
 
 __global__ void sft_combine_kernel(const float4* __restrict__ dec, const float4* __restrict__ sc, const float4* __restrict__ sh,
-                                   float4* __restrict__ out, float w, long long n4) {
+                                   float4* __restrict__ out, float w, long long n4, int c4, int ld4) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const float4 d = dec[i], a = sc[i], b = sh[i];
+    // dec may be a channel slice of a wider buffer (row stride ld4 float4s); scale / shift / out are dense
+    const long long row = i / c4;
+    const float4 d = dec[ld4 == c4 ? i : row * ld4 + (i - row * c4)], a = sc[i], b = sh[i];
     out[i] = make_float4(d.x + w * (d.x * a.x + b.x), d.y + w * (d.y * a.y + b.y), d.z + w * (d.z * a.z + b.z), d.w + w * (d.w * a.w + b.w));
   }
 }
@@ -325,11 +327,12 @@ extern "C" int smx_motion_ignore_f32(const float* flow, uint8_t* ignore, int B, 
   return smx_launch_status();
 }
 
-extern "C" int smx_sft_combine_f32(const float* dec, const float* scale, const float* shift, float* out, float w,
-                                   int64_t n, void* stream) {
-  if (!dec || !scale || !shift || !out || n <= 0 || n % 4 != 0) return SMX_EINVAL;
-  SMX_LAUNCH(sft_combine_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dec,
-                     (const float4*)scale, (const float4*)shift, (float4*)out, w, (long long)(n / 4));
+extern "C" int smx_sft_combine_f32(const float* dec, int ld_dec, const float* scale, const float* shift, float* out, float w,
+                                   int64_t P, int C, void* stream) {
+  if (!dec || !scale || !shift || !out || P <= 0 || C <= 0 || C % 4 != 0 || ld_dec < C || ld_dec % 4 != 0) return SMX_EINVAL;
+  const long long n4 = (long long)P * (C / 4);
+  SMX_LAUNCH(sft_combine_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dec,
+                     (const float4*)scale, (const float4*)shift, (float4*)out, w, n4, C / 4, ld_dec / 4);
   return smx_launch_status();
 }
 

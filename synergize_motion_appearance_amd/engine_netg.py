@@ -196,10 +196,14 @@ class NetGEngine:
         return Conv.from_torch(P[pre + ".weight"], P[pre + ".bias"])
 
     @staticmethod
-    def _run(kind, blk, x):
+    def _run(kind, blk, x, out=None):
+        if kind == "res":
+            return blk(x, out=out)
+        if out is not None:
+            raise ValueError(f"in-place output is only planned for res blocks, not {kind}")
         if kind == "conv":
             return ops.conv(x, blk)
-        if kind in ("res", "attn"):
+        if kind == "attn":
             return blk(x)
         if kind == "down":      # pad (0,1,0,1) + conv3x3 s2 p0  (vqgan_arch.py:144-153)
             return ops.conv(x, blk, stride=2, pad=(0, 0), out_hw=(x.shape[1] // 2, x.shape[2] // 2))
@@ -209,15 +213,16 @@ class NetGEngine:
             return ops.groupnorm(x, blk[0], blk[1], swish=False)
         raise ValueError(kind)
 
-    def _run_seq(self, kinds, blocks, x, hook=None):
-        """run a block list; a trailing [gn, conv] pair (blocks 17, 18) is fused: GN folded into the conv loader."""
+    def _run_seq(self, kinds, blocks, x, hook=None, out_for=None):
+        """run a block list; a trailing [gn, conv] pair (blocks 17, 18) is fused: GN folded into the conv loader.
+        out_for(i, x_in) may hand block i a channel-slice view to write its output into (in-place concat)."""
         i = 0
         while i < len(kinds):
             if kinds[i] == "gn" and i + 1 < len(kinds) and kinds[i + 1] == "conv":
                 x = ops.conv(x, blocks[i + 1], in_ss=ops.groupnorm_stats(x, blocks[i][0], blocks[i][1]), in_swish=False)
                 i += 2
             else:
-                x = self._run(kinds[i], blocks[i], x)
+                x = self._run(kinds[i], blocks[i], x, None if out_for is None else out_for(i, x))
                 i += 1
             if hook is not None:
                 x = hook(i - 1, x)
@@ -297,7 +302,7 @@ class NetGEngine:
             return ops.conv(q, self.app_out[32], out=out)
         return ops.conv(q, self.app_out[s], out=out, d2s=(s // 32, C))
 
-    def _one_scale(self, st, feat, s, first):
+    def _one_scale(self, st, feat, s, first, out=None):
         flow = st["flows"][-1]
         warp0 = ops.warp(feat, flow)
         wsrc = warp0 if s == 32 else ops.resize(warp0, 32, 32)
@@ -313,17 +318,17 @@ class NetGEngine:
         st["occ"].append(occ)
         warped = ops.warp(feat, m_com, occ)
         st["before"].append(warped)
-        comp = self._app_comp(warped, m_com, s)
+        comp = self._app_comp(warped, m_com, s, out=out)
         st["comp"].append(comp)
         return comp
 
     # ---- A13 ------------------------------------------------------------------------------
-    def _fuse(self, s, enc, dec, w):
+    def _fuse(self, s, cat, w):
+        """cat = [enc | dec] (NHWC, 2C channels): both halves were written in place by their producers
+        (the appearance-compensation un-patchify conv and the decoder ResBlock), no concat copy."""
         f = self.sft[s]
-        B, H, W, C = dec.shape
-        cat = torch.empty((B, H, W, 2 * C), device=dec.device, dtype=torch.float32)
-        ops.copy_slice(enc, cat[..., :C])
-        ops.copy_slice(dec, cat[..., C:])
+        C = cat.shape[-1] // 2
+        enc, dec = cat[..., :C], cat[..., C:]
         e = f["res"](cat)
         ss = ops.conv(e, f["ss0"], act=ACT_LRELU02)                           # [.., 2C] = [scale.0 | shift.0]
         scale = ops.conv(ss[..., :C], f["scale2"])
@@ -338,11 +343,27 @@ class NetGEngine:
         st["kp_feat"] = ops.conv(ops.resize(heat_nhwc, 32, 32), self.kp_enc, act=ACT_RELU)
         x = self._one_scale(st, cache.feats[32], 32, True)
         st["lq"] = x
+        cats = {}
+
+        def out_for(i, x_in):
+            if i in self.fuse_after and w > 0 and self.gen_kinds[i] == "res":
+                B, H, W_, _ = x_in.shape
+                C = self.gen[i].c2.cout
+                cats[i] = torch.empty((B, H, W_, 2 * C), device=x_in.device, dtype=torch.float32)
+                return cats[i][..., C:]
+            return None
+
         def fuse(i, t):
             if i in self.fuse_after and w > 0:
                 s = self.fuse_after[i]
-                ew = self._one_scale(st, cache.feats[s], s, False)
-                t = self._fuse(s, ew, t, w)
+                cat = cats.pop(i, None)
+                if cat is None:                                               # producer was not a ResBlock: copy
+                    C = t.shape[-1]
+                    cat = torch.empty(t.shape[:-1] + (2 * C,), device=t.device, dtype=torch.float32)
+                    ops.copy_slice(t, cat[..., C:])
+                C = cat.shape[-1] // 2
+                self._one_scale(st, cache.feats[s], s, False, out=cat[..., :C])
+                t = self._fuse(s, cat, w)
             return t
-        st["out"] = self._run_seq(self.gen_kinds, self.gen, x, fuse)
+        st["out"] = self._run_seq(self.gen_kinds, self.gen, x, fuse, out_for)
         return st

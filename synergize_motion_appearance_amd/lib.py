@@ -59,7 +59,7 @@ SIGNATURES = {
     "smx_flow_to_residual_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "smx_flow_occ_update_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "smx_motion_ignore_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
-    "smx_sft_combine_f32": (_i, [_p, _p, _p, _p, _f, _i64, _p]),
+    "smx_sft_combine_f32": (_i, [_p, _i, _p, _p, _p, _f, _i64, _i, _p]),
     "smx_add_f32": (_i, [_p, _p, _p, _i64, _p]),
     "smx_copy_slice_f32": (_i, [_p, _i, _p, _i, _i64, _i, _p]),
     "smx_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

@@ -381,9 +381,14 @@ def motion_ignore(flow, Ht=32, Wt=32):
 
 
 def sft_combine(dec, scale, shift, w=1.0):
-    out = torch.empty_like(dec)
-    L.check(L.load().smx_sft_combine_f32(_dev(dec).data_ptr(), _dev(scale).data_ptr(), _dev(shift).data_ptr(), out.data_ptr(),
-                                         float(w), dec.numel(), _stream()), "sft_combine")
+    """dec may be a channel-slice view (the dec half of the [enc|dec] buffer); scale / shift dense."""
+    dp, ldd = _pix(dec, "dec")
+    Cc = dec.shape[-1]
+    if not (scale.is_contiguous() and shift.is_contiguous()):
+        raise L.SmxError("sft_combine: dense scale / shift expected")
+    out = torch.empty(dec.shape, device=dec.device, dtype=torch.float32)
+    L.check(L.load().smx_sft_combine_f32(dp, ldd, _dev(scale).data_ptr(), _dev(shift).data_ptr(), out.data_ptr(),
+                                         float(w), dec.numel() // Cc, Cc, _stream()), "sft_combine")
     return out
 
 

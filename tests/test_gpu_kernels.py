@@ -476,6 +476,8 @@ def test_flow_stage_kernels(ops):
     assert not (diff & ~near).any() and 0.05 < ign.float().mean() < 0.9
     d, sc, sh = rnd("s1", (2, 8, 8, 64)), rnd("s2", (2, 8, 8, 64)), rnd("s3", (2, 8, 8, 64))
     assert maxabs(ops.sft_combine(d.cuda(), sc.cuda(), sh.cuda(), 0.7).cpu(), d + 0.7 * (d * sc + sh)) < 1e-6
+    wide = torch.cat([sh, d], -1).cuda()                      # dec as the upper channel half of an [enc|dec] buffer
+    assert maxabs(ops.sft_combine(wide[..., 64:], sc.cuda(), sh.cuda(), 0.7).cpu(), d + 0.7 * (d * sc + sh)) < 1e-6
     assert maxabs(ops.add(d.cuda(), sc.cuda()).cpu(), d + sc) == 0.0
 
 
