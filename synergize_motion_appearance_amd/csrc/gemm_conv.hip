@@ -32,6 +32,7 @@ struct GP {
   int M, N, K;
   int lda, ldb, ldc, ldres;
   int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
+  int cin_bk;      // Cin % BK == 0: a k-slice never straddles two filter taps (running tap counters)
   int act; float alpha; int bias_per_row; int d2s_p, d2s_c;
   int tiles_n; int is1x1;
   int xcd_swizzle; int variant;
@@ -117,17 +118,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
 
   auto load_slice = [&](int k0) {
     if (VEC) {
+      // Cin % 32 == 0: the slice lies inside one tap (running counters).  Cin % 4 == 0 only (e.g. the
+      // 36-channel keypoint head): this lane's float4 column has its own (tap, channel) -- two integer
+      // divisions per slice per lane, shared by all its rows; K % 32 != 0 needs the k < K guard.
+      int l_ky = tap_ky, l_kx = tap_kx, l_c = tap_c0 + c4 * 4; bool kin = true;
+      if (!p.cin_bk) {
+        const int k = k0 + c4 * 4; kin = k < p.K;
+        const int tap = k / p.Cin; l_c = k - tap * p.Cin; l_ky = tap / p.kw; l_kx = tap - l_ky * p.kw;
+      }
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_ok[i]) {
+        if (a_ok[i] && kin) {
           if (p.is1x1) {
             v = *reinterpret_cast<const float4*>(A + a_base[i] + k0 + c4 * 4);
           } else {
-            int iy = a_iy0[i] + tap_ky, ix = a_ix0[i] + tap_kx;
+            int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
             if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim) {
               if (p.up2) { iy >>= 1; ix >>= 1; }
-              v = *reinterpret_cast<const float4*>(A + a_base[i] + ((long long)iy * p.Win + ix) * p.lda + tap_c0 + c4 * 4);
+              v = *reinterpret_cast<const float4*>(A + a_base[i] + ((long long)iy * p.Win + ix) * p.lda + l_c);
             }
           }
         }
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b_ok[i]) v = *reinterpret_cast<const float4*>(Bt + b_base[i] + k0 + c4 * 4);
+        if (b_ok[i] && kin) v = *reinterpret_cast<const float4*>(Bt + b_base[i] + k0 + c4 * 4);
         breg[i] = v;
       }
       tap_c0 += BK;
@@ -394,7 +403,8 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
   if (p.ksplit > 1 && (!d->ws || nb != 1 || d->d2s_p || p.ksplit > (d->K + BK - 1) / BK)) return SMX_EINVAL;
   p.is1x1 = (d->kh == 1 && d->kw == 1 && d->stride == 1 && !d->up2 && d->pad_t == 0 && d->pad_l == 0 &&
              d->Hin == d->Ho && d->Win == d->Wo) ? 1 : 0;
-  const bool vec = (d->Cin % BK == 0) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) &&
+  p.cin_bk = d->Cin % BK == 0 ? 1 : 0;
+  const bool vec = (d->Cin % 4 == 0) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) &&
                    (((uintptr_t)d->a & 15) == 0) && (((uintptr_t)d->bt & 15) == 0) &&
                    (d->a_bs0 % 4 == 0) && (d->a_bs1 % 4 == 0) && (d->bt_bs0 % 4 == 0) && (d->bt_bs1 % 4 == 0);
   hipStream_t st = (hipStream_t)stream;

@@ -25,7 +25,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   const int p0 = chunk * ppc, p1 = min(p0 + ppc, HW);
   float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
   const float* xb = x + (long long)b * HW * ldx + tx * 4;
-  for (int p = p0 + ty; p < p1; p += rows) {
+  int p = p0 + ty;
+  for (; p + 3 * rows < p1; p += 4 * rows) {             // 4 independent 16-byte loads in flight per lane
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (long long)(p + u * rows) * ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
+      q[0] += v[u].x * v[u].x; q[1] += v[u].y * v[u].y; q[2] += v[u].z * v[u].z; q[3] += v[u].w * v[u].w;
+    }
+  }
+  for (; p < p1; p += rows) {
     float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
     s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
     q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;

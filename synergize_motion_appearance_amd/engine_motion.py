@@ -39,8 +39,12 @@ class HourglassPlan:
     def alloc_input(self, B, res, device):
         """the last concat buffer [B,res,res,cy+in] ; its tail slice is the hourglass input."""
         cy = self.up_ch[-1][1]
-        buf = torch.empty((B, res, res, cy + self.in_features), device=device, dtype=torch.float32)
-        return buf, buf[..., cy:]
+        c = cy + self.in_features
+        if c % 4:       # zero pad channels up to a multiple of 4: the consuming 7x7 head gathers float4s (Cin 35 -> 36)
+            buf = torch.zeros((B, res, res, c + (-c) % 4), device=device, dtype=torch.float32)
+        else:
+            buf = torch.empty((B, res, res, c), device=device, dtype=torch.float32)
+        return buf, buf[..., cy:c]
 
     def run(self, final_buf, B, res):
         """final_buf from alloc_input with its tail filled -> same buffer, fully written."""
@@ -55,7 +59,7 @@ class HourglassPlan:
             cskip = self.down_ch[nb - 2 - j][1]
             cats[j] = torch.empty((B, r, r, cy + cskip), device=dev, dtype=torch.float32)
         # encoder: outs[0] = input slice, outs[i] (i>=1) pooled into the skip slice of cat[nb-1-i]
-        cur = final_buf[..., self.up_ch[-1][1]:]
+        cur = final_buf[..., self.up_ch[-1][1]:self.up_ch[-1][1] + self.in_features]
         r = res
         for i in range(nb):
             y = ops.conv(cur, self.down[i], act=ACT_RELU)
@@ -84,8 +88,10 @@ class MotionEngine:
                                    kp["num_blocks"], kp["max_features"])
         # kp (15) and jacobian (60) heads share their input and geometry (7x7 valid): one conv with
         # N = 60 + 15 + 1 pad -> [jac | kp | 0]; 76 keeps the float4 reads of the jacobian maps aligned
-        kpc = Conv.from_torch(P["kp_detector.kp.weight"], P["kp_detector.kp.bias"])
-        jc = Conv.from_torch(P["kp_detector.jacobian.weight"], P["kp_detector.jacobian.bias"])
+        cin = P["kp_detector.kp.weight"].shape[1]
+        padc = lambda w: torch.nn.functional.pad(w, (0, 0, 0, 0, 0, (-cin) % 4))      # zero weights for the pad channels  # noqa: E731
+        kpc = Conv.from_torch(padc(P["kp_detector.kp.weight"]), P["kp_detector.kp.bias"])
+        jc = Conv.from_torch(padc(P["kp_detector.jacobian.weight"]), P["kp_detector.jacobian.bias"])
         zero = Conv(torch.zeros_like(kpc.w[:1]), torch.zeros_like(kpc.b[:1]), 7, 7, kpc.cin, 1)
         self.head_conv = Conv.cat([jc, kpc, zero])
         self.n_jac = jc.cout
@@ -103,7 +109,7 @@ class MotionEngine:
         B = image_nchw.shape[0]
         buf, inp = self.kp_hg.alloc_input(B, 64, image_nchw.device)
         ops.antialias_down(image_nchw, self.kp_down, out=inp)
-        fm = self.kp_hg.run(buf, B, 64)                       # [B,64,64,35]
+        fm = self.kp_hg.run(buf, B, 64)                       # [B,64,64,35 (+1 zero pad)]
         heads = ops.conv(fm, self.head_conv, pad=(0, 0))      # 7x7 valid -> [B,58,58,76] = [jac 60 | kp 15 | 0]
         value, jac = ops.kp_head(heads[..., self.n_jac:self.n_jac + self.num_kp], heads[..., :self.n_jac],
                                  self.num_kp, self.temperature)

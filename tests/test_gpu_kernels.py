@@ -55,6 +55,10 @@ CONV_CASES = [
     (2, 2, 32, 32, 3, 1, None, None, False, 0, 0, "3x3 2->32 generic"),
     (2, 2, 128, 24, 7, 1, None, None, False, 1, 0, "7x7 2->128 pad3 relu"),
     (2, 35, 15, 32, 7, 1, (0, 0), None, False, 0, 0, "7x7 valid 35->15"),
+    (2, 36, 76, 32, 7, 1, (0, 0), None, False, 0, 0, "7x7 valid 36->76 float4 gather, slices straddle taps"),
+    (2, 12, 40, 24, 3, 1, None, None, False, 1, 0, "3x3 12->40 K=108 float4 gather, K%32!=0"),
+    (2, 20, 24, 16, 1, 1, None, None, False, 0, 0, "1x1 20->24 K<32 float4"),
+    (1, 40, 64, 20, 3, 2, (0, 0), (10, 10), False, 0, 5, "3x3 s2 40->64 float4 gather tile5"),
     (1, 128, 16, 32, 7, 1, None, None, False, 0, 0, "7x7 128->16"),
     (1, 128, 1, 32, 7, 1, None, None, False, 5, 0, "7x7 128->1 sigmoid"),
     (2, 256, 192, 32, 1, 1, None, None, False, 1, 0, "1x1 256->192 relu"),
