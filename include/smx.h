@@ -87,10 +87,15 @@ int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream);
  * y NHWC [B][H][W][ldc]; act/bias/res as in smx_gemm_conv_f32.  H%8==0, W%16==0, Cin%32==0. */
 int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
                              const float* res, int ldres, float* y, int ldc, int B, int H, int W,
-                             int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish, void* stream);
+                             int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
+                             float* stats_part, void* stream);
 /* in_ss != NULL: the GroupNorm(+swish, if in_swish) that precedes the conv in ResBlock
  * (archs/vqgan_arch.py:183-188) is applied by the region loader: x*in_ss[b][c][0] + in_ss[b][c][1],
- * with in_ss from smx_groupnorm_stats_f32 -- the separate normalise read+write pass disappears. */
+ * with in_ss from smx_groupnorm_stats_f32 -- the separate normalise read+write pass disappears.
+ * stats_part != NULL: the epilogue also emits, per block of 8x16 output pixels, the per-channel
+ * {sum, sum of squares} of the values it stores: [B][(H/8)*(W/16)][Cout][2] floats -- the statistics pass
+ * of the NEXT GroupNorm (ResBlock norm2 / the following block's norm1) reduces to
+ * smx_groupnorm_finalize_f32 over these partials, the activation is not re-read. */
 
 /* ---------------------------------------------------------------------------------------
  * GroupNorm(32 groups, eps) [+ swish] on NHWC.   normalize/swish archs/vqgan_arch.py:14-20.
@@ -106,6 +111,10 @@ int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float* gamma, co
  * ss[B][C][2] (ws: B*nchunks*C*2 floats, smx_groupnorm_ws_floats is enough), and the apply pass */
 int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float* ss,
                             int B, int HW, int C, int groups, float eps, float* ws, void* stream);
+/* partials [B][nch][C][2] ({sum, sum^2} per channel over disjoint pixel chunks covering the image; from
+ * smx_winograd_conv3x3_f32(stats_part) or the first pass of smx_groupnorm_stats_f32) -> ss [B][C][2] */
+int smx_groupnorm_finalize_f32(const float* part, const float* gamma, const float* beta, float* ss,
+                               int B, int HW, int C, int groups, int nch, float eps, void* stream);
 int smx_groupnorm_apply_f32(const float* x, int ldx, const float* ss, float* y, int ldy, int B, int HW, int C,
                             int swish, void* stream);
 

@@ -206,6 +206,13 @@ extern "C" int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gam
   return smx_launch_status();
 }
 
+extern "C" int smx_groupnorm_finalize_f32(const float* part, const float* gamma, const float* beta, float* ss,
+                                          int B, int HW, int C, int groups, int nch, float eps, void* stream) {
+  if (!part || !gamma || !beta || !ss || B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || nch <= 0) return SMX_EINVAL;
+  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, part, gamma, beta, ss, HW, C, groups, nch, eps);
+  return smx_launch_status();
+}
+
 extern "C" int smx_groupnorm_apply_f32(const float* x, int ldx, const float* ss, float* y, int ldy, int B, int HW, int C,
                                        int swish, void* stream) {
   if (!x || !ss || !y || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < C || ldy < C) return SMX_EINVAL;

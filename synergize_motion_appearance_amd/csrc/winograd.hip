@@ -37,6 +37,7 @@ constexpr int RLD = 36;                             // floats per region pixel i
 
 struct WP {
   const float* x; const float* u; const float* bias; const float* res; float* y;
+  float* stats;                       // optional [B][tiles_y*tiles_x][Cout][2]: per-block {sum, sum of squares} of the STORED values
   const float* in_ss; int in_swish;   // fused GroupNorm apply on the loaded input: x*ss[b][c][0]+ss[b][c][1] (+swish)
   int lda, ldc, ldres;
   int B, H, W, Cin, Cout, up2, act;
@@ -212,6 +213,9 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   float* zb = smem;
   float* __restrict__ Yp = p.y;
   const float* __restrict__ Rp = p.res;
+  // GroupNorm statistics of the consumer, produced here: per channel {sum, sum^2} of what is stored
+  float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NB = 32 * NW, NQ = NB / 4;
   for (int q = 0; q < 2; ++q) {
     __syncthreads();
 #pragma unroll
@@ -223,7 +227,6 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     }
     __syncthreads();
     // 32 tiles x (32*NW / 4) channel quads = NTHR items: one float4 column group per thread
-    constexpr int NB = 32 * NW, NQ = NB / 4;
     {
       const int tile = tid / NQ, n4 = (tid % NQ) * 4;
       const int n = nblk * NB + n4;
@@ -258,12 +261,34 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (n + e >= p.Cout) continue;
-            Yp[pix0 * p.ldc + n + e] = o0[e] + (Rp ? Rp[pix0 * p.ldres + n + e] : 0.f);
-            Yp[(pix0 + p.W) * p.ldc + n + e] = o1[e] + (Rp ? Rp[(pix0 + p.W) * p.ldres + n + e] : 0.f);
+            if (n + e >= p.Cout) { o0[e] = 0.f; o1[e] = 0.f; continue; }
+            if (Rp) { o0[e] += Rp[pix0 * p.ldres + n + e]; o1[e] += Rp[(pix0 + p.W) * p.ldres + n + e]; }
+            Yp[pix0 * p.ldc + n + e] = o0[e];
+            Yp[(pix0 + p.W) * p.ldc + n + e] = o1[e];
           }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ps[e] += o0[e] + o1[e]; pq[e] += o0[e] * o0[e] + o1[e] * o1[e]; }
       }
+    }
+  }
+  if (p.stats) {
+    // block reduction over the 32 tiles (zb's first 4*32*NB floats are still being read by slow waves of
+    // the last q pass: the reduction buffer sits behind them)
+    float* red = smem + 4 * 32 * NB;                               // [32 tiles][NB][2]
+    {
+      const int tile = tid / NQ, n4 = (tid % NQ) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(tile * NB + n4 + e) * 2] = ps[e]; red[(tile * NB + n4 + e) * 2 + 1] = pq[e]; }
+    }
+    __syncthreads();
+    if (tid < NB && nblk * NB + tid < p.Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll 8
+      for (int tl = 0; tl < 32; ++tl) { a += red[(tl * NB + tid) * 2]; b += red[(tl * NB + tid) * 2 + 1]; }
+      const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
+      float* o = p.stats + (chunk * p.Cout + nblk * NB + tid) * 2;
+      o[0] = a; o[1] = b;
     }
   }
 }
@@ -273,14 +298,14 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
 extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
                                         const float* res, int ldres, float* y, int ldc, int B, int H, int W,
                                         int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
-                                        void* stream) {
+                                        float* stats_part, void* stream) {
   if (!x || !u_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0) return SMX_EINVAL;
   if (in_ss && (((uintptr_t)in_ss) & 15)) return SMX_EINVAL;
   if (H % 8 != 0 || W % 16 != 0 || Cin % 32 != 0 || lda % 4 != 0 || lda < Cin || ldc < Cout) return SMX_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)u_packed & 15) || (res && ldres < Cout)) return SMX_EINVAL;
   WP p;
   p.x = x; p.u = u_packed; p.bias = bias; p.res = res; p.y = y; p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0;
-  p.in_ss = in_ss; p.in_swish = in_swish;
+  p.in_ss = in_ss; p.in_swish = in_swish; p.stats = stats_part;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
   p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32;
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;

@@ -38,9 +38,11 @@ class _Res:
         """ResBlock.forward archs/vqgan_arch.py:180-191."""
         # GN statistics are their own (read-only) pass; the normalise + swish is applied by the
         # consuming conv's region loader, so no normalised copy of the activation is ever written
-        h = ops.conv(x, self.c1, in_ss=ops.groupnorm_stats(x, *self.n1), in_swish=True)
+        # ... and the statistics themselves come out of the producing conv's epilogue where it is the fused
+        # Winograd kernel (want_stats): norm2 never re-reads h, the next block's norm1 never re-reads y
+        h = ops.conv(x, self.c1, in_ss=ops.groupnorm_stats(x, *self.n1), in_swish=True, want_stats=True)
         skip = x if self.sc is None else ops.conv(x, self.sc)
-        return ops.conv(h, self.c2, out=out, res=skip, in_ss=ops.groupnorm_stats(h, *self.n2), in_swish=True)
+        return ops.conv(h, self.c2, out=out, res=skip, in_ss=ops.groupnorm_stats(h, *self.n2), in_swish=True, want_stats=True)
 
 
 class _Attn:
@@ -202,13 +204,13 @@ class NetGEngine:
         if out is not None:
             raise ValueError(f"in-place output is only planned for res blocks, not {kind}")
         if kind == "conv":
-            return ops.conv(x, blk)
+            return ops.conv(x, blk, want_stats=True)
         if kind == "attn":
             return blk(x)
         if kind == "down":      # pad (0,1,0,1) + conv3x3 s2 p0  (vqgan_arch.py:144-153)
             return ops.conv(x, blk, stride=2, pad=(0, 0), out_hw=(x.shape[1] // 2, x.shape[2] // 2))
         if kind == "up":        # nearest x2 folded into the gather (vqgan_arch.py:156-165)
-            return ops.conv(x, blk, up2=True)
+            return ops.conv(x, blk, up2=True, want_stats=True)
         if kind == "gn":
             return ops.groupnorm(x, blk[0], blk[1], swish=False)
         raise ValueError(kind)
@@ -334,7 +336,7 @@ class NetGEngine:
         scale = ops.conv(ss[..., :C], f["scale2"])
         shift = ops.conv(ss[..., C:], f["shift2"])
         x = ops.sft_combine(dec, scale, shift, w)
-        return ops.conv(enc, f["ms"], res=x)                                  # x + fuse_ms(enc)
+        return ops.conv(enc, f["ms"], res=x, want_stats=True)                 # x + fuse_ms(enc)
 
     def forward(self, cache, deformation, occ64, heat_nhwc, w=1.0):
         """cache: SourceCache; deformation [B,64,64,2]; occ64 [B,64,64]; heat [B,64,64,15] NHWC.

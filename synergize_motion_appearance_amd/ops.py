@@ -131,10 +131,13 @@ def gemm_raw(**kw):
 
 
 def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None,
-         d2s=None, tile=0, in_ss=None, in_swish=False):
+         d2s=None, tile=0, in_ss=None, in_swish=False, want_stats=False):
     """y = act(conv(x) + bias) [+ res].  x [B,H,W,Cin] (slice ok) -> out [B,Ho,Wo,Cout] (slice ok).
     pad: (top, left) (default (kh//2, kw//2)); out_hw for asymmetric pads / strides.
-    d2s=(p, C): un-patchify store, out is [B,Ho*p,Wo*p,C]."""
+    d2s=(p, C): un-patchify store, out is [B,Ho*p,Wo*p,C].
+    want_stats: the output feeds a GroupNorm -- on the fused Winograd path the epilogue also emits the
+    per-block {sum, sum^2} partials and tags the returned tensor with them (`_gn_part`), so that
+    `groupnorm_stats(y, ...)` is a finalize over a few KB instead of a read of y."""
     B, H, W, Cin = x.shape
     if Cin != cv.cin:
         raise L.SmxError(f"conv: input has {Cin} channels, layer expects {cv.cin}")
@@ -153,15 +156,21 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     a_ptr, lda = _pix(x, "conv input")
     c_ptr, ldc = _pix(out, "conv output")
     r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
+    if getattr(out, "_gn_part", None) is not None:      # a caller-provided buffer tagged by an earlier producer
+        out._gn_part = None
     if (WINOGRAD and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s
             and (Ho, Wo) == (He, We) and Cin % 32 == 0 and He % 8 == 0 and We % 16 == 0
             and lda % 4 == 0 and a_ptr % 16 == 0):
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * Ho * Wo * cv.cout * 4 * Cin,
                 "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1} if _PROFILE is not None else None
+        part = torch.empty((B, (He // 8) * (We // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
         L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                        None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,
-                       int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish), _stream()),
+                       int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish),
+                       None if part is None else part.data_ptr(), _stream()),
                 "smx_winograd_conv3x3_f32")
+        if part is not None:
+            out._gn_part = part
         return out
     if in_ss is not None:      # layer not eligible for the fused loader: normalise in its own pass, then convolve
         x = groupnorm_apply(x, in_ss, in_swish)
@@ -217,8 +226,15 @@ def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
     B, H, W, Cc = x.shape
     xp, ldx = _pix(x, "groupnorm input")
     lib = L.load()
-    ws = torch.empty(int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)), device=x.device, dtype=torch.float32)
     ss = torch.empty((B, Cc, 2), device=x.device, dtype=torch.float32)
+    part = getattr(x, "_gn_part", None)
+    if part is not None and part.shape[0] == B and part.shape[2] == Cc and not _os.environ.get("SMX_NO_EPILOGUE_STATS"):
+        # the producing conv already reduced its output per block: finalize only (reads B*nch*C*8 bytes)
+        L.check(_timed("groupnorm", {"bytes": 8.0 * part.numel() / 2}, lib.smx_groupnorm_finalize_f32, part.data_ptr(),
+                       _dev(gamma).data_ptr(), _dev(beta).data_ptr(), ss.data_ptr(), B, H * W, Cc, groups, part.shape[1], eps,
+                       _stream()), "groupnorm_finalize")
+        return ss
+    ws = torch.empty(int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)), device=x.device, dtype=torch.float32)
     L.check(_timed("groupnorm", {"bytes": 4.0 * B * H * W * Cc}, lib.smx_groupnorm_stats_f32, xp, ldx, _dev(gamma).data_ptr(),
                    _dev(beta).data_ptr(), ss.data_ptr(), B, H * W, Cc, groups, eps, ws.data_ptr(), _stream()), "groupnorm_stats")
     return ss

@@ -142,6 +142,37 @@ def test_winograd_fused_groupnorm_loader(ops):
         assert maxabs(nchw(y2), ref) < 5e-5
 
 
+@pytest.mark.parametrize("B,C,Co,H,W,act,res", [(2, 64, 64, 32, 32, 0, True), (3, 128, 128, 16, 32, 3, False), (1, 32, 96, 64, 64, 0, True),
+                                                 (2, 64, 126, 8, 16, 1, False)])
+def test_winograd_epilogue_emits_groupnorm_partials(ops, B, C, Co, H, W, act, res, monkeypatch):
+    """want_stats: the conv's epilogue emits per-block {sum, sum^2} of what it stores (after bias, activation,
+    residual); groupnorm_stats on the tagged output is then a finalize only and must equal the two-pass
+    statistics of the same tensor, and GroupNorm through it must match F.group_norm."""
+    x = rnd(f"ws{C}{Co}{H}", (B, C, H, W))
+    w = rnd(f"wsw{C}{Co}", (Co, C, 3, 3), 1.0 / math.sqrt(9 * C))
+    b = rnd(f"wsb{Co}", (Co,), 0.1)
+    r = rnd(f"wsr{Co}{H}", (B, Co, H, W)) if res else None
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    y = ops.conv(nhwc(x), cv, act=act, res=None if r is None else nhwc(r), want_stats=True)
+    part = y._gn_part
+    assert part is not None and tuple(part.shape) == (B, (H // 8) * (W // 16), Co, 2)
+    yc = y.cpu().double()
+    blocks = yc.view(B, H // 8, 8, W // 16, 16, Co).permute(0, 1, 3, 5, 2, 4).reshape(B, -1, Co, 128)
+    assert maxabs(part[..., 0].cpu(), blocks.sum(-1)) < 2e-4 and maxabs(part[..., 1].cpu(), (blocks ** 2).sum(-1)) < 2e-3
+    if Co & (Co - 1) == 0:                                    # the two-pass kernel takes power-of-two C
+        g, bt = rnd(f"wsg{Co}", (Co,)) * 0.2 + 1.0, rnd(f"wsbt{Co}", (Co,), 0.1)
+        ss_fused = ops.groupnorm_stats(y, g.cuda(), bt.cuda())
+        monkeypatch.setenv("SMX_NO_EPILOGUE_STATS", "1")
+        ss_two_pass = ops.groupnorm_stats(y, g.cuda(), bt.cuda())
+        monkeypatch.delenv("SMX_NO_EPILOGUE_STATS")
+        assert maxabs(ss_fused.cpu(), ss_two_pass.cpu()) < 2e-5
+        ref = F.group_norm(nchw(y), 32, g, bt, 1e-6)
+        assert maxabs(nchw(ops.groupnorm_apply(y, ss_fused, swish=False)), ref) < 5e-5
+    # a reused output buffer loses the tag when a later conv without statistics overwrites it
+    ops.conv(nhwc(x), cv, out=y, act=act)
+    assert y._gn_part is None
+
+
 def test_conv_residual_and_slices(ops):
     """output into a channel slice of a concat buffer, input from a slice, fused residual."""
     x = rnd("sx", (2, 96, 32, 32))
