@@ -203,6 +203,17 @@ def main():
             "algorithmic_gflop_per_frame": round(g["flops"] / nprof / B / 1e9, 2),
             "share_of_step_time": round(g["ms"] / nprof / (1e3 * dt / K), 3),
             "method": f"HIP events around every launch on the launch stream, {nprof} instrumented steps after the timed region"}
+        # HBM-side traffic of the same command from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE, separate runs, gfx950 correction applied by tools/pmc_traffic.py): bytes per launch
+        pmc = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_m_traffic_pmc.json")
+        if os.path.exists(tpath) and B == 30:
+            pmc = json.load(open(tpath))["families"]
+            if "conv_gemm_family" in pmc:
+                result["roofline"]["traffic"] = round(pmc["conv_gemm_family"]["hbm_bytes_per_launch"])
+                result["roofline"]["traffic_note"] = ("HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), average over the family's launches; "
+                                                      "measured in separate rocprofv3 --pmc passes of this command at B=30 "
+                                                      "(profiles/r01_m_traffic_pmc.json), not in this run")
         kern = {}
         for name, f in fam.items():
             e = {"calls_per_step": f["calls"] // nprof, "ms_per_step": round(f["ms"] / nprof, 3)}
@@ -211,6 +222,9 @@ def main():
                 e["hbm_frac"] = round(e["algorithmic_GBps"] / PEAK_HBM_GBS, 4)
             if f["flops"]:
                 e["TFLOPs"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
+            pf = {"gemm_conv": "conv_gemm_family"}.get(name, "attention" if name.startswith("attention") else name)
+            if pmc and pf in pmc and not name.startswith("attention"):
+                e["pmc_hbm_bytes_per_launch"] = round(pmc[pf]["hbm_bytes_per_launch"])
             kern[name] = e
         # warp by scale (A7) and the VQ micro-benchmark (A12, train-only in the reference)
         for s in (32, 64, 128, 256):

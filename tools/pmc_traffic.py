@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` (separate runs, csv) into
+per-kernel-family HBM-side bytes per launch.   usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the 128-B requests of wide coalesced
+(16 B/lane) reads at 64 B -> doubled here for the kernels whose global reads are all float4; WRITE_SIZE
+matched the algorithmic bytes of the warp / conv kernels exactly (profiles/r01_c_pmc_*) and is taken as is.
+Counter values are KB."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, counter):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def family(name):
+    for key, fam in (("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("attn_", "attention"),
+                     ("warp_", "warp"), ("gn_", "groupnorm"), ("layernorm", "layernorm")):
+        if key in name:
+            return fam
+    return None
+
+
+def main(fetch_dir, write_dir, out):
+    fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    fams = collections.defaultdict(lambda: {"launches": 0, "fetch_kb_raw": 0.0, "write_kb": 0.0, "wlaunches": 0})
+    for name, vals in fe.items():
+        fam = family(name)
+        if fam:
+            fams[fam]["launches"] += len(vals)
+            fams[fam]["fetch_kb_raw"] += sum(vals)
+    for name, vals in wr.items():
+        fam = family(name)
+        if fam:
+            fams[fam]["write_kb"] += sum(vals)
+            fams[fam]["wlaunches"] += len(vals)
+    res = {}
+    for fam, v in fams.items():
+        n = max(v["launches"], 1)
+        res[fam] = {"launches_profiled": v["launches"], "fetch_bytes_per_launch_corrected": 2.0 * 1024 * v["fetch_kb_raw"] / n,
+                    "fetch_bytes_per_launch_raw": 1024 * v["fetch_kb_raw"] / n, "write_bytes_per_launch": 1024 * v["write_kb"] / max(v["wlaunches"], 1)}
+        res[fam]["hbm_bytes_per_launch"] = res[fam]["fetch_bytes_per_launch_corrected"] + res[fam]["write_bytes_per_launch"]
+    conv = {k: res[k] for k in ("winograd", "gemm_conv") if k in res}
+    nl = sum(v["launches_profiled"] for v in conv.values())
+    if nl:
+        res["conv_gemm_family"] = {"launches_profiled": nl,
+                                   "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in conv.values()) / nl}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 "
+                         "--no-cpu-baseline --no-roofline`; FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B)",
+               "families": res}, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
