@@ -111,6 +111,13 @@ int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float* gamma, co
  * ss[B][C][2] (ws: B*nchunks*C*2 floats, smx_groupnorm_ws_floats is enough), and the apply pass */
 int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float* ss,
                             int B, int HW, int C, int groups, float eps, float* ws, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution with Cout <= 4 on the vector ALUs (Generator conv_out 64->3,
+ * archs/vqgan_arch.py:339-342; RefineFlow conv2|convo2 256->3, archs/appmotioncodebook_arch.py:150-167):
+ * HBM-shaped layers that would waste 10x MFMA passes on N padding.  x NHWC [B][H][W][lda], w [Cout][3][3][Cin],
+ * Cin in {64,128,256}; y NHWC [B][H][W][ldc]; in_ss / in_swish as in smx_winograd_conv3x3_f32. */
+int smx_conv3x3_smalln_f32(const float* x, int lda, const float* w, const float* bias, float* y, int ldc,
+                           int B, int H, int W, int Cin, int Cout, int act, const float* in_ss, int in_swish,
+                           void* stream);
 /* partials [B][nch][C][2] ({sum, sum^2} per channel over disjoint pixel chunks covering the image; from
  * smx_winograd_conv3x3_f32(stats_part) or the first pass of smx_groupnorm_stats_f32) -> ss [B][C][2] */
 int smx_groupnorm_finalize_f32(const float* part, const float* gamma, const float* beta, float* ss,

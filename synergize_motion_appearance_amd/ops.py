@@ -76,6 +76,8 @@ def _pix(t, name="tensor"):
 
 import os as _os
 
+SMALLN = not _os.environ.get("SMX_NO_SMALLN")
+
 WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 
@@ -158,6 +160,15 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
     if getattr(out, "_gn_part", None) is not None:      # a caller-provided buffer tagged by an earlier producer
         out._gn_part = None
+    if (SMALLN and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s and not up2
+            and res is None and cv.cout <= 4 and Cin in (64, 128, 256) and (Ho, Wo) == (H, W) and W % 4 == 0 and lda % 4 == 0 and a_ptr % 16 == 0):
+        # N <= 4: HBM-shaped, runs on the vector ALUs (the matrix cores would pad N to 32)
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 0.0, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin,
+                "nb": 1, "k": 3, "bytes": 4.0 * B * Ho * Wo * (Cin + cv.cout)} if _PROFILE is not None else None
+        L.check(_timed("conv_small_n", meta, L.load().smx_conv3x3_smalln_f32, a_ptr, lda, _dev(cv.w).data_ptr(),
+                       None if cv.b is None else cv.b.data_ptr(), c_ptr, ldc, B, H, W, Cin, cv.cout, act,
+                       None if in_ss is None else in_ss.data_ptr(), int(in_swish), _stream()), "smx_conv3x3_smalln_f32")
+        return out
     if (WINOGRAD and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s
             and (Ho, Wo) == (He, We) and Cin % 32 == 0 and He % 8 == 0 and We % 16 == 0
             and lda % 4 == 0 and a_ptr % 16 == 0):

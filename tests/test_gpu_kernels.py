@@ -173,6 +173,38 @@ def test_winograd_epilogue_emits_groupnorm_partials(ops, B, C, Co, H, W, act, re
     assert y._gn_part is None
 
 
+@pytest.mark.parametrize("B,Cin,Co,H,W,act,gn", [(2, 64, 3, 32, 32, 0, 0), (1, 256, 3, 16, 16, 0, 0), (2, 128, 1, 16, 24, 5, 0),
+                                                 (2, 64, 3, 32, 48, 0, 1), (1, 64, 4, 8, 20, 1, 2), (1, 256, 2, 8, 12, 0, 0)])
+def test_conv3x3_small_n_vector_alu_kernel(ops, B, Cin, Co, H, W, act, gn, monkeypatch):
+    """C_out <= 4 layers (decoder image head, RefineFlow outputs) run on the VALU kernel: vs F.conv2d, with
+    the fused GroupNorm (gn=1) / GroupNorm+swish (gn=2) loader, channel-slice input / output views, and
+    against the matrix-core path on the same operands."""
+    x = rnd(f"sn{Cin}{H}{W}", (B, Cin, H, W))
+    w = rnd(f"snw{Cin}{Co}", (Co, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd(f"snb{Co}", (Co,), 0.1)
+    xin = x
+    ss = None
+    if gn:
+        g, bt = rnd(f"sng{Cin}", (Cin,)) * 0.2 + 1.0, rnd(f"snbt{Cin}", (Cin,), 0.1)
+        xin = F.group_norm(x, 32, g, bt, 1e-6)
+        if gn == 2:
+            xin = O.swish(xin)
+        ss = ops.groupnorm_stats(nhwc(x), g.cuda(), bt.cuda())
+    ref = {0: lambda t: t, 1: F.relu, 5: torch.sigmoid}[act](F.conv2d(xin, w, b, padding=1))
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    wide = torch.zeros((B, H, W, Cin + 8), device="cuda")
+    wide[..., 4:4 + Cin] = nhwc(x)
+    outw = torch.full((B, H, W, Co + 5), 7.0, device="cuda")
+    with ops.profile() as rec:
+        y = ops.conv(wide[..., 4:4 + Cin], cv, out=outw[..., 2:2 + Co], act=act, in_ss=ss, in_swish=gn == 2)
+    assert [r[0] for r in rec.rows] == ["conv_small_n"]
+    assert maxabs(nchw(y.contiguous()), ref) < 2e-5
+    assert float(outw[..., :2].min()) == 7.0 and float(outw[..., 2 + Co:].min()) == 7.0      # neighbours untouched
+    monkeypatch.setattr(ops, "SMALLN", False)
+    y2 = ops.conv(nhwc(x), cv, act=act, in_ss=ss, in_swish=gn == 2)
+    assert maxabs(y2.cpu(), y.cpu()) < 2e-5
+
+
 def test_conv_residual_and_slices(ops):
     """output into a channel slice of a concat buffer, input from a slice, fused residual."""
     x = rnd("sx", (2, 96, 32, 32))
