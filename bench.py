@@ -96,14 +96,29 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    collective = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SMX_BENCH_BACKEND", "nccl")                          # "nccl" == RCCL on ROCm
+        import datetime
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)                       # creates the communicator now, not inside the timed region
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:                           # noqa: BLE001 -- keep the scaling run alive, say so in the JSON
+                print(f"[bench] rank {rank}: RCCL init failed ({type(e).__name__}: {e}); falling back to gloo for the one "
+                      "source-cache broadcast", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        collective = "RCCL" if backend == "nccl" else backend
 
     from synergize_motion_appearance_amd import ops, driver
     from synergize_motion_appearance_amd.synth import synth_clip
@@ -166,7 +181,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: 256x256, 1 source + 300-frame driving clip, fp32, options/test.yml, "
                                "name-keyed random-init weights", "frames_per_step": B, "frames_total": world * K * B,
-                   "parallelism": f"frames sharded x{world}, RCCL broadcast of the source cache" if world > 1 else "1 GPU",
+                   "parallelism": f"frames sharded x{world}, {collective} broadcast of the source cache" if world > 1 else "1 GPU",
                    "relative": True, "adapt_movement_scale": True, "output": "uint8 HWC frames in HBM"},
     }
 
