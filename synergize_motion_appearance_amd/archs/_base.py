@@ -1,7 +1,6 @@
 """Common behaviour of the HIP-backed arch modules: parameters live in a ParamNode tree
 (checkpoint contract); the packed-weight engine is rebuilt lazily whenever parameters may
 have changed (load_state_dict, .cuda()/.to())."""
-import torch
 from torch import nn
 
 from ..lib import SmxError

@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 from .manifest import hourglass_channels
-from .ops import Conv, ACT_RELU, ACT_SIGMOID, ACT_NONE
+from .ops import Conv, ACT_RELU
 
 
 def _fold_bn(P, pre):

@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from .manifest import encoder_plan, generator_plan, CHANNELS
-from .ops import Conv, ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_GELU
+from .ops import Conv, ACT_RELU, ACT_LRELU02, ACT_GELU
 
 _SCALE_K = {32: 1, 64: 2, 128: 3, 256: 4}
 

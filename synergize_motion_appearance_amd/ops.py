@@ -5,7 +5,6 @@ fp32 tensors `[B,H,W,C]`; a channel slice `buf[..., a:b]` is a legal operand (it
 stride is the channel count of `buf`), which is how concatenations are built in place.
 Every launcher raises on CPU tensors: there is no fallback path."""
 import ctypes as C
-import math
 
 import torch
 
