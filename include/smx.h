@@ -158,8 +158,15 @@ int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float* flow, cons
 int smx_resize_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int B, int Hin, int Win,
                                     int Hout, int Wout, int C, void* stream);
 
-/* relu(1x1conv(x)) evaluated only at the align_corners bilinear taps is NOT exact (relu is
- * non-linear) -- not provided; see DESIGN.md. */
+/* A per-pixel op followed by a bilinear (align_corners=True) down-sampling only has to be evaluated at the 4 taps
+ * of each OUTPUT pixel -- exact, the op is per pixel (to_context: relu(conv1x1(warp)) on 256x256 kept at 64x64,
+ * appmotioncodebook_arch.py:416-418: 1/4 of the pixels).  gather: taps[b][oy][ox][tap][C] (dense) <- x at
+ * (y0,x0) (y0,x1) (y1,x0) (y1,x1); the caller runs the per-pixel op on the B*Hout*Wout*4 rows; combine: the bilinear
+ * blend of the 4 rows of each pixel, in the association of smx_resize_bilinear_ac_nhwc_f32 (equal up to FMA contraction, <= 1 ulp). */
+int smx_resize_taps_gather_f32(const float* x, int ldx, float* taps, int B, int Hin, int Win, int Hout, int Wout,
+                               int C, void* stream);
+int smx_resize_taps_combine_f32(const float* taps, float* y, int ldy, int B, int Hin, int Win, int Hout, int Wout,
+                                int C, void* stream);
 
 /* avg_pool2d 2x2 NHWC (DownBlock2d.pool, utils/motion_estimator_util.py:374) */
 int smx_avgpool2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int B, int Hin, int Win, int C, void* stream);

@@ -16,6 +16,7 @@ namespace {
 
 // align_corners=True source index + weights (ATen area_pixel_compute_source_index)
 __device__ __forceinline__ void ac_src(int o, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+#pragma clang fp contract(off)   // scale*o must not fuse into the subtraction below: every kernel (and ATen) sees the same source index
   const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
   const float real = scale * o;
   i0 = (int)real; if (i0 > in - 1) i0 = in - 1;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(const float* __restrict_
       const float2 f11 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x1) * 2);
       // unfused, in ATen's association (and bit-identical to warp_kernel's lane-parallel resize)
       auto bil = [&](float v00, float v01, float v10, float v11) {
+#pragma clang fp contract(off)   // (HIP's __fmul_rn / __fadd_rn are plain * and + : only the pragma stops the contraction)
         return __fadd_rn(__fmul_rn(ly0, __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx1, v01))),
                          __fmul_rn(ly1, __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx1, v11))));
       };
@@ -238,6 +240,42 @@ __global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict_
     const float v = ly0 * (lx0 * xb[((long long)y0 * Win + x0) * ldx] + lx1 * xb[((long long)y0 * Win + x1) * ldx]) +
                     ly1 * (lx0 * xb[((long long)y1 * Win + x0) * ldx] + lx1 * xb[((long long)y1 * Win + x1) * ldx]);
     y[(((long long)b * Hout + oy) * Wout + ox) * ldy + c] = v;
+  }
+}
+
+// Bilinear (align_corners=True) down-sampling reads 4 taps per OUTPUT pixel: when a per-pixel op precedes
+// it (to_context: relu(conv1x1(x)) at 256x256, kept at 64x64 -- appmotioncodebook_arch.py:416-418), the op
+// only has to be evaluated at those taps (1/4 of the 256x256 pixels; exact, the op is per pixel).
+// gather:  t[b][oy][ox][tap][c] = x[b][y_tap][x_tap][c],  taps (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+// combine: y = ly0*(lx0*t0 + lx1*t1) + ly1*(lx0*t2 + lx1*t3)   (resize_ac_kernel's association)
+__global__ __launch_bounds__(256) void resize_taps_gather_kernel(const float* __restrict__ x, int ldx, float4* __restrict__ t,
+                                                                 long long total4, int Hin, int Win, int Hout, int Wout, int c4n) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n); long long p = i / c4n;
+    const int tap = (int)(p & 3); p >>= 2;
+    const int ox = (int)(p % Wout); p /= Wout; const int oy = (int)(p % Hout); const int b = (int)(p / Hout);
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    ac_src(oy, Hin, Hout, y0, y1, ly0, ly1); ac_src(ox, Win, Wout, x0, x1, lx0, lx1);
+    const int yy = (tap >> 1) ? y1 : y0, xx = (tap & 1) ? x1 : x0;
+    t[i] = *reinterpret_cast<const float4*>(x + (((long long)b * Hin + yy) * Win + xx) * ldx + c4 * 4);
+  }
+}
+
+__global__ __launch_bounds__(256) void resize_taps_combine_kernel(const float4* __restrict__ t, float* __restrict__ y, int ldy,
+                                                                  long long total4, int Hin, int Win, int Hout, int Wout, int c4n) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n); long long p = i / c4n;
+    const int ox = (int)(p % Wout); const long long q = p / Wout; const int oy = (int)(q % Hout);
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    ac_src(oy, Hin, Hout, y0, y1, ly0, ly1); ac_src(ox, Win, Wout, x0, x1, lx0, lx1);
+    const float4* tp = t + p * 4 * c4n + c4;
+    const float4 a = tp[0], b_ = tp[c4n], c = tp[2 * c4n], d = tp[3 * c4n];
+    float4 o;
+    o.x = ly0 * (lx0 * a.x + lx1 * b_.x) + ly1 * (lx0 * c.x + lx1 * d.x);
+    o.y = ly0 * (lx0 * a.y + lx1 * b_.y) + ly1 * (lx0 * c.y + lx1 * d.y);
+    o.z = ly0 * (lx0 * a.z + lx1 * b_.z) + ly1 * (lx0 * c.z + lx1 * d.z);
+    o.w = ly0 * (lx0 * a.w + lx1 * b_.w) + ly1 * (lx0 * c.w + lx1 * d.w);
+    *reinterpret_cast<float4*>(y + p * ldy + c4 * 4) = o;
   }
 }
 
@@ -317,6 +355,26 @@ extern "C" int smx_resize_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y
   if (!x || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
   const long long total = (long long)B * Hout * Wout * C;
   SMX_LAUNCH(resize_ac_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, Hin, Win, Hout, Wout, C);
+  return smx_launch_status();
+}
+
+extern "C" int smx_resize_taps_gather_f32(const float* x, int ldx, float* taps, int B, int Hin, int Win, int Hout, int Wout,
+                                          int C, void* stream) {
+  if (!x || !taps || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || C % 4 != 0 || ldx < C || ldx % 4 != 0) return SMX_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)taps & 15)) return SMX_EINVAL;
+  const long long total4 = (long long)B * Hout * Wout * 4 * (C / 4);
+  SMX_LAUNCH(resize_taps_gather_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, ldx, (float4*)taps, total4,
+             Hin, Win, Hout, Wout, C / 4);
+  return smx_launch_status();
+}
+
+extern "C" int smx_resize_taps_combine_f32(const float* taps, float* y, int ldy, int B, int Hin, int Win, int Hout, int Wout,
+                                           int C, void* stream) {
+  if (!taps || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || C % 4 != 0 || ldy < C || ldy % 4 != 0) return SMX_EINVAL;
+  if (((uintptr_t)y & 15) || ((uintptr_t)taps & 15)) return SMX_EINVAL;
+  const long long total4 = (long long)B * Hout * Wout * (C / 4);
+  SMX_LAUNCH(resize_taps_combine_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const float4*)taps, y, ldy,
+             total4, Hin, Win, Hout, Wout, C / 4);
   return smx_launch_status();
 }
 

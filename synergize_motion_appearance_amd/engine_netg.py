@@ -281,9 +281,15 @@ class NetGEngine:
         inp = torch.empty((B, 64, 64, 256), device=q.device, dtype=torch.float32)
         ops.conv(cf, self.bme["conv"], out=inp[..., :126], act=ACT_RELU)
         ops.copy_slice(flow_res, inp[..., 126:128])
-        wf = ops.conv(warp0, self.to_ctx[s], act=ACT_RELU)                    # [B,s,s,192]
-        if s != 64:
-            wf = ops.resize(wf, 64, 64)
+        if s > 128:
+            # relu(to_context(.)) is per pixel and only its 4 bilinear taps per 64x64 output pixel survive the
+            # resize: evaluate it on the gathered taps (1/4 of the 256x256 pixels), then blend (same values up to 1 ulp)
+            taps = ops.resize_taps_gather(warp0, 64, 64)                      # [B,64,256,C]
+            wf = ops.resize_taps_combine(ops.conv(taps, self.to_ctx[s], act=ACT_RELU), s, s)
+        else:
+            wf = ops.conv(warp0, self.to_ctx[s], act=ACT_RELU)                # [B,s,s,192]
+            if s != 64:
+                wf = ops.resize(wf, 64, 64)
         ops.conv(wf, self.ref_c1, out=inp[..., 128:], act=ACT_RELU)
         h = ops.conv(inp, self.ref_h, act=ACT_RELU)                           # [B,64,64,256] = [conv1 | convo1]
         return ops.conv(h, self.ref_out)                                      # [B,64,64,3] = [dflow(2) | docc(1)]

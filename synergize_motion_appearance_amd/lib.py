@@ -43,6 +43,8 @@ SIGNATURES = {
     "smx_winograd_conv3x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "smx_groupnorm_stats_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
     "smx_conv3x3_smalln_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "smx_resize_taps_gather_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_resize_taps_combine_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_groupnorm_finalize_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "smx_groupnorm_apply_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smx_groupnorm_ws_floats": (_i64, [_i, _i, _i]),

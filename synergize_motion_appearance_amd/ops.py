@@ -310,6 +310,29 @@ def resize(x, Ho, Wo, out=None):
     return out
 
 
+def resize_taps_gather(x, Ho, Wo):
+    """x [B,H,W,C] -> the 4 bilinear (align_corners=True) taps of every output pixel, [B,Ho,Wo*4,C] (a dense NHWC
+    map 4x as wide: row-compatible with a 1x1 conv)."""
+    B, H, W, Cc = x.shape
+    xp, ldx = _pix(x, "resize_taps input")
+    t = torch.empty((B, Ho, Wo * 4, Cc), device=x.device, dtype=torch.float32)
+    L.check(L.load().smx_resize_taps_gather_f32(xp, ldx, t.data_ptr(), B, H, W, Ho, Wo, Cc, _stream()), "resize_taps_gather")
+    return t
+
+
+def resize_taps_combine(t, Hin, Win, out=None):
+    """t [B,Ho,Wo*4,C] (a per-pixel op applied to `resize_taps_gather`) -> the bilinear blend [B,Ho,Wo,C]: equals
+    resize(op(x), Ho, Wo) for the [B,Hin,Win,*] map the taps were gathered from."""
+    B, Ho, W4, Cc = t.shape
+    if not t.is_contiguous() or W4 % 4:
+        raise L.SmxError("resize_taps_combine: dense [B,Ho,Wo*4,C] expected")
+    if out is None:
+        out = torch.empty((B, Ho, W4 // 4, Cc), device=t.device, dtype=torch.float32)
+    yp, ldy = _pix(out, "resize_taps output")
+    L.check(L.load().smx_resize_taps_combine_f32(_dev(t).data_ptr(), yp, ldy, B, Hin, Win, Ho, W4 // 4, Cc, _stream()), "resize_taps_combine")
+    return out
+
+
 def avgpool2(x, out=None):
     B, H, W, Cc = x.shape
     if out is None:

@@ -438,6 +438,26 @@ def test_sparse_motion_config4_128_grid(ops):
     assert maxabs(d.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("B,C,N,s", [(2, 64, 192, 256), (1, 32, 48, 128), (2, 16, 20, 72)])
+def test_per_pixel_op_at_the_bilinear_taps_only(ops, B, C, N, s):
+    """relu(conv1x1(x)) followed by the align_corners=True down-sampling == the same op evaluated only at the 4 taps
+    of each output pixel and blended (to_context at 256x256: a quarter of the pixels): equal up to the FMA contraction
+    of the blend (<= 1 ulp), and vs F.interpolate."""
+    x = rnd(f"tp{C}{s}", (B, C, s, s))
+    w, b = rnd(f"tpw{C}{N}", (N, C, 1, 1), 1.0 / math.sqrt(C)), rnd(f"tpb{N}", (N,), 0.1)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    full = ops.resize(ops.conv(nhwc(x), cv, act=1), 64, 64)
+    taps = ops.resize_taps_gather(nhwc(x), 64, 64)
+    assert tuple(taps.shape) == (B, 64, 256, C)
+    sampled = ops.resize_taps_combine(ops.conv(taps, cv, act=1), s, s)
+    assert maxabs(full.cpu(), sampled.cpu()) < 1e-6          # same source indices (unfused scale*o); blend FMAs may differ by 1 ulp
+    ref = F.interpolate(F.relu(F.conv2d(x, w, b)), size=(64, 64), mode="bilinear", align_corners=True)
+    assert maxabs(nchw(sampled), ref) < 2e-5
+    wide = torch.zeros((B, 64, 64, N + 8), device="cuda")
+    ops.resize_taps_combine(ops.conv(taps, cv, act=1), s, s, out=wide[..., 4:4 + N])
+    assert torch.equal(wide[..., 4:4 + N], sampled) and float(wide[..., :4].abs().max()) == 0.0
+
+
 def test_resize_avgpool_antialias(ops):
     x = rnd("rs", (2, 15, 64, 64))
     assert maxabs(nchw(ops.resize(nhwc(x), 32, 32)), O.resize_ac(x, (32, 32))) < 1e-6
