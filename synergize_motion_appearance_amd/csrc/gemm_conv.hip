@@ -413,6 +413,7 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
     // measured on MI355X (profiles/r01_b_gemm_tile_tuning.txt): 16 resident waves per CU win --
     // 64x64 tiles (4 waves, 4 blocks/CU) almost everywhere, 128x128 with 8 waves for big-M, N%128==0
     if (d->N <= 32) tile = 3;
+    else if (d->N % 128 == 0 && (long long)d->M * nb >= 49152 && d->K <= 256 && d->N <= 512 && !d->d2s_p) tile = 12;   // short K, big M: 256x128, 16 waves
     else if (d->N % 128 == 0 && (long long)d->M * nb >= 24576) tile = 8;
     else tile = 5;
   }

@@ -3,8 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from synergize_motion_appearance_amd import ops
-SH = [(30, 32, 256, 256), (30, 32, 256, 512), (30, 32, 256, 4096), (30, 256, 64, 128), (30, 256, 64, 192), (30, 128, 128, 192), (30, 64, 128, 128)]
-TILES = [5, 8, 10, 11, 2, 4, 1]
+SH = [(60, 32, 256, 256), (60, 32, 256, 512), (60, 32, 256, 4096), (60, 32, 256, 2048), (60, 256, 64, 128), (60, 128, 128, 192), (60, 64, 128, 128), (60, 128, 128, 256)]
+TILES = [5, 8, 10, 11, 2, 4, 1, 6, 7, 9, 12]
 print("B H Cin Cout | " + " ".join(f"t{t:<5d}" for t in TILES))
 for (B, H, Cin, Cout) in SH:
     x = torch.randn(B, H, H, Cin, device="cuda")
