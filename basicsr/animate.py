@@ -33,17 +33,12 @@ def parse_options(root_path, is_train=False, argv=None):
     return opt
 
 
-class _RankShard:
-    """every world_size-th video of a loader, starting at `rank` (videos are independent units)."""
-
-    def __init__(self, loader, rank, world):
-        self.loader, self.rank, self.world, self.dataset = loader, rank, world, loader.dataset
-
-    def __len__(self):
-        return (len(self.loader) - self.rank + self.world - 1) // self.world
-
-    def __iter__(self):
-        return (d for i, d in enumerate(self.loader) if i % self.world == self.rank)
+def rank_subset(dataset, rank, world):
+    """every world-th item of `dataset` starting at `rank`, selected by INDEX before any loader exists, so a rank only
+    reads and decodes its own videos (videos are independent units; no collective on the data path)."""
+    sub = torch.utils.data.Subset(dataset, range(rank, len(dataset), world))
+    sub.opt = dataset.opt
+    return sub
 
 
 def test_pipeline(root_path, argv=None):
@@ -52,9 +47,11 @@ def test_pipeline(root_path, argv=None):
     loaders = []
     for _, dataset_opt in sorted(opt["datasets"].items()):
         test_set = build_dataset(dataset_opt)
+        if opt["world_size"] > 1:
+            test_set = rank_subset(test_set, opt["rank"], opt["world_size"])
         loader = build_dataloader(test_set, dataset_opt, num_gpu=opt["num_gpu"], dist=opt["dist"], sampler=None,
                                   seed=opt["manual_seed"])
-        loaders.append(_RankShard(loader, opt["rank"], opt["world_size"]) if opt["world_size"] > 1 else loader)
+        loaders.append(loader)
     model = build_model(opt)
     results = {}
     for loader in loaders:

@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- reenactment frames/sec at 256x256 on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--dtype f32|bf16]
 
 A "step" is one pass of the per-frame hot path (keypoints -> relative-kp transfer -> dense
 motion -> warp / codebook compensation / decoder -> uint8 frames) over one batch of B
-synthetic 256x256 driving frames already resident in HBM; the source encoding is the
-frame-invariant cache (computed before the timed region, like the reference's weights).
-Workload = BASELINE.json configs[1]: 1 source + 300-frame driving clip, fp32 -> 5 steps
-of B=60 frames by default (measured on the device: 451 / 468 / 481 / 479 frames/s at B = 30 / 40 / 60 / 75).  N>1: every rank owns its own contiguous block of frames (weak
-scaling: per-GPU work fixed), the source cache is broadcast once over RCCL inside the
-timed region; no other collective is on the data path.
+synthetic 256x256 driving frames already resident in HBM.
+
+Workload.  N = 1: BASELINE.json configs[1] -- 1 source + the 300-frame driving clip, fp32, 5 steps of B = 60.
+N > 1: the same per-GPU work (weak scaling, contract (5)): N sources x the 300-frame clip (configs[2]'s "batch of
+8 sources x 300 frames sharded over 8 GPUs" at N = 8), i.e. a stream of N*300 independent (source, frame) units;
+step i takes the window of N*B consecutive units [i*N*B, (i+1)*N*B) and rank r renders its `driver.shard_frames`
+block of it (B units -- with B = 60 and a 300-frame clip a block never straddles two sources).  Source j is encoded
+ONCE by its owner rank j % N and its packed frame-invariant state (encoder taps 28.3 MB + down(source) + kp_source +
+kp_driving_initial + hull scale) is broadcast over RCCL/xGMI inside the timed region; there is no other collective on
+the data path.  RCCL failing to initialise is FATAL (no silent fallback); SMX_BENCH_BACKEND=gloo selects gloo
+explicitly (test boxes with one device) and is reported in config.parallelism.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     dominant kernel family (implicit-GEMM conv on the fp32 MFMA) measured with
-                  HIP events on the launch stream in an instrumented pass of the same steps,
-  "kernels":      per-family breakdown incl. the HBM-bound warp kernel (algorithmic GB/s) and
-                  the VQ micro-benchmark (the metric asks for warp+VQ HBM GB/s),
-  "cpu_baseline": the CPU oracle (a port of the reference's demo.py loop) timed on this
-                  box's host cores on a bounded sample of the same clip.
+  "roofline":     the DOMINANT KERNEL ALONE (winograd_kernel): executed fp32-MFMA flops / launch time against the
+                  157.3 TF matrix peak (frac <= 1), the algorithmic (direct-convolution) rate as a side field, HBM
+                  traffic per launch and the MFMA-busy counters from the committed rocprofv3 PMC passes,
+  "kernels":      per-family breakdown incl. the HBM-bound warp kernel (algorithmic AND counter GB/s) and the VQ kernel,
+  "value_incl_uint8_d2h": the same steps with every uint8 output batch copied to pinned host memory,
+  "batch_consistency": frames of the last timed batch re-rendered at B=1 and compared (<= 1 LSB),
+  "cpu_baseline": the CPU oracle (a port of the reference's demo.py loop) timed on this box's host cores.
 """
 import argparse
+import datetime
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,7 +41,9 @@ import torch  # noqa: E402
 import yaml  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
+CLIP = 300                       # frames of the driving clip (BASELINE.json configs[1])
 
 
 def build_nets(device):
@@ -48,30 +58,69 @@ def build_nets(device):
     return net_g.to(device).eval(), me.to(device).eval(), Pg, Pm
 
 
-def cpu_baseline(Pg, Pm, src, drv, budget_s=12.0, max_frames=12, threads=None):
-    """oracle port of demo.make_animation (B=1, sequential, source re-encoded per frame)."""
+def cpu_baseline(Pg, Pm, src, drv, frames=20, warmup=2, threads=None):
+    """SURVEY 8(d) protocol: the oracle port of demo.make_animation (B=1, sequential), warm-up 2 frames, MEDIAN of
+    >= 20 per-frame times; once as the reference runs it (source re-encoded every frame, demo.py:130) and once with
+    the source encoder cached; host core count and thread count printed."""
     from oracle import reenact_oracle as O
-    cores = threads or min(os.cpu_count() or 1, 32)      # torch CPU convs stop scaling (and thrash) far below 256 threads
+    host = os.cpu_count() or 1
+    cores = threads or min(host, 32)       # torch CPU convolutions stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     with torch.no_grad():
         s = src.unsqueeze(0)
         kp_s = O.kp_detector(Pm, s)
         kp_0 = O.kp_detector(Pm, drv[0:1])
+        enc = O.encode_source(Pg, s)
 
-        def one(t):
+        def one(t, cached):
             kp_d = O.kp_detector(Pm, drv[t:t + 1])
-            kp_n = O.normalize_kp(kp_s, kp_d, kp_0, False, True, True)
+            kp_n = O.normalize_kp(kp_s, kp_d, kp_0, True, True, True)
             dm = O.dense_motion(Pm, s, kp_n, kp_s)
-            return O.tensor2img(O.netg_forward(Pg, s, dm)["out"])
-        one(0)                                            # warm-up
-        n, t0 = 0, time.perf_counter()
-        while n < max_frames and (time.perf_counter() - t0) < budget_s:
-            one(n % drv.shape[0])
-            n += 1
-        dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frames of the same 256x256 clip, B=1 sequential, source re-encoded per frame "
-                      f"(demo.py:117-131 semantics), torch CPU fp32, {cores} threads, {dt:.1f} s"}
+            return O.tensor2img(O.netg_forward(Pg, s, dm, enc=enc if cached else None)["out"])
+
+        def run(cached):
+            for t in range(warmup):
+                one(t, cached)
+            ts = []
+            for t in range(frames):
+                t0 = time.perf_counter()
+                one((warmup + t) % drv.shape[0], cached)
+                ts.append(time.perf_counter() - t0)
+            return ts
+        t_ref, t_cached = run(False), run(True)
+    med, medc = statistics.median(t_ref), statistics.median(t_cached)
+    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "host_cpu_count": host, "kind": "port",
+            "value_cached_encoder": round(1.0 / medc, 4),
+            "sample": f"median of {frames} per-frame times after {warmup} warm-up frames of the same 256x256 clip, B=1 sequential, "
+                      f"torch CPU fp32, {cores} threads on a {host}-CPU host; value: source re-encoded per frame "
+                      f"(demo.py:117-131 semantics), value_cached_encoder: source encoder computed once; "
+                      f"{sum(t_ref) + sum(t_cached):.1f} s of timed CPU work"}
+
+
+def init_distributed(rank, world, dev):
+    """one process per GPU over RCCL ("nccl" on ROCm).  No fallback: a failed RCCL init raises on the failing rank and
+    times out the others -- a scaling run must never silently become a host-staged gloo broadcast."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("SMX_BENCH_BACKEND", "nccl")
+    tmo = datetime.timedelta(seconds=int(os.environ.get("SMX_BENCH_INIT_TIMEOUT_S", "300")))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                               # creates the communicator now, not inside the timed region
+        torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise RuntimeError(f"RCCL all_reduce probe returned {probe.item()} on rank {rank}, expected {world}")
+        return dist, "RCCL"
+    if backend != "gloo":
+        raise SystemExit(f"SMX_BENCH_BACKEND={backend}: only 'nccl' (RCCL, default) and 'gloo' (explicit, test boxes) are supported")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+    return dist, "gloo (explicitly requested via SMX_BENCH_BACKEND)"
+
+
+def load_profile_json(name):
+    p = os.path.join(REPO, "profiles", name)
+    return json.load(open(p)) if os.path.exists(p) else None
 
 
 def main():
@@ -79,9 +128,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=60, help="driving frames per step (frames in flight); 5 steps x 60 = the 300-frame clip")
+    ap.add_argument("--batch", type=int, default=60, help="driving frames per step per GPU (frames in flight); 5 steps x 60 = the 300-frame clip")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32: BASELINE configs[1] (headline); bf16: configs[2] storage/MFMA dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-d2h", action="store_true")
     ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")
     args = ap.parse_args()
 
@@ -91,66 +142,57 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the HIP path)"
-    if os.environ.get("SMX_BENCH_ONE_DEVICE"):          # test knob: exercise the N>1 control flow on a 1-GPU box
+    one_device = bool(os.environ.get("SMX_BENCH_ONE_DEVICE"))   # test knob: exercise the N>1 control flow on a 1-GPU box
+    if one_device:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    collective = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SMX_BENCH_BACKEND", "nccl")                          # "nccl" == RCCL on ROCm
-        import datetime
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe)                       # creates the communicator now, not inside the timed region
-                torch.cuda.synchronize()
-                assert int(probe.item()) == world
-            except Exception as e:                           # noqa: BLE001 -- keep the scaling run alive, say so in the JSON
-                print(f"[bench] rank {rank}: RCCL init failed ({type(e).__name__}: {e}); falling back to gloo for the one "
-                      "source-cache broadcast", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        collective = "RCCL" if backend == "nccl" else backend
+    dist, collective = (None, None) if world == 1 else init_distributed(rank, world, dev)
 
     from synergize_motion_appearance_amd import ops, driver
     from synergize_motion_appearance_amd.synth import synth_clip
 
     net_g, me, Pg, Pm = build_nets(dev)
+    if args.dtype == "bf16":
+        net_g.set_compute_dtype("bf16")
+        me.set_compute_dtype("bf16")
     B, K, W = args.batch, args.steps, args.warmup
-    # one synthetic clip, every rank takes its own rotation of it (device resident before timing)
-    n_clip = min(300, B * (K + W))
-    src_cpu, drv_cpu = synth_clip(max(n_clip, B), seed=123)
-    src = src_cpu.unsqueeze(0).to(dev)
+    # N sources (seeds 123, 124, ...), one driving clip shared by all of them (device resident before timing)
+    src_cpu, drv_cpu = synth_clip(CLIP, seed=123)
     drv = drv_cpu.to(dev)
-    nfr = drv.shape[0]
-    batches = [drv[torch.arange(i * B + rank, i * B + rank + B, device=dev) % nfr].contiguous() for i in range(K + W)]
-    eng_g, eng_m = net_g.engine(), me.engine()
-    kp_0 = eng_m.estimate_kp(drv[0:1])
+    n_src = world
+    my_sources = {j: (src_cpu if j == 0 else synth_clip(1, seed=123 + j)[0]).unsqueeze(0).to(dev) for j in range(n_src) if j % world == rank}
+    total_units = n_src * CLIP
 
-    state = {}
+    def segments(step_idx):
+        """this rank's B units of the global window `step_idx` -> [(source j, frames tensor)] (views of the clip where contiguous)."""
+        a, b = driver.shard_frames(world * B, rank, world)
+        u0, segs = step_idx * world * B + a, []
+        n = b - a
+        while n > 0:
+            u = u0 % total_units
+            j, t = u // CLIP, u % CLIP
+            m = min(n, CLIP - t)
+            segs.append((j, drv[t:t + m]))
+            u0 += m
+            n -= m
+        return segs
+    work = [segments(i) for i in range(K + W)]
+    states = {}
 
     def prologue():
-        """frame-invariant work of one clip: source cache (+ RCCL broadcast for N>1)."""
-        if world > 1:
-            cache, kp_s = driver.broadcast_source_cache(net_g, me, src, src=0)
-        else:
-            cache, kp_s = eng_g.encode_source(src), eng_m.estimate_kp(src)
-        state.update(cache=cache, kp_s=kp_s, src64=eng_m.source_down(src), scale=driver.adapt_scale(kp_s, kp_0))
+        """frame-invariant work of the job: every source is encoded once, by its owner (+ one RCCL broadcast each for N>1)."""
+        for j in range(n_src):
+            if world > 1:
+                owner = j % world
+                states[j] = driver.broadcast_source_state(net_g, me, my_sources.get(j), drv[0:1] if owner == rank else None, True,
+                                                          src=owner, device=dev)
+            else:
+                states[j] = driver.encode_source_state(net_g, me, my_sources[j], drv[0:1], True)
 
-    def step(frames):
-        kp_d = eng_m.estimate_kp(frames)
-        kp_n = driver.normalize_kp(state["kp_s"], kp_d, kp_0, True, True, True, state["scale"])
-        dm = eng_m.dense_motion(state["src64"], kp_n, state["kp_s"])
-        st = eng_g.forward(state["cache"], dm["deformation"], dm["occlusion_nhwc"].view(-1, 64, 64), dm["heat_nhwc"], 1.0)
-        return ops.to_uint8(st["out"], -1.0, 1.0)
+    def step(segs):
+        outs = [driver.render_frames(states[j], fr, net_g, me, True, True, batch=B) for j, fr in segs]
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,88 +202,150 @@ def main():
 
     prologue()
     for i in range(W):
-        step(batches[i])
+        step(work[i])
     barrier()
     t0 = time.perf_counter()
     prologue()
     for i in range(K):
-        out = step(batches[W + i])
+        out = step(work[W + i])
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if collective == "RCCL" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out.shape == (B, 256, 256, 3) and out.dtype == torch.uint8
     fps = world * K * B / dt
 
+    # the benchmark's own batch, checked: first / middle / last frame of the last timed batch re-rendered at B=1
+    (j_last, fr_last) = work[W + K - 1][-1]
+    off = B - fr_last.shape[0]
+    picks = sorted({0, fr_last.shape[0] // 2, fr_last.shape[0] - 1})
+    worst, ndiff, ntot = 0, 0, 0
+    for i in picks:
+        one = driver.render_frames(states[j_last], fr_last[i:i + 1], net_g, me, True, True, batch=1)
+        d = (one[0].int() - out[off + i].int()).abs()
+        worst, ndiff, ntot = max(worst, int(d.max())), ndiff + int((d > 0).sum()), ntot + d.numel()
+    consistency = {"frames_checked": len(picks), "max_lsb_vs_b1": worst, "bytes_differing": ndiff, "bytes": ntot,
+                   "what": f"frames {picks} of the last timed batch (B={B}) re-rendered one at a time; uint8 outputs compared"}
+    if worst > 1:
+        raise SystemExit(f"[bench] batch consistency FAILED: B={B} output differs from B=1 by {worst} LSB")
+
+    dname = {"f32": "f32", "bf16": "bf16"}[args.dtype]
+    cfg_ix = 1 if (world == 1 and args.dtype == "f32") else 2
     result = {
         "metric": "reenactment frames/sec at 256x256", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: 256x256, 1 source + 300-frame driving clip, fp32, options/test.yml, "
-                               "name-keyed random-init weights", "frames_per_step": B, "frames_total": world * K * B,
-                   "parallelism": f"frames sharded x{world}, {collective} broadcast of the source cache" if world > 1 else "1 GPU",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "config": {"workload": (f"BASELINE.json configs[{cfg_ix}]: 256x256, {n_src} source(s) x 300-frame driving clip, {dname}, options/test.yml, "
+                                "name-keyed random-init weights"), "frames_per_step": B, "frames_total": world * K * B,
+                   "sources": n_src,
+                   "parallelism": (f"{n_src} sources x {CLIP} frames = {total_units} (source, frame) units; each step's window of {world * B} "
+                                   f"units sharded x{world} (driver.shard_frames); one {collective} broadcast per source of its packed "
+                                   f"frame-invariant state ({4 * driver.cache_numel() / 1e6:.1f} MB) from the owner rank, inside the timed region")
+                   if world > 1 else "1 GPU",
                    "relative": True, "adapt_movement_scale": True, "output": "uint8 HWC frames in HBM"},
+        "batch_consistency": consistency,
     }
+    if one_device:
+        result["config"]["one_device_test_knob"] = True
+
+    # ---- PCIe-inclusive figure ("separately incl. uint8 D2H"): the same K steps, every uint8 batch
+    # copied to pinned host memory on a second stream (double buffered); never `value`
+    if rank == 0 and not args.no_d2h:
+        host = [torch.empty((B, 256, 256, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        copy_stream, done = torch.cuda.Stream(), [None, None]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(K):
+            o = step(work[W + i])
+            ready = torch.cuda.Event()
+            ready.record()
+            if done[i & 1] is not None:
+                done[i & 1].synchronize()                    # the host buffer is free again
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                host[i & 1].copy_(o, non_blocking=True)
+                o.record_stream(copy_stream)
+                done[i & 1] = torch.cuda.Event()
+                done[i & 1].record()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        result["value_incl_uint8_d2h"] = round(K * B / dt2, 3)
+        result["value_incl_uint8_d2h_note"] = ("this rank's frames/s with every uint8 output batch also copied D2H to pinned host memory on a "
+                                               "second stream (double buffered), source state already resident; per GPU")
+    if dist is not None:
+        dist.barrier()
 
     if rank == 0 and not args.no_roofline:
         nprof = min(K, 3)
         with ops.profile() as rec:
             for i in range(nprof):
-                step(batches[W + i])
+                step(work[W + i])
+        step_ms = 1e3 * dt / K
         fam = {}
         for name, meta, ms in rec.rows:
-            f = fam.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "mfma_flops": 0.0, "wino_ms": 0.0, "wino_calls": 0})
+            meta = meta or {}
+            key = "winograd" if meta.get("wino") else name
+            f = fam.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "mfma_flops": 0.0})
             f["calls"] += 1
             f["ms"] += ms
-            f["flops"] += (meta or {}).get("flops", 0.0)
-            f["mfma_flops"] += (meta or {}).get("mfma_flops", (meta or {}).get("flops", 0.0))
-            if (meta or {}).get("wino"):
-                f["wino_ms"] += ms
-                f["wino_calls"] += 1
-            f["bytes"] += (meta or {}).get("bytes", 0.0)
-        g = fam["gemm_conv"]
-        tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            f["flops"] += meta.get("flops", 0.0)
+            f["mfma_flops"] += meta.get("mfma_flops", meta.get("flops", 0.0))
+            f["bytes"] += meta.get("bytes", 0.0)
+        traffic = load_profile_json("r02_traffic_pmc.json") or load_profile_json("r01_o_traffic_pmc.json")
+        tfam = (traffic or {}).get("families", {}) if B == 60 else {}
+        mfma_pmc = load_profile_json("r02_mfma_pmc.json") if B == 60 else None
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        dom = max((k for k in fam if fam[k]["mfma_flops"] > 0), key=lambda k: fam[k]["ms"])
+        g = fam[dom]
         tf_exec = g["mfma_flops"] / (g["ms"] * 1e-3) / 1e12
-        result["roofline"] = {
-            "kernel": "conv/GEMM family on v_mfma_f32_32x32x2_f32: winograd_kernel<SWZ,NW> (fused F(2x2,3x3), 3x3 s1 convs) + "
-                      "gemm_conv_kernel<BM,BN,..> (implicit GEMM: 1x1, 7x7, strided, patch (un)embedding, attention-block bmm)",
-            "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "note": "achieved = ALGORITHMIC flops (2*M*N*K of the direct convolution) / kernel time, so the Winograd layers "
-                    "(2.25x fewer multiplies) can exceed the direct-algorithm MFMA peak; mfma_executed_* counts the flops the "
-                    "matrix cores actually run",
-            "mfma_executed_tflops": round(tf_exec, 2), "mfma_executed_frac": round(tf_exec / PEAK_F32_MFMA_TFLOPS, 4),
-            "winograd_share_of_family_time": round(g["wino_ms"] / g["ms"], 3), "winograd_launches_per_step": g["wino_calls"] // nprof,
+        tf_alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        kname = {"winograd": "winograd_kernel<SWZ=false,NW> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
+                 "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM)"}.get(dom, dom)
+        roof = {
+            "kernel": kname, "bound": "mfma", "achieved": round(tf_exec, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(tf_exec / peak, 4),
+            "traffic": round(tfam[dom]["hbm_bytes_per_launch"]) if dom in tfam else None,
+            "achieved_algorithmic": round(tf_alg, 2),
+            "note": "achieved/frac = flops the matrix cores EXECUTE in this kernel (2*M*N*16/4*Cin per launch for F(2x2,3x3): 16 multiplies per "
+                    "2x2 output tile and channel) / its summed launch time; achieved_algorithmic = the direct convolution's 2*M*N*9*Cin over "
+                    "the same time (2.25x the executed rate by construction, not a utilisation)",
             "launches_per_step": g["calls"] // nprof, "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
-            "algorithmic_gflop_per_frame": round(g["flops"] / nprof / B / 1e9, 2),
-            "share_of_step_time": round(g["ms"] / nprof / (1e3 * dt / K), 3),
+            "share_of_step_time": round(g["ms"] / nprof / step_ms, 3),
             "method": f"HIP events around every launch on the launch stream, {nprof} instrumented steps after the timed region"}
-        # HBM-side traffic of the same command from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE, separate runs, gfx950 correction applied by tools/pmc_traffic.py): bytes per launch
-        pmc = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_o_traffic_pmc.json")
-        if os.path.exists(tpath) and B == 60:
-            pmc = json.load(open(tpath))["families"]
-            if "conv_gemm_family" in pmc:
-                result["roofline"]["traffic"] = round(pmc["conv_gemm_family"]["hbm_bytes_per_launch"])
-                result["roofline"]["traffic_note"] = ("HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), average over the family's launches; "
-                                                      "measured in separate rocprofv3 --pmc passes of this command at B=60 "
-                                                      "(profiles/r01_o_traffic_pmc.json), not in this run")
+        if dom in tfam:
+            roof["traffic_note"] = ("HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of the guide), from separate rocprofv3 --pmc "
+                                    "passes of this command at B=60 committed under profiles/ (not measured in this run)")
+        if mfma_pmc and dom in mfma_pmc.get("kernels", {}):
+            roof["mfma_pmc"] = dict(mfma_pmc["kernels"][dom], source="profiles/r02_mfma_pmc.json (rocprofv3 --pmc pass of this command, B=60)")
+        result["roofline"] = roof
+        conv_ms = sum(fam[k]["ms"] for k in ("winograd", "gemm_conv") if k in fam)
+        conv_fl = sum(fam[k]["flops"] for k in ("winograd", "gemm_conv") if k in fam)
+        result["conv_gemm_family"] = {"algorithmic_gflop_per_frame": round(conv_fl / nprof / B / 1e9, 2),
+                                      "share_of_step_time": round(conv_ms / nprof / step_ms, 3),
+                                      "algorithmic_TFLOPs": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
         kern = {}
         for name, f in fam.items():
             e = {"calls_per_step": f["calls"] // nprof, "ms_per_step": round(f["ms"] / nprof, 3)}
+            avg_s = f["ms"] * 1e-3 / f["calls"]
             if f["bytes"]:
                 e["algorithmic_GBps"] = round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)
-                e["hbm_frac"] = round(e["algorithmic_GBps"] / PEAK_HBM_GBS, 4)
+                e["hbm_frac_algorithmic"] = round(e["algorithmic_GBps"] / PEAK_HBM_GBS, 4)
             if f["flops"]:
-                e["TFLOPs"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
-            pf = {"gemm_conv": "conv_gemm_family"}.get(name, "attention" if name.startswith("attention") else name)
-            if pmc and pf in pmc and not name.startswith("attention"):
-                e["pmc_hbm_bytes_per_launch"] = round(pmc[pf]["hbm_bytes_per_launch"])
+                e["TFLOPs_algorithmic"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
+            if f["mfma_flops"] and f["mfma_flops"] != f["flops"]:
+                e["TFLOPs_executed"] = round(f["mfma_flops"] / (f["ms"] * 1e-3) / 1e12, 2)
+            pf = "attention" if name.startswith("attention") else name
+            if pf in tfam and not name.startswith("attention"):
+                e["pmc_hbm_bytes_per_launch"] = round(tfam[pf]["hbm_bytes_per_launch"])
+                e["pmc_hbm_GBps"] = round(tfam[pf]["hbm_bytes_per_launch"] / avg_s / 1e9, 1)
+                e["hbm_frac_pmc"] = round(e["pmc_hbm_GBps"] / PEAK_HBM_GBS, 4)
             kern[name] = e
-        # warp by scale (A7) and the VQ micro-benchmark (A12, train-only in the reference)
+        if "warp" in kern:
+            kern["warp"]["note"] = ("algorithmic = SURVEY 8(d) bytes (every frame charged a source read + output write + flow + occlusion); pmc = "
+                                    "what reaches HBM (the broadcast source stays in L2/MALL, the output stream is compulsory)")
+        # warp by scale (A7) and the VQ kernel (A12)
         for s in (32, 64, 128, 256):
             rows = [(m, ms) for n, m, ms in rec.rows if n == "warp" and m["s"] == s]
             if rows:
@@ -265,15 +369,15 @@ def main():
             for n, m, ms in rec.rows:
                 if n != "gemm_conv":
                     continue
-                key = (m["M"], m["N"], m["K"], m["nb"], m["k"])
+                key = (m["M"], m["N"], m["K"], m["nb"], m["k"], int(bool(m.get("wino"))))
                 t = tab.setdefault(key, [0, 0.0, m["flops"]])
                 t[0] += 1
                 t[1] += ms
             rows = sorted(((k, v) for k, v in tab.items()), key=lambda kv: -kv[1][1])
             with open(args.dump_shapes, "w") as f:
-                f.write("M N K nb ksize calls/step ms/step TFLOPs\n")
-                for (M_, N_, K_, nb_, ks_), (c, ms, fl) in rows:
-                    f.write(f"{M_} {N_} {K_} {nb_} {ks_} {c / nprof:.1f} {ms / nprof:.3f} {fl * c / (ms * 1e-3) / 1e12:.1f}\n")
+                f.write("M N K nb ksize winograd calls/step ms/step TFLOPs(algorithmic)\n")
+                for (M_, N_, K_, nb_, ks_, wn_), (c, ms, fl) in rows:
+                    f.write(f"{M_} {N_} {K_} {nb_} {ks_} {wn_} {c / nprof:.1f} {ms / nprof:.3f} {fl * c / (ms * 1e-3) / 1e12:.1f}\n")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(Pg, Pm, src_cpu, drv_cpu)

@@ -38,6 +38,13 @@ enum { SMX_ACT_NONE = 0, SMX_ACT_RELU = 1, SMX_ACT_LRELU02 = 2, SMX_ACT_SWISH = 
 /* library identification: returns a static string "smx <version> gfx950" */
 const char* smx_version(void);
 
+/* Launch-selection knobs (tests / tuning tools; the defaults are the device-tuned choices).  Names: "wino_nw"
+ * (1|2 N tiles per Winograd block, -1 auto), "wino_swz", "wino_ablate", "wino_epi", "gemm_variant",
+ * "gemm_xcd_swizzle", "warp_rows", "warp_reorder".  Initialised once from the SMX_* environment; the launch paths
+ * read the table, never the environment.  Returns SMX_EINVAL for an unknown name. */
+int smx_set_tuning(const char* name, int value);
+int smx_get_tuning(const char* name, int* value);
+
 /* ---------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / batched NT-GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
  *   C[g][m][n] = epi( alpha * sum_k A[g][m][k] * Bt[g][n][k] )
@@ -93,7 +100,7 @@ int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, con
  * (archs/vqgan_arch.py:183-188) is applied by the region loader: x*in_ss[b][c][0] + in_ss[b][c][1],
  * with in_ss from smx_groupnorm_stats_f32 -- the separate normalise read+write pass disappears.
  * stats_part != NULL: the epilogue also emits, per block of 8x16 output pixels, the per-channel
- * {sum, sum of squares} of the values it stores: [B][(H/8)*(W/16)][Cout][2] floats -- the statistics pass
+ * {mean, M2 = sum (v - mean)^2} (Welford form, 128 values) of the values it stores: [B][(H/8)*(W/16)][Cout][2] floats -- the statistics pass
  * of the NEXT GroupNorm (ResBlock norm2 / the following block's norm1) reduces to
  * smx_groupnorm_finalize_f32 over these partials, the activation is not re-read. */
 
@@ -118,7 +125,7 @@ int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gamma, const f
 int smx_conv3x3_smalln_f32(const float* x, int lda, const float* w, const float* bias, float* y, int ldc,
                            int B, int H, int W, int Cin, int Cout, int act, const float* in_ss, int in_swish,
                            void* stream);
-/* partials [B][nch][C][2] ({sum, sum^2} per channel over disjoint pixel chunks covering the image; from
+/* partials [B][nch][C][2] ({mean, M2} per channel over nch equal disjoint pixel chunks covering the image; from
  * smx_winograd_conv3x3_f32(stats_part) or the first pass of smx_groupnorm_stats_f32) -> ss [B][C][2] */
 int smx_groupnorm_finalize_f32(const float* part, const float* gamma, const float* beta, float* ss,
                                int B, int HW, int C, int groups, int nch, float eps, void* stream);
@@ -222,6 +229,10 @@ int smx_motion_ignore_f32(const float* flow, uint8_t* ignore, int B, int Hf, int
  * channel slice (row stride ld_dec floats) of the [enc|dec] concat buffer, the others are dense */
 int smx_sft_combine_f32(const float* dec, int ld_dec, const float* scale, const float* shift, float* out, float w,
                         int64_t P, int C, void* stream);
+/* content fingerprint {sum x_i, sum x_i w_i} (fixed pseudo-random weights, deterministic) of n floats -> out2[2]:
+ * the host layer keys its frame-invariant source caches on it (the reference recomputes the source encoding every
+ * frame, demo.py:130; a pointer-based key would miss raw-pointer rewrites of a reused buffer) */
+int smx_fingerprint_f32(const float* x, int64_t n, float* out2, void* stream);
 /* y = a + b (n elements) */
 int smx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
 /* copy a channel slice: y[.., 0:C] (ld ldy) = x[.., 0:C] (ld ldx) over P pixels */

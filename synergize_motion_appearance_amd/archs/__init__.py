@@ -4,7 +4,8 @@ from copy import deepcopy
 
 from ..registry import ARCH_REGISTRY
 from .appmotioncodebook_arch import AppMotionCompFormer  # noqa: F401  (registers)
-from .motion_estimator_arch import Motion_Estimator_keypoint_aware  # noqa: F401  (registers)
+from .motion_estimator_arch import Motion_Estimator_keypoint_aware, KPDetector, DenseMotionNetwork  # noqa: F401  (register)
+from .vqgan_arch import VQGANDiscriminator  # noqa: F401  (registers)
 
 __all__ = ["build_network", "ARCH_REGISTRY"]
 

@@ -65,13 +65,20 @@ class AppMotionCompFormer(HipArch):
     @torch.no_grad()
     def encode_source(self, x):
         """frame-invariant encoder taps (the reference recomputes them every frame, demo.py:130)."""
-        key = (x.data_ptr(), x._version, tuple(x.shape))
-        if self.cache_source and key == self._src_key:
-            return self._src_cache
-        c = self.engine().encode_source(x.float())
-        self._src_key, self._src_cache = key, c
-        self._src_ref = x            # keep the tensor alive: its address cannot be recycled while the key is cached
-        return c
+        eng = self.engine()
+        if not self.cache_source:
+            return eng.encode_source(x.float())
+        # keyed on CONTENT (shape + device fingerprint), not on (data_ptr, _version): raw-pointer writers (this
+        # package's own kernels with out=, DLPack, custom ops) do not bump _version, and _version is not readable
+        # under torch.inference_mode()
+        key = (tuple(x.shape), ops.fingerprint(x.float()))
+        if key != self._src_key:
+            self._src_key, self._src_cache = key, eng.encode_source(x.float())
+        return self._src_cache
+
+    def invalidate_source_cache(self):
+        """drop the cached source encoding (the next forward re-encodes)."""
+        self._src_key, self._src_cache = None, None
 
     @torch.no_grad()
     def encode_driving(self, x):

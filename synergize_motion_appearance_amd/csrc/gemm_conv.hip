@@ -397,8 +397,8 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.up2 = d->up2;
   p.act = d->act; p.alpha = d->alpha; p.bias_per_row = d->bias_per_row; p.d2s_p = d->d2s_p; p.d2s_c = d->d2s_c;
   p.tiles_n = 1;
-  p.xcd_swizzle = getenv("SMX_NO_XCD_SWIZZLE") ? 0 : 1;
-  p.variant = getenv("SMX_GEMM_VARIANT") ? atoi(getenv("SMX_GEMM_VARIANT")) : 3;
+  p.xcd_swizzle = smx_tune(SMX_TUNE_GEMM_XCD_SWIZZLE) ? 1 : 0;
+  p.variant = smx_tune(SMX_TUNE_GEMM_VARIANT);
   p.ksplit = d->ksplit > 1 ? d->ksplit : 1; p.ws = d->ws;
   if (p.ksplit > 1 && (!d->ws || nb != 1 || d->d2s_p || p.ksplit > (d->K + BK - 1) / BK)) return SMX_EINVAL;
   p.is1x1 = (d->kh == 1 && d->kw == 1 && d->stride == 1 && !d->up2 && d->pad_t == 0 && d->pad_l == 0 &&

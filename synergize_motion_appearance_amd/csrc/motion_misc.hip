@@ -336,6 +336,31 @@ extern "C" int smx_sft_combine_f32(const float* dec, int ld_dec, const float* sc
   return smx_launch_status();
 }
 
+// content fingerprint of a small tensor (cache keys on the host side): {sum x_i, sum x_i * w_i} with fixed
+// pseudo-random weights w_i in [0,1); one block, fixed reduction order -> deterministic for equal contents
+__global__ __launch_bounds__(1024) void fingerprint_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ double red[2][1024];
+  double a = 0.0, b = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 1024) {
+    const float v = x[i];
+    const unsigned h = ((unsigned)i * 2654435761u) >> 8;
+    a += v; b += (double)v * (double)(h & 0xffffu) * (1.0 / 65536.0);
+  }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = (float)red[0][0]; out[1] = (float)red[1][0]; }
+}
+
+extern "C" int smx_fingerprint_f32(const float* x, int64_t n, float* out2, void* stream) {
+  if (!x || !out2 || n <= 0) return SMX_EINVAL;
+  SMX_LAUNCH(fingerprint_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long long)n, out2);
+  return smx_launch_status();
+}
+
 extern "C" int smx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream) {
   if (!a || !b || !y || n <= 0) return SMX_EINVAL;
   SMX_LAUNCH(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n);

@@ -16,9 +16,13 @@ __device__ __forceinline__ int gn_ppc(int HW) {
   int p = HW / 64; if (p < 32) p = 32; if (p > 256) p = 256; return p;
 }
 
+// Partials are {mean, M2 = sum (x - mean)^2} per (b, chunk, channel) -- Welford/Chan form, NOT {sum, sum^2}:
+// var = E[x^2] - mean^2 cancels catastrophically in fp32 once |mean| >> std (real checkpoints after a few
+// stacked ResBlocks), whereas per-thread sums shifted by the thread's first value and pairwise Chan merges only
+// ever subtract numbers of similar size.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int ldx, float* __restrict__ part,
                                                          int HW, int C, int ppc, int nch) {
-  extern __shared__ float red[];                       // [rows][C][2]
+  extern __shared__ float red[];                       // [rows][C][3] = {n, mean, M2}
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int cq = C >> 2;                               // float4 columns
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, rows = 256 / cq;
@@ -26,50 +30,78 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
   const float* xb = x + (long long)b * HW * ldx + tx * 4;
   int p = p0 + ty;
+  float piv[4] = {0.f, 0.f, 0.f, 0.f};                 // shift: this thread's first value per channel
+  if (p < p1) { const float4 v0 = *reinterpret_cast<const float4*>(xb + (long long)p * ldx); piv[0] = v0.x; piv[1] = v0.y; piv[2] = v0.z; piv[3] = v0.w; }
+  int cnt = 0;
   for (; p + 3 * rows < p1; p += 4 * rows) {             // 4 independent 16-byte loads in flight per lane
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (long long)(p + u * rows) * ldx);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
-      q[0] += v[u].x * v[u].x; q[1] += v[u].y * v[u].y; q[2] += v[u].z * v[u].z; q[3] += v[u].w * v[u].w;
+      const float d0 = v[u].x - piv[0], d1 = v[u].y - piv[1], d2 = v[u].z - piv[2], d3 = v[u].w - piv[3];
+      s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
+      q[0] += d0 * d0; q[1] += d1 * d1; q[2] += d2 * d2; q[3] += d3 * d3;
     }
+    cnt += 4;
   }
   for (; p < p1; p += rows) {
     float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
-    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-    q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+    const float d0 = v.x - piv[0], d1 = v.y - piv[1], d2 = v.z - piv[2], d3 = v.w - piv[3];
+    s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
+    q[0] += d0 * d0; q[1] += d1 * d1; q[2] += d2 * d2; q[3] += d3 * d3;
+    ++cnt;
   }
-  float* r = red + ((ty * C) + tx * 4) * 2;
+  float* r = red + ((ty * C) + tx * 4) * 3;
+  const float fn = (float)cnt, inv = cnt ? 1.f / fn : 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { r[2 * e] = s[e]; r[2 * e + 1] = q[e]; }
+  for (int e = 0; e < 4; ++e) {
+    const float ms = s[e] * inv;                       // mean of the shifted values
+    r[3 * e] = fn; r[3 * e + 1] = piv[e] + ms; r[3 * e + 2] = fmaxf(q[e] - s[e] * ms, 0.f);
+  }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    float ss = 0.f, qq = 0.f;
-    for (int t = 0; t < rows; ++t) { ss += red[(t * C + c) * 2]; qq += red[(t * C + c) * 2 + 1]; }
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int t = 0; t < rows; ++t) {                   // Chan merge
+      const float nb = red[(t * C + c) * 3], mb = red[(t * C + c) * 3 + 1], qb = red[(t * C + c) * 3 + 2];
+      if (nb > 0.f) {
+        const float nn = n + nb, d = mb - mean, f = nb / nn;
+        mean += d * f; m2 += qb + d * d * n * f; n = nn;
+      }
+    }
     float* o = part + (((long long)b * nch + chunk) * C + c) * 2;
-    o[0] = ss; o[1] = qq;
+    o[0] = mean; o[1] = m2;
   }
 }
 
-// pass 2 -- one wave per (b, group): reduce the chunk partials in double with a wavefront
-// shuffle tree, mean/rstd -> per-channel scale/shift
+// pass 2 -- one wave per (b, group): merge the (chunk, channel) partials {mean, M2} (chunk c holds
+// min(ppc, HW - c*ppc) pixels) in double -- group mean first, then M2 + n (mean_i - mean)^2 -- -> per-channel
+// scale/shift
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ ss, int HW, int C,
-                                                         int groups, int nch, float eps) {
+                                                         int groups, int nch, int ppc, float eps) {
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
   const int cpg = C / groups, items = nch * cpg;
-  double s = 0.0, q = 0.0;
+  double s = 0.0;
   for (int i = threadIdx.x; i < items; i += 64) {
     const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
-    const float* pp = part + (((long long)b * nch + chunk) * C + c) * 2;
-    s += pp[0]; q += pp[1];
+    const int n_i = min(ppc, HW - chunk * ppc);
+    s += (double)part[(((long long)b * nch + chunk) * C + c) * 2] * n_i;
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const double n = (double)HW * cpg, mean = s / n;
-  double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
+  double q = 0.0;
+  for (int i = threadIdx.x; i < items; i += 64) {
+    const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
+    const int n_i = min(ppc, HW - chunk * ppc);
+    const float* pp = part + (((long long)b * nch + chunk) * C + c) * 2;
+    const double d = (double)pp[0] - mean;
+    q += (double)pp[1] + d * d * n_i;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const double var = q / n;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   for (int j = threadIdx.x; j < cpg; j += 64) {
     const int c = g * cpg + j;
@@ -185,8 +217,8 @@ extern "C" int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float
   const int nch = (HW + ppc - 1) / ppc;
   float* part = ws; float* ss = ws + (int64_t)B * nch * C * 2;
   const int rows = 256 / (C / 4);
-  SMX_LAUNCH(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, part, HW, C, ppc, nch);
-  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, gamma, beta, ss, HW, C, groups, nch, eps);
+  SMX_LAUNCH(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 3 * sizeof(float), st, x, ldx, part, HW, C, ppc, nch);
+  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, gamma, beta, ss, HW, C, groups, nch, ppc, eps);
   const long long total4 = (long long)B * HW * (C / 4);
   int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
   SMX_LAUNCH(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, ss, total4, HW, C, swish);
@@ -201,15 +233,16 @@ extern "C" int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gam
   int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
   const int nch = (HW + ppc - 1) / ppc;
   const int rows = 256 / (C / 4);
-  SMX_LAUNCH(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, ws, HW, C, ppc, nch);
-  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, ws, gamma, beta, ss, HW, C, groups, nch, eps);
+  SMX_LAUNCH(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 3 * sizeof(float), st, x, ldx, ws, HW, C, ppc, nch);
+  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, ws, gamma, beta, ss, HW, C, groups, nch, ppc, eps);
   return smx_launch_status();
 }
 
 extern "C" int smx_groupnorm_finalize_f32(const float* part, const float* gamma, const float* beta, float* ss,
                                           int B, int HW, int C, int groups, int nch, float eps, void* stream) {
-  if (!part || !gamma || !beta || !ss || B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || nch <= 0) return SMX_EINVAL;
-  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, part, gamma, beta, ss, HW, C, groups, nch, eps);
+  if (!part || !gamma || !beta || !ss || B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || nch <= 0 || HW % nch != 0) return SMX_EINVAL;
+  const int ppc = HW / nch;                            // equal chunks (the Winograd epilogue: 8x16-pixel blocks)
+  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, part, gamma, beta, ss, HW, C, groups, nch, ppc, eps);
   return smx_launch_status();
 }
 

@@ -1,0 +1,55 @@
+// Library-wide tuning / test knobs: one table, initialised ONCE from the environment (so the tools that set
+// SMX_* variables keep working), changed at run time through smx_set_tuning -- the launch paths read plain
+// ints, never getenv.  -1 = "auto" (the launcher's own device-tuned choice).
+#include <string.h>
+#include <stdlib.h>
+#include "smx.h"
+#include "smx_common.h"
+
+namespace {
+struct Knob { const char* name; const char* env; int value; };
+Knob g_knobs[SMX_TUNE_COUNT] = {
+  {"wino_nw", "SMX_WINO_NW", -1},               // Winograd: 32-wide N tiles per block (1 | 2)
+  {"wino_swz", "SMX_WINO_SWZ", 0},              // Winograd: conflict-free LDS swizzle
+  {"wino_ablate", "SMX_WINO_ABLATE", 0},        // Winograd: timing-only ablation mask (tools)
+  {"gemm_variant", "SMX_GEMM_VARIANT", 3},      // implicit GEMM: bit0 store-early pipeline, bit1 s_setprio
+  {"gemm_xcd_swizzle", "SMX_GEMM_XCD_SWIZZLE", 1},
+  {"warp_rows", "SMX_WARP_ROWS", 1},            // warp: row-chunk kernel when eligible (0 = per-lane kernel)
+  {"warp_reorder", "SMX_WARP_REORDER", 1},      // warp: (XCD, chunk, frame) block order
+  {"wino_epi", "SMX_WINO_EPI", -1},             // Winograd: epilogue variant
+};
+bool g_init = false;
+void init_once() {
+  if (g_init) return;
+  g_init = true;
+  for (int i = 0; i < SMX_TUNE_COUNT; ++i) {
+    const char* e = getenv(g_knobs[i].env);
+    if (e && *e) g_knobs[i].value = atoi(e);
+  }
+  // round-1 spellings of the negative switches
+  if (getenv("SMX_NO_XCD_SWIZZLE")) g_knobs[SMX_TUNE_GEMM_XCD_SWIZZLE].value = 0;
+  if (getenv("SMX_WARP_OLD")) g_knobs[SMX_TUNE_WARP_ROWS].value = 0;
+  if (getenv("SMX_WARP_NO_REORDER")) g_knobs[SMX_TUNE_WARP_REORDER].value = 0;
+}
+}  // namespace
+
+int smx_tune(int key) {
+  init_once();
+  return (key >= 0 && key < SMX_TUNE_COUNT) ? g_knobs[key].value : -1;
+}
+
+extern "C" int smx_set_tuning(const char* name, int value) {
+  init_once();
+  if (!name) return SMX_EINVAL;
+  for (int i = 0; i < SMX_TUNE_COUNT; ++i)
+    if (!strcmp(name, g_knobs[i].name)) { g_knobs[i].value = value; return SMX_OK; }
+  return SMX_EINVAL;
+}
+
+extern "C" int smx_get_tuning(const char* name, int* value) {
+  init_once();
+  if (!name || !value) return SMX_EINVAL;
+  for (int i = 0; i < SMX_TUNE_COUNT; ++i)
+    if (!strcmp(name, g_knobs[i].name)) { *value = g_knobs[i].value; return SMX_OK; }
+  return SMX_EINVAL;
+}

@@ -330,7 +330,7 @@ extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float*
   dim3 grid(smx_cdiv(npix * lpp, 256 * ppt)), block(256);
   // whole row chunks and enough blocks: coordinates computed once per pixel (warp_rows_kernel)
   const int rchunk = 256 / (lpp > 0 ? lpp : 1) * 4;
-  if (lpp >= 16 && W % rchunk == 0 && npix / rchunk >= 256 && (long long)H * W * C < (1LL << 31) && !getenv("SMX_WARP_OLD")) {
+  if (lpp >= 16 && W % rchunk == 0 && npix / rchunk >= 256 && (long long)H * W * C < (1LL << 31) && smx_tune(SMX_TUNE_WARP_ROWS)) {
     const int cpi2 = (H * W) / rchunk;
     dim3 grid2(cpi2 * B);
     if (lpp == 16) SMX_LAUNCH((warp_rows_kernel<16>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
@@ -339,7 +339,7 @@ extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float*
     return smx_launch_status();
   }
   const int chunk = 256 / lpp * ppt;                                // pixels per block
-  int cpi = ((H * W) % chunk == 0 && !getenv("SMX_WARP_NO_REORDER")) ? (H * W) / chunk : 0;
+  int cpi = ((H * W) % chunk == 0 && smx_tune(SMX_TUNE_WARP_REORDER)) ? (H * W) / chunk : 0;
 #define SMX_WARP(L) do { if (ppt == 4) SMX_LAUNCH((warp_kernel<L, 4>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); \
                          else SMX_LAUNCH((warp_kernel<L, 1>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); } while (0)
   switch (lpp) {

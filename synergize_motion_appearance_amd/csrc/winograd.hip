@@ -37,7 +37,7 @@ constexpr int RLD = 36;                             // floats per region pixel i
 
 struct WP {
   const float* x; const float* u; const float* bias; const float* res; float* y;
-  float* stats;                       // optional [B][tiles_y*tiles_x][Cout][2]: per-block {sum, sum of squares} of the STORED values
+  float* stats;                       // optional [B][tiles_y*tiles_x][Cout][2]: per-block {mean, M2 = sum (v - mean)^2} of the STORED values
   const float* in_ss; int in_swish;   // fused GroupNorm apply on the loaded input: x*ss[b][c][0]+ss[b][c][1] (+swish)
   int lda, ldc, ldres;
   int B, H, W, Cin, Cout, up2, act;
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   float* __restrict__ Yp = p.y;
   const float* __restrict__ Rp = p.res;
   // GroupNorm statistics of the consumer, produced here: per channel {sum, sum^2} of what is stored
-  float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
+  // in Welford form ({mean, M2} of the block's 128 values per channel; see gn_partial_kernel for why not {sum, sum^2})
+  float gs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gd[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   constexpr int NB = 32 * NW, NQ = NB / 4;
   for (int q = 0; q < 2; ++q) {
     __syncthreads();
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
           }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ps[e] += o0[e] + o1[e]; pq[e] += o0[e] * o0[e] + o1[e] * o1[e]; }
+        for (int e = 0; e < 4; ++e) { gs[q][e] = o0[e] + o1[e]; gd[q][e] = o0[e] - o1[e]; }
       }
     }
   }
@@ -283,13 +284,23 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     {
       const int tile = tid / NQ, n4 = (tid % NQ) * 4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { red[(tile * NB + n4 + e) * 2] = ps[e]; red[(tile * NB + n4 + e) * 2 + 1] = pq[e]; }
+      for (int e = 0; e < 4; ++e) {
+        // this thread's 4 values a,b (q=0), c,d (q=1): mean = (a+b+c+d)/4, M2 = ((a-b)^2 + (c-d)^2)/2 + ((a+b)-(c+d))^2/4
+        const float ds = gs[0][e] - gs[1][e];
+        red[(tile * NB + n4 + e) * 2] = 0.25f * (gs[0][e] + gs[1][e]);
+        red[(tile * NB + n4 + e) * 2 + 1] = 0.5f * (gd[0][e] * gd[0][e] + gd[1][e] * gd[1][e]) + 0.25f * ds * ds;
+      }
     }
     __syncthreads();
     if (tid < NB && nblk * NB + tid < p.Cout) {
       float a = 0.f, b = 0.f;
 #pragma unroll 8
       for (int tl = 0; tl < 32; ++tl) { a += red[(tl * NB + tid) * 2]; b += red[(tl * NB + tid) * 2 + 1]; }
+      a *= (1.f / 32.f);                                           // block mean (32 threads x 4 values each)
+      float c2 = 0.f;
+#pragma unroll 8
+      for (int tl = 0; tl < 32; ++tl) { const float d = red[(tl * NB + tid) * 2] - a; c2 += d * d; }
+      b += 4.f * c2;
       const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
       float* o = p.stats + (chunk * p.Cout + nblk * NB + tid) * 2;
       o[0] = a; o[1] = b;
@@ -319,10 +330,11 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   // measured (profiles/r01_e_winograd_variants.txt): 8-wave blocks (N=64) win once there are >= 1024 of
   // them, 4-wave blocks (N=32, 3 per CU) otherwise; the conflict-free LDS swizzle is neutral (LDS is
   // not the limiter) and stays off by default.
-  const int swz = getenv("SMX_WINO_SWZ") ? atoi(getenv("SMX_WINO_SWZ")) : 0;
-  const int nw = getenv("SMX_WINO_NW") ? atoi(getenv("SMX_WINO_NW")) : ((Cout % 64 == 0 && blocks * (Cout / 64) >= 1024) ? 2 : 1);
+  const int swz = smx_tune(SMX_TUNE_WINO_SWZ);
+  const int nw_t = smx_tune(SMX_TUNE_WINO_NW);
+  const int nw = (nw_t == 1 || nw_t == 2) ? nw_t : ((Cout % 64 == 0 && blocks * (Cout / 64) >= 1024) ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
-  const int abl = getenv("SMX_WINO_ABLATE") ? atoi(getenv("SMX_WINO_ABLATE")) : 0;
+  const int abl = smx_tune(SMX_TUNE_WINO_ABLATE);
   if (abl && nw == 2) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
     switch (abl) {

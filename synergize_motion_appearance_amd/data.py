@@ -35,15 +35,41 @@ def build_dataloader(dataset, dataset_opt, num_gpu=1, dist=False, sampler=None, 
                                        pin_memory=dataset_opt.get("pin_memory", False))
 
 
-def _read(path):
-    with open(path, "rb") as f:
-        return imfrombytes(f.read(), float32=True)
+def _list_driving_frames(folder, max_frame):
+    """frame files of a driving folder in the reference's order and with its quirks (`frames_dataset.py:248-255`):
+    png first, jpg only if no png; the FIRST file is skipped; at most `max_frame` frames are kept."""
+    if not os.path.isdir(folder):
+        return []
+    files = sorted(glob.glob(os.path.join(folder, "*.png"))) or sorted(glob.glob(os.path.join(folder, "*.jpg")))
+    files = files[1:]
+    return files if max_frame is None else files[:max_frame]
 
 
-def _normalize_(t, mean, std):
-    m = torch.tensor(mean, dtype=t.dtype).view(-1, 1, 1)
-    s = torch.tensor(std, dtype=t.dtype).view(-1, 1, 1)
-    return t.sub_(m).div_(s)
+class _FramePrep:
+    """decode -> (resize to gt_size) -> CHW RGB float -> (x - mean) / std, one frame at a time."""
+
+    def __init__(self, gt_size, mean, std):
+        self.size = int(gt_size)
+        self.mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+        self.std = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+        self.resize = None                 # decided by the source frame, applied to every frame of the item
+
+    def decode(self, path):
+        with open(path, "rb") as f:
+            return imfrombytes(f.read(), float32=True)
+
+    def finish(self, img):
+        if self.resize:
+            img = resize_linear(img, (self.size, self.size))
+        t = img2tensor(np.ascontiguousarray(img), bgr2rgb=True, float32=True)
+        return t.sub_(self.mean).div_(self.std)
+
+
+def _video_name(path_source, path_driving):
+    """`<source folder minus 4 chars>_<source file minus 4 chars>_<driving folder minus 4 chars>`
+    (`frames_dataset.py:244-246`: the reference strips a 4-character suffix from each component)."""
+    parts = (os.path.basename(os.path.dirname(path_source)), os.path.basename(path_source), os.path.basename(path_driving))
+    return "_".join(p[:-4] for p in parts)
 
 
 @DATASET_REGISTRY.register()
@@ -60,50 +86,29 @@ class FramesMotionTransferTestDataset_CrossID_videopair_anchor(Dataset):
         self.mean = opt.get("mean", [0.5, 0.5, 0.5])
         self.std = opt.get("std", [0.5, 0.5, 0.5])
         self.max_frame = opt.get("max_frame", None)
-        pairs_list = opt.get("pairs_list", None)
-        if pairs_list is None:
-            raise NotImplementedError("Shoule provide cross id pairs for dataset.")
-        pairs = pd.read_csv(pairs_list)
-        self.source = pairs["source"].tolist()
-        self.driving = pairs["driving"].tolist()
-        self.anchors = pairs["anchor"].tolist() if "anchor" in pairs else None
-        self.anchor_idx = pairs["anchor_idx"].tolist() if "anchor_idx" in pairs else None
+        if opt.get("pairs_list") is None:
+            raise NotImplementedError("a pairs_list csv (source, driving[, anchor, anchor_idx]) is required for this dataset")
+        table = pd.read_csv(opt["pairs_list"])
+        column = lambda name: table[name].tolist() if name in table else None
+        self.source, self.driving = column("source"), column("driving")
+        self.anchors, self.anchor_idx = column("anchor"), column("anchor_idx")
 
     def __len__(self):
         return len(self.source)
 
     def __getitem__(self, idx):
-        path_source, path_driving = self.source[idx], self.driving[idx]
-        path_anchor = self.anchors[idx] if self.anchors is not None else None
-        anchor_idx = self.anchor_idx[idx] if self.anchor_idx is not None else None
-        video_name = (os.path.basename(os.path.dirname(path_source))[:-4] + "_" + os.path.basename(path_source)[:-4]
-                      + "_" + os.path.basename(path_driving)[:-4])
-        source = _read(path_source)
-        driving, driving_name = [], []
-        if os.path.isdir(path_driving):
-            frames = sorted(glob.glob(path_driving + "/*.png"))
-            if len(frames) == 0:
-                frames = sorted(glob.glob(path_driving + "/*.jpg"))
-            num_frames = len(frames)
-            if self.max_frame is not None and num_frames - 1 > self.max_frame:
-                num_frames = self.max_frame + 1
-            for i in range(num_frames - 1):
-                driving.append(_read(frames[i + 1]))
-                driving_name.append(os.path.basename(frames[i + 1]))
-        if path_anchor is not None:
-            anchor = _read(path_anchor)
-        else:
-            anchor, anchor_idx = driving[0], 0
-        if source.shape[-2] != self.gt_size:
-            sz = (int(self.gt_size), int(self.gt_size))
-            source = resize_linear(source, sz)
-            driving = [resize_linear(f, sz) for f in driving]
-            anchor = resize_linear(anchor, sz)
-        source, anchor = img2tensor([np.ascontiguousarray(source), np.ascontiguousarray(anchor)], bgr2rgb=True, float32=True)
-        driving = [img2tensor(np.ascontiguousarray(f), bgr2rgb=True, float32=True) for f in driving]
-        _normalize_(source, self.mean, self.std)
-        _normalize_(anchor, self.mean, self.std)
-        for f in driving:
-            _normalize_(f, self.mean, self.std)
-        return {"source": source, "driving_video": driving, "anchor": anchor, "video_name": video_name,
-                "driving_name_list": driving_name, "anchor_idx": anchor_idx}
+        src_path, drv_path = self.source[idx], self.driving[idx]
+        prep = _FramePrep(self.gt_size, self.mean, self.std)
+        src_img = prep.decode(src_path)
+        prep.resize = src_img.shape[-2] != self.gt_size          # the reference tests the source only (`:268`)
+        files = _list_driving_frames(drv_path, self.max_frame)
+        item = {"source": prep.finish(src_img),
+                "driving_video": [prep.finish(prep.decode(f)) for f in files],
+                "video_name": _video_name(src_path, drv_path),
+                "driving_name_list": [os.path.basename(f) for f in files]}
+        if self.anchors is not None:
+            item["anchor"] = prep.finish(prep.decode(self.anchors[idx]))
+            item["anchor_idx"] = self.anchor_idx[idx] if self.anchor_idx is not None else None
+        else:                                                     # no anchor column: the first driving frame
+            item["anchor"], item["anchor_idx"] = item["driving_video"][0].clone(), 0
+        return item

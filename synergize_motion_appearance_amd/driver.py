@@ -4,7 +4,7 @@ loop `make_animation` / `normalize_kp` (`basicsr/demo.py:24-44,103-134`).
 Given (kp_source, kp_driving_initial, adapt scale) every driving frame is independent
 (no recurrent state), so frames are processed `batch` at a time with the source encoding
 cached, and -- across GPUs -- sharded in contiguous blocks with one RCCL broadcast of the
-source cache (`shard_frames`, `broadcast_source_cache`).
+source state (`shard_frames`, `broadcast_source_state`, `animate_sharded`).
 """
 import math
 
@@ -33,10 +33,13 @@ def normalize_kp(kp_source, kp_driving, kp_driving_initial, adapt_movement_scale
         s = adapt_scale(kp_source, kp_driving_initial) if scale is None else scale
     else:
         s = 1
-    if use_relative_movement and kp_driving["value"].is_cuda and kp_source["value"].shape[0] == 1:
-        # device tensors: one small HIP kernel for the whole batch (no ATen matmul / inverse on the path)
-        return ops.normalize_kp(kp_driving, kp_driving_initial, kp_source, s, True, use_relative_jacobian)
-    kp_new = {k: v for k, v in kp_driving.items()}
+    kp_new = {k: v for k, v in kp_driving.items()}       # every key of kp_driving survives (demo.py:34)
+    if (use_relative_movement and kp_driving["value"].is_cuda and kp_source["value"].shape[0] == 1
+            and kp_driving_initial["value"].shape[0] == 1):
+        # device tensors, ONE source and ONE initial frame (the kernel indexes row 0 of both): one small HIP kernel
+        # for the whole batch (no ATen matmul / inverse on the path); batched initial keypoints take the torch path
+        kp_new.update(ops.normalize_kp(kp_driving, kp_driving_initial, kp_source, s, True, use_relative_jacobian))
+        return kp_new
     if use_relative_movement:
         kp_new["value"] = (kp_driving["value"] - kp_driving_initial["value"]) * s + kp_source["value"]
         if use_relative_jacobian:
@@ -55,56 +58,144 @@ def shard_frames(n_frames: int, rank: int, world: int):
 CACHE_SHAPES = {32: (1, 32, 32, 256), 64: (1, 64, 64, 128), 128: (1, 128, 128, 128), 256: (1, 256, 256, 64)}
 CACHE_ORDER = (32, 64, 128, 256)
 _KP_VALUE, _KP_JAC = 15 * 2, 15 * 4
+_SRC64 = 64 * 64 * 3
+# the frame-invariant state of one (source, clip): encoder taps | down(source) 64x64x3 | kp_source | kp_driving_initial | adapt scale
+_TAIL = _SRC64 + 2 * (_KP_VALUE + _KP_JAC) + 1
+
+
+def _numel(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
 
 
 def cache_numel() -> int:
-    n = _KP_VALUE + _KP_JAC
-    for s in CACHE_ORDER:
-        c = 1
-        for d in CACHE_SHAPES[s]:
-            c *= d
-        n += c
-    return n          # 7,077,888 encoder elements (28.3 MB fp32) + 90 keypoint floats
+    """7,077,888 encoder elements (28.3 MB fp32) + 12,288 (down-sampled source) + 2 x 90 keypoint floats + 1."""
+    return sum(_numel(CACHE_SHAPES[s]) for s in CACHE_ORDER) + _TAIL
 
 
-def pack_source_cache(cache, kp_source) -> torch.Tensor:
-    """flatten the frame-invariant state of one source into ONE buffer (one collective, not six)."""
+class SourceState:
+    """everything a rank needs to render frames of one (source, clip): the SourceCache, src64, kp_source,
+    kp_driving_initial and the adapt-movement scale.  `flat` is the packed buffer it was unpacked from (views)."""
+    __slots__ = ("cache", "src64", "kp_source", "kp_initial", "scale", "flat")
+
+    def __init__(self, cache, src64, kp_source, kp_initial, scale, flat=None):
+        self.cache, self.src64, self.kp_source, self.kp_initial, self.scale, self.flat = cache, src64, kp_source, kp_initial, scale, flat
+
+
+def pack_source_state(cache, src64, kp_source, kp_initial, scale) -> torch.Tensor:
+    """flatten the frame-invariant state into ONE buffer (one collective, not ten)."""
+    dev = src64.device
+    kp0 = kp_initial if kp_initial is not None else {"value": torch.zeros((1, 15, 2), device=dev), "jacobian": torch.zeros((1, 15, 2, 2), device=dev)}
     return torch.cat([cache.feats[s].reshape(-1) for s in CACHE_ORDER] +
-                     [kp_source["value"].reshape(-1), kp_source["jacobian"].reshape(-1)])
+                     [src64.reshape(-1), kp_source["value"].reshape(-1), kp_source["jacobian"].reshape(-1),
+                      kp0["value"].reshape(-1), kp0["jacobian"].reshape(-1),
+                      torch.full((1,), float("nan") if scale is None else float(scale), device=dev, dtype=torch.float32)])
 
 
-def unpack_source_cache(flat: torch.Tensor):
+def unpack_source_state(flat: torch.Tensor) -> SourceState:
     from .engine_netg import SourceCache
     feats, off = {}, 0
     for s in CACHE_ORDER:
-        n = 1
-        for d in CACHE_SHAPES[s]:
-            n *= d
+        n = _numel(CACHE_SHAPES[s])
         feats[s] = flat[off:off + n].view(CACHE_SHAPES[s])
         off += n
-    kp = {"value": flat[off:off + _KP_VALUE].view(1, 15, 2),
-          "jacobian": flat[off + _KP_VALUE:off + _KP_VALUE + _KP_JAC].view(1, 15, 2, 2)}
-    return SourceCache(feats, 1), kp
+    src64 = flat[off:off + _SRC64].view(1, 64, 64, 3)
+    off += _SRC64
+    kps = []
+    for _ in range(2):
+        kps.append({"value": flat[off:off + _KP_VALUE].view(1, 15, 2),
+                    "jacobian": flat[off + _KP_VALUE:off + _KP_VALUE + _KP_JAC].view(1, 15, 2, 2)})
+        off += _KP_VALUE + _KP_JAC
+    scale = float(flat[off].item())
+    return SourceState(SourceCache(feats, 1), src64, kps[0], kps[1], None if scale != scale else scale, flat)
 
 
-def broadcast_flat(flat_or_none, device, src=0):
-    """rank `src` passes the packed cache, the others None; everyone returns the broadcast buffer.
+def broadcast_flat(flat_or_none, device, src=0, group=None):
+    """rank `src` passes the packed state, the others None; everyone returns the broadcast buffer.
     torch.distributed broadcast == RCCL over xGMI on the GPU box (gloo in the CPU tests)."""
     import torch.distributed as dist
     buf = flat_or_none if dist.get_rank() == src else torch.empty(cache_numel(), device=device, dtype=torch.float32)
-    dist.broadcast(buf, src=src)
+    dist.broadcast(buf, src=src, group=group)
     return buf
 
 
-def broadcast_source_cache(net_g, motion_estimator, source, src=0):
-    """rank `src` encodes the source once; every rank receives the frame-invariant cache
-    (encoder taps 28.3 MB fp32 + kp_source) with ONE broadcast."""
+def encode_source_state(net_g, motion_estimator, source, initial_frame=None, adapt_movement_scale=True) -> SourceState:
+    """the frame-invariant work of one (source, clip) on THIS rank: source encoder taps (A8), down(source), kp_source,
+    kp(initial driving frame) and the hull-area scale (demo.py:24-32, 114-121)."""
+    eng_g, eng_m = net_g.engine(), motion_estimator.engine()
+    src = source if source.dim() == 4 else source.unsqueeze(0)
+    src = src.float()
+    kp_s = eng_m.estimate_kp(src)
+    kp_0 = None if initial_frame is None else eng_m.estimate_kp((initial_frame if initial_frame.dim() == 4 else initial_frame.unsqueeze(0)).float())
+    scale = adapt_scale(kp_s, kp_0) if (adapt_movement_scale and kp_0 is not None) else None
+    return SourceState(eng_g.encode_source(src), eng_m.source_down(src), kp_s, kp_0, scale)
+
+
+def broadcast_source_state(net_g, motion_estimator, source=None, initial_frame=None, adapt_movement_scale=True,
+                           src=0, device=None, group=None) -> SourceState:
+    """rank `src` encodes the source once (`source` / `initial_frame` are only read there); every rank receives the
+    frame-invariant state with ONE broadcast of 28.4 MB -- the only collective on the data path."""
     import torch.distributed as dist
     flat = None
     if dist.get_rank() == src:
-        cache = net_g.engine().encode_source(source.float())
-        flat = pack_source_cache(cache, motion_estimator.engine().estimate_kp(source.float()))
-    return unpack_source_cache(broadcast_flat(flat, source.device, src))
+        st = encode_source_state(net_g, motion_estimator, source, initial_frame, adapt_movement_scale)
+        flat = pack_source_state(st.cache, st.src64, st.kp_source, st.kp_initial, st.scale)
+        device = flat.device
+    if device is None:
+        device = next(net_g.parameters()).device
+    return unpack_source_state(broadcast_flat(flat, device, src, group))
+
+
+def render_frames(state: SourceState, frames, net_g, motion_estimator, relative=True, adapt_movement_scale=True,
+                  batch=8, want="uint8", w=1.0):
+    """frames [n,3,H,W] (any subset of a clip, in any order: frames are independent given `state`) -> uint8 [n,H,W,3]
+    / fp32 NCHW [n,3,H,W] / both."""
+    eng_g, eng_m = net_g.engine(), motion_estimator.engine()
+    u8, fl = [], []
+    for i in range(0, frames.shape[0], batch):
+        kp_d = eng_m.estimate_kp(frames[i:i + batch].float())
+        kp_n = normalize_kp(state.kp_source, kp_d, state.kp_initial, adapt_movement_scale, relative, relative, state.scale)
+        dm = eng_m.dense_motion(state.src64, kp_n, state.kp_source)
+        st = eng_g.forward(state.cache, dm["deformation"], dm["occlusion_nhwc"].view(-1, 64, 64), dm["heat_nhwc"], float(w))
+        if want in ("uint8", "both"):
+            u8.append(ops.to_uint8(st["out"], -1.0, 1.0))
+        if want in ("float", "both"):
+            fl.append(ops.nhwc_to_nchw(st["out"]))
+    r8 = torch.cat(u8) if u8 else None
+    rf = torch.cat(fl) if fl else None
+    return r8 if want == "uint8" else rf if want == "float" else (r8, rf)
+
+
+@torch.no_grad()
+def animate_sharded(source, driving, net_g, motion_estimator, relative=True, adapt_movement_scale=True, batch=8,
+                    root=0, anchor_idx=0, gather=True, group=None):
+    """The N>1 form of `animate_batched` (one process per GPU, torch.distributed initialised): rank `root` encodes the
+    source (+ the anchor frame's keypoints and the hull scale) and broadcasts the packed state once; every rank
+    renders its contiguous `shard_frames` block of `driving` [N,3,H,W] -- no other collective on the data path.
+    gather=True: the uint8 frames are collected on `root` in clip order (returns [N,H,W,3] there, None elsewhere);
+    gather=False: returns ((start, stop), frames_of_this_rank)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = driving.device
+    need0 = relative or adapt_movement_scale
+    state = broadcast_source_state(net_g, motion_estimator, source if rank == root else None,
+                                   driving[anchor_idx:anchor_idx + 1] if (rank == root and need0) else None,
+                                   adapt_movement_scale, src=root, device=dev, group=group)
+    n = driving.shape[0]
+    a, b = shard_frames(n, rank, world)
+    mine = render_frames(state, driving[a:b], net_g, motion_estimator, relative, adapt_movement_scale, batch)
+    if not gather:
+        return (a, b), mine
+    sizes = [shard_frames(n, r, world)[1] - shard_frames(n, r, world)[0] for r in range(world)]
+    pad = torch.zeros((max(sizes),) + tuple(mine.shape[1:]), device=dev, dtype=mine.dtype)
+    pad[:mine.shape[0]] = mine
+    if dist.get_backend(group) == "gloo":            # gloo has no device gather: stage the uint8 frames through the host
+        pad = pad.cpu()
+    parts = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
+    dist.gather(pad, parts, dst=root, group=group)
+    return torch.cat([p[:k] for p, k in zip(parts, sizes)]).to(dev) if rank == root else None
 
 
 @torch.no_grad()
@@ -124,21 +215,8 @@ def animate_batched(source, driving, net_g, motion_estimator, relative=True, ada
         kp_driving_initial = eng_m.estimate_kp(driving[anchor_idx:anchor_idx + 1].float())
     scale = adapt_scale(kp_source, kp_driving_initial) if adapt_movement_scale else None
     cache = eng_g.encode_source(src.float()) if source_cache is None else source_cache
-    src64 = eng_m.source_down(src.float())
-    u8, fl = [], []
-    for i in range(0, driving.shape[0], batch):
-        frames = driving[i:i + batch].float()
-        kp_d = eng_m.estimate_kp(frames)
-        kp_n = normalize_kp(kp_source, kp_d, kp_driving_initial, adapt_movement_scale, relative, relative, scale)
-        dm = eng_m.dense_motion(src64, kp_n, kp_source)
-        st = eng_g.forward(cache, dm["deformation"], dm["occlusion_nhwc"].view(-1, 64, 64), dm["heat_nhwc"], float(w))
-        if want in ("uint8", "both"):
-            u8.append(ops.to_uint8(st["out"], -1.0, 1.0))
-        if want in ("float", "both"):
-            fl.append(ops.nhwc_to_nchw(st["out"]))
-    r8 = torch.cat(u8) if u8 else None
-    rf = torch.cat(fl) if fl else None
-    return r8 if want == "uint8" else rf if want == "float" else (r8, rf)
+    state = SourceState(cache, eng_m.source_down(src.float()), kp_source, kp_driving_initial, scale)
+    return render_frames(state, driving, net_g, motion_estimator, relative, adapt_movement_scale, batch, want, w)
 
 
 @torch.no_grad()

@@ -78,55 +78,59 @@ class HourglassPlan:
         return out
 
 
-class MotionEngine:
-    """packed weights + forward plans for Motion_Estimator_keypoint_aware."""
+class KPEngine:
+    """packed weights + plan of KPDetector (rows A1-A3); `pre` = parameter-name prefix ('' for the standalone arch)."""
 
-    def __init__(self, P, common, dense, kp):
+    def __init__(self, P, pre, common, kp):
         self.num_kp = common["num_kp"]
         self.temperature = kp["temperature"]
-        self.kp_hg = HourglassPlan(P, "kp_detector.predictor", kp["block_expansion"], common["num_channels"],
-                                   kp["num_blocks"], kp["max_features"])
+        self.hg = HourglassPlan(P, pre + "predictor", kp["block_expansion"], common["num_channels"], kp["num_blocks"], kp["max_features"])
         # kp (15) and jacobian (60) heads share their input and geometry (7x7 valid): one conv with
         # N = 60 + 15 + 1 pad -> [jac | kp | 0]; 76 keeps the float4 reads of the jacobian maps aligned
-        cin = P["kp_detector.kp.weight"].shape[1]
+        cin = P[pre + "kp.weight"].shape[1]
         padc = lambda w: torch.nn.functional.pad(w, (0, 0, 0, 0, 0, (-cin) % 4))      # zero weights for the pad channels  # noqa: E731
-        kpc = Conv.from_torch(padc(P["kp_detector.kp.weight"]), P["kp_detector.kp.bias"])
-        jc = Conv.from_torch(padc(P["kp_detector.jacobian.weight"]), P["kp_detector.jacobian.bias"])
+        kpc = Conv.from_torch(padc(P[pre + "kp.weight"]), P[pre + "kp.bias"])
+        jc = Conv.from_torch(padc(P[pre + "jacobian.weight"]), P[pre + "jacobian.bias"])
         zero = Conv(torch.zeros_like(kpc.w[:1]), torch.zeros_like(kpc.b[:1]), 7, 7, kpc.cin, 1)
         self.head_conv = Conv.cat([jc, kpc, zero])
         self.n_jac = jc.cout
-        self.kp_down = P["kp_detector.down.weight"].reshape(common["num_channels"], 13, 13).contiguous()
-        self.dm_hg = HourglassPlan(P, "dense_motion_network.hourglass", dense["block_expansion"],
-                                   (self.num_kp + 1) * (common["num_channels"] + 1), dense["num_blocks"], dense["max_features"])
-        # mask (16) and occlusion (1) heads: one stacked 7x7 conv, N = 17
-        self.mo_conv = Conv.cat([Conv.from_torch(P["dense_motion_network.mask.weight"], P["dense_motion_network.mask.bias"]),
-                                 Conv.from_torch(P["dense_motion_network.occlusion.weight"], P["dense_motion_network.occlusion.bias"])])
-        self.dm_down = P["dense_motion_network.down.weight"].reshape(common["num_channels"], 13, 13).contiguous()
-        self.kp_variance = 0.01
+        self.down = P[pre + "down.weight"].reshape(common["num_channels"], 13, 13).contiguous()
 
-    # ---- A1-A3 -------------------------------------------------------------------------
     def estimate_kp(self, image_nchw):
         B = image_nchw.shape[0]
-        buf, inp = self.kp_hg.alloc_input(B, 64, image_nchw.device)
-        ops.antialias_down(image_nchw, self.kp_down, out=inp)
-        fm = self.kp_hg.run(buf, B, 64)                       # [B,64,64,35 (+1 zero pad)]
+        buf, inp = self.hg.alloc_input(B, 64, image_nchw.device)
+        ops.antialias_down(image_nchw, self.down, out=inp)
+        fm = self.hg.run(buf, B, 64)                          # [B,64,64,35 (+1 zero pad)]
         heads = ops.conv(fm, self.head_conv, pad=(0, 0))      # 7x7 valid -> [B,58,58,76] = [jac 60 | kp 15 | 0]
         value, jac = ops.kp_head(heads[..., self.n_jac:self.n_jac + self.num_kp], heads[..., :self.n_jac],
                                  self.num_kp, self.temperature)
         return {"value": value, "jacobian": jac}
 
-    # ---- A4-A6b ------------------------------------------------------------------------
+
+class DenseEngine:
+    """packed weights + plan of DenseMotionNetwork (rows A4-A6b)."""
+
+    def __init__(self, P, pre, common, dense):
+        self.num_kp = common["num_kp"]
+        self.hg = HourglassPlan(P, pre + "hourglass", dense["block_expansion"],
+                                (self.num_kp + 1) * (common["num_channels"] + 1), dense["num_blocks"], dense["max_features"])
+        # mask (16) and occlusion (1) heads: one stacked 7x7 conv, N = 17
+        self.mo_conv = Conv.cat([Conv.from_torch(P[pre + "mask.weight"], P[pre + "mask.bias"]),
+                                 Conv.from_torch(P[pre + "occlusion.weight"], P[pre + "occlusion.bias"])])
+        self.down = P[pre + "down.weight"].reshape(common["num_channels"], 13, 13).contiguous()
+        self.kp_variance = dense.get("kp_variance", 0.01)
+
     def source_down(self, source_nchw):
         """frame-invariant: anti-aliased 64x64 source, NHWC (dense_motion_arch.py:119-120)."""
-        return ops.antialias_down(source_nchw, self.dm_down)
+        return ops.antialias_down(source_nchw, self.down)
 
     def dense_motion(self, src64, kp_driving, kp_source, want_aux=False):
         B = kp_driving["value"].shape[0]
-        buf, inp = self.dm_hg.alloc_input(B, 64, src64.device)
+        buf, inp = self.hg.alloc_input(B, 64, src64.device)
         sparse, heat = ops.sparse_motion(src64, kp_driving["value"], kp_driving["jacobian"].reshape(B, -1, 4),
                                          kp_source["value"], kp_source["jacobian"].reshape(kp_source["value"].shape[0], -1, 4),
                                          inp, B, self.num_kp, self.kp_variance)
-        pred = self.dm_hg.run(buf, B, 64)                     # [B,64,64,128]
+        pred = self.hg.run(buf, B, 64)                        # [B,64,64,128]
         mlog = ops.conv(pred, self.mo_conv)                   # 7x7 pad 3 -> [B,64,64,17] = [mask 16 | occlusion logit]
         deformation, mask, occ = ops.mask_deformation(mlog, sparse, want_mask=want_aux, K1=self.num_kp + 1, fused_occ=True)
         out = {"deformation": deformation, "occlusion_nhwc": occ, "heat_nhwc": heat, "sparse_motion": sparse}
@@ -134,3 +138,21 @@ class MotionEngine:
             out["mask_nhwc"] = mask
             out["hg_in_nhwc"] = inp
         return out
+
+
+class MotionEngine:
+    """Motion_Estimator_keypoint_aware = KPDetector + DenseMotionNetwork."""
+
+    def __init__(self, P, common, dense, kp):
+        self.kp = KPEngine(P, "kp_detector.", common, kp)
+        self.dm = DenseEngine(P, "dense_motion_network.", common, dense)
+        self.num_kp = common["num_kp"]
+
+    def estimate_kp(self, image_nchw):
+        return self.kp.estimate_kp(image_nchw)
+
+    def source_down(self, source_nchw):
+        return self.dm.source_down(source_nchw)
+
+    def dense_motion(self, src64, kp_driving, kp_source, want_aux=False):
+        return self.dm.dense_motion(src64, kp_driving, kp_source, want_aux)

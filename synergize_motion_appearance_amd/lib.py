@@ -39,6 +39,8 @@ class GemmDesc(C.Structure):
 # name -> (restype, argtypes); every symbol include/smx.h declares
 SIGNATURES = {
     "smx_version": (C.c_char_p, []),
+    "smx_set_tuning": (_i, [C.c_char_p, _i]),
+    "smx_get_tuning": (_i, [C.c_char_p, C.POINTER(_i)]),
     "smx_gemm_conv_f32": (_i, [C.POINTER(GemmDesc), _p]),
     "smx_winograd_conv3x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "smx_groupnorm_stats_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
@@ -64,6 +66,7 @@ SIGNATURES = {
     "smx_flow_occ_update_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "smx_motion_ignore_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "smx_sft_combine_f32": (_i, [_p, _i, _p, _p, _p, _f, _i64, _i, _p]),
+    "smx_fingerprint_f32": (_i, [_p, _i64, _p, _p]),
     "smx_add_f32": (_i, [_p, _p, _p, _i64, _p]),
     "smx_copy_slice_f32": (_i, [_p, _i, _p, _i, _i64, _i, _p]),
     "smx_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

@@ -206,3 +206,19 @@ def motion_estimator_manifest(common_params, dense_motion_params, kp_detector_pa
     if dm.get("estimate_occlusion_map", False):
         out += [("dense_motion_network.occlusion.weight", (1, of, 7, 7)), ("dense_motion_network.occlusion.bias", (1,))]
     return out
+
+
+def _strip(entries, prefix):
+    return [(n[len(prefix):], shp) for n, shp in entries if n.startswith(prefix)]
+
+
+def kp_detector_manifest(common_params, kp_detector_params):
+    """[(name, shape)] of a standalone KPDetector (archs/keypoint_detector_arch.py:13-47): the kp_detector.* entries."""
+    dm_stub = {"block_expansion": 64, "max_features": 1024, "num_blocks": 5}
+    return _strip(motion_estimator_manifest(common_params, dm_stub, kp_detector_params), "kp_detector.")
+
+
+def dense_motion_manifest(common_params, dense_motion_params):
+    """[(name, shape)] of a standalone DenseMotionNetwork (archs/dense_motion_arch.py:12-63)."""
+    kp_stub = {"block_expansion": 32, "max_features": 1024, "num_blocks": 5}
+    return _strip(motion_estimator_manifest(common_params, dense_motion_params, kp_stub), "dense_motion_network.")

@@ -75,6 +75,15 @@ def _pix(t, name="tensor"):
 
 import os as _os
 
+
+def set_tuning(name, value):
+    """launch-selection knob of libsmx (include/smx.h: smx_set_tuning); returns the previous value."""
+    old = C.c_int(0)
+    L.check(L.load().smx_get_tuning(name.encode(), C.byref(old)), f"smx_get_tuning({name})")
+    L.check(L.load().smx_set_tuning(name.encode(), int(value)), f"smx_set_tuning({name})")
+    return old.value
+
+
 SMALLN = not _os.environ.get("SMX_NO_SMALLN")
 
 WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
@@ -439,6 +448,15 @@ def sft_combine(dec, scale, shift, w=1.0):
     L.check(L.load().smx_sft_combine_f32(dp, ldd, _dev(scale).data_ptr(), _dev(shift).data_ptr(), out.data_ptr(),
                                          float(w), dec.numel() // Cc, Cc, _stream()), "sft_combine")
     return out
+
+
+def fingerprint(x):
+    """(sum, weighted sum) of a small device tensor as a host tuple -- a content key for the source caches
+    (one tiny launch + an 8-byte D2H copy)."""
+    xc = _dev(x).contiguous()
+    out = torch.empty((2,), device=x.device, dtype=torch.float32)
+    L.check(L.load().smx_fingerprint_f32(xc.data_ptr(), xc.numel(), out.data_ptr(), _stream()), "fingerprint")
+    return tuple(out.tolist())
 
 
 def add(a, b):

@@ -18,42 +18,52 @@ def ordered_yaml():
     return Loader, Dumper
 
 
+_CHECKPOINT_KEYS = ("resume_state", "pretrain_network")
+
+
+def _expand_user_paths(section, wanted):
+    """`~` -> home for every non-empty entry of `section` whose key satisfies `wanted`."""
+    from os.path import expanduser
+    for key in list(section):
+        if section[key] is not None and wanted(key):
+            section[key] = expanduser(section[key])
+
+
 def parse(opt_path, root_path, is_train=True):
-    """yml -> option dict with the derived test paths (reference `basicsr/utils/options.py:32-88`):
-    name prefixed with a time stamp, dataset `phase` from the key, `~` expanded in checkpoint paths,
-    `path.results_root / log / visualization` under `<save_path>/results/<name>`.  A yml without a
-    `datasets:` section (the shipped test.yml) parses to an empty dataset dict instead of a KeyError."""
+    """Test yml -> option dict with the derived entries `animate.py` / the model expect (reference
+    `basicsr/utils/options.py:32-88`): `is_train`, a time-stamped `name`, per-dataset `phase` (+ `scale`), `~`
+    expanded in dataset / checkpoint paths, and `path.{results_root, log, visualization}` under
+    `<path.save_path or root_path>/results/<name>`.  A yml without `datasets:` / `path:` (the shipped test.yml)
+    gets empty sections instead of a KeyError.  Training ymls are SURVEY row N2 and are rejected."""
     import time
-    from os import path as osp
-    with open(opt_path, mode="r") as f:
-        opt = yaml.load(f, Loader=ordered_yaml()[0])
+    from os.path import join
     if is_train:
         raise NotImplementedError("training options are SURVEY row N2; the MI355X-native build parses test ymls")
+    with open(opt_path, "r") as f:
+        opt = yaml.load(f, Loader=ordered_yaml()[0])
     opt["is_train"] = False
-    opt["name"] = f"{time.strftime('%Y%m%d_%H%M%S', time.localtime())}_{opt['name']}"
-    opt.setdefault("datasets", OrderedDict())
-    for phase, dataset in opt["datasets"].items():
-        dataset["phase"] = phase.split("_")[0]
+    opt["name"] = time.strftime("%Y%m%d_%H%M%S", time.localtime()) + "_" + opt["name"]
+    datasets = opt.setdefault("datasets", OrderedDict())
+    for key in datasets:
+        datasets[key]["phase"] = key.split("_")[0]
         if "scale" in opt:
-            dataset["scale"] = opt["scale"]
-        if dataset.get("dataroot_gt") is not None:
-            dataset["dataroot_gt"] = osp.expanduser(dataset["dataroot_gt"])
-    opt.setdefault("path", OrderedDict())
-    for key, val in opt["path"].items():
-        if val is not None and ("resume_state" in key or "pretrain_network" in key):
-            opt["path"][key] = osp.expanduser(val)
-    results_root = osp.join(opt["path"].get("save_path", root_path), "results", opt["name"])
-    opt["path"]["results_root"] = results_root
-    opt["path"]["log"] = results_root
-    opt["path"]["visualization"] = osp.join(results_root, "visualization")
+            datasets[key]["scale"] = opt["scale"]
+        _expand_user_paths(datasets[key], lambda k: k == "dataroot_gt")
+    paths = opt.setdefault("path", OrderedDict())
+    _expand_user_paths(paths, lambda k: any(tag in k for tag in _CHECKPOINT_KEYS))
+    root = join(paths.get("save_path", root_path), "results", opt["name"])
+    paths.update(results_root=root, log=root, visualization=join(root, "visualization"))
     return opt
 
 
 def dict2str(opt, indent_level=1):
-    msg = "\n"
-    for k, v in opt.items():
-        if isinstance(v, dict):
-            msg += " " * (indent_level * 2) + k + ":[" + dict2str(v, indent_level + 1) + " " * (indent_level * 2) + "]\n"
+    """nested option dict -> the indented `key: value` / `key:[ ... ]` listing the reference logs
+    (`basicsr/utils/options.py:91-109`): two spaces per level, sub-dicts bracketed."""
+    pad = "  " * indent_level
+    lines = [""]
+    for key, value in opt.items():
+        if isinstance(value, dict):
+            lines.append(f"{pad}{key}:[{dict2str(value, indent_level + 1)}{pad}]")
         else:
-            msg += " " * (indent_level * 2) + k + ": " + str(v) + "\n"
-    return msg
+            lines.append(f"{pad}{key}: {value}")
+    return "\n".join(lines) + "\n"

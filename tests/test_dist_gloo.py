@@ -28,9 +28,11 @@ def _worker(rank, world, port, n_frames, q):
     if rank == 0:       # only the root owns the source encoding
         feats = {s: synth_input(f"cache{s}", sh) for s, sh in driver.CACHE_SHAPES.items()}
         kp = {"value": synth_input("cv", (1, 15, 2)), "jacobian": synth_input("cj", (1, 15, 2, 2))}
-        flat = driver.pack_source_cache(SourceCache(feats, 1), kp)
+        flat = driver.pack_source_state(SourceCache(feats, 1), synth_input("s64", (1, 64, 64, 3)), kp, kp, 1.5)
     buf = driver.broadcast_flat(flat, torch.device("cpu"), src=0)
-    cache, kp_s = driver.unpack_source_cache(buf)
+    st = driver.unpack_source_state(buf)
+    assert st.scale == 1.5
+    cache, kp_s = st.cache, st.kp_source
     # every frame is independent given the cache: a rank's "render" depends on (cache, frame id) only
     a, b = driver.shard_frames(n_frames, rank, world)
     mine = torch.tensor([float(cache.feats[32].sum() + kp_s["value"].sum()) + t for t in range(a, b)], dtype=torch.float64)

@@ -1,0 +1,114 @@
+"""The N>1 data path on hardware, before the 8-GPU scaling run sees it: two ranks (one process each, like
+`torch.distributed.run`) share the ONE MI355X of the test box and run the real engines through
+`driver.animate_sharded` -- rank 0 encodes the source, the packed state (encoder taps + down(source) + keypoints +
+hull scale, 28.4 MB) is broadcast once, each rank renders its `shard_frames` block, rank 0 gathers -- and the result must
+equal the 1-rank `animate_batched` frames (<= 1 LSB on uint8: the two runs batch the frames differently).
+RCCL refuses two ranks on one device ("duplicate GPU"), so the process group here is gloo carrying device tensors;
+`bench.py --gpus 2` is exercised the same way (SMX_BENCH_ONE_DEVICE=1, SMX_BENCH_BACKEND=gloo, stated in its JSON)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import yaml
+        from basicsr.archs import build_network
+        from synergize_motion_appearance_amd import driver
+        from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
+        cfg = yaml.safe_load(open(os.path.join(REPO, "options/test.yml")))
+        net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+        net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
+        me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
+        net_g, me = net_g.cuda().eval(), me.cuda().eval()
+        src, drv = synth_clip(n_frames, seed=31)
+        drv = drv.cuda()
+        # only the root is given the source image: the other rank must live off the broadcast
+        source = src.cuda() if rank == 0 else torch.full_like(src, float("nan")).cuda()
+        out = driver.animate_sharded(source, drv, net_g, me, relative=True, adapt_movement_scale=True, batch=4, root=0,
+                                     anchor_idx=2, gather=True)
+        span, mine = driver.animate_sharded(source, drv, net_g, me, batch=3, root=0, anchor_idx=2, gather=False)
+        res = {"rank": rank, "span": span, "mine_shape": tuple(mine.shape)}
+        if rank == 0:
+            one = driver.animate_batched(src.cuda(), drv, net_g, me, True, True, batch=5, anchor_idx=2)
+            d = (out.int() - one.int()).abs()
+            res.update(shape=tuple(out.shape), max_lsb=int(d.max()), frac_diff=float((d > 0).float().mean()),
+                       shard_equal=int((mine.int() - one[span[0]:span[1]].int()).abs().max()))
+        else:
+            assert out is None
+        q.put(res)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_device_sharded_animation_equals_single_rank():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    world, n_frames = 2, 13                                # ragged shards: 7 + 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r["rank"])
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    r0, r1 = res
+    assert r0["span"] == (0, 7) and r1["span"] == (7, 13) and r0["mine_shape"] == (7, 256, 256, 3) and r1["mine_shape"] == (6, 256, 256, 3)
+    assert r0["shape"] == (n_frames, 256, 256, 3)
+    assert r0["max_lsb"] <= 1 and r0["shard_equal"] <= 1, r0
+    assert r0["frac_diff"] < 0.01, r0                     # rounding ties only
+
+
+def test_bench_two_ranks_control_flow_on_one_device(tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), both ranks on
+    the one device of this box: the N>1 branch (per-source owner encodes, state broadcast, window sharding) executes and
+    prints a well-formed line.  The number is NOT a scaling measurement (two ranks share one GPU)."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    env = dict(os.environ, SMX_BENCH_ONE_DEVICE="1", SMX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "6", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["frames_total"] == 2 * 2 * 6 and j["config"]["sources"] == 2
+    assert "gloo" in j["config"]["parallelism"] and j["config"]["one_device_test_knob"] is True
+    assert j["batch_consistency"]["max_lsb_vs_b1"] <= 1
+
+
+def test_bench_refuses_a_silent_backend_fallback():
+    """RCCL cannot put two ranks on one device; without SMX_BENCH_BACKEND=gloo the bench must fail loudly on every
+    rank (non-zero exit, no JSON line) instead of quietly measuring a host-staged broadcast."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    env = dict(os.environ, SMX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SMX_BENCH_INIT_TIMEOUT_S="60")
+    env.pop("SMX_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--batch", "2", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]

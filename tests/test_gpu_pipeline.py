@@ -196,6 +196,82 @@ def test_anchor_animation_equals_forward_backward_splice(nets):
     assert int((splice.int() - one.int()).abs().max()) <= 1
 
 
+def test_bench_batch_of_60_equals_single_frame_runs(nets):
+    """The benchmark's own configuration (bench.py: B = 60 frames per launch -- the 8-wave Winograd blocks, GEMM tile
+    12 and the row-chunk warp kernel are all selected by launch size): 3 sampled frames of a 60-frame batch against
+    their B = 1 runs, fp32 <= 2e-4 (different tile shapes change the accumulation order, nothing else), uint8 <= 1 LSB."""
+    from synergize_motion_appearance_amd import driver
+    from synergize_motion_appearance_amd.synth import synth_clip
+    net_g, me = nets
+    src, drv = synth_clip(60, seed=123)
+    src, drv = src.cuda(), drv.cuda()
+    st = driver.encode_source_state(net_g, me, src, drv[0:1], True)
+    u8, fl = driver.render_frames(st, drv, net_g, me, True, True, batch=60, want="both")
+    assert u8.shape == (60, 256, 256, 3) and fl.shape == (60, 3, 256, 256)
+    for i in (0, 31, 59):
+        u1, f1 = driver.render_frames(st, drv[i:i + 1], net_g, me, True, True, batch=1, want="both")
+        assert maxabs(fl[i:i + 1].cpu(), f1.cpu()) < 2e-4, i
+        assert int((u8[i].int() - u1[0].int()).abs().max()) <= 1, i
+    # and the state built on this rank equals a packed / unpacked (broadcast-shaped) copy of itself
+    st2 = driver.unpack_source_state(driver.pack_source_state(st.cache, st.src64, st.kp_source, st.kp_initial, st.scale))
+    u2 = driver.render_frames(st2, drv[7:9], net_g, me, True, True, batch=2)
+    assert torch.equal(u2, driver.render_frames(st, drv[7:9], net_g, me, True, True, batch=2))
+
+
+def test_source_cache_is_keyed_on_content_not_on_the_pointer(nets):
+    """refilling a preallocated source buffer through a raw-pointer writer (this package's own kernels do not
+    bump tensor._version) must re-encode; an equal image at another address must hit the cache; and the key must be
+    computable under torch.inference_mode()."""
+    from synergize_motion_appearance_amd import ops
+    from synergize_motion_appearance_amd.synth import synth_clip
+    net_g, me = nets
+    a, _ = synth_clip(1, seed=5)
+    b, _ = synth_clip(1, seed=6)
+    buf = a[None].cuda().contiguous()
+    c1 = net_g.encode_source(buf)
+    assert net_g.encode_source(a[None].cuda()) is c1                        # same content, other address: hit
+    v = buf._version
+    ops.copy_slice(b[None].cuda().view(1, -1, 1), buf.view(1, -1, 1))       # raw-pointer rewrite of the SAME buffer
+    assert buf._version == v and maxabs(buf.cpu(), b[None]) == 0.0
+    c2 = net_g.encode_source(buf)
+    assert c2 is not c1 and maxabs(c2.feats[32].cpu(), c1.feats[32].cpu()) > 1e-3
+    with torch.inference_mode():
+        x = b[None].cuda()
+        assert net_g.encode_source(x) is c2
+    s1 = me._source64(buf)
+    ops.copy_slice(a[None].cuda().view(1, -1, 1), buf.view(1, -1, 1))
+    assert me._source64(buf) is not s1
+    net_g.invalidate_source_cache()
+    assert net_g.encode_source(buf) is not c1
+
+
+def test_standalone_registered_archs_vs_reference():
+    """KPDetector / DenseMotionNetwork / VQGANDiscriminator built by name (the reference registers them too): outputs vs
+    the fixture produced by the reference's own standalone modules (tests/golden/make_golden_r2.py)."""
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip, synth_input
+    from tests.test_host_logic import STANDALONE_OPTS
+    nets_ = {}
+    for name, opt in STANDALONE_OPTS.items():
+        n = build_network(opt)
+        n.load_state_dict(synth_state_dict([(k, tuple(v.shape)) for k, v in n.state_dict().items()]), strict=True)
+        nets_[name] = n.cuda().eval()
+    g = golden("standalone_motion.npz")
+    src, drv = synth_clip(3, seed=123)
+    kp_s = nets_["KPDetector"](src[None].cuda(), isSource=True)
+    kp_d = nets_["KPDetector"](drv.cuda())
+    assert maxabs(kp_s["value"].cpu(), g["src_value"]) < 1e-5 and maxabs(kp_s["jacobian"].cpu(), g["src_jacobian"]) < 2e-5
+    assert maxabs(kp_d["value"].cpu(), g["drv_value"]) < 1e-5 and maxabs(kp_d["jacobian"].cpu(), g["drv_jacobian"]) < 2e-5
+    dm = nets_["DenseMotionNetwork"](source_image=src[None].cuda(), kp_driving=kp_d, kp_source=kp_s)
+    assert set(g["keys"].tolist()) <= set(dm.keys())
+    assert maxabs(dm["deformation"].cpu(), g["deformation"]) < 2e-5 and maxabs(dm["occlusion_map"].cpu(), g["occlusion_map"]) < 2e-5
+    assert maxabs(dm["driving_kp_heatmap"].cpu(), g["driving_kp_heatmap"]) < 1e-5
+    assert maxabs(dm["mask"].cpu()[:, :, ::4, ::4], g["mask"]) < 2e-5
+    d = nets_["VQGANDiscriminator"](synth_input("disc_in", (2, 3, 64, 64)).cuda())
+    ref = golden("discriminator.npz")["out"]
+    assert tuple(d.shape) == ref.shape and maxabs(d.cpu(), ref) < 1e-4
+
+
 def test_batch_of_distinct_sources(nets):
     """configs[2]-style batches: every sample has its OWN source image (x batch == dense_motion batch);
     equals per-sample calls, and sample 0 equals the reference fixture."""

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --pmc pass (counter_collection.csv) of `bench.py` into per-kernel-family MFMA utilisation.
+usage: pmc_mfma.py <pmc_dir> <out.json> [command string]
+
+Counters expected in ONE pass (SQ has 8 slots, GRBM 2; see MI355X_MICROARCH.md "rocprofv3 PMC slots"):
+  SQ_INSTS_VALU_MFMA_MOPS_F32 (or _BF16)  matrix ops in units of 512 flops (a v_mfma_f32_32x32x2_f32 = 4096 flops = 8)
+  SQ_VALU_MFMA_BUSY_CYCLES                 cycles the matrix pipe is busy, summed over the chip's 1024 SIMDs (64 per 32x32x2 f32 MFMA)
+  SQ_INSTS_MFMA, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES (optional)
+  GRBM_GUI_ACTIVE                          active shader-clock cycles summed over the 8 XCDs
+Derived per family:  clock = GUI_ACTIVE/8/duration;  mfma_busy = MFMA_BUSY / (GUI_ACTIVE/8 * 1024 SIMDs) (fraction of the
+cycles the chip actually ran);  executed TFLOP/s = MOPS*512/duration;  frac_of_peak = executed / dense peak (= mfma_busy * clock/2.4 GHz).
+Durations are the dispatch timestamps of the SAME (counter-collecting, hence serialised and slower-clocked) pass."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+SIMDS, XCDS, SPEC_GHZ = 1024, 8, 2.4
+PEAK = {"F32": 157.3, "BF16": 2500.0}
+FAMILIES = (("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("attn_mfma", "attention_mfma"),
+            ("attn_flash", "attention_flash"), ("vq_kernel", "vq"))
+
+
+def family(name):
+    for key, fam in FAMILIES:
+        if key in name:
+            return fam
+    return None
+
+
+def main(pmc_dir, out, command=""):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))   # family -> counter -> sum
+    disp = collections.defaultdict(dict)                                   # family -> dispatch id -> duration ns
+    for f in glob.glob(pmc_dir + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            fam = family(r["Kernel_Name"])
+            if not fam:
+                continue
+            per[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[fam][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    res = {}
+    for fam, c in per.items():
+        n = len(disp[fam])
+        dur_s = sum(disp[fam].values()) * 1e-9
+        e = {"launches_profiled": n, "avg_launch_us": round(1e6 * dur_s / n, 2)}
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+        if gui:
+            e["shader_clock_GHz"] = round(gui / XCDS / dur_s / 1e9, 3)
+        for dt in ("F32", "BF16"):
+            mops = c.get(f"SQ_INSTS_VALU_MFMA_MOPS_{dt}", 0.0)
+            if mops:
+                tf = mops * 512.0 / dur_s / 1e12
+                e[f"executed_TFLOPs_{dt.lower()}"] = round(tf, 2)
+                e[f"frac_of_{dt.lower()}_mfma_peak"] = round(tf / PEAK[dt], 4)
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and gui:
+            e["mfma_busy_frac_of_active_cycles"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / XCDS * SIMDS), 4)
+        if c.get("SQ_INSTS_MFMA"):
+            e["mfma_insts_per_launch"] = round(c["SQ_INSTS_MFMA"] / n)
+            if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                e["busy_cycles_per_mfma"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_MFMA"], 2)
+        if c.get("SQ_BUSY_CYCLES") and gui:
+            e["sq_busy_frac"] = round(c["SQ_BUSY_CYCLES"] / gui, 4) if c["SQ_BUSY_CYCLES"] <= gui * 1.01 else None
+        for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU", "SQ_INSTS_LDS"):
+            if k in c:
+                e[k + "_per_launch"] = round(c[k] / n)
+        res[fam] = e
+    json.dump({"source": "rocprofv3 --pmc (one pass) -- " + command, "definitions": __doc__.split("Derived per family:")[1].strip(),
+               "kernels": res}, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], " ".join(sys.argv[3:]))
