@@ -86,6 +86,37 @@ typedef struct smx_gemm_desc {
 
 int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * BASELINE configs[2] form of the same contraction: bf16 storage, v_mfma_f32_32x32x16_bf16 with fp32 accumulate.
+ * A: NHWC activation in bf16 (raw 16-bit) or, with a_f32, in fp32 (converted while staging: the fp32 keypoint / flow
+ * maps enter the bf16 path here); Bt: bf16 [N][K]; C: bf16 or (c_f32) fp32; bias fp32; residual bf16 or (res_f32) fp32.
+ * Strides are in elements of the operand's own type.  in_ss != NULL (nb0 = nb1 = 1): GroupNorm(+swish) of the producer
+ * applied to A while staging, x*in_ss[img][c][0] + in_ss[img][c][1] (padding stays 0), as in smx_winograd_conv3x3_f32.
+ * Same call sites as smx_gemm_conv_f32.
+ * ------------------------------------------------------------------------------------- */
+typedef struct smx_gemm16_desc {
+  const void* a;     int64_t a_bs0, a_bs1;
+  const void* bt;    int64_t bt_bs0, bt_bs1;
+  void* c;           int64_t c_bs0, c_bs1;
+  const float* bias;
+  const void* res;   int64_t res_bs0, res_bs1;
+  const float* in_ss;
+  int32_t nb0, nb1;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc, ldres;
+  int32_t Hin, Win, Cin, Ho, Wo;
+  int32_t kh, kw, stride, pad_t, pad_l, up2;
+  int32_t act; float alpha;
+  int32_t bias_per_row;
+  int32_t d2s_p, d2s_c;
+  int32_t tile;
+  int32_t ksplit;
+  float* ws;
+  int32_t a_f32, c_f32, res_f32, in_swish;
+} smx_gemm16_desc;
+
+int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream);
+
 /* Fused Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 convolutions (same call sites as above for
  * the eligible layers: ResBlock / Upsample / SFT / FFN / RefineFlow 3x3 convs): 2.25x fewer MFMA
  * passes, fp32, input + output transforms fused (nothing transformed touches HBM).

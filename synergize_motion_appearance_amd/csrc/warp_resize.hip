@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include "smx.h"
 #include "smx_common.h"
+#include "bf16.h"
 
 namespace {
 
@@ -28,10 +29,11 @@ __device__ __forceinline__ void ac_src(int o, int in, int out, int& i0, int& i1,
 // dependent chain (flow taps -> shuffle -> 4 feature taps -> store), so one pixel per thread is
 // latency-bound (measured 3.6 TB/s at s=256); PPT independent pixels per thread put 4*PPT
 // feature loads in flight per lane.
-template <int LPP, int PPT>
-__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ feat, long long feat_bs,
+// T = storage type of the features (float | bf16_t); flow / occlusion and all coordinate math are fp32 in both.
+template <typename T, int LPP, int PPT>
+__global__ __launch_bounds__(256) void warp_kernel(const T* __restrict__ feat, long long feat_bs,
                                                    const float* __restrict__ flow, const float* __restrict__ occ,
-                                                   float* __restrict__ out, long long npix, int H, int W, int C,
+                                                   T* __restrict__ out, long long npix, int H, int W, int C,
                                                    int Hf, int Wf, int chunks_per_img, int nframes) {
   constexpr int PPB = 256 / LPP;                                     // pixels per block per pass
   const int sub = threadIdx.x % LPP;
@@ -122,13 +124,13 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
     const bool sane = ix > -2.f && ix < (float)W + 1.f && iy > -2.f && iy < (float)H + 1.f;
     const int x0 = sane ? (int)fx : -4, y0 = sane ? (int)fy : -4;
     w[i][0] = (1.f - tx) * (1.f - ty); w[i][1] = tx * (1.f - ty); w[i][2] = (1.f - tx) * ty; w[i][3] = tx * ty;
-    const float* fbase = feat + (long long)bb[i] * feat_bs + sub * 4;
+    const T* fbase = feat + (long long)bb[i] * feat_bs + sub * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
       v[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (live[i] && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        v[i][k] = *reinterpret_cast<const float4*>(fbase + ((long long)yy * W + xx) * C);
+        v[i][k] = St<T>::ld4(fbase + ((long long)yy * W + xx) * C);
     }
   }
 #pragma unroll
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
       acc.x += v[i][k].x * w[i][k]; acc.y += v[i][k].y * w[i][k]; acc.z += v[i][k].z * w[i][k]; acc.w += v[i][k].w * w[i][k];
     }
     if (occ) { acc.x *= oc[i]; acc.y *= oc[i]; acc.z *= oc[i]; acc.w *= oc[i]; }
-    *reinterpret_cast<float4*>(out + (long long)(pix0 + i * PPB) * C + sub * 4) = acc;
+    St<T>::st4(out + (long long)(pix0 + i * PPB) * C + sub * 4, acc);
   }
 }
 
@@ -152,10 +154,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ fea
 // row and x-base are block-uniform (scalar ALU); lane j < NPW of each wave computes the sampling
 // position of the wave's j-th pixel ONCE and the pixel's lane group fetches it with three
 // wavefront shuffles.  Arithmetic and association order are those of the scalar path of warp_kernel.
-template <int LPP>
-__global__ __launch_bounds__(256) void warp_rows_kernel(const float* __restrict__ feat, long long feat_bs,
+template <typename T, int LPP>
+__global__ __launch_bounds__(256) void warp_rows_kernel(const T* __restrict__ feat, long long feat_bs,
                                                         const float* __restrict__ flow, const float* __restrict__ occ,
-                                                        float* __restrict__ out, int H, int W, int C, int Hf, int Wf,
+                                                        T* __restrict__ out, int H, int W, int C, int Hf, int Wf,
                                                         int chunks_per_img, int nframes) {
   constexpr int PPT = 4, PPB = 256 / LPP, GPW = 64 / LPP, NPW = GPW * PPT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPP, g = lane / LPP;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(const float* __restrict_
     cix = ((fxv + 1.f) / 2.f) * (W - 1); ciy = ((fyv + 1.f) / 2.f) * (H - 1); coc = ov;
   }
   float4 v[PPT][4]; float w[PPT][4]; float oc[PPT];
-  const float* fbase = feat + (long long)b * feat_bs + sub * 4;
+  const T* fbase = feat + (long long)b * feat_bs + sub * 4;
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int src = i * GPW + g;
@@ -213,10 +215,10 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(const float* __restrict_
       const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
       v[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-        v[i][k] = *reinterpret_cast<const float4*>(fbase + (yy * W + xx) * C);
+        v[i][k] = St<T>::ld4(fbase + (yy * W + xx) * C);
     }
   }
-  float* ob_ = out + ((long long)b * H * W + (long long)y * W + xb + wave * GPW + g) * C + sub * 4;
+  T* ob_ = out + ((long long)b * H * W + (long long)y * W + xb + wave * GPW + g) * C + sub * 4;
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -225,21 +227,22 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(const float* __restrict_
       acc.x += v[i][k].x * w[i][k]; acc.y += v[i][k].y * w[i][k]; acc.z += v[i][k].z * w[i][k]; acc.w += v[i][k].w * w[i][k];
     }
     if (occ) { acc.x *= oc[i]; acc.y *= oc[i]; acc.z *= oc[i]; acc.w *= oc[i]; }
-    *reinterpret_cast<float4*>(ob_ + i * PPB * C) = acc;
+    St<T>::st4(ob_ + i * PPB * C, acc);
   }
 }
 
-__global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void resize_ac_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ y, int ldy,
                                                         long long total, int Hin, int Win, int Hout, int Wout, int C) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); long long p = i / C;
     const int ox = (int)(p % Wout); p /= Wout; const int oy = (int)(p % Hout); const int b = (int)(p / Hout);
     int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
     ac_src(oy, Hin, Hout, y0, y1, ly0, ly1); ac_src(ox, Win, Wout, x0, x1, lx0, lx1);
-    const float* xb = x + (long long)b * Hin * Win * ldx + c;
-    const float v = ly0 * (lx0 * xb[((long long)y0 * Win + x0) * ldx] + lx1 * xb[((long long)y0 * Win + x1) * ldx]) +
-                    ly1 * (lx0 * xb[((long long)y1 * Win + x0) * ldx] + lx1 * xb[((long long)y1 * Win + x1) * ldx]);
-    y[(((long long)b * Hout + oy) * Wout + ox) * ldy + c] = v;
+    const TI* xb = x + (long long)b * Hin * Win * ldx + c;
+    const float v = ly0 * (lx0 * St<TI>::ld(xb + ((long long)y0 * Win + x0) * ldx) + lx1 * St<TI>::ld(xb + ((long long)y0 * Win + x1) * ldx)) +
+                    ly1 * (lx0 * St<TI>::ld(xb + ((long long)y1 * Win + x0) * ldx) + lx1 * St<TI>::ld(xb + ((long long)y1 * Win + x1) * ldx));
+    St<TO>::st(y + (((long long)b * Hout + oy) * Wout + ox) * ldy + c, v);
   }
 }
 
@@ -248,7 +251,8 @@ __global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict_
 // only has to be evaluated at those taps (1/4 of the 256x256 pixels; exact, the op is per pixel).
 // gather:  t[b][oy][ox][tap][c] = x[b][y_tap][x_tap][c],  taps (y0,x0) (y0,x1) (y1,x0) (y1,x1)
 // combine: y = ly0*(lx0*t0 + lx1*t1) + ly1*(lx0*t2 + lx1*t3)   (resize_ac_kernel's association)
-__global__ __launch_bounds__(256) void resize_taps_gather_kernel(const float* __restrict__ x, int ldx, float4* __restrict__ t,
+template <typename T>
+__global__ __launch_bounds__(256) void resize_taps_gather_kernel(const T* __restrict__ x, int ldx, T* __restrict__ t,
                                                                  long long total4, int Hin, int Win, int Hout, int Wout, int c4n) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
     const int c4 = (int)(i % c4n); long long p = i / c4n;
@@ -257,25 +261,26 @@ __global__ __launch_bounds__(256) void resize_taps_gather_kernel(const float* __
     int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
     ac_src(oy, Hin, Hout, y0, y1, ly0, ly1); ac_src(ox, Win, Wout, x0, x1, lx0, lx1);
     const int yy = (tap >> 1) ? y1 : y0, xx = (tap & 1) ? x1 : x0;
-    t[i] = *reinterpret_cast<const float4*>(x + (((long long)b * Hin + yy) * Win + xx) * ldx + c4 * 4);
+    St<T>::st4(t + i * 4, St<T>::ld4(x + (((long long)b * Hin + yy) * Win + xx) * ldx + c4 * 4));
   }
 }
 
-__global__ __launch_bounds__(256) void resize_taps_combine_kernel(const float4* __restrict__ t, float* __restrict__ y, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void resize_taps_combine_kernel(const T* __restrict__ t, T* __restrict__ y, int ldy,
                                                                   long long total4, int Hin, int Win, int Hout, int Wout, int c4n) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
     const int c4 = (int)(i % c4n); long long p = i / c4n;
     const int ox = (int)(p % Wout); const long long q = p / Wout; const int oy = (int)(q % Hout);
     int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
     ac_src(oy, Hin, Hout, y0, y1, ly0, ly1); ac_src(ox, Win, Wout, x0, x1, lx0, lx1);
-    const float4* tp = t + p * 4 * c4n + c4;
-    const float4 a = tp[0], b_ = tp[c4n], c = tp[2 * c4n], d = tp[3 * c4n];
+    const T* tp = t + (p * 4 * c4n + c4) * 4;
+    const float4 a = St<T>::ld4(tp), b_ = St<T>::ld4(tp + 4 * c4n), c = St<T>::ld4(tp + 8 * c4n), d = St<T>::ld4(tp + 12 * c4n);
     float4 o;
     o.x = ly0 * (lx0 * a.x + lx1 * b_.x) + ly1 * (lx0 * c.x + lx1 * d.x);
     o.y = ly0 * (lx0 * a.y + lx1 * b_.y) + ly1 * (lx0 * c.y + lx1 * d.y);
     o.z = ly0 * (lx0 * a.z + lx1 * b_.z) + ly1 * (lx0 * c.z + lx1 * d.z);
     o.w = ly0 * (lx0 * a.w + lx1 * b_.w) + ly1 * (lx0 * c.w + lx1 * d.w);
-    *reinterpret_cast<float4*>(y + p * ldy + c4 * 4) = o;
+    St<T>::st4(y + p * ldy + c4 * 4, o);
   }
 }
 
@@ -315,8 +320,10 @@ inline int grid_for(long long total) { int g = smx_cdiv(total, 256); return g > 
 
 }  // namespace
 
-extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float* flow, const float* occ,
-                                 float* out, int B, int H, int W, int C, int Hf, int Wf, void* stream) {
+namespace {
+template <typename T>
+int warp_launch(const T* feat, int feat_batch, const float* flow, const float* occ, T* out, int B, int H, int W, int C, int Hf, int Wf,
+                void* stream) {
   if (!feat || !flow || !out || B <= 0 || H <= 1 || W <= 1 || Hf <= 1 || Wf <= 1) return SMX_EINVAL;
   if (feat_batch != 1 && feat_batch != B) return SMX_EINVAL;
   const int lpp = C / 4;
@@ -333,15 +340,15 @@ extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float*
   if (lpp >= 16 && W % rchunk == 0 && npix / rchunk >= 256 && (long long)H * W * C < (1LL << 31) && smx_tune(SMX_TUNE_WARP_ROWS)) {
     const int cpi2 = (H * W) / rchunk;
     dim3 grid2(cpi2 * B);
-    if (lpp == 16) SMX_LAUNCH((warp_rows_kernel<16>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
-    else if (lpp == 32) SMX_LAUNCH((warp_rows_kernel<32>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
-    else SMX_LAUNCH((warp_rows_kernel<64>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+    if (lpp == 16) SMX_LAUNCH((warp_rows_kernel<T, 16>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+    else if (lpp == 32) SMX_LAUNCH((warp_rows_kernel<T, 32>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+    else SMX_LAUNCH((warp_rows_kernel<T, 64>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
     return smx_launch_status();
   }
   const int chunk = 256 / lpp * ppt;                                // pixels per block
   int cpi = ((H * W) % chunk == 0 && smx_tune(SMX_TUNE_WARP_REORDER)) ? (H * W) / chunk : 0;
-#define SMX_WARP(L) do { if (ppt == 4) SMX_LAUNCH((warp_kernel<L, 4>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); \
-                         else SMX_LAUNCH((warp_kernel<L, 1>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); } while (0)
+#define SMX_WARP(L) do { if (ppt == 4) SMX_LAUNCH((warp_kernel<T, L, 4>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); \
+                         else SMX_LAUNCH((warp_kernel<T, L, 1>), grid, block, 0, st, feat, feat_bs, flow, occ, out, npix, H, W, C, Hf, Wf, cpi, B); } while (0)
   switch (lpp) {
     case 1: SMX_WARP(1); break; case 2: SMX_WARP(2); break; case 4: SMX_WARP(4); break; case 8: SMX_WARP(8); break;
     case 16: SMX_WARP(16); break; case 32: SMX_WARP(32); break; default: SMX_WARP(64); break;
@@ -350,32 +357,69 @@ extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float*
   return smx_launch_status();
 }
 
-extern "C" int smx_resize_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int B, int Hin, int Win,
-                                               int Hout, int Wout, int C, void* stream) {
+template <typename TI, typename TO>
+int resize_launch(const TI* x, int ldx, TO* y, int ldy, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream) {
   if (!x || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
   const long long total = (long long)B * Hout * Wout * C;
-  SMX_LAUNCH(resize_ac_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, Hin, Win, Hout, Wout, C);
+  SMX_LAUNCH((resize_ac_kernel<TI, TO>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, Hin, Win, Hout, Wout, C);
   return smx_launch_status();
 }
 
-extern "C" int smx_resize_taps_gather_f32(const float* x, int ldx, float* taps, int B, int Hin, int Win, int Hout, int Wout,
-                                          int C, void* stream) {
+template <typename T>
+int taps_gather_launch(const T* x, int ldx, T* taps, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream) {
   if (!x || !taps || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || C % 4 != 0 || ldx < C || ldx % 4 != 0) return SMX_EINVAL;
-  if (((uintptr_t)x & 15) || ((uintptr_t)taps & 15)) return SMX_EINVAL;
+  if (((uintptr_t)x & (4 * sizeof(T) - 1)) || ((uintptr_t)taps & (4 * sizeof(T) - 1))) return SMX_EINVAL;
   const long long total4 = (long long)B * Hout * Wout * 4 * (C / 4);
-  SMX_LAUNCH(resize_taps_gather_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, ldx, (float4*)taps, total4,
+  SMX_LAUNCH(resize_taps_gather_kernel<T>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, ldx, taps, total4,
              Hin, Win, Hout, Wout, C / 4);
   return smx_launch_status();
 }
 
-extern "C" int smx_resize_taps_combine_f32(const float* taps, float* y, int ldy, int B, int Hin, int Win, int Hout, int Wout,
-                                           int C, void* stream) {
+template <typename T>
+int taps_combine_launch(const T* taps, T* y, int ldy, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream) {
   if (!taps || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || C % 4 != 0 || ldy < C || ldy % 4 != 0) return SMX_EINVAL;
-  if (((uintptr_t)y & 15) || ((uintptr_t)taps & 15)) return SMX_EINVAL;
+  if (((uintptr_t)y & (4 * sizeof(T) - 1)) || ((uintptr_t)taps & (4 * sizeof(T) - 1))) return SMX_EINVAL;
   const long long total4 = (long long)B * Hout * Wout * (C / 4);
-  SMX_LAUNCH(resize_taps_combine_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const float4*)taps, y, ldy,
+  SMX_LAUNCH(resize_taps_combine_kernel<T>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, taps, y, ldy,
              total4, Hin, Win, Hout, Wout, C / 4);
   return smx_launch_status();
+}
+}  // namespace
+
+extern "C" int smx_warp_nhwc_f32(const float* feat, int feat_batch, const float* flow, const float* occ,
+                                 float* out, int B, int H, int W, int C, int Hf, int Wf, void* stream) {
+  return warp_launch<float>(feat, feat_batch, flow, occ, out, B, H, W, C, Hf, Wf, stream);
+}
+extern "C" int smx_warp_nhwc_bf16(const void* feat, int feat_batch, const float* flow, const float* occ,
+                                  void* out, int B, int H, int W, int C, int Hf, int Wf, void* stream) {
+  return warp_launch<bf16_t>((const bf16_t*)feat, feat_batch, flow, occ, (bf16_t*)out, B, H, W, C, Hf, Wf, stream);
+}
+
+extern "C" int smx_resize_bilinear_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int B, int Hin, int Win,
+                                               int Hout, int Wout, int C, void* stream) {
+  return resize_launch<float, float>(x, ldx, y, ldy, B, Hin, Win, Hout, Wout, C, stream);
+}
+extern "C" int smx_resize_bilinear_ac_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int Hin, int Win,
+                                                int Hout, int Wout, int C, void* stream) {
+  return resize_launch<bf16_t, bf16_t>((const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, Hin, Win, Hout, Wout, C, stream);
+}
+
+extern "C" int smx_resize_taps_gather_f32(const float* x, int ldx, float* taps, int B, int Hin, int Win, int Hout, int Wout,
+                                          int C, void* stream) {
+  return taps_gather_launch<float>(x, ldx, taps, B, Hin, Win, Hout, Wout, C, stream);
+}
+extern "C" int smx_resize_taps_gather_bf16(const void* x, int ldx, void* taps, int B, int Hin, int Win, int Hout, int Wout,
+                                           int C, void* stream) {
+  return taps_gather_launch<bf16_t>((const bf16_t*)x, ldx, (bf16_t*)taps, B, Hin, Win, Hout, Wout, C, stream);
+}
+
+extern "C" int smx_resize_taps_combine_f32(const float* taps, float* y, int ldy, int B, int Hin, int Win, int Hout, int Wout,
+                                           int C, void* stream) {
+  return taps_combine_launch<float>(taps, y, ldy, B, Hin, Win, Hout, Wout, C, stream);
+}
+extern "C" int smx_resize_taps_combine_bf16(const void* taps, void* y, int ldy, int B, int Hin, int Win, int Hout, int Wout,
+                                            int C, void* stream) {
+  return taps_combine_launch<bf16_t>((const bf16_t*)taps, (bf16_t*)y, ldy, B, Hin, Win, Hout, Wout, C, stream);
 }
 
 extern "C" int smx_avgpool2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int B, int Hin, int Win, int C, void* stream) {

@@ -36,12 +36,38 @@ class GemmDesc(C.Structure):
     ]
 
 
+class Gemm16Desc(C.Structure):
+    """mirror of `smx_gemm16_desc` (include/smx.h)."""
+    _fields_ = [
+        ("a", _p), ("a_bs0", _i64), ("a_bs1", _i64),
+        ("bt", _p), ("bt_bs0", _i64), ("bt_bs1", _i64),
+        ("c", _p), ("c_bs0", _i64), ("c_bs1", _i64),
+        ("bias", _p),
+        ("res", _p), ("res_bs0", _i64), ("res_bs1", _i64),
+        ("in_ss", _p),
+        ("nb0", C.c_int32), ("nb1", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldres", C.c_int32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("up2", C.c_int32),
+        ("act", C.c_int32), ("alpha", C.c_float),
+        ("bias_per_row", C.c_int32),
+        ("d2s_p", C.c_int32), ("d2s_c", C.c_int32),
+        ("tile", C.c_int32),
+        ("ksplit", C.c_int32),
+        ("ws", _p),
+        ("a_f32", C.c_int32), ("c_f32", C.c_int32), ("res_f32", C.c_int32), ("in_swish", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/smx.h declares
 SIGNATURES = {
     "smx_version": (C.c_char_p, []),
     "smx_set_tuning": (_i, [C.c_char_p, _i]),
     "smx_get_tuning": (_i, [C.c_char_p, C.POINTER(_i)]),
     "smx_gemm_conv_f32": (_i, [C.POINTER(GemmDesc), _p]),
+    "smx_gemm_conv_bf16": (_i, [C.POINTER(Gemm16Desc), _p]),
     "smx_winograd_conv3x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "smx_groupnorm_stats_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
     "smx_conv3x3_smalln_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),

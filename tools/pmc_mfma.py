@@ -29,16 +29,25 @@ def family(name):
     return None
 
 
+def variants(name):
+    """family + finer keys: the Winograd block shapes separately (the 8-wave N=64 block is the big-launch variant)."""
+    fam = family(name)
+    if not fam:
+        return []
+    out = [fam]
+    if fam == "winograd":
+        out.append("winograd_nw2" if "winograd_kernel<false, 2" in name or "winograd_kernel<true, 2" in name else "winograd_nw1")
+    return out
+
+
 def main(pmc_dir, out, command=""):
     per = collections.defaultdict(lambda: collections.defaultdict(float))   # family -> counter -> sum
     disp = collections.defaultdict(dict)                                   # family -> dispatch id -> duration ns
     for f in glob.glob(pmc_dir + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            fam = family(r["Kernel_Name"])
-            if not fam:
-                continue
-            per[fam][r["Counter_Name"]] += float(r["Counter_Value"])
-            disp[fam][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            for fam in variants(r["Kernel_Name"]):
+                per[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+                disp[fam][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     res = {}
     for fam, c in per.items():
         n = len(disp[fam])
