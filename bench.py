@@ -221,15 +221,20 @@ def main():
     (j_last, fr_last) = work[W + K - 1][-1]
     off = B - fr_last.shape[0]
     picks = sorted({0, fr_last.shape[0] // 2, fr_last.shape[0] - 1})
-    worst, ndiff, ntot = 0, 0, 0
+    worst, ndiff, ntot, dsum = 0, 0, 0, 0.0
     for i in picks:
         one = driver.render_frames(states[j_last], fr_last[i:i + 1], net_g, me, True, True, batch=1)
         d = (one[0].int() - out[off + i].int()).abs()
-        worst, ndiff, ntot = max(worst, int(d.max())), ndiff + int((d > 0).sum()), ntot + d.numel()
-    consistency = {"frames_checked": len(picks), "max_lsb_vs_b1": worst, "bytes_differing": ndiff, "bytes": ntot,
-                   "what": f"frames {picks} of the last timed batch (B={B}) re-rendered one at a time; uint8 outputs compared"}
-    if worst > 1:
-        raise SystemExit(f"[bench] batch consistency FAILED: B={B} output differs from B=1 by {worst} LSB")
+        worst, ndiff, ntot, dsum = max(worst, int(d.max())), ndiff + int((d > 0).sum()), ntot + d.numel(), dsum + float(d.sum())
+    consistency = {"frames_checked": len(picks), "max_lsb_vs_b1": worst, "mean_lsb_vs_b1": round(dsum / ntot, 5), "bytes_differing": ndiff,
+                   "bytes": ntot, "what": f"frames {picks} of the last timed batch (B={B}) re-rendered one at a time; uint8 outputs compared"}
+    # fp32: another batch size only reorders fp32 sums (<= 1 LSB).  bf16 storage: a reordered sum can round to the other
+    # neighbour (2^-8) and the flip propagates through ~100 layers, so two bf16 evaluations are as far from each other as
+    # each is from fp32; the bar there is the reference-under-autocast error (tests/golden/autocast_bf16.npz: mean 0.0078,
+    # max 0.33 on [-1,1] = 1.0 / 42 LSB): mean < 1.5 LSB, worst pixel <= 42 LSB
+    bad = worst > 1 if args.dtype == "f32" else (dsum / ntot >= 1.5 or worst > 42)
+    if bad:
+        raise SystemExit(f"[bench] batch consistency FAILED: B={B} output differs from B=1 by {worst} LSB (mean {dsum / ntot:.3f})")
 
     dname = {"f32": "f32", "bf16": "bf16"}[args.dtype]
     cfg_ix = 1 if (world == 1 and args.dtype == "f32") else 2
@@ -242,7 +247,7 @@ def main():
                    "sources": n_src,
                    "parallelism": (f"{n_src} sources x {CLIP} frames = {total_units} (source, frame) units; each step's window of {world * B} "
                                    f"units sharded x{world} (driver.shard_frames); one {collective} broadcast per source of its packed "
-                                   f"frame-invariant state ({4 * driver.cache_numel() / 1e6:.1f} MB) from the owner rank, inside the timed region")
+                                   f"frame-invariant state ({4 * driver.cache_numel(net_g.engine().adt) / 1e6:.1f} MB) from the owner rank, inside the timed region")
                    if world > 1 else "1 GPU",
                    "relative": True, "adapt_movement_scale": True, "output": "uint8 HWC frames in HBM"},
         "batch_consistency": consistency,
@@ -302,7 +307,10 @@ def main():
         tf_exec = g["mfma_flops"] / (g["ms"] * 1e-3) / 1e12
         tf_alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
         kname = {"winograd": "winograd_kernel<SWZ=false,NW> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
-                 "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM)"}.get(dom, dom)
+                 "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x2_f32)",
+                 "gemm_bf16": "gemm_bf16_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom)
+        if dom.startswith("attention"):
+            peak = PEAK_F32_MFMA_TFLOPS                      # the attention cores run on the fp32 MFMA in both storage modes
         roof = {
             "kernel": kname, "bound": "mfma", "achieved": round(tf_exec, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(tf_exec / peak, 4),
@@ -367,7 +375,7 @@ def main():
         if args.dump_shapes:
             tab = {}
             for n, m, ms in rec.rows:
-                if n != "gemm_conv":
+                if n not in ("gemm_conv", "gemm_bf16"):
                     continue
                 key = (m["M"], m["N"], m["K"], m["nb"], m["k"], int(bool(m.get("wino"))))
                 t = tab.setdefault(key, [0, 0.0, m["flops"]])

@@ -284,6 +284,35 @@ int smx_to_uint8_f32(const float* x, uint8_t* y, int64_t n, float lo, float hi, 
 int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, float* zq, float* dmin,
                        float* sqerr, int N, int D, int Ks, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * BASELINE configs[2]: bf16 STORAGE variants (activation pointers are raw 16-bit bfloat16, void* here; every
+ * statistic, coordinate, weight of a normalisation and accumulator stays fp32).  Same semantics, argument meaning
+ * and reference call sites as the _f32 entry point of the same name.
+ * ------------------------------------------------------------------------------------- */
+int smx_groupnorm_swish_nhwc_bf16(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int B, int HW,
+                                  int C, int groups, float eps, int swish, float* ws, void* stream);
+int smx_groupnorm_stats_bf16(const void* x, int ldx, const float* gamma, const float* beta, float* ss, int B, int HW, int C,
+                             int groups, float eps, float* ws, void* stream);
+int smx_groupnorm_apply_bf16(const void* x, int ldx, const float* ss, void* y, int ldy, int B, int HW, int C, int swish, void* stream);
+int smx_layernorm_pos_bf16(const void* x, const float* gamma, const float* beta, const float* pos, void* y, void* y_pos, int T, int E,
+                           int npos, float eps, void* stream);
+int smx_attention_bf16(const void* q, int ldq, int64_t q_bs, const void* k, int ldk, int64_t k_bs, const void* v, int ldv, int64_t v_bs,
+                       void* o, int ldo, int64_t o_bs, const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream);
+int smx_softmax_rows_bf16(void* s, int ld, int R, int S, float scale, const uint8_t* mask, int rows_per_mask, void* stream);
+int smx_warp_nhwc_bf16(const void* feat, int feat_batch, const float* flow, const float* occ, void* out, int B, int H, int W, int C,
+                       int Hf, int Wf, void* stream);
+int smx_resize_bilinear_ac_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream);
+int smx_resize_taps_gather_bf16(const void* x, int ldx, void* taps, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream);
+int smx_resize_taps_combine_bf16(const void* taps, void* y, int ldy, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream);
+int smx_conv3x3_smalln_bf16(const void* x, int lda, const float* w, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
+                            int Cout, int act, const float* in_ss, int in_swish, void* stream);   /* fp32 weights / bias / output */
+int smx_sft_combine_bf16(const void* dec, int ld_dec, const void* scale, const void* shift, void* out, float w, int64_t P, int C, void* stream);
+int smx_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* copy / convert a channel slice between storage types (dtype codes: 0 = fp32, 1 = bf16) */
+int smx_convert_slice(const void* x, int x_dtype, int ldx, void* y, int y_dtype, int ldy, int64_t P, int C, void* stream);
+int smx_nchw_to_nhwc_bf16(const float* x, void* y, int ldy, int B, int C, int H, int W, void* stream);   /* fp32 NCHW -> bf16 NHWC */
+int smx_nhwc_to_nchw_bf16(const void* x, int ldx, float* y, int B, int C, int H, int W, void* stream);   /* bf16 NHWC -> fp32 NCHW */
+
 #ifdef __cplusplus
 }
 #endif

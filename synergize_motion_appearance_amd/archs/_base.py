@@ -12,6 +12,18 @@ class HipArch(nn.Module):
         super().__init__()
         attach(self, manifest)
         self._engine = None
+        self.compute_dtype = "f32"       # "f32": BASELINE configs[1] (reference arithmetic); "bf16": configs[2]
+
+    def set_compute_dtype(self, name):
+        """'f32' (default; fp32 storage, fp32 MFMA: the reference's arithmetic) or 'bf16' (BASELINE configs[2]: bf16
+        activation / weight storage on the bf16 MFMA with fp32 accumulate; keypoint, flow, grid, normalisation-statistic and
+        softmax math stay fp32).  Drops the packed engine; parameters keep their fp32 master copy."""
+        if name not in ("f32", "bf16"):
+            raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+        if name != self.compute_dtype:
+            self.compute_dtype = name
+            self._engine = None
+        return self
 
     # any of these may change parameter storage -> drop the packed engine
     def _apply(self, fn, *a, **k):

@@ -18,7 +18,8 @@ class _GeneratorNode(ParamNode):
     @torch.no_grad()
     def forward(self, x):
         owner = self.__dict__["_owner"][0]
-        return ops.nhwc_to_nchw(owner.engine().generator_only(ops.nchw_to_nhwc(x.float())))
+        eng = owner.engine()
+        return ops.nhwc_to_nchw(eng.generator_only(ops.nchw_to_nhwc(x.float(), dtype=eng.adt)))
 
 
 @ARCH_REGISTRY.register()
@@ -58,7 +59,7 @@ class AppMotionCompFormer(HipArch):
 
     def engine(self):
         if self._engine is None:
-            self._engine = NetGEngine(self._params_on_device(), self.cfg)
+            self._engine = NetGEngine(self._params_on_device(), self.cfg, torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32)
             self._src_key = None
         return self._engine
 

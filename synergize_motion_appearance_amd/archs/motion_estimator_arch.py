@@ -47,7 +47,7 @@ class KPDetector(HipArch):
 
     def engine(self):
         if self._engine is None:
-            self._engine = KPEngine(self._params_on_device(), "", *self._cfg)
+            self._engine = KPEngine(self._params_on_device(), "", *self._cfg, mfma16=self.compute_dtype == "bf16")
         return self._engine
 
     @torch.no_grad()
@@ -78,7 +78,7 @@ class DenseMotionNetwork(HipArch):
 
     def engine(self):
         if self._engine is None:
-            self._engine = DenseEngine(self._params_on_device(), "", *self._cfg)
+            self._engine = DenseEngine(self._params_on_device(), "", *self._cfg, mfma16=self.compute_dtype == "bf16")
         return self._engine
 
     @torch.no_grad()
@@ -112,7 +112,7 @@ class Motion_Estimator_keypoint_aware(HipArch):
 
     def engine(self):
         if self._engine is None:
-            self._engine = MotionEngine(self._params_on_device(), *self._cfg)
+            self._engine = MotionEngine(self._params_on_device(), *self._cfg, mfma16=self.compute_dtype == "bf16")
             self._src_key = None
         return self._engine
 

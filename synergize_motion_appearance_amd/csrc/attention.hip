@@ -22,20 +22,23 @@
 #include <math.h>
 #include "smx.h"
 #include "smx_common.h"
+#include "bf16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// T = storage type of q / k / v / o (float | bf16_t); products and softmax statistics are fp32 in both
+template <typename T>
 struct AP {
-  const float* q; const float* k; const float* v; float* o; const uint8_t* mask;
+  const T* q; const T* k; const T* v; T* o; const uint8_t* mask;
   long long q_bs, k_bs, v_bs, o_bs;
   int ldq, ldk, ldv, ldo;
   int H, L, S; float scale;
 };
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(AP<T> p) {
   constexpr int TK = 32, KLD = DH + 4, KS = DH / 8, DT = DH / 32;
   __shared__ __attribute__((aligned(16))) float Ks[2][TK * KLD];
   __shared__ __attribute__((aligned(16))) float Vs[2][TK * DH];
@@ -44,15 +47,15 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
   const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
   const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
   const int hh = lane >> 5;
-  const float* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq + h * DH;
-  const float* K = p.k + b * p.k_bs + h * DH;
-  const float* V = p.v + b * p.v_bs + h * DH;
+  const T* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq + h * DH;
+  const T* K = p.k + b * p.k_bs + h * DH;
+  const T* V = p.v + b * p.v_bs + h * DH;
   const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
 
   float4 qf[KS];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
-    float4 t = *reinterpret_cast<const float4*>(Q + kk * 8 + hh * 4);
+    float4 t = St<T>::ld4(Q + kk * 8 + hh * 4);
     const float sc = p.scale * 1.44269504088896340736f;      // scores in log2 units: softmax via v_exp_f32 (exp2)
     qf[kk] = make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc);
   }
@@ -72,8 +75,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
       const int f = threadIdx.x + 256 * i;
       if (f < NF4) {
         const int r = f / (DH / 4), c4 = f % (DH / 4);
-        kreg[i] = *reinterpret_cast<const float4*>(K + (long long)(key0 + r) * p.ldk + c4 * 4);
-        vreg[i] = *reinterpret_cast<const float4*>(V + (long long)(key0 + r) * p.ldv + c4 * 4);
+        kreg[i] = St<T>::ld4(K + (long long)(key0 + r) * p.ldk + c4 * 4);
+        vreg[i] = St<T>::ld4(V + (long long)(key0 + r) * p.ldv + c4 * 4);
       }
     }
     if (M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
     if (t + 1 < ntiles) store_tile(buf ^ 1);
     __syncthreads();
   }
-  float* O = p.o + b * p.o_bs + (long long)qrow * p.ldo + h * DH;
+  T* O = p.o + b * p.o_bs + (long long)qrow * p.ldo + h * DH;
   const float inv = 1.f / l;                                  // l == 0 (fully masked row) -> inf * 0 = NaN like the reference
 #pragma unroll
   for (int d = 0; d < DT; ++d)
@@ -150,14 +153,15 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP p) {
     for (int g = 0; g < 4; ++g) {
       float4 w = make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
       if (l == 0.f) w = make_float4(NAN, NAN, NAN, NAN);
-      *reinterpret_cast<float4*>(O + d * 32 + 8 * g + 4 * hh) = w;
+      St<T>::st4(O + d * 32 + 8 * g + 4 * hh, w);
     }
 }
 
 // d_head = 4: one query per lane, 64 queries per block; the block's 4 waves split the S keys
 // (wave w owns keys [w*S/4, (w+1)*S/4)), K/V broadcast from LDS, 8 keys per online-softmax step,
 // and the four partial (m, l, acc) states are merged through LDS at the end.
-__global__ __launch_bounds__(256) void attn_valu4_kernel(AP p) {
+template <typename T>
+__global__ __launch_bounds__(256) void attn_valu4_kernel(AP<T> p) {
   extern __shared__ __attribute__((aligned(16))) float4 smem4[];
   float4* Ks = smem4;                       // [S]
   float4* Vs = smem4 + p.S;                 // [S]
@@ -166,14 +170,14 @@ __global__ __launch_bounds__(256) void attn_valu4_kernel(AP p) {
   const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qrow = blockIdx.x * 64 + lane;
-  float4 q = *reinterpret_cast<const float4*>(p.q + b * p.q_bs + (long long)qrow * p.ldq + h * 4);
+  float4 q = St<T>::ld4(p.q + b * p.q_bs + (long long)qrow * p.ldq + h * 4);
   { const float sc = p.scale * 1.44269504088896340736f; q = make_float4(q.x * sc, q.y * sc, q.z * sc, q.w * sc); }
-  const float* K = p.k + b * p.k_bs + h * 4;
-  const float* V = p.v + b * p.v_bs + h * 4;
+  const T* K = p.k + b * p.k_bs + h * 4;
+  const T* V = p.v + b * p.v_bs + h * 4;
   const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
   for (int i = threadIdx.x; i < p.S; i += 256) {
-    Ks[i] = *reinterpret_cast<const float4*>(K + (long long)i * p.ldk);
-    Vs[i] = *reinterpret_cast<const float4*>(V + (long long)i * p.ldv);
+    Ks[i] = St<T>::ld4(K + (long long)i * p.ldk);
+    Vs[i] = St<T>::ld4(V + (long long)i * p.ldv);
     Ms[i] = M ? M[i] : 0;
   }
   __syncthreads();
@@ -217,30 +221,44 @@ __global__ __launch_bounds__(256) void attn_valu4_kernel(AP p) {
       ll += q6[1] * f; a.x += q6[2] * f; a.y += q6[3] * f; a.z += q6[4] * f; a.w += q6[5] * f;
     }
     // ll == 0 (every key masked) -> 0/0 = NaN like the reference
-    *reinterpret_cast<float4*>(p.o + b * p.o_bs + (long long)qrow * p.ldo + h * 4) = make_float4(a.x / ll, a.y / ll, a.z / ll, a.w / ll);
+    St<T>::st4(p.o + b * p.o_bs + (long long)qrow * p.ldo + h * 4, make_float4(a.x / ll, a.y / ll, a.z / ll, a.w / ll));
   }
 }
 
 }  // namespace
 
-extern "C" int smx_attention_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
-                                 const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs,
-                                 const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream) {
+namespace {
+template <typename T>
+int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int64_t k_bs, const T* v, int ldv, int64_t v_bs, T* o, int ldo,
+                     int64_t o_bs, const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream) {
   if (!q || !k || !v || !o || B <= 0 || H <= 0 || L <= 0 || S <= 0 || (long long)B * H > 65535) return SMX_EINVAL;
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || q_bs % 4 || k_bs % 4 || v_bs % 4 || o_bs % 4) return SMX_EINVAL;
-  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SMX_EINVAL;
-  AP p{q, k, v, o, key_mask, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo, H, L, S, scale};
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & (4 * sizeof(T) - 1)) return SMX_EINVAL;
+  AP<T> p{q, k, v, o, key_mask, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo, H, L, S, scale};
   hipStream_t st = (hipStream_t)stream;
   if (dh == 4) {
     if (L % 64 || S % 32 || S > 2048) return SMX_EINVAL;
     const size_t lds = (size_t)S * 33 + 4 * 64 * 6 * sizeof(float);
-    SMX_LAUNCH(attn_valu4_kernel, dim3(L / 64, B * H), dim3(256), lds, st, p);
+    SMX_LAUNCH(attn_valu4_kernel<T>, dim3(L / 64, B * H), dim3(256), lds, st, p);
   } else if (dh == 32 || dh == 64) {
     if (L % 128 || S % 32) return SMX_EINVAL;
-    if (dh == 32) SMX_LAUNCH(attn_mfma_kernel<32>, dim3(L / 128, B * H), dim3(256), 0, st, p);
-    else SMX_LAUNCH(attn_mfma_kernel<64>, dim3(L / 128, B * H), dim3(256), 0, st, p);
+    if (dh == 32) SMX_LAUNCH((attn_mfma_kernel<T, 32>), dim3(L / 128, B * H), dim3(256), 0, st, p);
+    else SMX_LAUNCH((attn_mfma_kernel<T, 64>), dim3(L / 128, B * H), dim3(256), 0, st, p);
   } else {
     return SMX_EINVAL;
   }
   return smx_launch_status();
+}
+}  // namespace
+
+extern "C" int smx_attention_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
+                                 const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs,
+                                 const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream) {
+  return attention_launch<float>(q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, o, ldo, o_bs, key_mask, B, H, L, S, dh, scale, stream);
+}
+extern "C" int smx_attention_bf16(const void* q, int ldq, int64_t q_bs, const void* k, int ldk, int64_t k_bs,
+                                  const void* v, int ldv, int64_t v_bs, void* o, int ldo, int64_t o_bs,
+                                  const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream) {
+  return attention_launch<bf16_t>((const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs, (const bf16_t*)v, ldv, v_bs, (bf16_t*)o, ldo, o_bs,
+                                  key_mask, B, H, L, S, dh, scale, stream);
 }

@@ -16,11 +16,14 @@
 #include <math.h>
 #include "smx.h"
 #include "smx_common.h"
+#include "bf16.h"
 
 namespace {
 
+// TX = storage type of the input activation (float | bf16_t); weights, bias and the <= 4-channel output are fp32
+template <typename TX>
 struct SP {
-  const float* x; const float* w; const float* bias; float* y; const float* in_ss;
+  const TX* x; const float* w; const float* bias; float* y; const float* in_ss;
   int in_swish, lda, ldc, B, H, W, Cin, Cout, act, run;
 };
 
@@ -57,8 +60,8 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-template <int LPP, int NO, int RUN, bool SW>
-__global__ __launch_bounds__(256) void conv3x3_small_kernel(SP p) {
+template <typename TX, int LPP, int NO, int RUN, bool SW>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(SP<TX> p) {
   constexpr int GPB = 256 / LPP;                           // pixel groups per block
   const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
   const int runs_per_row = p.W / RUN;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SP p) {
   // row validity / base offsets are per group, the column test only bites on the first tap of the first
   // run and the last tap of the last run of a row (x0 is RUN-aligned): no per-tap bounds logic in the loop;
   // 32-bit element offsets (checked on the host)
-  const float* xb = p.x + (long long)b * p.H * p.W * p.lda + sub * 4;
+  const TX* xb = p.x + (long long)b * p.H * p.W * p.lda + sub * 4;
   bool rv[3]; int ro[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) { const int yy = y - 1 + r; rv[r] = yy >= 0 && yy < p.H; ro[r] = (rv[r] ? yy : y) * p.W * p.lda; }
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SP p) {
   // the current pixel and every step waits a full memory latency (measured 2 us per pixel step).
   // GroupNorm is always applied (identity scale/shift without in_ss); swish is a template switch.
   auto tap = [&](int r, int xx, bool colok) -> float4 {
-    float4 v = *reinterpret_cast<const float4*>(xb + ro[r] + (colok ? xx : x0) * p.lda);
+    float4 v = St<TX>::ld4(xb + ro[r] + (colok ? xx : x0) * p.lda);
     v = make_float4(fmaf(v.x, s0.x, s1.x), fmaf(v.y, s0.y, s1.y), fmaf(v.z, s0.z, s1.z), fmaf(v.w, s0.w, s1.w));
     if (SW) {
       constexpr float L2E = 1.44269504088896340736f;
@@ -148,13 +151,14 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SP p) {
 
 }  // namespace
 
-extern "C" int smx_conv3x3_smalln_f32(const float* x, int lda, const float* w, const float* bias, float* y, int ldc,
-                                      int B, int H, int W, int Cin, int Cout, int act, const float* in_ss, int in_swish,
-                                      void* stream) {
+namespace {
+template <typename TX>
+int smalln_launch(const TX* x, int lda, const float* w, const float* bias, float* y, int ldc, int B, int H, int W, int Cin, int Cout,
+                  int act, const float* in_ss, int in_swish, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 4 || ldc < Cout) return SMX_EINVAL;
   if ((Cin != 64 && Cin != 128 && Cin != 256) || lda % 4 != 0 || lda < Cin) return SMX_EINVAL;
-  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (in_ss && ((uintptr_t)in_ss & 15))) return SMX_EINVAL;
-  SP p;
+  if (((uintptr_t)x & (4 * sizeof(TX) - 1)) || ((uintptr_t)w & 15) || (in_ss && ((uintptr_t)in_ss & 15))) return SMX_EINVAL;
+  SP<TX> p;
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.in_ss = in_ss; p.in_swish = in_swish; p.lda = lda; p.ldc = ldc;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.act = act;
   if (W % 4 != 0 || (long long)H * W * lda > 2147483647LL) return SMX_EINVAL;
@@ -167,8 +171,8 @@ extern "C" int smx_conv3x3_smalln_f32(const float* x, int lda, const float* w, c
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)blocks), block(256);
   const bool sw = in_ss && in_swish;
-#define SMX_SMALL_S(L, R, S) do { if (Cout <= 3) SMX_LAUNCH((conv3x3_small_kernel<L, 3, R, S>), grid, block, 0, st, p); \
-                                  else SMX_LAUNCH((conv3x3_small_kernel<L, 4, R, S>), grid, block, 0, st, p); } while (0)
+#define SMX_SMALL_S(L, R, S) do { if (Cout <= 3) SMX_LAUNCH((conv3x3_small_kernel<TX, L, 3, R, S>), grid, block, 0, st, p); \
+                                  else SMX_LAUNCH((conv3x3_small_kernel<TX, L, 4, R, S>), grid, block, 0, st, p); } while (0)
 #define SMX_SMALL_R(L, R) do { if (sw) SMX_SMALL_S(L, R, true); else SMX_SMALL_S(L, R, false); } while (0)
 #define SMX_SMALL(L) do { if (run == 16) SMX_SMALL_R(L, 16); else SMX_SMALL_R(L, 4); } while (0)
   if (lpp == 16) SMX_SMALL(16); else if (lpp == 32) SMX_SMALL(32); else SMX_SMALL(64);
@@ -176,4 +180,17 @@ extern "C" int smx_conv3x3_smalln_f32(const float* x, int lda, const float* w, c
 #undef SMX_SMALL_R
 #undef SMX_SMALL_S
   return smx_launch_status();
+}
+}  // namespace
+
+extern "C" int smx_conv3x3_smalln_f32(const float* x, int lda, const float* w, const float* bias, float* y, int ldc,
+                                      int B, int H, int W, int Cin, int Cout, int act, const float* in_ss, int in_swish,
+                                      void* stream) {
+  return smalln_launch<float>(x, lda, w, bias, y, ldc, B, H, W, Cin, Cout, act, in_ss, in_swish, stream);
+}
+/* bf16 input activation, fp32 weights / bias / output (the image head and the RefineFlow outputs stay fp32) */
+extern "C" int smx_conv3x3_smalln_bf16(const void* x, int lda, const float* w, const float* bias, float* y, int ldc,
+                                       int B, int H, int W, int Cin, int Cout, int act, const float* in_ss, int in_swish,
+                                       void* stream) {
+  return smalln_launch<bf16_t>((const bf16_t*)x, lda, w, bias, y, ldc, B, H, W, Cin, Cout, act, in_ss, in_swish, stream);
 }

@@ -5,6 +5,7 @@
 #include <math.h>
 #include "smx.h"
 #include "smx_common.h"
+#include "bf16.h"
 
 namespace {
 
@@ -207,42 +208,47 @@ __global__ void motion_ignore_kernel(const float* __restrict__ flow, uint8_t* __
   }
 }
 
-__global__ void sft_combine_kernel(const float4* __restrict__ dec, const float4* __restrict__ sc, const float4* __restrict__ sh,
-                                   float4* __restrict__ out, float w, long long n4, int c4, int ld4) {
+template <typename T>
+__global__ void sft_combine_kernel(const T* __restrict__ dec, const T* __restrict__ sc, const T* __restrict__ sh,
+                                   T* __restrict__ out, float w, long long n4, int c4, int ld4) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     // dec may be a channel slice of a wider buffer (row stride ld4 float4s); scale / shift / out are dense
     const long long row = i / c4;
-    const float4 d = dec[ld4 == c4 ? i : row * ld4 + (i - row * c4)], a = sc[i], b = sh[i];
-    out[i] = make_float4(d.x + w * (d.x * a.x + b.x), d.y + w * (d.y * a.y + b.y), d.z + w * (d.z * a.z + b.z), d.w + w * (d.w * a.w + b.w));
+    const float4 d = St<T>::ld4(dec + 4 * (ld4 == c4 ? i : row * ld4 + (i - row * c4))), a = St<T>::ld4(sc + 4 * i), b = St<T>::ld4(sh + 4 * i);
+    St<T>::st4(out + 4 * i, make_float4(d.x + w * (d.x * a.x + b.x), d.y + w * (d.y * a.y + b.y), d.z + w * (d.z * a.z + b.z), d.w + w * (d.w * a.w + b.w)));
   }
 }
 
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long n) {
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = a[i] + b[i];
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) St<T>::st(y + i, St<T>::ld(a + i) + St<T>::ld(b + i));
 }
 
-__global__ void copy_slice_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long total, int C) {
+template <typename TI, typename TO>
+__global__ void copy_slice_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ y, int ldy, long long total, int C) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long p = i / C; const int c = (int)(i - p * C);
-    y[p * ldy + c] = x[p * ldx + c];
+    St<TO>::st(y + p * ldy + c, St<TI>::ld(x + p * ldx + c));
   }
 }
 
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int ldy, long long total, int C, int HW) {
+template <typename TO>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, TO* __restrict__ y, int ldy, long long total, int C, int HW) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); const long long p = i / C; const long long b = p / HW; const int r = (int)(p - b * HW);
-    y[p * ldy + c] = x[(b * C + c) * HW + r];
+    St<TO>::st(y + p * ldy + c, x[(b * C + c) * HW + r]);
   }
 }
 
 // tiled transpose: NHWC (ld) -> NCHW, coalesced on both sides through LDS
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int C, int HW) {
+template <typename TI>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const TI* __restrict__ x, int ldx, float* __restrict__ y, int C, int HW) {
   __shared__ float t[32][33];
   const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int j = ty; j < 32; j += 8) {
     const int p = p0 + j, c = c0 + tx;
-    t[j][tx] = (p < HW && c < C) ? x[((long long)b * HW + p) * ldx + c] : 0.f;
+    t[j][tx] = (p < HW && c < C) ? St<TI>::ld(x + ((long long)b * HW + p) * ldx + c) : 0.f;
   }
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
@@ -331,8 +337,16 @@ extern "C" int smx_sft_combine_f32(const float* dec, int ld_dec, const float* sc
                                    int64_t P, int C, void* stream) {
   if (!dec || !scale || !shift || !out || P <= 0 || C <= 0 || C % 4 != 0 || ld_dec < C || ld_dec % 4 != 0) return SMX_EINVAL;
   const long long n4 = (long long)P * (C / 4);
-  SMX_LAUNCH(sft_combine_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dec,
-                     (const float4*)scale, (const float4*)shift, (float4*)out, w, n4, C / 4, ld_dec / 4);
+  SMX_LAUNCH(sft_combine_kernel<float>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, dec, scale, shift, out, w, n4, C / 4, ld_dec / 4);
+  return smx_launch_status();
+}
+
+extern "C" int smx_sft_combine_bf16(const void* dec, int ld_dec, const void* scale, const void* shift, void* out, float w,
+                                    int64_t P, int C, void* stream) {
+  if (!dec || !scale || !shift || !out || P <= 0 || C <= 0 || C % 4 != 0 || ld_dec < C || ld_dec % 4 != 0) return SMX_EINVAL;
+  const long long n4 = (long long)P * (C / 4);
+  SMX_LAUNCH(sft_combine_kernel<bf16_t>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dec, (const bf16_t*)scale,
+             (const bf16_t*)shift, (bf16_t*)out, w, n4, C / 4, ld_dec / 4);
   return smx_launch_status();
 }
 
@@ -363,28 +377,61 @@ extern "C" int smx_fingerprint_f32(const float* x, int64_t n, float* out2, void*
 
 extern "C" int smx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream) {
   if (!a || !b || !y || n <= 0) return SMX_EINVAL;
-  SMX_LAUNCH(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n);
+  SMX_LAUNCH(add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long long)n);
   return smx_launch_status();
 }
 
 extern "C" int smx_copy_slice_f32(const float* x, int ldx, float* y, int ldy, int64_t P, int C, void* stream) {
   if (!x || !y || P <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
   const long long total = (long long)P * C;
-  SMX_LAUNCH(copy_slice_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, C);
+  SMX_LAUNCH((copy_slice_kernel<float, float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, C);
   return smx_launch_status();
 }
 
 extern "C" int smx_nchw_to_nhwc_f32(const float* x, float* y, int ldy, int B, int C, int H, int W, void* stream) {
   if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldy < C) return SMX_EINVAL;
   const long long total = (long long)B * C * H * W;
-  SMX_LAUNCH(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, ldy, total, C, H * W);
+  SMX_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, ldy, total, C, H * W);
   return smx_launch_status();
 }
 
 extern "C" int smx_nhwc_to_nchw_f32(const float* x, int ldx, float* y, int B, int C, int H, int W, void* stream) {
   if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldx < C || B > 65535) return SMX_EINVAL;
   const int HW = H * W;
-  SMX_LAUNCH(nhwc_to_nchw_kernel, dim3(smx_cdiv(HW, 32), smx_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, C, HW);
+  SMX_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(smx_cdiv(HW, 32), smx_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, C, HW);
+  return smx_launch_status();
+}
+
+extern "C" int smx_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+  if (!a || !b || !y || n <= 0) return SMX_EINVAL;
+  SMX_LAUNCH(add_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (long long)n);
+  return smx_launch_status();
+}
+
+// copy / convert a channel slice between storage types: dtype codes 0 = fp32, 1 = bf16
+extern "C" int smx_convert_slice(const void* x, int x_dtype, int ldx, void* y, int y_dtype, int ldy, int64_t P, int C, void* stream) {
+  if (!x || !y || P <= 0 || C <= 0 || ldx < C || ldy < C || (x_dtype & ~1) || (y_dtype & ~1)) return SMX_EINVAL;
+  const long long total = (long long)P * C;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(grid_for(total)), b(256);
+  if (!x_dtype && !y_dtype) SMX_LAUNCH((copy_slice_kernel<float, float>), g, b, 0, st, (const float*)x, ldx, (float*)y, ldy, total, C);
+  else if (!x_dtype) SMX_LAUNCH((copy_slice_kernel<float, bf16_t>), g, b, 0, st, (const float*)x, ldx, (bf16_t*)y, ldy, total, C);
+  else if (!y_dtype) SMX_LAUNCH((copy_slice_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)x, ldx, (float*)y, ldy, total, C);
+  else SMX_LAUNCH((copy_slice_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, total, C);
+  return smx_launch_status();
+}
+
+extern "C" int smx_nchw_to_nhwc_bf16(const float* x, void* y, int ldy, int B, int C, int H, int W, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldy < C) return SMX_EINVAL;
+  const long long total = (long long)B * C * H * W;
+  SMX_LAUNCH(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, ldy, total, C, H * W);
+  return smx_launch_status();
+}
+
+extern "C" int smx_nhwc_to_nchw_bf16(const void* x, int ldx, float* y, int B, int C, int H, int W, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ldx < C || B > 65535) return SMX_EINVAL;
+  const int HW = H * W;
+  SMX_LAUNCH(nhwc_to_nchw_kernel<bf16_t>, dim3(smx_cdiv(HW, 32), smx_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, y, C, HW);
   return smx_launch_status();
 }
 

@@ -6,6 +6,7 @@
 #include <math.h>
 #include "smx.h"
 #include "smx_common.h"
+#include "bf16.h"
 
 namespace {
 
@@ -20,7 +21,8 @@ __device__ __forceinline__ int gn_ppc(int HW) {
 // var = E[x^2] - mean^2 cancels catastrophically in fp32 once |mean| >> std (real checkpoints after a few
 // stacked ResBlocks), whereas per-thread sums shifted by the thread's first value and pairwise Chan merges only
 // ever subtract numbers of similar size.
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int ldx, float* __restrict__ part,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int ldx, float* __restrict__ part,
                                                          int HW, int C, int ppc, int nch) {
   extern __shared__ float red[];                       // [rows][C][3] = {n, mean, M2}
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -28,15 +30,15 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, rows = 256 / cq;
   const int p0 = chunk * ppc, p1 = min(p0 + ppc, HW);
   float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* xb = x + (long long)b * HW * ldx + tx * 4;
+  const T* xb = x + (long long)b * HW * ldx + tx * 4;
   int p = p0 + ty;
   float piv[4] = {0.f, 0.f, 0.f, 0.f};                 // shift: this thread's first value per channel
-  if (p < p1) { const float4 v0 = *reinterpret_cast<const float4*>(xb + (long long)p * ldx); piv[0] = v0.x; piv[1] = v0.y; piv[2] = v0.z; piv[3] = v0.w; }
+  if (p < p1) { const float4 v0 = St<T>::ld4(xb + (long long)p * ldx); piv[0] = v0.x; piv[1] = v0.y; piv[2] = v0.z; piv[3] = v0.w; }
   int cnt = 0;
   for (; p + 3 * rows < p1; p += 4 * rows) {             // 4 independent 16-byte loads in flight per lane
     float4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (long long)(p + u * rows) * ldx);
+    for (int u = 0; u < 4; ++u) v[u] = St<T>::ld4(xb + (long long)(p + u * rows) * ldx);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float d0 = v[u].x - piv[0], d1 = v[u].y - piv[1], d2 = v[u].z - piv[2], d3 = v[u].w - piv[3];
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     cnt += 4;
   }
   for (; p < p1; p += rows) {
-    float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
+    float4 v = St<T>::ld4(xb + (long long)p * ldx);
     const float d0 = v.x - piv[0], d1 = v.y - piv[1], d2 = v.z - piv[2], d3 = v.w - piv[3];
     s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
     q[0] += d0 * d0; q[1] += d1 * d1; q[2] += d2 * d2; q[3] += d3 * d3;
@@ -112,12 +114,13 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 }
 
 // pass 3 -- y = swish(x*scale + shift)
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ y, int ldy,
                                                        const float* __restrict__ ss, long long total4, int HW, int C, int swish) {
   const int cq = C >> 2;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
     const int c4 = (int)(i % cq); const long long pix = i / cq; const int b = (int)(pix / HW);
-    float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c4 * 4);
+    float4 v = St<TI>::ld4(x + pix * ldx + c4 * 4);
     const float4 s0 = *reinterpret_cast<const float4*>(ss + ((long long)b * C + c4 * 4) * 2);
     const float4 s1 = *reinterpret_cast<const float4*>(ss + ((long long)b * C + c4 * 4) * 2 + 4);
     float r[4] = {v.x * s0.x + s0.y, v.y * s0.z + s0.w, v.z * s1.x + s1.y, v.w * s1.z + s1.w};
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = r[e] / (1.f + expf(-r[e]));
     }
-    *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    St<TO>::st4(y + pix * ldy + c4 * 4, make_float4(r[0], r[1], r[2], r[3]));
   }
 }
 
@@ -143,18 +146,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-template <int EPL>   // elements per lane = ceil(E/64)
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <typename TS, int EPL>   // TS: token storage type; elements per lane = ceil(E/64)
+__global__ __launch_bounds__(256) void layernorm_kernel(const TS* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ pos,
-                                                        float* __restrict__ y, float* __restrict__ ypos, int T, int E,
+                                                        TS* __restrict__ y, TS* __restrict__ ypos, int T, int E,
                                                         int npos, float eps) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
-  const float* xr = x + (long long)t * E;
+  const TS* xr = x + (long long)t * E;
   float v[EPL]; float s = 0.f;
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) { int c = lane + 64 * e; v[e] = c < E ? xr[c] : 0.f; s += v[e]; }
+  for (int e = 0; e < EPL; ++e) { int c = lane + 64 * e; v[e] = c < E ? St<TS>::ld(xr + c) : 0.f; s += v[e]; }
   const float mean = wave_sum(s) / E;
   float q = 0.f;
 #pragma unroll
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     int c = lane + 64 * e;
     if (c < E) {
       float o = (v[e] - mean) * rstd * gamma[c] + beta[c];
-      y[(long long)t * E + c] = o;
-      if (ypos) ypos[(long long)t * E + c] = o + pr[c];
+      St<TS>::st(y + (long long)t * E + c, o);
+      if (ypos) St<TS>::st(ypos + (long long)t * E + c, o + pr[c]);
     }
   }
 }
@@ -175,19 +178,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------
 // masked row softmax in place: one wave per row, S <= 64*SPL
 // ---------------------------------------------------------------------------------------
-template <int SPL>
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int ld, long long R, int S, float scale,
+template <typename TS, int SPL>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(TS* __restrict__ s, int ld, long long R, int S, float scale,
                                                            const uint8_t* __restrict__ mask, int rows_per_mask) {
   const int lane = threadIdx.x & 63;
   const long long r = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (r >= R) return;
-  float* row = s + r * ld;
+  TS* row = s + r * ld;
   const uint8_t* mrow = mask ? mask + (r / rows_per_mask) * S : nullptr;
   float v[SPL]; float mx = -INFINITY;
 #pragma unroll
   for (int e = 0; e < SPL; ++e) {
     int c = lane + 64 * e; float t = -INFINITY;
-    if (c < S) { t = row[c] * scale; if (mrow && mrow[c]) t = -INFINITY; }
+    if (c < S) { t = St<TS>::ld(row + c) * scale; if (mrow && mrow[c]) t = -INFINITY; }
     v[e] = t; mx = fmaxf(mx, t);
   }
   mx = wave_max(mx);
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
   for (int e = 0; e < SPL; ++e) { int c = lane + 64 * e; v[e] = c < S ? expf(v[e] - mx) : 0.f; sum += v[e]; }
   sum = wave_sum(sum);
 #pragma unroll
-  for (int e = 0; e < SPL; ++e) { int c = lane + 64 * e; if (c < S) row[c] = v[e] / sum; }
+  for (int e = 0; e < SPL; ++e) { int c = lane + 64 * e; if (c < S) St<TS>::st(row + c, v[e] / sum); }
 }
 
 }  // namespace
@@ -207,9 +210,10 @@ extern "C" int64_t smx_groupnorm_ws_floats(int B, int HW, int C) {
   return (int64_t)B * nch * C * 2 + (int64_t)B * C * 2;
 }
 
-extern "C" int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float* gamma, const float* beta,
-                                            float* y, int ldy, int B, int HW, int C, int groups, float eps,
-                                            int swish, float* ws, void* stream) {
+namespace {
+template <typename T>
+int gn_swish_launch(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, int B, int HW, int C, int groups,
+                    float eps, int swish, float* ws, void* stream) {
   if (!x || !y || !gamma || !beta || !ws || B <= 0 || HW <= 0) return SMX_EINVAL;
   if (C < 4 || C > 1024 || (C & (C - 1)) != 0 || C % groups != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < C || ldy < C) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -217,25 +221,79 @@ extern "C" int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float
   const int nch = (HW + ppc - 1) / ppc;
   float* part = ws; float* ss = ws + (int64_t)B * nch * C * 2;
   const int rows = 256 / (C / 4);
-  SMX_LAUNCH(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 3 * sizeof(float), st, x, ldx, part, HW, C, ppc, nch);
+  SMX_LAUNCH(gn_partial_kernel<T>, dim3(nch, B), dim3(256), (size_t)rows * C * 3 * sizeof(float), st, x, ldx, part, HW, C, ppc, nch);
   SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, gamma, beta, ss, HW, C, groups, nch, ppc, eps);
   const long long total4 = (long long)B * HW * (C / 4);
   int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
-  SMX_LAUNCH(gn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, ss, total4, HW, C, swish);
+  SMX_LAUNCH((gn_apply_kernel<T, T>), dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, ss, total4, HW, C, swish);
   return smx_launch_status();
 }
 
-extern "C" int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float* ss,
-                                       int B, int HW, int C, int groups, float eps, float* ws, void* stream) {
+template <typename T>
+int gn_stats_launch(const T* x, int ldx, const float* gamma, const float* beta, float* ss, int B, int HW, int C, int groups, float eps,
+                    float* ws, void* stream) {
   if (!x || !ss || !gamma || !beta || !ws || B <= 0 || HW <= 0) return SMX_EINVAL;
   if (C < 4 || C > 1024 || (C & (C - 1)) != 0 || C % groups != 0 || ldx % 4 != 0 || ldx < C) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
   const int nch = (HW + ppc - 1) / ppc;
   const int rows = 256 / (C / 4);
-  SMX_LAUNCH(gn_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 3 * sizeof(float), st, x, ldx, ws, HW, C, ppc, nch);
+  SMX_LAUNCH(gn_partial_kernel<T>, dim3(nch, B), dim3(256), (size_t)rows * C * 3 * sizeof(float), st, x, ldx, ws, HW, C, ppc, nch);
   SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, ws, gamma, beta, ss, HW, C, groups, nch, ppc, eps);
   return smx_launch_status();
+}
+
+template <typename T>
+int gn_apply_launch(const T* x, int ldx, const float* ss, T* y, int ldy, int B, int HW, int C, int swish, void* stream) {
+  if (!x || !ss || !y || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < C || ldy < C) return SMX_EINVAL;
+  const long long total4 = (long long)B * HW * (C / 4);
+  int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
+  SMX_LAUNCH((gn_apply_kernel<T, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, ss, total4, HW, C, swish);
+  return smx_launch_status();
+}
+
+template <typename T>
+int layernorm_launch(const T* x, const float* gamma, const float* beta, const float* pos, T* y, T* y_pos, int Tn, int E, int npos,
+                     float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || Tn <= 0 || E <= 0 || E > 512 || (y_pos && (!pos || npos <= 0))) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(smx_cdiv(Tn, 4)), block(256);
+  if (E <= 64) SMX_LAUNCH((layernorm_kernel<T, 1>), grid, block, 0, st, x, gamma, beta, pos, y, y_pos, Tn, E, npos, eps);
+  else if (E <= 256) SMX_LAUNCH((layernorm_kernel<T, 4>), grid, block, 0, st, x, gamma, beta, pos, y, y_pos, Tn, E, npos, eps);
+  else SMX_LAUNCH((layernorm_kernel<T, 8>), grid, block, 0, st, x, gamma, beta, pos, y, y_pos, Tn, E, npos, eps);
+  return smx_launch_status();
+}
+
+template <typename T>
+int softmax_launch(T* s, int ld, int R, int S, float scale, const uint8_t* mask, int rows_per_mask, void* stream) {
+  if (!s || R <= 0 || S <= 0 || S > 1024 || ld < S || (mask && rows_per_mask <= 0)) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(smx_cdiv(R, 4)), block(256);
+  if (S <= 256) SMX_LAUNCH((softmax_rows_kernel<T, 4>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else if (S <= 512) SMX_LAUNCH((softmax_rows_kernel<T, 8>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else SMX_LAUNCH((softmax_rows_kernel<T, 16>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  return smx_launch_status();
+}
+}  // namespace
+
+extern "C" int smx_groupnorm_swish_nhwc_f32(const float* x, int ldx, const float* gamma, const float* beta,
+                                            float* y, int ldy, int B, int HW, int C, int groups, float eps,
+                                            int swish, float* ws, void* stream) {
+  return gn_swish_launch<float>(x, ldx, gamma, beta, y, ldy, B, HW, C, groups, eps, swish, ws, stream);
+}
+extern "C" int smx_groupnorm_swish_nhwc_bf16(const void* x, int ldx, const float* gamma, const float* beta,
+                                             void* y, int ldy, int B, int HW, int C, int groups, float eps,
+                                             int swish, float* ws, void* stream) {
+  return gn_swish_launch<bf16_t>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, B, HW, C, groups, eps, swish, ws, stream);
+}
+
+extern "C" int smx_groupnorm_stats_f32(const float* x, int ldx, const float* gamma, const float* beta, float* ss,
+                                       int B, int HW, int C, int groups, float eps, float* ws, void* stream) {
+  return gn_stats_launch<float>(x, ldx, gamma, beta, ss, B, HW, C, groups, eps, ws, stream);
+}
+extern "C" int smx_groupnorm_stats_bf16(const void* x, int ldx, const float* gamma, const float* beta, float* ss,
+                                        int B, int HW, int C, int groups, float eps, float* ws, void* stream) {
+  return gn_stats_launch<bf16_t>((const bf16_t*)x, ldx, gamma, beta, ss, B, HW, C, groups, eps, ws, stream);
 }
 
 extern "C" int smx_groupnorm_finalize_f32(const float* part, const float* gamma, const float* beta, float* ss,
@@ -248,31 +306,27 @@ extern "C" int smx_groupnorm_finalize_f32(const float* part, const float* gamma,
 
 extern "C" int smx_groupnorm_apply_f32(const float* x, int ldx, const float* ss, float* y, int ldy, int B, int HW, int C,
                                        int swish, void* stream) {
-  if (!x || !ss || !y || B <= 0 || HW <= 0 || C < 4 || C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < C || ldy < C) return SMX_EINVAL;
-  const long long total4 = (long long)B * HW * (C / 4);
-  int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
-  SMX_LAUNCH(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, ss, total4, HW, C, swish);
-  return smx_launch_status();
+  return gn_apply_launch<float>(x, ldx, ss, y, ldy, B, HW, C, swish, stream);
+}
+extern "C" int smx_groupnorm_apply_bf16(const void* x, int ldx, const float* ss, void* y, int ldy, int B, int HW, int C,
+                                        int swish, void* stream) {
+  return gn_apply_launch<bf16_t>((const bf16_t*)x, ldx, ss, (bf16_t*)y, ldy, B, HW, C, swish, stream);
 }
 
 extern "C" int smx_layernorm_pos_f32(const float* x, const float* gamma, const float* beta, const float* pos,
                                      float* y, float* y_pos, int T, int E, int npos, float eps, void* stream) {
-  if (!x || !y || !gamma || !beta || T <= 0 || E <= 0 || E > 512 || (y_pos && (!pos || npos <= 0))) return SMX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(smx_cdiv(T, 4)), block(256);
-  if (E <= 64) SMX_LAUNCH(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
-  else if (E <= 256) SMX_LAUNCH(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
-  else SMX_LAUNCH(layernorm_kernel<8>, grid, block, 0, st, x, gamma, beta, pos, y, y_pos, T, E, npos, eps);
-  return smx_launch_status();
+  return layernorm_launch<float>(x, gamma, beta, pos, y, y_pos, T, E, npos, eps, stream);
+}
+extern "C" int smx_layernorm_pos_bf16(const void* x, const float* gamma, const float* beta, const float* pos,
+                                      void* y, void* y_pos, int T, int E, int npos, float eps, void* stream) {
+  return layernorm_launch<bf16_t>((const bf16_t*)x, gamma, beta, pos, (bf16_t*)y, (bf16_t*)y_pos, T, E, npos, eps, stream);
 }
 
 extern "C" int smx_softmax_rows_f32(float* s, int ld, int R, int S, float scale, const uint8_t* mask,
                                     int rows_per_mask, void* stream) {
-  if (!s || R <= 0 || S <= 0 || S > 1024 || ld < S || (mask && rows_per_mask <= 0)) return SMX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(smx_cdiv(R, 4)), block(256);
-  if (S <= 256) SMX_LAUNCH(softmax_rows_kernel<4>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
-  else if (S <= 512) SMX_LAUNCH(softmax_rows_kernel<8>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
-  else SMX_LAUNCH(softmax_rows_kernel<16>, grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
-  return smx_launch_status();
+  return softmax_launch<float>(s, ld, R, S, scale, mask, rows_per_mask, stream);
+}
+extern "C" int smx_softmax_rows_bf16(void* s, int ld, int R, int S, float scale, const uint8_t* mask,
+                                     int rows_per_mask, void* stream) {
+  return softmax_launch<bf16_t>((bf16_t*)s, ld, R, S, scale, mask, rows_per_mask, stream);
 }

@@ -70,9 +70,11 @@ def _numel(shape):
     return n
 
 
-def cache_numel() -> int:
-    """7,077,888 encoder elements (28.3 MB fp32) + 12,288 (down-sampled source) + 2 x 90 keypoint floats + 1."""
-    return sum(_numel(CACHE_SHAPES[s]) for s in CACHE_ORDER) + _TAIL
+def cache_numel(dtype=torch.float32) -> int:
+    """floats in the packed state: 7,077,888 encoder elements (28.3 MB fp32; bf16 taps travel as raw bits, two per
+    float: 14.2 MB) + 12,288 (down-sampled source) + 2 x 90 keypoint floats + 1."""
+    n = sum(_numel(CACHE_SHAPES[s]) for s in CACHE_ORDER)
+    return (n // 2 if dtype == torch.bfloat16 else n) + _TAIL
 
 
 class SourceState:
@@ -88,19 +90,25 @@ def pack_source_state(cache, src64, kp_source, kp_initial, scale) -> torch.Tenso
     """flatten the frame-invariant state into ONE buffer (one collective, not ten)."""
     dev = src64.device
     kp0 = kp_initial if kp_initial is not None else {"value": torch.zeros((1, 15, 2), device=dev), "jacobian": torch.zeros((1, 15, 2, 2), device=dev)}
-    return torch.cat([cache.feats[s].reshape(-1) for s in CACHE_ORDER] +
+    bits = lambda t: t.reshape(-1).view(torch.float32) if t.dtype == torch.bfloat16 else t.reshape(-1)   # noqa: E731  (bf16 taps: raw bits)
+    return torch.cat([bits(cache.feats[s]) for s in CACHE_ORDER] +
                      [src64.reshape(-1), kp_source["value"].reshape(-1), kp_source["jacobian"].reshape(-1),
                       kp0["value"].reshape(-1), kp0["jacobian"].reshape(-1),
                       torch.full((1,), float("nan") if scale is None else float(scale), device=dev, dtype=torch.float32)])
 
 
-def unpack_source_state(flat: torch.Tensor) -> SourceState:
+def unpack_source_state(flat: torch.Tensor, dtype=torch.float32) -> SourceState:
+    """dtype: storage type of the encoder taps inside `flat` (the receiving engine's activation type)."""
     from .engine_netg import SourceCache
     feats, off = {}, 0
     for s in CACHE_ORDER:
         n = _numel(CACHE_SHAPES[s])
-        feats[s] = flat[off:off + n].view(CACHE_SHAPES[s])
-        off += n
+        if dtype == torch.bfloat16:
+            feats[s] = flat[off:off + n // 2].view(torch.bfloat16).view(CACHE_SHAPES[s])
+            off += n // 2
+        else:
+            feats[s] = flat[off:off + n].view(CACHE_SHAPES[s])
+            off += n
     src64 = flat[off:off + _SRC64].view(1, 64, 64, 3)
     off += _SRC64
     kps = []
@@ -112,11 +120,11 @@ def unpack_source_state(flat: torch.Tensor) -> SourceState:
     return SourceState(SourceCache(feats, 1), src64, kps[0], kps[1], None if scale != scale else scale, flat)
 
 
-def broadcast_flat(flat_or_none, device, src=0, group=None):
+def broadcast_flat(flat_or_none, device, src=0, group=None, dtype=torch.float32):
     """rank `src` passes the packed state, the others None; everyone returns the broadcast buffer.
     torch.distributed broadcast == RCCL over xGMI on the GPU box (gloo in the CPU tests)."""
     import torch.distributed as dist
-    buf = flat_or_none if dist.get_rank() == src else torch.empty(cache_numel(), device=device, dtype=torch.float32)
+    buf = flat_or_none if dist.get_rank() == src else torch.empty(cache_numel(dtype), device=device, dtype=torch.float32)
     dist.broadcast(buf, src=src, group=group)
     return buf
 
@@ -145,7 +153,8 @@ def broadcast_source_state(net_g, motion_estimator, source=None, initial_frame=N
         device = flat.device
     if device is None:
         device = next(net_g.parameters()).device
-    return unpack_source_state(broadcast_flat(flat, device, src, group))
+    adt = net_g.engine().adt
+    return unpack_source_state(broadcast_flat(flat, device, src, group, adt), adt)
 
 
 def render_frames(state: SourceState, frames, net_g, motion_estimator, relative=True, adapt_movement_scale=True,

@@ -29,7 +29,11 @@ def _fold_bn(P, pre):
 
 
 class HourglassPlan:
-    def __init__(self, P, pre, block_expansion, in_features, num_blocks, max_features):
+    def __init__(self, P, pre, block_expansion, in_features, num_blocks, max_features, mfma16=False):
+        # mfma16 (configs[2]): the hourglass convolutions run on the bf16 MFMA (fp32-stored activations converted while
+        # staging, bf16 weights, fp32 accumulate and fp32 outputs); the 7x7 keypoint / jacobian / mask / occlusion heads and
+        # everything downstream of them (softmax expectation, sparse motions, flow blend) stay fp32
+        self.m16 = mfma16
         self.down_ch, self.up_ch, self.out_filters = hourglass_channels(block_expansion, in_features, num_blocks, max_features)
         self.nb = num_blocks
         self.in_features = in_features
@@ -62,7 +66,7 @@ class HourglassPlan:
         cur = final_buf[..., self.up_ch[-1][1]:self.up_ch[-1][1] + self.in_features]
         r = res
         for i in range(nb):
-            y = ops.conv(cur, self.down[i], act=ACT_RELU)
+            y = ops.conv(cur, self.down[i], act=ACT_RELU, mfma16=self.m16, out_dtype=torch.float32)
             r //= 2
             if i < nb - 1:
                 j = nb - 2 - i
@@ -73,7 +77,7 @@ class HourglassPlan:
         # decoder
         out = cur
         for j in range(nb):
-            ops.conv(out, self.up[j], out=cats[j][..., :self.up_ch[j][1]], up2=True, act=ACT_RELU)
+            ops.conv(out, self.up[j], out=cats[j][..., :self.up_ch[j][1]], up2=True, act=ACT_RELU, mfma16=self.m16)
             out = cats[j]
         return out
 
@@ -81,10 +85,10 @@ class HourglassPlan:
 class KPEngine:
     """packed weights + plan of KPDetector (rows A1-A3); `pre` = parameter-name prefix ('' for the standalone arch)."""
 
-    def __init__(self, P, pre, common, kp):
+    def __init__(self, P, pre, common, kp, mfma16=False):
         self.num_kp = common["num_kp"]
         self.temperature = kp["temperature"]
-        self.hg = HourglassPlan(P, pre + "predictor", kp["block_expansion"], common["num_channels"], kp["num_blocks"], kp["max_features"])
+        self.hg = HourglassPlan(P, pre + "predictor", kp["block_expansion"], common["num_channels"], kp["num_blocks"], kp["max_features"], mfma16)
         # kp (15) and jacobian (60) heads share their input and geometry (7x7 valid): one conv with
         # N = 60 + 15 + 1 pad -> [jac | kp | 0]; 76 keeps the float4 reads of the jacobian maps aligned
         cin = P[pre + "kp.weight"].shape[1]
@@ -110,10 +114,10 @@ class KPEngine:
 class DenseEngine:
     """packed weights + plan of DenseMotionNetwork (rows A4-A6b)."""
 
-    def __init__(self, P, pre, common, dense):
+    def __init__(self, P, pre, common, dense, mfma16=False):
         self.num_kp = common["num_kp"]
         self.hg = HourglassPlan(P, pre + "hourglass", dense["block_expansion"],
-                                (self.num_kp + 1) * (common["num_channels"] + 1), dense["num_blocks"], dense["max_features"])
+                                (self.num_kp + 1) * (common["num_channels"] + 1), dense["num_blocks"], dense["max_features"], mfma16)
         # mask (16) and occlusion (1) heads: one stacked 7x7 conv, N = 17
         self.mo_conv = Conv.cat([Conv.from_torch(P[pre + "mask.weight"], P[pre + "mask.bias"]),
                                  Conv.from_torch(P[pre + "occlusion.weight"], P[pre + "occlusion.bias"])])
@@ -143,9 +147,9 @@ class DenseEngine:
 class MotionEngine:
     """Motion_Estimator_keypoint_aware = KPDetector + DenseMotionNetwork."""
 
-    def __init__(self, P, common, dense, kp):
-        self.kp = KPEngine(P, "kp_detector.", common, kp)
-        self.dm = DenseEngine(P, "dense_motion_network.", common, dense)
+    def __init__(self, P, common, dense, kp, mfma16=False):
+        self.kp = KPEngine(P, "kp_detector.", common, kp, mfma16)
+        self.dm = DenseEngine(P, "dense_motion_network.", common, dense, mfma16)
         self.num_kp = common["num_kp"]
 
     def estimate_kp(self, image_nchw):

@@ -63,14 +63,14 @@ class _Attn:
         N = H * W
         hn = ops.groupnorm(x, *self.n, swish=False)
         qk = ops.conv(hn, self.qk)                                            # [B,H,W,2C]
-        vt = torch.empty((B, Cc, N), device=x.device, dtype=torch.float32)    # V^T = Wv . hn^T + bv
+        vt = torch.empty((B, Cc, N), device=x.device, dtype=x.dtype)          # V^T = Wv . hn^T + bv
         ops.gemm_nt(self.wv, hn, vt, M=Cc, N=N, K=Cc, lda=Cc, ldb=Cc, ldc=N, nb0=B, bt_bs=(N * Cc, 0),
                     c_bs=(Cc * N, 0), bias=self.bv, bias_per_row=True)
-        s = torch.empty((B, N, N), device=x.device, dtype=torch.float32)
+        s = torch.empty((B, N, N), device=x.device, dtype=x.dtype)
         ops.gemm_nt(qk, qk, s, M=N, N=N, K=Cc, lda=2 * Cc, ldb=2 * Cc, ldc=N, nb0=B, a_bs=(N * 2 * Cc, 0),
                     bt_bs=(N * 2 * Cc, 0), c_bs=(N * N, 0), bt_off=Cc)
         ops.softmax_rows(s, N, float(int(Cc) ** (-0.5)))
-        h = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+        h = torch.empty((B, H, W, Cc), device=x.device, dtype=x.dtype)
         ops.gemm_nt(s, vt, h, M=N, N=Cc, K=N, lda=N, ldb=N, ldc=Cc, nb0=B, a_bs=(N * N, 0), bt_bs=(Cc * N, 0),
                     c_bs=(N * Cc, 0))
         return ops.conv(h, self.proj, res=x)
@@ -80,7 +80,7 @@ class _Transformer:
     """TransformerLayer archs/appmotioncodebook_arch.py:65-126 with nn.MultiheadAttention
     restated: codebook K / V^T precomputed for all rows."""
 
-    def __init__(self, P, pre, E, nhead, codebook):
+    def __init__(self, P, pre, E, nhead, codebook, adt=torch.float32):
         self.E, self.H, self.dh = E, nhead, E // nhead
         W, b = P[pre + ".self_attn.in_proj_weight"], P[pre + ".self_attn.in_proj_bias"]
         self.s_qk = Conv(W[:2 * E].contiguous(), b[:2 * E].contiguous(), 1, 1, E, 2 * E)
@@ -94,6 +94,8 @@ class _Transformer:
         # [Kc | Vc] = cb [Wk;Wv]^T + [bk;bv]  -> [Kc, 2E]   (input independent, all codebook rows)
         self.ckv = torch.empty((Kc, 2 * E), device=codebook.device, dtype=torch.float32)
         ops.gemm_nt(codebook, W[E:].contiguous(), self.ckv, M=Kc, N=2 * E, K=E, lda=E, ldb=E, ldc=2 * E, bias=b[E:].contiguous())
+        if adt != torch.float32:               # pack time, once: the projected codebook in the activation storage type
+            self.ckv = self.ckv.to(adt)
         self.n1 = (P[pre + ".norm1.weight"], P[pre + ".norm1.bias"])
         self.n2 = (P[pre + ".norm2.weight"], P[pre + ".norm2.bias"])
         self.n3 = (P[pre + ".norm3.weight"], P[pre + ".norm3.bias"])
@@ -130,8 +132,13 @@ class SourceCache:
 
 
 class NetGEngine:
-    def __init__(self, P, cfg):
+    def __init__(self, P, cfg, dtype=torch.float32):
+        """dtype: activation storage / MFMA input type -- torch.float32 (BASELINE configs[1]) or torch.bfloat16 (configs[2]:
+        bf16 NHWC activations and weights on v_mfma_f32_32x32x16_bf16 with fp32 accumulate; flows, occlusion maps, keypoint
+        heatmaps, normalisation statistics, softmax and the output image stay fp32)."""
         self.cfg = cfg
+        self.adt = dtype
+        self.is16 = dtype == torch.bfloat16
         nf, ch_mult, rb = cfg["nf"], tuple(cfg["ch_mult"]), cfg["res_blocks"]
         attn = tuple(cfg["attn_resolutions"])
         eplan, _ = encoder_plan(nf, ch_mult, rb, cfg["img_size"], attn)
@@ -146,8 +153,8 @@ class NetGEngine:
         self.cb_app = P["quantize_app.embedding.weight"].contiguous()
         self.pos_motion = P["position_emb_motion"].contiguous()
         self.pos_app = P["position_emb_app"].contiguous()
-        self.motion_blocks = [_Transformer(P, f"motion_block.{l}", Em, self.nhead, self.cb_motion) for l in range(cfg["n_layers_motion"])]
-        self.app_blocks = [_Transformer(P, f"app_block.{l}", Ea, self.nhead, self.cb_app) for l in range(cfg["n_layers_app"])]
+        self.motion_blocks = [_Transformer(P, f"motion_block.{l}", Em, self.nhead, self.cb_motion, dtype) for l in range(cfg["n_layers_motion"])]
+        self.app_blocks = [_Transformer(P, f"app_block.{l}", Ea, self.nhead, self.cb_app, dtype) for l in range(cfg["n_layers_app"])]
         cv = lambda n: Conv.from_torch(P[n + ".weight"], P[n + ".bias"])
         self.motion_emb0 = cv("motion_emb.0")
         self.motion_emb1 = cv("motion_emb.1.conv")
@@ -221,7 +228,8 @@ class NetGEngine:
         i = 0
         while i < len(kinds):
             if kinds[i] == "gn" and i + 1 < len(kinds) and kinds[i + 1] == "conv":
-                x = ops.conv(x, blocks[i + 1], in_ss=ops.groupnorm_stats(x, blocks[i][0], blocks[i][1]), in_swish=False)
+                x = ops.conv(x, blocks[i + 1], in_ss=ops.groupnorm_stats(x, blocks[i][0], blocks[i][1]), in_swish=False,
+                             out_dtype=torch.float32 if blocks[i + 1].cout <= 4 else None)      # the image head stays fp32
                 i += 2
             else:
                 x = self._run(kinds[i], blocks[i], x, None if out_for is None else out_for(i, x))
@@ -231,24 +239,30 @@ class NetGEngine:
         return x
 
     # ---- A8 encoder: frame-invariant -------------------------------------------------------
-    def encode_source(self, x_nchw):
+    def _image_in(self, x_nchw):
+        """NCHW fp32 image -> NHWC fp32; blocks[0] (3 -> nf) reads it in fp32 either way (converted while staging on the bf16 path)."""
         x = ops.nchw_to_nhwc(x_nchw)
+        return ops.conv(x, self.enc[0], want_stats=True, mfma16=self.is16)
+
+    def encode_source(self, x_nchw):
+        x = self._image_in(x_nchw)
         feats = {}
 
         def tap(i, t):
             if i in self.taps_after:
                 feats[self.taps_after[i]] = t
             return t
-        x = self._run_seq(self.enc_kinds, self.enc, x, tap)
+        x = self._run_seq(self.enc_kinds[1:], self.enc[1:], x, lambda i, t: tap(i + 1, t))
         feats[32] = x
         return SourceCache(feats, x_nchw.shape[0])
 
     def encode_driving(self, x_nchw):
         """taps after encoder blocks 2, 5, 8, 11 keyed by size (appmotioncodebook_arch.py:364-371), NHWC."""
-        x = ops.nchw_to_nhwc(x_nchw)
+        x = self._image_in(x_nchw)
         out = {}
         for i, (kind, blk) in enumerate(zip(self.enc_kinds, self.enc)):
-            x = self._run(kind, blk, x)
+            if i > 0:
+                x = self._run(kind, blk, x)
             if i in (2, 5, 8, 11):
                 out[str(x.shape[1])] = x
             if i == 11:
@@ -263,9 +277,9 @@ class NetGEngine:
     def _motion_comp(self, flow_res, mq, warp0, s):
         B = flow_res.shape[0]
         Em = self.Em
-        m1 = ops.conv(flow_res, self.motion_emb0)                             # [B,64,64,32]
+        m1 = ops.conv(flow_res, self.motion_emb0, mfma16=self.is16)           # [B,64,64,32]  (fp32 flow in)
         m2 = ops.conv(m1, self.motion_emb1, stride=2, pad=(0, 0), out_hw=(32, 32))
-        qin = torch.empty((B, 32, 32, 2 * Em), device=flow_res.device, dtype=torch.float32)
+        qin = torch.empty((B, 32, 32, 2 * Em), device=flow_res.device, dtype=self.adt)
         self.motion_emb2(m2, out=qin[..., :Em])
         ops.copy_slice(mq, qin[..., Em:])
         q = ops.conv(qin, self.mq2)                                           # tokens [B,1024,32]
@@ -273,12 +287,12 @@ class NetGEngine:
         for blk in self.motion_blocks:
             q = blk(q, S, self.pos_motion)
         motion_f = ops.resize(q, 64, 64)
-        cf = torch.empty((B, 64, 64, 160), device=q.device, dtype=torch.float32)
+        cf = torch.empty((B, 64, 64, 160), device=q.device, dtype=self.adt)
         cor = ops.conv(motion_f, self.bme["convc1"], act=ACT_RELU)
         ops.conv(cor, self.bme["convc2"], out=cf[..., :96], act=ACT_RELU)
-        flo = ops.conv(flow_res, self.bme["convf1"], act=ACT_RELU)            # 7x7 pad 3
+        flo = ops.conv(flow_res, self.bme["convf1"], act=ACT_RELU, mfma16=self.is16)   # 7x7 pad 3 (fp32 flow in)
         ops.conv(flo, self.bme["convf2"], out=cf[..., 96:], act=ACT_RELU)
-        inp = torch.empty((B, 64, 64, 256), device=q.device, dtype=torch.float32)
+        inp = torch.empty((B, 64, 64, 256), device=q.device, dtype=self.adt)
         ops.conv(cf, self.bme["conv"], out=inp[..., :126], act=ACT_RELU)
         ops.copy_slice(flow_res, inp[..., 126:128])
         if s > 128:
@@ -292,7 +306,7 @@ class NetGEngine:
                 wf = ops.resize(wf, 64, 64)
         ops.conv(wf, self.ref_c1, out=inp[..., 128:], act=ACT_RELU)
         h = ops.conv(inp, self.ref_h, act=ACT_RELU)                           # [B,64,64,256] = [conv1 | convo1]
-        return ops.conv(h, self.ref_out)                                      # [B,64,64,3] = [dflow(2) | docc(1)]
+        return ops.conv(h, self.ref_out, out_dtype=torch.float32)             # [B,64,64,3] = [dflow(2) | docc(1)], always fp32
 
     # ---- A10 ------------------------------------------------------------------------------
     def _app_comp(self, feat, m_com, s, out=None):
@@ -315,7 +329,7 @@ class NetGEngine:
         warp0 = ops.warp(feat, flow)
         wsrc = warp0 if s == 32 else ops.resize(warp0, 32, 32)
         B = flow.shape[0]
-        mqin = torch.empty((B, 32, 32, 2 * self.Em), device=flow.device, dtype=torch.float32)
+        mqin = torch.empty((B, 32, 32, 2 * self.Em), device=flow.device, dtype=self.adt)
         ops.conv(wsrc, self.wsrc[s], out=mqin[..., :self.Em], act=ACT_RELU)
         ops.copy_slice(st["kp_feat"], mqin[..., self.Em:])
         mq = ops.conv(mqin, self.mq1)
@@ -348,7 +362,7 @@ class NetGEngine:
         """cache: SourceCache; deformation [B,64,64,2]; occ64 [B,64,64]; heat [B,64,64,15] NHWC.
         -> state dict with NHWC 'out' [B,256,256,3] and the intermediate lists."""
         st = {"flows": [deformation.contiguous()], "occ": [occ64.contiguous()], "res": [], "before": [], "comp": []}
-        st["kp_feat"] = ops.conv(ops.resize(heat_nhwc, 32, 32), self.kp_enc, act=ACT_RELU)
+        st["kp_feat"] = ops.conv(ops.resize(heat_nhwc, 32, 32), self.kp_enc, act=ACT_RELU, mfma16=self.is16)   # fp32 heatmaps in
         x = self._one_scale(st, cache.feats[32], 32, True)
         st["lq"] = x
         cats = {}
@@ -357,7 +371,7 @@ class NetGEngine:
             if i in self.fuse_after and w > 0 and self.gen_kinds[i] == "res":
                 B, H, W_, _ = x_in.shape
                 C = self.gen[i].c2.cout
-                cats[i] = torch.empty((B, H, W_, 2 * C), device=x_in.device, dtype=torch.float32)
+                cats[i] = torch.empty((B, H, W_, 2 * C), device=x_in.device, dtype=self.adt)
                 return cats[i][..., C:]
             return None
 
@@ -367,7 +381,7 @@ class NetGEngine:
                 cat = cats.pop(i, None)
                 if cat is None:                                               # producer was not a ResBlock: copy
                     C = t.shape[-1]
-                    cat = torch.empty(t.shape[:-1] + (2 * C,), device=t.device, dtype=torch.float32)
+                    cat = torch.empty(t.shape[:-1] + (2 * C,), device=t.device, dtype=self.adt)
                     ops.copy_slice(t, cat[..., C:])
                 C = cat.shape[-1] // 2
                 self._one_scale(st, cache.feats[s], s, False, out=cat[..., :C])

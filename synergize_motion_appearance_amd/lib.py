@@ -98,6 +98,22 @@ SIGNATURES = {
     "smx_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "smx_nhwc_to_nchw_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "smx_to_uint8_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
+    "smx_groupnorm_swish_nhwc_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
+    "smx_groupnorm_stats_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
+    "smx_groupnorm_apply_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_layernorm_pos_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "smx_attention_bf16": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "smx_softmax_rows_bf16": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
+    "smx_warp_nhwc_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_resize_bilinear_ac_nhwc_bf16": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_resize_taps_gather_bf16": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_resize_taps_combine_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_conv3x3_smalln_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "smx_sft_combine_bf16": (_i, [_p, _i, _p, _p, _p, _f, _i64, _i, _p]),
+    "smx_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
+    "smx_convert_slice": (_i, [_p, _i, _i, _p, _i, _i, _i64, _i, _p]),
+    "smx_nchw_to_nhwc_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_nhwc_to_nchw_bf16": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "smx_vq_nearest_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

@@ -49,18 +49,40 @@ def _timed(name, meta, fn, *args):
     return rc
 
 
-def _dev(t, name="tensor"):
+BF16 = torch.bfloat16
+
+
+def _dev(t, name="tensor", dtypes=(torch.float32,)):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise L.SmxError(f"{name}: the HIP path needs a device tensor (got {type(t).__name__} on "
                          f"{getattr(t, 'device', '?')}); there is no CPU fallback")
-    if t.dtype != torch.float32:
-        raise L.SmxError(f"{name}: fp32 expected, got {t.dtype}")
+    if t.dtype not in dtypes:
+        raise L.SmxError(f"{name}: {' / '.join(str(d) for d in dtypes)} expected, got {t.dtype}")
     return t
 
 
+_ANY = (torch.float32, torch.bfloat16)
+
+
+def _sfx(t):
+    """entry-point suffix for the storage type of an activation (configs[1] fp32 / configs[2] bf16)."""
+    return "_bf16" if t.dtype == BF16 else "_f32"
+
+
+def _fn(base, t):
+    return getattr(L.load(), base + _sfx(t))
+
+
+def _same(name, *ts):
+    d = ts[0].dtype
+    for t in ts[1:]:
+        if t is not None and t.dtype != d:
+            raise L.SmxError(f"{name}: operands must share one storage type ({d} vs {t.dtype})")
+
+
 def _pix(t, name="tensor"):
-    """(ptr, ld) of an NHWC tensor or channel-slice view: last stride 1, dense pixels."""
-    _dev(t, name)
+    """(ptr, ld) of an NHWC tensor or channel-slice view (fp32 or bf16): last stride 1, dense pixels."""
+    _dev(t, name, _ANY)
     if t.dim() < 2 or t.stride(-1) != 1:
         raise L.SmxError(f"{name}: innermost (channel) stride must be 1")
     ld = t.stride(-2) if t.shape[-2] > 1 else max(t.shape[-1], t.stride(-2))
@@ -91,11 +113,19 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
         self._u = None
+        self._w16 = None
+
+    @property
+    def w16(self):
+        """bf16 copy of the packed weights (round-to-nearest-even), built once per layer for the bf16 MFMA path."""
+        if self._w16 is None:
+            self._w16 = self.w.to(BF16).contiguous()
+        return self._w16
 
     def winograd_u(self):
         """U = G g G^T for F(2x2,3x3), fragment-ordered [16][ceil(Cout/32)][Cin/8][64 lanes][4]
@@ -140,8 +170,54 @@ def gemm_raw(**kw):
     L.check(_timed("gemm_conv", meta, L.load().smx_gemm_conv_f32, C.byref(d), _stream()), "smx_gemm_conv_f32")
 
 
+def gemm16_raw(**kw):
+    d = L.Gemm16Desc()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    meta = {"flops": 2.0 * d.M * d.N * d.K * d.nb0 * d.nb1, "M": d.M, "N": d.N, "K": d.K, "nb": d.nb0 * d.nb1,
+            "k": d.kh, "bf16": 1} if _PROFILE is not None else None
+    L.check(_timed("gemm_bf16", meta, L.load().smx_gemm_conv_bf16, C.byref(d), _stream()), "smx_gemm_conv_bf16")
+
+
+def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss, in_swish, out_dtype):
+    """bf16-MFMA form of conv(): x bf16 (or fp32, converted while staging), weights bf16, fp32 accumulate."""
+    B, H, W, Cin = x.shape
+    if out is None:
+        od = out_dtype or BF16
+        shape = (B, Ho * d2s[0], Wo * d2s[0], d2s[1]) if d2s else (B, Ho, Wo, cv.cout)
+        out = torch.empty(shape, device=x.device, dtype=od)
+    a_ptr, lda = _pix(x, "conv input")
+    c_ptr, ldc = _pix(out, "conv output")
+    r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
+    if (SMALLN and tile == 0 and x.dtype == BF16 and out.dtype == torch.float32 and cv.kh == 3 and cv.kw == 3 and stride == 1
+            and (pt, pl) == (1, 1) and not d2s and not up2 and res is None and cv.cout <= 4 and Cin in (64, 128, 256)
+            and (Ho, Wo) == (H, W) and W % 4 == 0 and lda % 4 == 0 and a_ptr % 8 == 0):
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 0.0, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin,
+                "nb": 1, "k": 3, "bytes": B * Ho * Wo * (2.0 * Cin + 4.0 * cv.cout)} if _PROFILE is not None else None
+        L.check(_timed("conv_small_n", meta, L.load().smx_conv3x3_smalln_bf16, a_ptr, lda, _dev(cv.w).data_ptr(),
+                       None if cv.b is None else cv.b.data_ptr(), c_ptr, ldc, B, H, W, Cin, cv.cout, act,
+                       None if in_ss is None else in_ss.data_ptr(), int(in_swish), _stream()), "smx_conv3x3_smalln_bf16")
+        return out
+    M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
+    ksplit, ws = 1, None
+    if not d2s and K >= 2048:
+        blocks = ((M + 63) // 64) * ((cv.cout + 63) // 64)
+        if blocks < 256:
+            ksplit = max(1, min(K // 64 // 8, (1024 + blocks - 1) // blocks, 32))
+            if ksplit > 1:
+                ws = torch.empty((ksplit, M, cv.cout), device=x.device, dtype=torch.float32)
+    gemm16_raw(a=a_ptr, bt=cv.w16.data_ptr(), c=c_ptr, bias=None if cv.b is None else cv.b.data_ptr(),
+               res=r_ptr, in_ss=None if in_ss is None else in_ss.data_ptr(), in_swish=int(in_swish), nb0=1, nb1=1,
+               M=M, N=cv.cout, K=K, lda=lda, ldb=cv.w16.shape[1], ldc=ldc, ldres=ldr, Hin=H, Win=W, Cin=Cin, Ho=Ho, Wo=Wo,
+               kh=cv.kh, kw=cv.kw, stride=stride, pad_t=pt, pad_l=pl, up2=int(up2), act=act, alpha=1.0,
+               d2s_p=d2s[0] if d2s else 0, d2s_c=d2s[1] if d2s else 0, tile=tile, ksplit=ksplit,
+               ws=None if ws is None else ws.data_ptr(), a_f32=int(x.dtype == torch.float32), c_f32=int(out.dtype == torch.float32),
+               res_f32=int(res is not None and res.dtype == torch.float32))
+    return out
+
+
 def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None,
-         d2s=None, tile=0, in_ss=None, in_swish=False, want_stats=False):
+         d2s=None, tile=0, in_ss=None, in_swish=False, want_stats=False, mfma16=False, out_dtype=None):
     """y = act(conv(x) + bias) [+ res].  x [B,H,W,Cin] (slice ok) -> out [B,Ho,Wo,Cout] (slice ok).
     pad: (top, left) (default (kh//2, kw//2)); out_hw for asymmetric pads / strides.
     d2s=(p, C): un-patchify store, out is [B,Ho*p,Wo*p,C].
@@ -158,6 +234,9 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
         Wo = (We + 2 * pl - cv.kw) // stride + 1
     else:
         Ho, Wo = out_hw
+    if x.dtype == BF16 or mfma16 or (out is not None and out.dtype == BF16) or (res is not None and res.dtype == BF16):
+        # configs[2]: bf16 storage and/or bf16 MFMA (mfma16: fp32-stored input converted while staging)
+        return _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss, in_swish, out_dtype)
     if out is None:
         if d2s:
             out = torch.empty((B, Ho * d2s[0], Wo * d2s[0], d2s[1]), device=x.device, dtype=torch.float32)
@@ -216,6 +295,20 @@ def gemm_nt(a, bt, c, *, M, N, K, lda, ldb, ldc, nb0=1, nb1=1, a_bs=(0, 0), bt_b
             bias=None, bias_per_row=False, alpha=1.0, act=ACT_NONE, res=None, ldres=0, res_bs=(0, 0),
             a_off=0, bt_off=0, c_off=0, tile=0):
     """batched C[g] = act(alpha * A[g] @ Bt[g]^T + bias) (+res); offsets/strides in elements."""
+    if a.dtype == BF16 or bt.dtype == BF16:
+        if bt.dtype != BF16:
+            raise L.SmxError("gemm_nt: the bf16 MFMA path needs bf16 Bt")
+        _dev(a, "gemm A", _ANY), _dev(c, "gemm C", _ANY)
+        asz, csz = a.element_size(), c.element_size()
+        gemm16_raw(a=a.data_ptr() + asz * a_off, a_bs0=a_bs[0], a_bs1=a_bs[1], bt=bt.data_ptr() + 2 * bt_off, bt_bs0=bt_bs[0], bt_bs1=bt_bs[1],
+                   c=c.data_ptr() + csz * c_off, c_bs0=c_bs[0], c_bs1=c_bs[1], bias=None if bias is None else _dev(bias).data_ptr(),
+                   res=None if res is None else _dev(res, "gemm res", _ANY).data_ptr(), res_bs0=res_bs[0], res_bs1=res_bs[1],
+                   in_ss=None, in_swish=0, nb0=nb0, nb1=nb1, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, ldres=ldres,
+                   Hin=M, Win=1, Cin=K, Ho=M, Wo=1, kh=1, kw=1, stride=1, pad_t=0, pad_l=0, up2=0, act=act, alpha=alpha,
+                   bias_per_row=int(bias_per_row), d2s_p=0, d2s_c=0, tile=tile, ksplit=1, ws=None,
+                   a_f32=int(a.dtype == torch.float32), c_f32=int(c.dtype == torch.float32),
+                   res_f32=int(res is not None and res.dtype == torch.float32))
+        return c
     gemm_raw(a=_dev(a).data_ptr() + 4 * a_off, a_bs0=a_bs[0], a_bs1=a_bs[1],
              bt=_dev(bt).data_ptr() + 4 * bt_off, bt_bs0=bt_bs[0], bt_bs1=bt_bs[1],
              c=_dev(c).data_ptr() + 4 * c_off, c_bs0=c_bs[0], c_bs1=c_bs[1],
@@ -230,18 +323,19 @@ def gemm_nt(a, bt, c, *, M, N, K, lda, ldb, ldc, nb0=1, nb1=1, a_bs=(0, 0), bt_b
 def groupnorm(x, gamma, beta, swish=True, out=None, groups=32, eps=1e-6):
     B, H, W, Cc = x.shape
     if out is None:
-        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=x.dtype)
+    _same("groupnorm", x, out)
     xp, ldx = _pix(x, "groupnorm input")
     yp, ldy = _pix(out, "groupnorm output")
     lib = L.load()
     ws = torch.empty(int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)), device=x.device, dtype=torch.float32)
-    L.check(_timed("groupnorm", {"bytes": 8.0 * B * H * W * Cc}, lib.smx_groupnorm_swish_nhwc_f32, xp, ldx, _dev(gamma).data_ptr(),
+    L.check(_timed("groupnorm", {"bytes": 2.0 * x.element_size() * B * H * W * Cc}, _fn("smx_groupnorm_swish_nhwc", x), xp, ldx, _dev(gamma).data_ptr(),
                    _dev(beta).data_ptr(), yp, ldy, B, H * W, Cc, groups, eps, int(swish), ws.data_ptr(), _stream()), "groupnorm")
     return out
 
 
 def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
-    """per-(b,c) {scale, shift} of GroupNorm for x [B,H,W,C] -> ss [B,C,2] (consumed by conv(in_ss=...))."""
+    """per-(b,c) {scale, shift} of GroupNorm for x [B,H,W,C] (fp32 or bf16 storage) -> ss [B,C,2] fp32 (consumed by conv(in_ss=...))."""
     B, H, W, Cc = x.shape
     xp, ldx = _pix(x, "groupnorm input")
     lib = L.load()
@@ -254,7 +348,7 @@ def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
                        _stream()), "groupnorm_finalize")
         return ss
     ws = torch.empty(int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)), device=x.device, dtype=torch.float32)
-    L.check(_timed("groupnorm", {"bytes": 4.0 * B * H * W * Cc}, lib.smx_groupnorm_stats_f32, xp, ldx, _dev(gamma).data_ptr(),
+    L.check(_timed("groupnorm", {"bytes": 1.0 * x.element_size() * B * H * W * Cc}, _fn("smx_groupnorm_stats", x), xp, ldx, _dev(gamma).data_ptr(),
                    _dev(beta).data_ptr(), ss.data_ptr(), B, H * W, Cc, groups, eps, ws.data_ptr(), _stream()), "groupnorm_stats")
     return ss
 
@@ -262,49 +356,52 @@ def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
 def groupnorm_apply(x, ss, swish=True, out=None):
     B, H, W, Cc = x.shape
     if out is None:
-        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=x.dtype)
+    _same("groupnorm_apply", x, out)
     xp, ldx = _pix(x, "groupnorm input")
     yp, ldy = _pix(out, "groupnorm output")
-    L.check(_timed("groupnorm", {"bytes": 8.0 * B * H * W * Cc}, L.load().smx_groupnorm_apply_f32, xp, ldx, ss.data_ptr(), yp, ldy,
+    L.check(_timed("groupnorm", {"bytes": 2.0 * x.element_size() * B * H * W * Cc}, _fn("smx_groupnorm_apply", x), xp, ldx, ss.data_ptr(), yp, ldy,
                    B, H * W, Cc, int(swish), _stream()), "groupnorm_apply")
     return out
 
 
 def layernorm(x, gamma, beta, pos=None, eps=1e-5):
-    """x tokens [..., E] contiguous -> (LN(x), LN(x)+pos or None)."""
-    _dev(x)
+    """x tokens [..., E] contiguous (fp32 or bf16 storage; gamma / beta / pos fp32) -> (LN(x), LN(x)+pos or None)."""
+    _dev(x, "layernorm input", _ANY)
+    if not x.is_contiguous():
+        raise L.SmxError("layernorm: contiguous tokens expected")
     E = x.shape[-1]
     T = x.numel() // E
     y = torch.empty_like(x)
     yp = torch.empty_like(x) if pos is not None else None
-    L.check(L.load().smx_layernorm_pos_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                           None if pos is None else pos.data_ptr(), y.data_ptr(),
-                                           None if yp is None else yp.data_ptr(), T, E,
-                                           0 if pos is None else pos.shape[0], eps, _stream()), "layernorm")
+    L.check(_timed("layernorm", {"bytes": x.element_size() * (2.0 + (pos is not None)) * x.numel()}, _fn("smx_layernorm_pos", x), x.data_ptr(),
+                   _dev(gamma).data_ptr(), _dev(beta).data_ptr(), None if pos is None else _dev(pos).data_ptr(), y.data_ptr(),
+                   None if yp is None else yp.data_ptr(), T, E, 0 if pos is None else pos.shape[0], eps, _stream()), "layernorm")
     return y, yp
 
 
 def softmax_rows(s, S, scale=1.0, mask=None, rows_per_mask=0):
     """in-place softmax over the last dim (S) of contiguous s."""
-    _dev(s)
+    _dev(s, "softmax", _ANY)
     R = s.numel() // S
-    L.check(_timed("softmax", {"bytes": 8.0 * R * S}, L.load().smx_softmax_rows_f32, s.data_ptr(), S, R, S, scale,
+    L.check(_timed("softmax", {"bytes": 2.0 * s.element_size() * R * S}, _fn("smx_softmax_rows", s), s.data_ptr(), S, R, S, scale,
                    None if mask is None else mask.data_ptr(), rows_per_mask, _stream()), "softmax_rows")
     return s
 
 
 def warp(feat, flow, occ=None, out=None):
-    """deform_input (+occlude_input): feat [1|B,H,W,C], flow [B,Hf,Wf,2], occ [B,Hf,Wf(,1)]."""
-    _dev(feat), _dev(flow)
+    """deform_input (+occlude_input): feat [1|B,H,W,C] (fp32 or bf16 storage), flow [B,Hf,Wf,2] fp32, occ [B,Hf,Wf(,1)] fp32."""
+    _dev(feat, "warp features", _ANY), _dev(flow)
     B, Hf, Wf, _ = flow.shape
     Bf, H, W, Cc = feat.shape
     if out is None:
-        out = torch.empty((B, H, W, Cc), device=feat.device, dtype=torch.float32)
+        out = torch.empty((B, H, W, Cc), device=feat.device, dtype=feat.dtype)
+    _same("warp", feat, out)
     if not (feat.is_contiguous() and flow.is_contiguous() and out.is_contiguous() and (occ is None or occ.is_contiguous())):
         raise L.SmxError("warp: contiguous operands expected")
     # algorithmic bytes (SURVEY.md section 8d): features read + written, flow, occlusion
-    meta = {"bytes": 4.0 * (2 * B * H * W * Cc + B * Hf * Wf * (2 + (0 if occ is None else 1))), "s": H, "C": Cc}
-    L.check(_timed("warp", meta, L.load().smx_warp_nhwc_f32, feat.data_ptr(), Bf, flow.data_ptr(),
+    meta = {"bytes": feat.element_size() * 2.0 * B * H * W * Cc + 4.0 * B * Hf * Wf * (2 + (0 if occ is None else 1)), "s": H, "C": Cc}
+    L.check(_timed("warp", meta, _fn("smx_warp_nhwc", feat), feat.data_ptr(), Bf, flow.data_ptr(),
                    None if occ is None else _dev(occ).data_ptr(), out.data_ptr(), B, H, W, Cc, Hf, Wf, _stream()), "warp")
     return out
 
@@ -312,10 +409,11 @@ def warp(feat, flow, occ=None, out=None):
 def resize(x, Ho, Wo, out=None):
     B, H, W, Cc = x.shape
     if out is None:
-        out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=x.dtype)
+    _same("resize", x, out)
     xp, ldx = _pix(x, "resize input")
     yp, ldy = _pix(out, "resize output")
-    L.check(L.load().smx_resize_bilinear_ac_nhwc_f32(xp, ldx, yp, ldy, B, H, W, Ho, Wo, Cc, _stream()), "resize")
+    L.check(_timed("resize", None, _fn("smx_resize_bilinear_ac_nhwc", x), xp, ldx, yp, ldy, B, H, W, Ho, Wo, Cc, _stream()), "resize")
     return out
 
 
@@ -324,8 +422,8 @@ def resize_taps_gather(x, Ho, Wo):
     map 4x as wide: row-compatible with a 1x1 conv)."""
     B, H, W, Cc = x.shape
     xp, ldx = _pix(x, "resize_taps input")
-    t = torch.empty((B, Ho, Wo * 4, Cc), device=x.device, dtype=torch.float32)
-    L.check(L.load().smx_resize_taps_gather_f32(xp, ldx, t.data_ptr(), B, H, W, Ho, Wo, Cc, _stream()), "resize_taps_gather")
+    t = torch.empty((B, Ho, Wo * 4, Cc), device=x.device, dtype=x.dtype)
+    L.check(_fn("smx_resize_taps_gather", x)(xp, ldx, t.data_ptr(), B, H, W, Ho, Wo, Cc, _stream()), "resize_taps_gather")
     return t
 
 
@@ -336,9 +434,10 @@ def resize_taps_combine(t, Hin, Win, out=None):
     if not t.is_contiguous() or W4 % 4:
         raise L.SmxError("resize_taps_combine: dense [B,Ho,Wo*4,C] expected")
     if out is None:
-        out = torch.empty((B, Ho, W4 // 4, Cc), device=t.device, dtype=torch.float32)
+        out = torch.empty((B, Ho, W4 // 4, Cc), device=t.device, dtype=t.dtype)
+    _same("resize_taps_combine", t, out)
     yp, ldy = _pix(out, "resize_taps output")
-    L.check(L.load().smx_resize_taps_combine_f32(_dev(t).data_ptr(), yp, ldy, B, Hin, Win, Ho, W4 // 4, Cc, _stream()), "resize_taps_combine")
+    L.check(_fn("smx_resize_taps_combine", t)(_dev(t, "taps", _ANY).data_ptr(), yp, ldy, B, Hin, Win, Ho, W4 // 4, Cc, _stream()), "resize_taps_combine")
     return out
 
 
@@ -441,12 +540,13 @@ def motion_ignore(flow, Ht=32, Wt=32):
 def sft_combine(dec, scale, shift, w=1.0):
     """dec may be a channel-slice view (the dec half of the [enc|dec] buffer); scale / shift dense."""
     dp, ldd = _pix(dec, "dec")
+    _same("sft_combine", dec, scale, shift)
     Cc = dec.shape[-1]
     if not (scale.is_contiguous() and shift.is_contiguous()):
         raise L.SmxError("sft_combine: dense scale / shift expected")
-    out = torch.empty(dec.shape, device=dec.device, dtype=torch.float32)
-    L.check(L.load().smx_sft_combine_f32(dp, ldd, _dev(scale).data_ptr(), _dev(shift).data_ptr(), out.data_ptr(),
-                                         float(w), dec.numel() // Cc, Cc, _stream()), "sft_combine")
+    out = torch.empty(dec.shape, device=dec.device, dtype=dec.dtype)
+    L.check(_timed("sft_combine", {"bytes": 4.0 * dec.element_size() * dec.numel()}, _fn("smx_sft_combine", dec), dp, ldd, scale.data_ptr(),
+                   shift.data_ptr(), out.data_ptr(), float(w), dec.numel() // Cc, Cc, _stream()), "sft_combine")
     return out
 
 
@@ -460,33 +560,37 @@ def fingerprint(x):
 
 
 def add(a, b):
+    _same("add", a, b)
     y = torch.empty_like(a)
-    L.check(L.load().smx_add_f32(_dev(a).data_ptr(), _dev(b).data_ptr(), y.data_ptr(), a.numel(), _stream()), "add")
+    L.check(_fn("smx_add", a)(_dev(a, "add", _ANY).data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "add")
     return y
 
 
 def copy_slice(x, out):
+    """out[..., :C] = x (channel-slice views ok); converts between fp32 and bf16 storage when the dtypes differ."""
     xp, ldx = _pix(x, "copy input")
     yp, ldy = _pix(out, "copy output")
     Cc = x.shape[-1]
-    L.check(L.load().smx_copy_slice_f32(xp, ldx, yp, ldy, x.numel() // Cc, Cc, _stream()), "copy_slice")
+    L.check(L.load().smx_convert_slice(xp, int(x.dtype == BF16), ldx, yp, int(out.dtype == BF16), ldy, x.numel() // Cc, Cc, _stream()), "copy_slice")
     return out
 
 
-def nchw_to_nhwc(x, out=None):
+def nchw_to_nhwc(x, out=None, dtype=torch.float32):
+    """fp32 NCHW -> NHWC in `dtype` storage (fp32 | bf16)."""
     B, Cc, H, W = x.shape
     if out is None:
-        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=dtype)
     yp, ldy = _pix(out, "nhwc output")
-    L.check(L.load().smx_nchw_to_nhwc_f32(_dev(x).contiguous().data_ptr(), yp, ldy, B, Cc, H, W, _stream()), "nchw_to_nhwc")
+    L.check(_fn("smx_nchw_to_nhwc", out)(_dev(x).contiguous().data_ptr(), yp, ldy, B, Cc, H, W, _stream()), "nchw_to_nhwc")
     return out
 
 
 def nhwc_to_nchw(x):
+    """NHWC (fp32 or bf16 storage, channel-slice ok) -> fp32 NCHW."""
     B, H, W, Cc = x.shape
     xp, ldx = _pix(x, "nhwc input")
     y = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
-    L.check(L.load().smx_nhwc_to_nchw_f32(xp, ldx, y.data_ptr(), B, Cc, H, W, _stream()), "nhwc_to_nchw")
+    L.check(_fn("smx_nhwc_to_nchw", x)(xp, ldx, y.data_ptr(), B, Cc, H, W, _stream()), "nhwc_to_nchw")
     return y
 
 
@@ -516,15 +620,17 @@ def attention(q, k, v, nhead, dh, S, *, k_shared=False, mask=None, k_off=0, scal
     width ld (head h at column h*dh); k_shared: codebook K/V common to the batch (batch stride 0)."""
     B = q.shape[0]
     Lq = q.numel() // B // q.shape[-1]
+    _same("attention", q, k, v)
     qp, ldq = _pix(q, "attention q")
     kp, ldk = _pix(k, "attention k")
     vp, ldv = _pix(v, "attention v")
     E = nhead * dh
-    o = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
+    es = q.element_size()
+    o = torch.empty((B, Lq, E), device=q.device, dtype=q.dtype)
     kbs = 0 if k_shared else (k.numel() // B // k.shape[-1]) * ldk
     vbs = 0 if k_shared else (v.numel() // B // v.shape[-1]) * ldv
-    meta = {"flops": 4.0 * B * nhead * Lq * S * dh, "bytes": 4.0 * (2 * B * Lq * E + 2 * (1 if k_shared else B) * S * E)}
-    L.check(_timed(f"attention_d{dh}", meta, L.load().smx_attention_f32, qp, ldq, Lq * ldq, kp + 4 * k_off, ldk, kbs, vp, ldv, vbs,
+    meta = {"flops": 4.0 * B * nhead * Lq * S * dh, "bytes": es * (2.0 * B * Lq * E + 2 * (1 if k_shared else B) * S * E)}
+    L.check(_timed(f"attention_d{dh}", meta, _fn("smx_attention", q), qp, ldq, Lq * ldq, kp + es * k_off, ldk, kbs, vp, ldv, vbs,
                    o.data_ptr(), E, Lq * E, None if mask is None else mask.data_ptr(), B, nhead, Lq, S, dh,
                    dh ** -0.5 if scale is None else scale, _stream()), "attention")
     return o

@@ -1,0 +1,355 @@
+"""BASELINE configs[2] (bf16 storage / bf16 MFMA, fp32 accumulate) on a real MI355X.
+
+Kernel level: every bf16 entry point against the SAME op evaluated in fp32 on the bf16-rounded operands, so the only
+differences are accumulation order and the final round-to-bf16 of the stored result (tolerances below are written in
+units of that rounding: one bf16 ulp = 2^-8 relative).  Pipeline level: the bf16 path against the reference's fp32
+output, judged by the error the REFERENCE ITSELF makes under CPU autocast(bfloat16) on the same inputs (fixture
+tests/golden/autocast_bf16.npz, produced by tests/golden/make_golden_r2.py) -- SURVEY 8(d) config 3: 1e-3 is not claimable
+in bf16; "same as reference-under-autocast" is."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import reenact_oracle as O
+from synergize_motion_appearance_amd.synth import synth_input
+from tests.util import maxabs, weights, golden, clip
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from synergize_motion_appearance_amd import ops as _ops
+    from synergize_motion_appearance_amd import lib
+    lib.load()
+    return _ops
+
+
+def rnd(name, shape, scale=1.0):
+    return synth_input(name, shape) * scale
+
+
+def r16(t):
+    """round to bf16 and back: the value a bf16-stored operand really has."""
+    return t.to(BF).float()
+
+
+def nhwc16(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda().to(BF)
+
+
+def nchw32(t):
+    return t.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def close16(got, ref, ulps=1.0, floor=1e-3):
+    """|got - ref| <= ulps * |ref| * 2^-8 (+ a small absolute floor for values near zero).  |ref| * 2^-8 is the worst-case
+    round-to-nearest error of storing ref in bf16 (half a unit in the last of 8 significand bits), so ulps=1.0 with a tiny
+    floor means "the stored value is the correctly rounded fp32 result"."""
+    got, ref = torch.as_tensor(got).double(), torch.as_tensor(ref).double()
+    tol = ulps * ref.abs() * 2.0 ** -8 + floor
+    bad = (got - ref).abs() > tol
+    return not bool(bad.any()), float(((got - ref).abs() / tol).max())
+
+
+# ---------------------------------------------------------------------------------------
+# MFMA fragment layout first: A = I against an ASYMMETRIC B catches a swapped row/col or a wrong k-half mapping
+# ---------------------------------------------------------------------------------------
+def test_bf16_mfma_fragment_layout_identity_times_asymmetric(ops):
+    M = N = K = 64
+    a = torch.eye(M, K)
+    bt = r16(torch.arange(N)[:, None] * 3.0 + torch.arange(K)[None, :] * 0.25 - 7.0)    # Bt[n][k], asymmetric (bf16-representable values)
+    c = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    ops.gemm_nt(a.cuda().to(BF), bt.cuda().to(BF), c, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    assert maxabs(c.cpu(), a @ bt.t()) == 0.0
+
+
+GEMM16_CASES = [
+    # (B, Cin, Cout, H, k, stride, pad, out_hw, up2, act, tile, a_f32, c_f32, tag)
+    (2, 64, 64, 32, 3, 1, None, None, False, 0, 0, False, False, "3x3 64->64"),
+    (1, 128, 128, 32, 3, 1, None, None, False, 3, 1, False, False, "3x3 128->128 swish tile1"),
+    (1, 64, 64, 32, 3, 1, None, None, False, 0, 2, False, True, "tile2 fp32 out"),
+    (1, 64, 64, 32, 3, 1, None, None, False, 1, 3, False, False, "tile3 relu"),
+    (2, 64, 32, 16, 3, 1, None, None, False, 0, 4, False, False, "tile4 N=32"),
+    (1, 64, 128, 32, 3, 1, None, None, False, 0, 5, False, False, "tile5"),
+    (1, 64, 64, 32, 3, 1, None, None, False, 0, 6, False, False, "tile6"),
+    (2, 32, 32, 64, 3, 2, (0, 0), (32, 32), False, 0, 0, False, False, "stride 2 pad(0,1,0,1), Cin=32 (chunks inside a 64-slice)"),
+    (2, 64, 64, 16, 3, 1, None, None, True, 0, 0, False, False, "nearest x2 folded"),
+    (2, 256, 192, 32, 1, 1, None, None, False, 1, 0, False, False, "1x1 256->192 relu"),
+    (2, 160, 126, 32, 3, 1, None, None, False, 1, 0, False, False, "3x3 160->126 odd Cout, Cin%64!=0"),
+    (2, 3, 64, 32, 3, 1, None, None, False, 0, 0, True, False, "3x3 3->64 generic path, fp32 input"),
+    (2, 2, 128, 24, 7, 1, None, None, False, 1, 0, True, False, "7x7 2->128 fp32 input"),
+    (2, 15, 32, 32, 1, 1, None, None, False, 1, 0, True, False, "1x1 15->32 fp32 input"),
+    (2, 64, 64, 32, 3, 1, None, None, False, 0, 0, True, True, "fp32 in / fp32 out on the bf16 MFMA (hourglass form)"),
+    (1, 1024, 512, 4, 3, 1, None, None, True, 1, 0, True, True, "hourglass deep up2, split-K"),
+    (1, 128, 128, 32, 2, 2, (0, 0), None, False, 0, 0, False, False, "patchify 2x2 stride 2"),
+    (1, 256, 512, 32, 3, 1, None, None, False, 4, 0, False, False, "3x3 256->512 gelu"),
+]
+
+
+@pytest.mark.parametrize("case", GEMM16_CASES, ids=[c[-1] for c in GEMM16_CASES])
+def test_gemm_conv_bf16(ops, case):
+    B, Cin, Cout, H, k, stride, pad, out_hw, up2, act, tile, a_f32, c_f32, tag = case
+    x = rnd("bx" + tag, (B, Cin, H, H))
+    w = rnd("bw" + tag, (Cout, Cin, k, k), 1.0 / math.sqrt(Cin * k * k))
+    b = rnd("bb" + tag, (Cout,), 0.1)
+    xq, wq = r16(x), r16(w)                                   # what the MFMA sees (fp32 inputs are rounded while staging)
+    xe = F.interpolate(xq, scale_factor=2.0, mode="nearest") if up2 else xq
+    if pad is None:
+        ref = F.conv2d(xe.double(), wq.double(), b.double(), stride=stride, padding=k // 2)
+    elif out_hw is not None:
+        need = (out_hw[0] - 1) * stride + k - xe.shape[2] - pad[0]
+        ref = F.conv2d(F.pad(xe, (pad[1], max(need, 0), pad[0], max(need, 0))).double(), wq.double(), b.double(), stride=stride)[:, :, :out_hw[0], :out_hw[1]]
+    else:
+        ref = F.conv2d(xe.double(), wq.double(), b.double(), stride=stride, padding=pad)
+    ref = {0: lambda t: t, 1: F.relu, 3: O.swish, 4: F.gelu}[act](ref).float()
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    xin = xin if a_f32 else xin.to(BF)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    with ops.profile() as rec:
+        y = ops.conv(xin, cv, stride=stride, pad=pad, out_hw=out_hw, up2=up2, act=act, tile=tile, mfma16=True,
+                     out_dtype=torch.float32 if c_f32 else None)
+    assert "gemm_bf16" in [r[0] for r in rec.rows]
+    assert y.dtype == (torch.float32 if c_f32 else BF)
+    if c_f32:
+        assert maxabs(nchw32(y), ref) < 2e-4 * max(1.0, float(ref.abs().max())), tag
+    else:
+        ok, worst = close16(nchw32(y), ref, ulps=1.0)
+        assert ok, (tag, worst)
+
+
+def test_gemm_conv_bf16_fused_groupnorm_residual_slices_and_d2s(ops):
+    """in_ss (GroupNorm + swish while staging), bf16 / fp32 residuals, channel-slice operands, un-patchify store."""
+    B, C, Co, H = 2, 64, 64, 32
+    x = r16(rnd("g16x", (B, C, H, H)) * 1.5 + 0.2)
+    g, bt = 1 + 0.1 * rnd("g16g", (C,)), 0.1 * rnd("g16b", (C,))
+    w = rnd("g16w", (Co, C, 3, 3), 1.0 / math.sqrt(9 * C))
+    b = rnd("g16bb", (Co,), 0.1)
+    res = r16(rnd("g16r", (B, Co, H, H)))
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    wide = torch.zeros((B, H, H, C + 16), device="cuda", dtype=BF)
+    wide[..., 8:8 + C] = nhwc16(x)
+    xin = wide[..., 8:8 + C]
+    ss = ops.groupnorm_stats(xin, g.cuda(), bt.cuda())
+    ss_ref = ops.groupnorm_stats(x.permute(0, 2, 3, 1).contiguous().cuda(), g.cuda(), bt.cuda())
+    assert maxabs(ss.cpu(), ss_ref.cpu()) < 1e-5                                  # same fp32 statistics from bf16 storage
+    hn = O.swish(F.group_norm(x, 32, g, bt, 1e-6))
+    ref = F.conv2d(r16(hn).double(), r16(w).double(), b.double(), padding=1).float() + res
+    outw = torch.full((B, H, H, Co + 24), 5.0, device="cuda", dtype=BF)
+    for rt in (nhwc16(res), res.permute(0, 2, 3, 1).contiguous().cuda()):         # bf16 and fp32 residual
+        ops.conv(xin, cv, out=outw[..., 8:8 + Co], in_ss=ss, in_swish=True, res=rt)
+        # the staged value is swish(GN(x)) rounded to bf16 from an fp32 evaluation: allow 2 ulp end to end
+        ok, worst = close16(nchw32(outw[..., 8:8 + Co]), ref, ulps=2.0, floor=4e-3)
+        assert ok, worst
+        assert float(outw[..., :8].float().min()) == 5.0 and float(outw[..., 8 + Co:].float().max()) == 5.0
+    # un-patchify (depth-to-space) store: Linear(256 -> p*p*C) + rearrange == 1x1 conv with d2s
+    p_, Cc = 4, 64
+    t = r16(rnd("d2sx", (1, 256, 32, 32)))
+    wl = rnd("d2sw", (p_ * p_ * Cc, 256, 1, 1), 1.0 / 16)
+    bl = rnd("d2sb", (p_ * p_ * Cc,), 0.1)
+    lin = F.conv2d(t.double(), r16(wl).double(), bl.double()).float()             # [1, p*p*C, 32, 32], n = (p1*p+p2)*C + c
+    ref2 = lin.view(1, p_, p_, Cc, 32, 32).permute(0, 3, 4, 1, 5, 2).reshape(1, Cc, 32 * p_, 32 * p_)
+    y = ops.conv(nhwc16(t), ops.Conv.from_torch(wl.cuda(), bl.cuda()), d2s=(p_, Cc))
+    ok, worst = close16(nchw32(y), ref2, ulps=1.0)
+    assert ok, worst
+
+
+def test_gemm_nt_bf16_batched(ops):
+    """AttnBlock-style batched products on the bf16 MFMA: Q K^T with an offset Bt view, alpha; P V^T; per-row bias."""
+    B, N, C = 2, 256, 64
+    qk = r16(rnd("nt16qk", (B, N, 2 * C)))
+    s = torch.empty((B, N, N), device="cuda", dtype=BF)
+    ops.gemm_nt(qk.cuda().to(BF), qk.cuda().to(BF), s, M=N, N=N, K=C, lda=2 * C, ldb=2 * C, ldc=N, nb0=B, a_bs=(N * 2 * C, 0),
+                bt_bs=(N * 2 * C, 0), c_bs=(N * N, 0), bt_off=C, alpha=0.125)
+    ref = 0.125 * torch.einsum("bik,bjk->bij", qk[..., :C].double(), qk[..., C:].double()).float()
+    ok, worst = close16(s.float().cpu(), ref)
+    assert ok, worst
+    wv, bv, hn = rnd("nt16w", (C, C), 0.2), rnd("nt16b", (C,), 0.1), r16(rnd("nt16h", (B, N, C)))
+    vt = torch.empty((B, C, N), device="cuda", dtype=BF)
+    ops.gemm_nt(wv.cuda(), hn.cuda().to(BF), vt, M=C, N=N, K=C, lda=C, ldb=C, ldc=N, nb0=B, bt_bs=(N * C, 0), c_bs=(C * N, 0),
+                bias=bv.cuda(), bias_per_row=True)
+    ref = torch.einsum("ck,bnk->bcn", r16(wv).double(), hn.double()).float() + bv[None, :, None]
+    ok, worst = close16(vt.float().cpu(), ref)
+    assert ok, worst
+
+
+# ---------------------------------------------------------------------------------------
+# storage-templated kernels: bf16 variant == fp32 variant on the bf16-rounded operands (+ one output rounding)
+# ---------------------------------------------------------------------------------------
+def test_warp_bf16_all_scales(ops):
+    B = 3
+    flow = (O.make_coordinate_grid(64, 64, torch.float32)[None].repeat(B, 1, 1, 1) + 0.3 * rnd("w16f", (B, 64, 64, 2))).cuda()
+    occ = torch.sigmoid(rnd("w16o", (B, 64, 64))).cuda()
+    for (C, s) in ((256, 32), (128, 64), (128, 128), (64, 256)):
+        for Bf in (1, B):
+            feat = r16(rnd(f"w16x{C}{s}{Bf}", (Bf, s, s, C))).cuda()
+            ref = ops.warp(feat, flow, occ)                                     # fp32 kernel on the same (bf16-valued) features
+            got = ops.warp(feat.to(BF), flow, occ)
+            assert got.dtype == BF
+            ok, worst = close16(got.float().cpu(), ref.cpu(), ulps=1.0, floor=1e-6)   # the stored result is the rounded fp32 result
+            assert ok, (C, s, Bf, worst)
+    z = ops.warp(r16(rnd("w16z", (1, 64, 64, 128))).cuda().to(BF), flow + 5.0)  # everything out of frame -> exact zeros
+    assert float(z.float().abs().max()) == 0.0
+
+
+def test_elementwise_bf16_variants(ops):
+    x = r16(rnd("e16x", (2, 64, 64, 128)) * 1.7 + 0.3).cuda()
+    g, b = (1 + 0.1 * rnd("e16g", (128,))).cuda(), (0.1 * rnd("e16b", (128,))).cuda()
+    x16 = x.to(BF)
+    half = lambda got, ref, what: close16(got.float().cpu(), ref.cpu(), ulps=1.0, floor=1e-6)[0] or pytest.fail(what)   # noqa: E731
+    for sw in (False, True):
+        half(ops.groupnorm(x16, g, b, swish=sw), ops.groupnorm(x, g, b, swish=sw), f"groupnorm swish={sw}")
+    ss = ops.groupnorm_stats(x16, g, b)
+    half(ops.groupnorm_apply(x16, ss, swish=True), ops.groupnorm_apply(x, ss, swish=True), "groupnorm_apply")
+    half(ops.resize(x16, 32, 32), ops.resize(x, 32, 32), "resize down")
+    half(ops.resize(x16[..., 32:96], 32, 32), ops.resize(x[..., 32:96], 32, 32), "resize (channel-slice view)")
+    half(ops.resize(x16[:, :32, :32].contiguous(), 64, 64), ops.resize(x[:, :32, :32].contiguous(), 64, 64), "resize up")
+    t16, t32 = ops.resize_taps_gather(x16, 16, 16), ops.resize_taps_gather(x, 16, 16)
+    assert torch.equal(t16.float(), t32)
+    half(ops.resize_taps_combine(t16, 64, 64), ops.resize_taps_combine(t32, 64, 64), "resize_taps_combine")
+    y = r16(rnd("e16y", (2, 64, 64, 128))).cuda()
+    half(ops.add(x16, y.to(BF)), ops.add(x, y), "add")
+    half(ops.sft_combine(x16, y.to(BF), x16, 0.7), ops.sft_combine(x, y, x, 0.7), "sft_combine")
+    tok = r16(rnd("e16t", (2, 1024, 256)) * 2 + 0.5).cuda()
+    gl, bl, pos = (1 + 0.1 * rnd("e16lg", (256,))).cuda(), (0.1 * rnd("e16lb", (256,))).cuda(), (0.2 * rnd("e16lp", (1024, 256))).cuda()
+    a16, ap16 = ops.layernorm(tok.to(BF), gl, bl, pos=pos)
+    a32, ap32 = ops.layernorm(tok, gl, bl, pos=pos)
+    half(a16, a32, "layernorm")
+    half(ap16, ap32, "layernorm + pos")
+    s = r16(rnd("e16s", (2, 64, 1024)) * 3).cuda()
+    half(ops.softmax_rows(s.to(BF), 1024, 0.5), ops.softmax_rows(s.clone(), 1024, 0.5), "softmax_rows")
+    # conversions: fp32 -> bf16 slice -> fp32 round trip, and the NCHW <-> NHWC layout kernels
+    buf = torch.zeros((2, 64, 64, 160), device="cuda", dtype=BF)
+    ops.copy_slice(x, buf[..., 16:144])
+    assert torch.equal(buf[..., 16:144].float(), x) and float(buf[..., :16].float().abs().max()) == 0.0
+    back = torch.empty_like(x)
+    ops.copy_slice(buf[..., 16:144], back)
+    assert torch.equal(back, x)
+    img = rnd("e16i", (2, 3, 32, 48)).cuda()
+    n16 = ops.nchw_to_nhwc(img, dtype=BF)
+    assert n16.dtype == BF and torch.equal(n16.float(), r16(img.cpu()).permute(0, 2, 3, 1).cuda())
+    assert torch.equal(ops.nhwc_to_nchw(n16), r16(img.cpu()).cuda())
+
+
+def test_attention_bf16_storage(ops):
+    B, H, N = 2, 8, 1024
+    for dh, S, shared in ((32, 1024, False), (32, 512, True), (4, 1024, False), (4, 256, True)):
+        E = H * dh
+        q = r16(rnd(f"a16q{dh}{S}", (B, N, E))).cuda()
+        kv = r16(rnd(f"a16k{dh}{S}", ((1 if shared else B), S, 2 * E))).cuda()
+        mask = None
+        if not shared:
+            mask = torch.zeros((B, S), dtype=torch.uint8)
+            mask[1, ::5] = 1
+            mask = mask.cuda()
+        k32, v32 = kv[..., :E], kv[..., E:]
+        ref = ops.attention(q, k32 if not shared else k32[0], v32 if not shared else v32[0], H, dh, S, k_shared=shared, mask=mask)
+        kv16 = kv.to(BF)
+        k16, v16 = kv16[..., :E], kv16[..., E:]
+        got = ops.attention(q.to(BF), k16 if not shared else k16[0], v16 if not shared else v16[0], H, dh, S, k_shared=shared, mask=mask)
+        assert got.dtype == BF
+        ok, worst = close16(got.float().cpu(), ref.cpu(), ulps=1.0, floor=1e-6)
+        assert ok, (dh, S, shared, worst)
+
+
+def test_conv3x3_small_n_bf16_input(ops):
+    B, Cin, Co, H = 2, 64, 3, 32
+    x = r16(rnd("sn16x", (B, Cin, H, H)))
+    w = rnd("sn16w", (Co, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd("sn16b", (Co,), 0.1)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    with ops.profile() as rec:
+        y = ops.conv(nhwc16(x), cv, out_dtype=torch.float32)
+    assert [r[0] for r in rec.rows] == ["conv_small_n"] and y.dtype == torch.float32
+    assert maxabs(nchw32(y), F.conv2d(x, w, b, padding=1)) < 2e-5             # fp32 weights, fp32 math, fp32 output
+
+
+# ---------------------------------------------------------------------------------------
+# pipeline: configs[2] against the reference's fp32 output, judged by the reference-under-autocast error
+# ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def nets16():
+    import os
+    import yaml
+    from basicsr.archs import build_network
+    from tests.util import HERE
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(HERE), "options/test.yml")))
+    net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+    net_g.load_state_dict(weights("network_g"), strict=True)
+    me.load_state_dict(weights("network_motion_estimator"), strict=True)
+    net_g, me = net_g.eval().cuda(), me.eval().cuda()
+    net_g.set_compute_dtype("bf16")
+    me.set_compute_dtype("bf16")
+    return net_g, me
+
+
+def test_bf16_netg_vs_fp32_reference_within_the_reference_autocast_error(nets16):
+    """net_g on the bf16 path, fed the reference's fp32 dense motion: max / mean |out - fp32 reference| must not exceed
+    what the reference itself loses under CPU autocast(bfloat16) on the same inputs (x1.25 margin for the different
+    bf16 operator coverage of the two implementations)."""
+    net_g, _ = nets16
+    g = golden("autocast_bf16.npz")
+    src, _ = clip()
+    dm = {"deformation": torch.from_numpy(g["deformation_fp32"]).cuda(), "occlusion_map": torch.from_numpy(g["occlusion_fp32"]).cuda(),
+          "driving_kp_heatmap": torch.from_numpy(g["heat_fp32"]).cuda()}
+    o = net_g(src[None].cuda(), dm, w=1, inference=True)
+    out = o["out"].cpu()
+    ref = torch.from_numpy(g["out_fp32"])
+    emax, emean = float((out - ref).abs().max()), float((out - ref).abs().mean())
+    rmax, rmean = [float(v) for v in g["err_out_netg_only"]]
+    print(f"bf16 net_g: max {emax:.4f} mean {emean:.5f}   reference under autocast: max {rmax:.4f} mean {rmean:.5f}")
+    assert emax <= 1.25 * rmax and emean <= 1.25 * rmean, (emax, emean, rmax, rmean)
+    assert torch.isfinite(out).all()
+
+
+def test_bf16_end_to_end_vs_fp32_reference_within_the_reference_autocast_error(nets16):
+    """keypoints -> dense motion -> net_g, all on the configs[2] path (hourglass convolutions on the bf16 MFMA, heads and
+    flow math fp32), against the fp32 reference; bar = the reference's own end-to-end autocast error."""
+    net_g, me = nets16
+    g = golden("autocast_bf16.npz")
+    src, drv = clip()
+    idx = [int(i) for i in g["frames"]]
+    s = src[None].cuda()
+    kp_s, kp_d = me.estimate_kp(s), me.estimate_kp(drv[idx].cuda())
+    kmax, _ = [float(v) for v in g["err_kp_value"]]
+    assert maxabs(kp_d["value"].cpu(), g["kp_value_fp32"]) <= 1.25 * kmax + 1e-4
+    dm = me.estimate_motion_w_kp(kp_source=kp_s, kp_driving=kp_d, source_image=s)
+    dmax, _ = [float(v) for v in g["err_deformation"]]
+    assert maxabs(dm["deformation"].cpu(), g["deformation_fp32"]) <= 1.25 * dmax + 1e-4
+    out = net_g(s, dm, w=1, inference=True)["out"].cpu()
+    ref = torch.from_numpy(g["out_fp32"])
+    emax, emean = float((out - ref).abs().max()), float((out - ref).abs().mean())
+    rmax, rmean = [float(v) for v in g["err_out_e2e"]]
+    print(f"bf16 e2e: max {emax:.4f} mean {emean:.5f}   reference under autocast: max {rmax:.4f} mean {rmean:.5f}")
+    assert emax <= 1.25 * rmax and emean <= 1.25 * rmean, (emax, emean, rmax, rmean)
+
+
+def test_bf16_batched_driver_and_packed_state_roundtrip(nets16):
+    """animate_batched on the bf16 engines (uint8 frames), batch-size independence (<= 2 LSB in bf16) and the packed
+    source state carrying bf16 encoder taps as raw bits (14.2 MB instead of 28.3 MB)."""
+    from synergize_motion_appearance_amd import driver
+    net_g, me = nets16
+    src, drv = clip()
+    src, drv = src.cuda(), drv.cuda()
+    st = driver.encode_source_state(net_g, me, src, drv[0:1], True)
+    assert st.cache.feats[256].dtype == BF
+    flat = driver.pack_source_state(st.cache, st.src64, st.kp_source, st.kp_initial, st.scale)
+    assert flat.dtype == torch.float32 and flat.numel() == driver.cache_numel(BF) == 7077888 // 2 + 12288 + 180 + 1
+    st2 = driver.unpack_source_state(flat, BF)
+    a = driver.render_frames(st, drv, net_g, me, True, True, batch=8)
+    b = driver.render_frames(st2, drv, net_g, me, True, True, batch=8)
+    assert torch.equal(a, b) and a.dtype == torch.uint8 and a.shape == (8, 256, 256, 3)
+    # a different batch size selects other tile shapes / split-K factors: another summation order, and in bf16 storage a
+    # result that lands on the other side of a rounding boundary is 2^-8 off and propagates through ~100 layers.  Two bf16
+    # evaluations are therefore as far from each other as each is from fp32; bar = the reference-under-autocast error itself
+    # (mean < 1.5x its mean error, worst pixel within its max error)
+    c = driver.render_frames(st, drv, net_g, me, True, True, batch=3)
+    d = (a.int() - c.int()).abs().float()
+    rmax = float(golden("autocast_bf16.npz")["err_out_netg_only"][0])
+    rmean = float(golden("autocast_bf16.npz")["err_out_netg_only"][1])
+    assert float(d.mean()) < 1.5 * rmean * 127.5 and float(d.max()) <= rmax * 127.5, (float(d.mean()), float(d.max()))
