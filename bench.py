@@ -375,7 +375,7 @@ def main():
         if args.dump_shapes:
             tab = {}
             for n, m, ms in rec.rows:
-                if n not in ("gemm_conv", "gemm_bf16"):
+                if n not in ("gemm_conv", "gemm_bf16", "conv3x3_bf16"):
                     continue
                 key = (m["M"], m["N"], m["K"], m["nb"], m["k"], int(bool(m.get("wino"))))
                 t = tab.setdefault(key, [0, 0.0, m["flops"]])

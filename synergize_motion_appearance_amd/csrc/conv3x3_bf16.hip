@@ -1,0 +1,295 @@
+// 3x3 / stride 1 / pad 1 convolution on the bf16 MFMA, "region-direct": the configs[2] counterpart of the fused
+// Winograd kernel (same call sites: ResBlock / Upsample / SFT / conv-FFN / RefineFlow 3x3 convolutions, ~85 % of the flops).
+//
+// At 16x the fp32 matrix rate these layers are bound by bytes, not by the matrix pipe -- HBM first, then L2 -> LDS and LDS
+// reads -- so the kernel is organised around moving each input byte ONCE:
+//   * a block owns a 16x16-pixel output tile x 64 output channels; per 64-channel slice the raw (16+2)x(16+2)-pixel input
+//     region is staged once into LDS (GroupNorm(+swish) of the producer and the nearest-x2 upsampling folded into the
+//     staging pass) and ALL NINE taps read their MFMA A operands straight out of it: im2col never exists, not even in LDS
+//     (the implicit-GEMM kernel stages 9 shifted copies: 9x the global->LDS traffic for the same bytes);
+//   * only the weights stream per tap: a [64 n][64 k] bf16 tile (8 KB) per (slice, tap), double buffered, one barrier per tap;
+//   * 4 waves, each 64 pixels x 64 channels (2 x 2 MFMA tiles of 32x32x16): 1 KB of LDS reads per MFMA;
+//   * the epilogue transposes the accumulators through LDS and stores 16-B chunks of 8 channels (bias / activation / residual
+//     fused) and can emit the Welford partials {mean, M2} of the stored tile for the NEXT GroupNorm (stats_part), so a
+//     ResBlock's activations are read by the convolutions only.
+// LDS: region 18*18 px * 144 B = 46.7 KB + 2 x 9.2 KB weights (the epilogue's 256 x 68 fp32 tile reuses it: 69.6 KB) -> 2 blocks / CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smx.h"
+#include "smx_common.h"
+#include "bf16.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TH = 16, TW = 16, RH = TH + 2, RW = TW + 2, RPX = RH * RW;   // output tile, staged region
+constexpr int PIXB = 144;                                                  // bytes per region pixel / weight row in LDS (128 + 16 pad)
+constexpr int BN = 64, CS = 64;                                            // output channels per block, channels per slice
+constexpr int NT = 256;
+constexpr int REGION_B = RPX * PIXB;                                       // 46,656
+constexpr int WT_B = BN * PIXB;                                            // 9,216
+constexpr int CLD = BN + 4;
+constexpr int LDS_B = (REGION_B + 2 * WT_B) > (TH * TW * CLD * 4) ? (REGION_B + 2 * WT_B) : (TH * TW * CLD * 4);
+
+struct CP {
+  const bf16_t* x; const bf16_t* w; const float* bias; const void* res; bf16_t* y; float* stats; const float* in_ss;
+  int in_swish, res_f32;
+  int lda, ldc, ldres, ldw;
+  int B, H, W, Cin, Cout, up2, act;
+  int tiles_y, tiles_x, ntiles, tpb;
+};
+
+__device__ __forceinline__ float c_act(float v, int act) {
+  switch (act) {
+    case SMX_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SMX_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
+    case SMX_ACT_SWISH: return v / (1.f + expf(-v));
+    case SMX_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case SMX_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+__global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Rg = smem;                       // region [RPX][PIXB]
+  unsigned char* Ws = smem + REGION_B;            // weights [2][BN][PIXB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware order: block b runs on XCD b%8; give each XCD a contiguous range of (image, tile) so neighbouring tiles'
+  // halos hit the same L2
+  int logical = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bx = logical % p.tiles_x; logical /= p.tiles_x;
+  const int by = logical % p.tiles_y; const int img = logical / p.tiles_y;
+  const int n0 = blockIdx.y * BN;
+  const int Hs = p.up2 ? p.H >> 1 : p.H, Ws_ = p.up2 ? p.W >> 1 : p.W;
+  const bf16_t* __restrict__ X = p.x + (long long)img * Hs * Ws_ * p.lda;
+
+  // ---- region staging: RPX * 8 chunks of 16 B per slice, 256 threads -> 11 chunks per thread (the last partially) -----
+  constexpr int NCH = (RPX * 8 + NT - 1) / NT;
+  uint4 rreg[NCH];
+  auto load_region = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int item = tid + NT * k;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (item < RPX * 8) {
+        const int px = item >> 3, c8 = item & 7;
+        const int ry = px / RW, rx = px - ry * RW;
+        int iy = by * TH - 1 + ry, ix = bx * TW - 1 + rx;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+          if (p.up2) { iy >>= 1; ix >>= 1; }
+          v = *reinterpret_cast<const uint4*>(X + ((long long)iy * Ws_ + ix) * p.lda + c0 + c8 * 8);
+          if (p.in_ss) {
+            // GroupNorm(+swish) of the producer, applied once per staged element; padding stays exactly 0
+            float f[8]; unpack8(v, f);
+            const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + c8 * 8) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const float4 s4 = *reinterpret_cast<const float4*>(sp + 2 * e);
+              f[e] = fmaf(f[e], s4.x, s4.y); f[e + 1] = fmaf(f[e + 1], s4.z, s4.w);
+            }
+            if (p.in_swish) {
+              constexpr float L2E = 1.44269504088896340736f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * f[e]));
+            }
+            v = pack8(f);
+          }
+        }
+      }
+      rreg[k] = v;
+    }
+  };
+  auto store_region = [&]() {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int item = tid + NT * k;
+      if (item < RPX * 8) *reinterpret_cast<uint4*>(Rg + (item >> 3) * PIXB + (item & 7) * 16) = rreg[k];
+    }
+  };
+  // ---- weight tile: [BN][64 k] bf16 of (tap, slice): 64 rows x 8 chunks = 512 chunks -> 2 per thread -----------------
+  uint4 wreg[2];
+  const int wr0 = tid >> 3, wc8 = tid & 7;
+  auto load_w = [&](int tap, int c0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n = n0 + wr0 + 32 * i;
+      wreg[i] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (long long)n * p.ldw + tap * p.Cin + c0 + wc8 * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(Ws + buf * WT_B + (wr0 + 32 * i) * PIXB + wc8 * 16) = wreg[i];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // A operand: lane l <-> MFMA row l&31 = pixel (tile row 4*wave + 2*i + ((l&31)>>4), col l&15), k chunk (l>>5)
+  const int arow = lane & 31, hh = lane >> 5;
+  const int abase = ((4 * wave + (arow >> 4)) * RW + (arow & 15)) * PIXB + hh * 16;      // + i*2*RW*PIXB + tap offset + kk*32
+  const int bbase = arow * PIXB + hh * 16;                                               // + j*32*PIXB + kk*32
+
+  // one step = one (slice, tap): this step's weight tile is in Ws[step & 1]; the next one is requested at the top of the step
+  // and written to the other buffer at its end.  (Measured dead ends at the 256-VGPR / 2-waves-per-SIMD budget: a two-step-deep
+  // weight ring -- two statically indexed register sets, loop unrolled by two -- and a multi-tile loop that holds the next
+  // tile's region in registers across the epilogue both spill 32-89 VGPRs.)
+  const int nsl = p.Cin / CS, nsteps = nsl * 9;
+  load_region(0); store_region();
+  load_w(0, 0); store_w(0);
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int s = step / 9, tap = step - s * 9, buf = step & 1;
+    if (step + 1 < nsteps) { const int s1 = (step + 1) / 9; load_w(step + 1 - s1 * 9, s1 * CS); }
+    if (tap == 5 && s + 1 < nsl) load_region((s + 1) * CS);            // in flight over the last taps of this slice
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const unsigned char* ap = Rg + abase + (ky * RW + kx) * PIXB;
+    const unsigned char* bp = Ws + buf * WT_B + bbase;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + i * 2 * RW * PIXB + kk * 32));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + j * 32 * PIXB + kk * 32));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (step + 1 < nsteps) store_w(buf ^ 1);
+    __syncthreads();
+    if (tap == 8 && s + 1 < nsl) { store_region(); __syncthreads(); }   // every wave is past its last read of the old slice
+  }
+
+  // ---- epilogue: block transpose through LDS -> 16-B chunks of 8 channels ------------------------------------------------
+  float* Cs = reinterpret_cast<float*>(smem);                            // [256 px][CLD]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;                   // MFMA row -> pixel of the wave's 32-pixel group i
+        const int px = (4 * wave + 2 * i + (m >> 4)) * TW + (m & 15);
+        Cs[px * CLD + j * 32 + arow] = acc[i][j][r];
+      }
+  __syncthreads();
+  const int cq = tid & 7;                                                // this thread's 8-channel chunk (same for all its pixels)
+  const int nc = n0 + cq * 8;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = (p.bias && nc + e < p.Cout) ? p.bias[nc + e] : 0.f;
+  const bool full = nc + 7 < p.Cout;
+  const bool al = (p.ldc % 8 == 0) && ((((uintptr_t)p.y) & 15) == 0) &&
+                  (!p.res || (p.res_f32 ? ((p.ldres % 4 == 0) && ((((uintptr_t)p.res) & 15) == 0)) : ((p.ldres % 8 == 0) && ((((uintptr_t)p.res) & 15) == 0))));
+  const bf16_t* __restrict__ R16 = reinterpret_cast<const bf16_t*>(p.res);
+  const float* __restrict__ R32 = reinterpret_cast<const float*>(p.res);
+  float piv[8], sm[8], sq[8];                                            // Welford partials of what is stored (shifted by the first value)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { piv[e] = 0.f; sm[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int px = (tid >> 3) + 32 * it;                                 // 256 pixels, 32 per pass
+    const int oy = by * TH + (px >> 4), ox = bx * TW + (px & 15);
+    const long long opix = ((long long)img * p.H + oy) * p.W + ox;
+    const float4 v0 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c_act(v[e] + bv[e], p.act);
+    if (nc < p.Cout) {
+      if (full && al) {
+        if (p.res) {
+          if (p.res_f32) {
+            const float4 q0 = *reinterpret_cast<const float4*>(R32 + opix * p.ldres + nc), q1 = *reinterpret_cast<const float4*>(R32 + opix * p.ldres + nc + 4);
+            v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+          } else {
+            float q[8]; unpack8(*reinterpret_cast<const uint4*>(R16 + opix * p.ldres + nc), q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += q[e];
+          }
+        }
+        const uint4 pk = pack8(v);
+        *reinterpret_cast<uint4*>(p.y + opix * p.ldc + nc) = pk;
+        if (p.stats) unpack8(pk, v);                                     // statistics of the values as STORED (bf16-rounded)
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (nc + e >= p.Cout) { v[e] = 0.f; continue; }
+          if (p.res) v[e] += p.res_f32 ? R32[opix * p.ldres + nc + e] : bf2f(R16[opix * p.ldres + nc + e]);
+          const bf16_t h = f2bf(v[e]);
+          p.y[opix * p.ldc + nc + e] = h;
+          v[e] = bf2f(h);
+        }
+      }
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (it == 0) piv[e] = v[e];
+        const float d = v[e] - piv[e];
+        sm[e] += d; sq[e] += d * d;
+      }
+    }
+  }
+  if (p.stats) {
+    // per channel: Chan-merge the 32 threads (8 values each) that share this channel chunk
+    __syncthreads();                                                     // Cs is dead: reuse as [32 threads][64 ch][2]
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float ms = sm[e] * 0.125f;
+      red[((tid >> 3) * BN + cq * 8 + e) * 2] = piv[e] + ms;
+      red[((tid >> 3) * BN + cq * 8 + e) * 2 + 1] = fmaxf(sq[e] - sm[e] * ms, 0.f);
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      float mean = 0.f;
+#pragma unroll 8
+      for (int t = 0; t < 32; ++t) mean += red[(t * BN + tid) * 2];
+      mean *= (1.f / 32.f);
+      float m2 = 0.f;
+#pragma unroll 8
+      for (int t = 0; t < 32; ++t) { const float d = red[(t * BN + tid) * 2] - mean; m2 += red[(t * BN + tid) * 2 + 1] + 8.f * d * d; }
+      const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
+      float* o = p.stats + (chunk * p.Cout + n0 + tid) * 2;
+      o[0] = mean; o[1] = m2;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32,
+                                int ldres, void* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act,
+                                const float* in_ss, int in_swish, float* stats_part, void* stream) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0) return SMX_EINVAL;
+  if (H % TH != 0 || W % TW != 0 || Cin % CS != 0 || lda % 8 != 0 || lda < Cin || ldc < Cout || ldw < 9 * Cin || ldw % 8 != 0) return SMX_EINVAL;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (in_ss && ((uintptr_t)in_ss & 15)) || (res && ldres < Cout)) return SMX_EINVAL;
+  if (up2 && ((H & 1) || (W & 1))) return SMX_EINVAL;
+  CP p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = res; p.res_f32 = res_f32; p.y = (bf16_t*)y; p.stats = stats_part;
+  p.in_ss = in_ss; p.in_swish = in_swish; p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0; p.ldw = ldw;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
+  p.tiles_y = H / TH; p.tiles_x = W / TW;
+  const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
+  if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
+  static bool attr = false;
+  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)); attr = true; }
+  p.ntiles = (int)blocks; p.tpb = 1;
+  dim3 grid((unsigned)blocks, (Cout + BN - 1) / BN);
+  SMX_LAUNCH(conv3x3_bf16_kernel, grid, dim3(NT), LDS_B, (hipStream_t)stream, p);
+  return smx_launch_status();
+}

@@ -179,7 +179,10 @@ def gemm16_raw(**kw):
     L.check(_timed("gemm_bf16", meta, L.load().smx_gemm_conv_bf16, C.byref(d), _stream()), "smx_gemm_conv_bf16")
 
 
-def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss, in_swish, out_dtype):
+REGION3X3 = not _os.environ.get("SMX_NO_REGION3X3")
+
+
+def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss, in_swish, out_dtype, want_stats=False):
     """bf16-MFMA form of conv(): x bf16 (or fp32, converted while staging), weights bf16, fp32 accumulate."""
     B, H, W, Cin = x.shape
     if out is None:
@@ -197,6 +200,22 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
         L.check(_timed("conv_small_n", meta, L.load().smx_conv3x3_smalln_bf16, a_ptr, lda, _dev(cv.w).data_ptr(),
                        None if cv.b is None else cv.b.data_ptr(), c_ptr, ldc, B, H, W, Cin, cv.cout, act,
                        None if in_ss is None else in_ss.data_ptr(), int(in_swish), _stream()), "smx_conv3x3_smalln_bf16")
+        return out
+    if getattr(out, "_gn_part", None) is not None:
+        out._gn_part = None
+    if (REGION3X3 and tile == 0 and x.dtype == BF16 and out.dtype == BF16 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1)
+            and not d2s and Cin % 64 == 0 and Ho % 16 == 0 and Wo % 16 == 0 and (Ho, Wo) == ((2 * H, 2 * W) if up2 else (H, W))
+            and lda % 8 == 0 and a_ptr % 16 == 0):
+        # region-direct 3x3 kernel: the input region is staged once per 64-channel slice and all nine taps read it from LDS
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1,
+                "bytes": 2.0 * B * Ho * Wo * (Cin / (4.0 if up2 else 1.0) + cv.cout * (2 if res is not None else 1))} if _PROFILE is not None else None
+        part = torch.empty((B, (Ho // 16) * (Wo // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
+        L.check(_timed("conv3x3_bf16", meta, L.load().smx_conv3x3_bf16, a_ptr, lda, cv.w16.data_ptr(), cv.w16.shape[1],
+                       None if cv.b is None else cv.b.data_ptr(), r_ptr, int(res is not None and res.dtype == torch.float32), ldr,
+                       c_ptr, ldc, B, Ho, Wo, Cin, cv.cout, int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish),
+                       None if part is None else part.data_ptr(), _stream()), "smx_conv3x3_bf16")
+        if part is not None:
+            out._gn_part = part
         return out
     M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
     ksplit, ws = 1, None
@@ -236,7 +255,7 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
         Ho, Wo = out_hw
     if x.dtype == BF16 or mfma16 or (out is not None and out.dtype == BF16) or (res is not None and res.dtype == BF16):
         # configs[2]: bf16 storage and/or bf16 MFMA (mfma16: fp32-stored input converted while staging)
-        return _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss, in_swish, out_dtype)
+        return _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss, in_swish, out_dtype, want_stats)
     if out is None:
         if d2s:
             out = torch.empty((B, Ho * d2s[0], Wo * d2s[0], d2s[1]), device=x.device, dtype=torch.float32)

@@ -159,6 +159,63 @@ def test_gemm_conv_bf16_fused_groupnorm_residual_slices_and_d2s(ops):
     assert ok, worst
 
 
+R3_CASES = [(2, 64, 64, 32, 32, False, 0, None), (1, 128, 128, 64, 32, False, 3, "bf16"), (2, 256, 128, 16, 16, False, 1, "f32"),
+            (2, 64, 64, 16, 16, True, 0, "bf16"), (1, 128, 96, 32, 48, False, 0, None), (1, 512, 256, 32, 32, False, 4, None),
+            (3, 64, 3 * 64, 16, 32, False, 0, None)]
+
+
+@pytest.mark.parametrize("case", R3_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_up{int(c[5])}_act{c[6]}_res{c[7]}" for c in R3_CASES])
+def test_conv3x3_region_direct_bf16(ops, case):
+    """the region-direct 3x3 kernel (input region staged once per 64-channel slice, nine taps read from LDS) against conv2d on
+    the bf16-rounded operands, against the implicit-GEMM bf16 kernel on the same operands, through channel-slice views, with
+    the fused GroupNorm+swish loader, and with the Welford partials it emits for the next GroupNorm."""
+    B, Cin, Cout, H, W, up2, act, resk = case
+    x = r16(rnd(f"r3x{case}", (B, Cin, H // (2 if up2 else 1), W // (2 if up2 else 1))))
+    w = rnd(f"r3w{case}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd(f"r3b{case}", (Cout,), 0.1)
+    xe = F.interpolate(x, scale_factor=2.0, mode="nearest") if up2 else x
+    ref = F.conv2d(xe.double(), r16(w).double(), b.double(), padding=1)
+    ref = {0: lambda t: t, 1: F.relu, 3: O.swish, 4: F.gelu}[act](ref).float()
+    res = r16(rnd(f"r3r{case}", tuple(ref.shape))) if resk else None
+    if res is not None:
+        ref = ref + res
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    xin = torch.zeros((B, x.shape[2], x.shape[3], Cin + 16), device="cuda", dtype=BF)
+    xin[..., 8:8 + Cin] = nhwc16(x)
+    out = torch.full((B, H, W, Cout + 16), 5.0, device="cuda", dtype=BF)
+    rt = None if res is None else (nhwc16(res) if resk == "bf16" else res.permute(0, 2, 3, 1).contiguous().cuda())
+    with ops.profile() as rec:
+        y = ops.conv(xin[..., 8:8 + Cin], cv, out=out[..., 8:8 + Cout], up2=up2, act=act, res=rt, want_stats=True)
+    assert [r[0] for r in rec.rows] == ["conv3x3_bf16"]
+    ok, worst = close16(nchw32(y), ref, ulps=1.0)
+    assert ok, worst
+    assert float(out[..., :8].float().min()) == 5.0 and float(out[..., 8 + Cout:].float().max()) == 5.0
+    gen = ops.conv(xin[..., 8:8 + Cin], cv, up2=up2, act=act, res=rt, tile=3)          # implicit-GEMM bf16 kernel, same operands
+    ok, worst = close16(gen.float().cpu(), y.float().cpu(), ulps=2.0)       # two correctly rounded sums in different k order: <= 2 half-ulps apart
+    assert ok, worst
+    # Welford partials of the stored tile: {mean, M2} per 16x16 pixels and channel
+    part = y._gn_part
+    assert part is not None and tuple(part.shape) == (B, (H // 16) * (W // 16), Cout, 2)
+    yc = y.float().cpu().double()
+    blocks = yc.view(B, H // 16, 16, W // 16, 16, Cout).permute(0, 1, 3, 5, 2, 4).reshape(B, -1, Cout, 256)
+    bm = blocks.mean(-1)
+    assert maxabs(part[..., 0].cpu(), bm) < 5e-6 * max(1.0, float(bm.abs().max()))
+    assert maxabs(part[..., 1].cpu(), ((blocks - bm[..., None]) ** 2).sum(-1)) < 1e-3
+    if Cout & (Cout - 1) == 0:
+        g, bt = (1 + 0.1 * rnd(f"r3g{Cout}", (Cout,))).cuda(), (0.1 * rnd(f"r3bt{Cout}", (Cout,))).cuda()
+        dense = y.contiguous()
+        assert getattr(dense, "_gn_part", None) is None
+        assert maxabs(ops.groupnorm_stats(y, g, bt).cpu(), ops.groupnorm_stats(dense, g, bt).cpu()) < 2e-5      # finalize == two-pass
+        # fused loader on the region kernel: GN + swish of THIS tensor while staging the next conv
+        ss = ops.groupnorm_stats(y, g, bt)
+        w2 = rnd(f"r3w2{case}", (64, Cout, 3, 3), 1.0 / math.sqrt(9 * Cout))
+        hn = r16(O.swish(F.group_norm(nchw32(y), 32, g.cpu(), bt.cpu(), 1e-6)))
+        ref2 = F.conv2d(hn.double(), r16(w2).double(), None, padding=1).float()
+        y2 = ops.conv(y, ops.Conv.from_torch(w2.cuda(), None), in_ss=ss, in_swish=True)
+        ok, worst = close16(nchw32(y2), ref2, ulps=2.0, floor=4e-3)
+        assert ok, worst
+
+
 def test_gemm_nt_bf16_batched(ops):
     """AttnBlock-style batched products on the bf16 MFMA: Q K^T with an offset Bt view, alpha; P V^T; per-row bias."""
     B, N, C = 2, 256, 64
