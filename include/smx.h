@@ -40,7 +40,7 @@ const char* smx_version(void);
 
 /* Launch-selection knobs (tests / tuning tools; the defaults are the device-tuned choices).  Names: "wino_nw"
  * (1|2 N tiles per Winograd block, -1 auto), "wino_swz", "wino_ablate", "wino_epi", "gemm_variant",
- * "gemm_xcd_swizzle", "warp_rows", "warp_reorder".  Initialised once from the SMX_* environment; the launch paths
+ * "gemm_xcd_swizzle", "warp_rows", "warp_reorder", "attn16" (bf16 storage, d_head 32: 1 = bf16 MFMA kernel, 0 = fp32 MFMA kernel).  Initialised once from the SMX_* environment; the launch paths
  * read the table, never the environment.  Returns SMX_EINVAL for an unknown name. */
 int smx_set_tuning(const char* name, int value);
 int smx_get_tuning(const char* name, int* value);

@@ -157,6 +157,121 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP<T> p) {
     }
 }
 
+// d_head = 32 on the bf16 MFMA (configs[2]): the same swapped-product scheme on v_mfma_f32_32x32x16_bf16.
+//   S^T = K Q^T   A = K tile [key][d] from LDS (lane: key l&31, d chunk 8*(l>>5)), B = Q^T fragments in registers
+//   O^T = V^T P^T A = V^T tile [d][key] from LDS,  B = P^T = exp2(S^T - m) packed to bf16 straight from the S^T registers
+// The MFMA only needs A and B to agree on which k sits in which of a lane's 8 slots, so P keeps the accumulator's own
+// key order (a lane holds keys {0-3, 8-11} + 4*(l>>5) of each 16) and V^T is WRITTEN to LDS with its key columns in that
+// order -- no cross-lane exchange (v_permlane32_swap) on the softmax path.  At 16x the fp32 matrix rate the tile is bound by
+// the softmax VALU work, not the matrix pipe: 64 keys per step (one barrier per 64 keys), scale folded into the exp2 argument.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_mfma16_kernel(AP<bf16_t> p) {
+  static_assert(DH == 32, "one 32-wide d tile");
+  constexpr int TK = 64, KROW = DH * 2 + 16, VROW = TK * 2 + 16;          // LDS row bytes (padded)
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][TK * KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[2][DH * VROW];
+  __shared__ uint8_t Ms[2][TK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int hh = lane >> 5;
+  const bf16_t* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq + h * DH;
+  const bf16_t* K = p.k + b * p.k_bs + h * DH;
+  const bf16_t* V = p.v + b * p.v_bs + h * DH;
+  const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
+  const float c = p.scale * 1.44269504088896340736f;                     // scores in log2 units
+
+  bf16x8 qf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Q + kk * 16 + hh * 8));
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  // staging: K tile 64 keys x 4 chunks(16 B) = 256 chunks, V tile likewise: one chunk of each per thread
+  const int skey = threadIdx.x >> 2, sc = threadIdx.x & 3;
+  // LDS column of a key inside V^T: per 16 keys the order {0-3, 8-11, 4-7, 12-15}
+  const int kq = skey & 15;
+  const int vcol = (skey & ~15) + (kq < 4 ? kq : kq < 8 ? kq + 4 : kq < 12 ? kq - 4 : kq);
+  uint4 kreg, vreg; uint8_t mreg = 0;
+  auto load_tile = [&](int key0) {
+    kreg = *reinterpret_cast<const uint4*>(K + (long long)(key0 + skey) * p.ldk + sc * 8);
+    vreg = *reinterpret_cast<const uint4*>(V + (long long)(key0 + skey) * p.ldv + sc * 8);
+    if (M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
+  };
+  auto store_tile = [&](int buf) {
+    *reinterpret_cast<uint4*>(&Ks[buf][skey * KROW + sc * 16]) = kreg;
+    const uint32_t w4[4] = {vreg.x, vreg.y, vreg.z, vreg.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)                                          // transpose: V[key][8sc+e] -> Vt[8sc+e][col(key)]
+      *reinterpret_cast<uint16_t*>(&Vt[buf][(sc * 8 + e) * VROW + vcol * 2]) = (uint16_t)(e & 1 ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffffu);
+    if (threadIdx.x < TK) Ms[buf][threadIdx.x] = M ? mreg : 0;
+  };
+
+  const int ntiles = p.S / TK;
+  load_tile(0); store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile((t + 1) * TK);
+    // S^T = K Q^T for the two 32-key halves of the tile
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+      const unsigned char* kp = &Ks[buf][(u * 32 + (lane & 31)) * KROW + hh * 16];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kp + kk * 32)), qf[kk], s[u], 0, 0, 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (Ms[buf][key]) s[u][r] = -INFINITY;
+        tmax = fmaxf(tmax, s[u][r]);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax * c);
+    const bool dead = (m_new == -INFINITY);                              // every key so far masked
+    const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
+    float psum = 0.f;
+    bf16x8 pf[4];                                                        // P^T fragments: 4 MFMAs x 16 keys
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float e[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { e[r] = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[u][r], c, -m_new)); psum += e[r]; }
+      // accumulator regs 0-7 = keys {0-3, 8-11} + 4hh of the first 16, regs 8-15 = the same of the second 16
+      pf[2 * u] = __builtin_bit_cast(bf16x8, make_uint4(pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])));
+      pf[2 * u + 1] = __builtin_bit_cast(bf16x8, make_uint4(pack2(e[8], e[9]), pack2(e[10], e[11]), pack2(e[12], e[13]), pack2(e[14], e[15])));
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum; m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    // O^T += V^T P^T: A = V^T rows d = lane&31, this lane's 8 key slots of each 16-key group
+    const unsigned char* vp = &Vt[buf][(lane & 31) * VROW + hh * 16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(vp + g * 32)), pf[g], oacc, 0, 0, 0);
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  bf16_t* O = p.o + b * p.o_bs + (long long)qrow * p.ldo + h * DH;
+  const float inv = 1.f / l;                                             // l == 0 (fully masked row) -> NaN like the reference
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 w = make_float4(oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv);
+    if (l == 0.f) w = make_float4(NAN, NAN, NAN, NAN);
+    St<bf16_t>::st4(O + 8 * g + 4 * hh, w);
+  }
+}
+
 // d_head = 4: one query per lane, 64 queries per block; the block's 4 waves split the S keys
 // (wave w owns keys [w*S/4, (w+1)*S/4)), K/V broadcast from LDS, 8 keys per online-softmax step,
 // and the four partial (m, l, acc) states are merged through LDS at the end.
@@ -242,7 +357,13 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
     SMX_LAUNCH(attn_valu4_kernel<T>, dim3(L / 64, B * H), dim3(256), lds, st, p);
   } else if (dh == 32 || dh == 64) {
     if (L % 128 || S % 32) return SMX_EINVAL;
-    if (dh == 32) SMX_LAUNCH((attn_mfma_kernel<T, 32>), dim3(L / 128, B * H), dim3(256), 0, st, p);
+    if (dh == 32 && sizeof(T) == 2 && S % 64 == 0 && smx_tune(SMX_TUNE_ATTN16)) {
+      if constexpr (sizeof(T) == 2) {
+        if ((ldq | ldk | ldv) % 8 || ((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return SMX_EINVAL;
+        SMX_LAUNCH(attn_mfma16_kernel<32>, dim3(L / 128, B * H), dim3(256), 0, st, p);
+      }
+    }
+    else if (dh == 32) SMX_LAUNCH((attn_mfma_kernel<T, 32>), dim3(L / 128, B * H), dim3(256), 0, st, p);
     else SMX_LAUNCH((attn_mfma_kernel<T, 64>), dim3(L / 128, B * H), dim3(256), 0, st, p);
   } else {
     return SMX_EINVAL;

@@ -114,7 +114,8 @@ def test_gemm_conv_bf16(ops, case):
     with ops.profile() as rec:
         y = ops.conv(xin, cv, stride=stride, pad=pad, out_hw=out_hw, up2=up2, act=act, tile=tile, mfma16=True,
                      out_dtype=torch.float32 if c_f32 else None)
-    assert "gemm_bf16" in [r[0] for r in rec.rows]
+    names = [r[0] for r in rec.rows]
+    assert names in (["gemm_bf16"], ["conv3x3_bf16"]) and (tile == 0 or names == ["gemm_bf16"])   # a forced tile always means the implicit GEMM
     assert y.dtype == (torch.float32 if c_f32 else BF)
     if c_f32:
         assert maxabs(nchw32(y), ref) < 2e-4 * max(1.0, float(ref.abs().max())), tag
@@ -294,6 +295,51 @@ def test_elementwise_bf16_variants(ops):
 
 
 def test_attention_bf16_storage(ops):
+    """bf16 storage on the fp32-MFMA attention kernels (d_head 4 always; d_head 32 with the bf16-MFMA kernel switched off):
+    the stored result is the correctly rounded fp32 result."""
+    old = ops.set_tuning("attn16", 0)
+    try:
+        _attention_bf16_storage(ops)
+    finally:
+        ops.set_tuning("attn16", old)
+
+
+def test_attention_bf16_mfma_kernel(ops):
+    """d_head 32 on v_mfma_f32_32x32x16_bf16 (P = exp2(S - m) rounded to bf16 before the PV product, like every bf16 flash
+    attention): against the fp32-MFMA kernel on the same bf16-rounded q / k / v.  Error model: sum_j p_j d_j v_j with
+    |d_j| <= 2^-9 and sum p_j = 1  =>  |err| <= 2^-9 max|v| (+ the output rounding); fully masked rows NaN in both."""
+    B, H, N, dh = 2, 8, 1024, 32
+    E = H * dh
+    for S, shared in ((1024, False), (512, True), (256, True), (768, True)):
+        q = r16(rnd(f"m16q{S}", (B, N, E))).cuda()
+        kv = r16(rnd(f"m16k{S}", ((1 if shared else B), S, 2 * E))).cuda()
+        mask = None
+        if not shared:
+            mask = torch.zeros((B, S), dtype=torch.uint8)
+            mask[1, ::5] = 1
+            mask[0, 100:200] = 1
+            mask = mask.cuda()
+        k32, v32 = (kv[..., :E], kv[..., E:]) if not shared else (kv[0, :, :E], kv[0, :, E:])
+        ref = ops.attention(q, k32, v32, H, dh, S, k_shared=shared, mask=mask)
+        kv16 = kv.to(BF)
+        k16, v16 = (kv16[..., :E], kv16[..., E:]) if not shared else (kv16[0, :, :E], kv16[0, :, E:])
+        with ops.profile() as rec:
+            got = ops.attention(q.to(BF), k16, v16, H, dh, S, k_shared=shared, mask=mask)
+        assert got.dtype == BF
+        vmax = float(kv[..., E:].abs().max())
+        err = float((got.float() - ref).abs().max())
+        assert err <= (2.0 ** -9 + 2.0 ** -8) * vmax, (S, shared, err, vmax)
+        assert float((got.float() - ref).abs().mean()) < 1e-3 * vmax
+    # fully masked row -> NaN like the reference (and like the fp32 kernel)
+    mask = torch.zeros((B, 1024), dtype=torch.uint8)
+    mask[1] = 1
+    q = r16(rnd("m16qn", (B, N, E))).cuda().to(BF)
+    kv = r16(rnd("m16kn", (B, 1024, 2 * E))).cuda().to(BF)
+    o = ops.attention(q, kv[..., :E], kv[..., E:], H, dh, 1024, mask=mask.cuda())
+    assert bool(torch.isnan(o[1].float()).all()) and bool(torch.isfinite(o[0].float()).all())
+
+
+def _attention_bf16_storage(ops):
     B, H, N = 2, 8, 1024
     for dh, S, shared in ((32, 1024, False), (32, 512, True), (4, 1024, False), (4, 256, True)):
         E = H * dh
