@@ -272,6 +272,11 @@ int smx_copy_slice_f32(const float* x, int ldx, float* y, int ldy, int64_t P, in
 /* layout + A14 */
 int smx_nchw_to_nhwc_f32(const float* x, float* y, int ldy, int B, int C, int H, int W, void* stream);
 int smx_nhwc_to_nchw_f32(const float* x, int ldx, float* y, int B, int C, int H, int W, void* stream);
+/* N3, the input side of demo.py's loop on the device (demo.py:177-185): uint8 HWC frames [B][Hin][Win][3] -> normalised fp32
+ * NCHW [B][3][Hout][Wout] = ((resize(frame) / 255) - mean) / std; resize = cv2.INTER_LINEAR geometry with its uint8 rounding
+ * (identity when Hin x Win == Hout x Wout); swap_rb = img2tensor's bgr2rgb.  H2D traffic is 1 byte per sample. */
+int smx_frames_u8_to_nchw_f32(const uint8_t* x, float* y, int B, int Hin, int Win, int Hout, int Wout, int swap_rb, float mean,
+                              float stdv, void* stream);
 /* tensor2img (utils/img_util.py:70,93): clamp[lo,hi] -> (x-lo)/(hi-lo)*255 -> round-half-even -> uint8, HWC */
 int smx_to_uint8_f32(const float* x, uint8_t* y, int64_t n, float lo, float hi, void* stream);
 

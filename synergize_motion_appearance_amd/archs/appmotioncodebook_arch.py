@@ -40,7 +40,7 @@ class AppMotionCompFormer(HipArch):
                      and embed_dim_motion == dim_embd_motion and embed_dim_app == dim_embd_app and list(attn_resolutions) == [32])
         if not supported:
             raise NotImplementedError("only the options/test.yml flag set has a HIP plan (SURVEY.md section 8b)")
-        self.cfg = dict(img_size=img_size, nf=nf, ch_mult=list(ch_mult), res_blocks=res_blocks,
+        self.cfg = dict(beta=beta, img_size=img_size, nf=nf, ch_mult=list(ch_mult), res_blocks=res_blocks,
                         attn_resolutions=list(attn_resolutions), n_head=n_head, dim_embd_motion=dim_embd_motion,
                         n_layers_motion=n_layers_motion, dim_embd_app=dim_embd_app, n_layers_app=n_layers_app,
                         num_kp=num_kp, connect_list=list(connect_list), connect_app_list=list(connect_app_list))
@@ -89,9 +89,9 @@ class AppMotionCompFormer(HipArch):
     @torch.no_grad()
     def forward(self, x, dense_motion, w=1, inference=False, vis_app_before_comp=False, gt=None,
                 visualize_app_feat=False):
-        if not inference or gt is not None or vis_app_before_comp or visualize_app_feat:
-            raise NotImplementedError("only forward(..., inference=True) has a HIP plan; the training / visualisation "
-                                      "branches are out of scope this round (SURVEY.md section 8f, N2)")
+        if vis_app_before_comp or visualize_app_feat:
+            raise NotImplementedError("the visualisation branches (vis_app_before_comp / visualize_app_feat) have no HIP plan")
+        train = not inference
         eng = self.engine()
         flow = dense_motion["deformation"]
         B = flow.shape[0]
@@ -104,7 +104,7 @@ class AppMotionCompFormer(HipArch):
         occ = dense_motion["occlusion_map"]
         if isinstance(occ, list):
             raise NotImplementedError("multi_mask occlusion lists are not part of options/test.yml")
-        st = eng.forward(cache, flow.float(), occ.float().reshape(B, 64, 64), heat, float(w))
+        st = eng.forward(cache, flow.float(), occ.float().reshape(B, 64, 64), heat, float(w), train=train)
         out = {"_out_nhwc": st["out"], "out": ops.nhwc_to_nchw(st["out"]), "lq_feat": ops.nhwc_to_nchw(st["lq"]),
                "out_occ": [o.view(B, 1, 64, 64) for o in st["occ"][1:]],
                "deformation_list": st["flows"], "res_deform_list": st["res"]}
@@ -112,4 +112,17 @@ class AppMotionCompFormer(HipArch):
             out["app_before_comp_list"] = [ops.nhwc_to_nchw(t) for t in st["before"]]
             out["deform_feat_list"] = out["app_before_comp_list"]     # same values (:615/:714 repeat the warp)
             out["app_comp_list"] = [ops.nhwc_to_nchw(t) for t in st["comp"]]
+        if train:
+            # the FORWARD of the training branch (SURVEY row N2 slice 1; reference :379-386, :426, :640-659, :752-761): the 8
+            # VectorQuantizer calls run on the fused HIP kernel.  No autograd graph is built (backward kernels: N2 slice 2).
+            tr = st["train"]
+            out["out_lr"] = [ops.nhwc_to_nchw(st["out_lr"])]
+            out["motion_recon_list"] = [m / 31.5 for m in tr["motion_recon"]]          # pixels@64x64 -> normalised ((64-1)/2)
+            out["codebook_loss_motion_list"] = tr["loss_motion"]
+            out["_vq_stats_motion"] = tr["stats_motion"]
+            if gt is not None:
+                recon, losses, stats = eng.app_codebook_loss(gt.float())
+                out["app_recon_list"] = [[ops.nhwc_to_nchw(t) for t in row] for row in recon]
+                out["codebook_loss_app_list"] = losses
+                out["_vq_stats_app"] = stats
         return out

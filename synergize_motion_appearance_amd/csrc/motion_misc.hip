@@ -435,6 +435,47 @@ extern "C" int smx_nhwc_to_nchw_bf16(const void* x, int ldx, float* y, int B, in
   return smx_launch_status();
 }
 
+// N3 (demo.py:177-185 on the device): uint8 HWC video frames -> normalised fp32 NCHW network input.  The host then moves
+// 1 byte per sample over PCIe instead of 4, and the resize / astype / div / normalize chain costs no host time.
+//   resize: cv2.resize(INTER_LINEAR) geometry (half-pixel centres, replicated border) with the uint8 rounding of its result
+//           (skipped when the frame already is Hout x Wout); then x/255 (fp32 division) and (x - mean)/std, exactly the
+//           reference's fp32 operation order; swap_rb = the bgr2rgb flag of img2tensor.
+__global__ __launch_bounds__(256) void frames_u8_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, long long total, int Hin, int Win,
+                                                        int Hout, int Wout, int swap_rb, float mean, float stdv) {
+#pragma clang fp contract(off)
+  const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+  const bool same = Hin == Hout && Win == Wout;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % Wout); long long r = i / Wout;
+    const int oy = (int)(r % Hout); r /= Hout;
+    const int c = (int)(r % 3); const long long b = r / 3;
+    const int cs = swap_rb ? 2 - c : c;
+    const uint8_t* xb = x + b * (long long)Hin * Win * 3 + cs;
+    float v;
+    if (same) v = (float)xb[((long long)oy * Win + ox) * 3];
+    else {
+      float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+      int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+      const float ty = fy - (float)y0, tx = fx - (float)x0;
+      const int y1 = min(max(y0 + 1, 0), Hin - 1), x1 = min(max(x0 + 1, 0), Win - 1);
+      y0 = min(max(y0, 0), Hin - 1); x0 = min(max(x0, 0), Win - 1);
+      const float a = (float)xb[((long long)y0 * Win + x0) * 3], bq = (float)xb[((long long)y0 * Win + x1) * 3];
+      const float cq = (float)xb[((long long)y1 * Win + x0) * 3], d = (float)xb[((long long)y1 * Win + x1) * 3];
+      v = rintf((a * (1.f - tx) + bq * tx) * (1.f - ty) + (cq * (1.f - tx) + d * tx) * ty);       // the resized frame is uint8 again
+      v = fminf(fmaxf(v, 0.f), 255.f);
+    }
+    y[i] = __fdiv_rn(__fsub_rn(__fdiv_rn(v, 255.f), mean), stdv);
+  }
+}
+
+extern "C" int smx_frames_u8_to_nchw_f32(const uint8_t* x, float* y, int B, int Hin, int Win, int Hout, int Wout, int swap_rb,
+                                         float mean, float stdv, void* stream) {
+  if (!x || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || !(stdv > 0.f)) return SMX_EINVAL;
+  const long long total = (long long)B * 3 * Hout * Wout;
+  SMX_LAUNCH(frames_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, Hin, Win, Hout, Wout, swap_rb, mean, stdv);
+  return smx_launch_status();
+}
+
 extern "C" int smx_to_uint8_f32(const float* x, uint8_t* y, int64_t n, float lo, float hi, void* stream) {
   if (!x || !y || n <= 0 || !(hi > lo)) return SMX_EINVAL;
   SMX_LAUNCH(to_uint8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, lo, hi);

@@ -240,3 +240,76 @@ def make_animation(source_image, driving_video, net_g, motion_estimator, relativ
     preds = list(out.cpu().numpy())
     drv8 = ops.to_uint8(drv.to(dev).permute(0, 2, 3, 1).contiguous(), -1.0, 1.0).cpu().numpy()
     return preds, list(drv8)
+
+
+class FramePipeline:
+    """N3 -- the host I/O around the loop (demo.py:166-185 in, :222 out) as an MI355X pipeline: uint8 driving frames leave
+    pinned host memory one byte per sample, are resized / normalised ON the device, rendered in batches, and the uint8 result
+    frames return to pinned host memory, with the H2D copy of batch i+1 and the D2H copy of batch i-1 overlapping the
+    compute of batch i on three HIP streams (double-buffered staging on both sides).  `run` accepts any CPU uint8 tensor /
+    numpy array [N,H,W,3] (or an iterable of such chunks) and returns / yields uint8 [n,256,256,3] host tensors."""
+
+    def __init__(self, net_g, motion_estimator, batch=60, frame_hw=(256, 256), swap_rb=False, relative=True, adapt_movement_scale=True):
+        self.net_g, self.me, self.B = net_g, motion_estimator, int(batch)
+        self.hw, self.swap_rb, self.relative, self.adapt = tuple(frame_hw), swap_rb, relative, adapt_movement_scale
+        dev = next(net_g.parameters()).device
+        if dev.type != "cuda":
+            raise ops.L.SmxError("FramePipeline: the networks must be on an MI355X (call .cuda())")
+        self.dev = dev
+        H, W = self.hw
+        self.pin_in = [torch.empty((self.B, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.dev_in = [torch.empty((self.B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.pin_out = [torch.empty((self.B, 256, 256, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.s_h2d, self.s_d2h = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+    @torch.no_grad()
+    def stream(self, state: SourceState, frames):
+        """generator: yields (start_index, uint8 host tensor [n,256,256,3]) per batch, in order.  The yielded tensor is a view
+        of a pinned staging buffer that is recycled two batches later: copy it if it must outlive that."""
+        frames = torch.as_tensor(frames)
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3 or tuple(frames.shape[1:3]) != self.hw:
+            raise ValueError(f"frames must be uint8 [N,{self.hw[0]},{self.hw[1]},3], got {frames.dtype} {tuple(frames.shape)}")
+        N, B = frames.shape[0], self.B
+        cur = torch.cuda.current_stream(self.dev)
+        in_free, out_ready, pending = [None, None], [None, None], None
+        nb = (N + B - 1) // B
+        for i in range(nb):
+            a, n, k = i * B, min(B, N - i * B), i & 1
+            if in_free[k] is not None:
+                in_free[k].synchronize()                         # compute has consumed the device copy staged from this host buffer
+            self.pin_in[k][:n].copy_(frames[a:a + n])            # host memcpy into pinned memory (a decoder would write here directly)
+            with torch.cuda.stream(self.s_h2d):
+                self.dev_in[k][:n].copy_(self.pin_in[k][:n], non_blocking=True)
+                h2d = torch.cuda.Event()
+                h2d.record()
+            cur.wait_event(h2d)
+            x = ops.frames_u8_to_nchw(self.dev_in[k][:n], (256, 256), self.swap_rb)
+            in_free[k] = torch.cuda.Event()
+            in_free[k].record(cur)
+            out = render_frames(state, x, self.net_g, self.me, self.relative, self.adapt, batch=B)
+            done = torch.cuda.Event()
+            done.record(cur)
+            with torch.cuda.stream(self.s_d2h):                  # pin_out[k] was handed out (and consumed) one iteration ago
+                self.s_d2h.wait_event(done)
+                self.pin_out[k][:n].copy_(out, non_blocking=True)
+                out.record_stream(self.s_d2h)
+                out_ready[k] = torch.cuda.Event()
+                out_ready[k].record()
+            if pending is not None:                              # hand batch i-1 to the caller while batch i runs
+                pa, pn, pk = pending
+                out_ready[pk].synchronize()
+                yield pa, self.pin_out[pk][:pn]
+            pending = (a, n, k)
+        if pending is not None:
+            pa, pn, pk = pending
+            out_ready[pk].synchronize()
+            yield pa, self.pin_out[pk][:pn]
+
+    def run(self, state: SourceState, frames, out=None):
+        """all frames -> one uint8 host tensor [N,256,256,3] (`out` may be a preallocated, e.g. pinned, destination)."""
+        frames = torch.as_tensor(frames)
+        if out is None:
+            out = torch.empty((frames.shape[0], 256, 256, 3), dtype=torch.uint8)
+        for a, chunk in self.stream(state, frames):
+            out[a:a + chunk.shape[0]].copy_(chunk)
+        return out

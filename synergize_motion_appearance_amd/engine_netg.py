@@ -189,6 +189,10 @@ class NetGEngine:
                            "ss0": Conv.cat([cv(pre + ".scale.0"), cv(pre + ".shift.0")]),
                            "scale2": cv(pre + ".scale.2"), "shift2": cv(pre + ".shift.2"),
                            "ms": cv(f"fuse_ms_dict.{s}")}
+        # to_motion (appmotioncodebook_arch.py:290-292): Upsample(E) -> ResBlock(E) -> GroupNorm -> conv3x3 E->2; only the
+        # training branch runs it (m_recon = to_motion(quant_motion), :426)
+        self.to_motion = (cv("to_motion.0.conv"), _Res(P, "to_motion.1"), (P["to_motion.2.weight"], P["to_motion.2.bias"]), cv("to_motion.3"))
+        self.beta = float(cfg.get("beta", 0.25))
         self.fuse_after = {9: 64, 12: 128, 15: 256}
         self.taps_after = {2: 256, 5: 128, 8: 64}
 
@@ -273,14 +277,58 @@ class NetGEngine:
         """Generator.forward without fusion (vqgan_arch.py:344-348): lq_recon = generator(lq_feat)."""
         return self._run_seq(self.gen_kinds, self.gen, x_nhwc)
 
+    # ---- A12 (live in the training branch, SURVEY row N2) -------------------------------------
+    def quantize(self, z_nhwc, codebook, Ks):
+        """VectorQuantizer.forward (archs/vqgan_arch.py:33-93) on NHWC tokens: -> (z_q NHWC, loss, stats).  One fused kernel:
+        distances over the first Ks rows, first-minimum argmin, gather, z_q = z + (e - z), sum (z_q - z)^2;
+        loss = beta * mse(sg(z_q), z) + mse(z_q, sg(z)) = (1 + beta) * mean((z_q - z)^2) in the forward pass."""
+        B, H, W, D = z_nhwc.shape
+        z = z_nhwc.float() if z_nhwc.dtype != torch.float32 else z_nhwc
+        if not z.is_contiguous():
+            z = ops.copy_slice(z, torch.empty((B, H, W, D), device=z.device, dtype=torch.float32))
+        idx, zq, dmin, sq = ops.vq_nearest(z.view(-1, D), codebook, Ks)
+        loss = sq * ((1.0 + self.beta) / float(z.numel()))
+        return zq.view(B, H, W, D), loss.view(()), {"min_encoding_indices": idx.view(-1, 1), "min_distance": dmin}
+
+    def _to_motion(self, zq):
+        up, res, gn, head = self.to_motion
+        h = ops.conv(zq, up, up2=True, want_stats=True)                       # [B,64,64,E]
+        h = res(h)
+        return ops.conv(h, head, in_ss=ops.groupnorm_stats(h, gn[0], gn[1]), in_swish=False, out_dtype=torch.float32)   # [B,64,64,2]
+
+    def app_codebook_loss(self, gt_nchw):
+        """appmotioncodebook_arch.py:429-469 on the driving frame `gt`: encoder taps -> patch embedding -> quantize_app at the
+        scale's codebook prefix -> un-patchify of the quantised and of the raw embedding.
+        -> ([app_recon, app_feat_original, quant_app, app_feat, feat_com] per scale (NHWC), [loss per scale], [stats per scale])"""
+        if self.is16:
+            raise NotImplementedError("the training branch is fp32 (configs[1] arithmetic)")
+        taps = self.encode_driving(gt_nchw)
+        recon, losses, stats = [], [], []
+        for s in sorted(self.app_in):
+            feat = taps[str(s)]
+            C = feat.shape[-1]
+            app_feat = ops.conv(feat, self.app_in[s]) if s == 32 else ops.conv(feat, self.app_in[s], stride=s // 32, pad=(0, 0))
+            zq, loss, st = self.quantize(app_feat, self.cb_app, self.cb_app.shape[0] // 4 * _SCALE_K[s])
+            un = (lambda t: ops.conv(t, self.app_out[32])) if s == 32 else (lambda t: ops.conv(t, self.app_out[s], d2s=(s // 32, C)))
+            recon.append([un(zq), un(app_feat), zq, app_feat, feat])
+            losses.append(loss)
+            stats.append(st)
+        return recon, losses, stats
+
     # ---- A9 -------------------------------------------------------------------------------
-    def _motion_comp(self, flow_res, mq, warp0, s):
+    def _motion_comp(self, flow_res, mq, warp0, s, train=None):
         B = flow_res.shape[0]
         Em = self.Em
         m1 = ops.conv(flow_res, self.motion_emb0, mfma16=self.is16)           # [B,64,64,32]  (fp32 flow in)
         m2 = ops.conv(m1, self.motion_emb1, stride=2, pad=(0, 0), out_hw=(32, 32))
         qin = torch.empty((B, 32, 32, 2 * Em), device=flow_res.device, dtype=self.adt)
         self.motion_emb2(m2, out=qin[..., :Em])
+        if train is not None:
+            # training branch (:379-386, :426): quantise m_feat against the scale's motion-codebook prefix, reconstruct the flow
+            zq, loss, st = self.quantize(qin[..., :Em], self.cb_motion, self.cb_motion.shape[0] // 4 * _SCALE_K[s])
+            train["motion_recon"].append(self._to_motion(zq))
+            train["loss_motion"].append(loss)
+            train["stats_motion"].append(st)
         ops.copy_slice(mq, qin[..., Em:])
         q = ops.conv(qin, self.mq2)                                           # tokens [B,1024,32]
         S = self.cb_motion.shape[0] // 4 * _SCALE_K[s]
@@ -333,7 +381,7 @@ class NetGEngine:
         ops.conv(wsrc, self.wsrc[s], out=mqin[..., :self.Em], act=ACT_RELU)
         ops.copy_slice(st["kp_feat"], mqin[..., self.Em:])
         mq = ops.conv(mqin, self.mq1)
-        r = self._motion_comp(ops.flow_to_residual(flow), mq, warp0, s)
+        r = self._motion_comp(ops.flow_to_residual(flow), mq, warp0, s, st.get("train"))
         m_com, res_norm, occ = ops.flow_occ_update(flow, r, st["occ"][-1])
         st["flows"].append(m_com)
         st["res"].append(res_norm)
@@ -358,10 +406,16 @@ class NetGEngine:
         x = ops.sft_combine(dec, scale, shift, w)
         return ops.conv(enc, f["ms"], res=x, want_stats=True)                 # x + fuse_ms(enc)
 
-    def forward(self, cache, deformation, occ64, heat_nhwc, w=1.0):
+    def forward(self, cache, deformation, occ64, heat_nhwc, w=1.0, train=False):
         """cache: SourceCache; deformation [B,64,64,2]; occ64 [B,64,64]; heat [B,64,64,15] NHWC.
-        -> state dict with NHWC 'out' [B,256,256,3] and the intermediate lists."""
+        -> state dict with NHWC 'out' [B,256,256,3] and the intermediate lists.
+        train=True: the forward of the training branch (inference=False): st['train'] carries the per-scale motion-codebook
+        quantisation (losses, indices, to_motion reconstructions in pixel units) and st['out_lr'] the un-fused decoder pass."""
         st = {"flows": [deformation.contiguous()], "occ": [occ64.contiguous()], "res": [], "before": [], "comp": []}
+        if train:
+            if self.is16:
+                raise NotImplementedError("the training branch is fp32 (configs[1] arithmetic)")
+            st["train"] = {"motion_recon": [], "loss_motion": [], "stats_motion": []}
         st["kp_feat"] = ops.conv(ops.resize(heat_nhwc, 32, 32), self.kp_enc, act=ACT_RELU, mfma16=self.is16)   # fp32 heatmaps in
         x = self._one_scale(st, cache.feats[32], 32, True)
         st["lq"] = x
@@ -388,4 +442,6 @@ class NetGEngine:
                 t = self._fuse(s, cat, w)
             return t
         st["out"] = self._run_seq(self.gen_kinds, self.gen, x, fuse, out_for)
+        if train:
+            st["out_lr"] = self.generator_only(st["lq"])                      # x_lr_32: every generator block, no fusion (:649-659)
         return st

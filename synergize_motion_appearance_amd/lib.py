@@ -97,6 +97,7 @@ SIGNATURES = {
     "smx_copy_slice_f32": (_i, [_p, _i, _p, _i, _i64, _i, _p]),
     "smx_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "smx_nhwc_to_nchw_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "smx_frames_u8_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "smx_to_uint8_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
     "smx_conv3x3_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "smx_groupnorm_swish_nhwc_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),

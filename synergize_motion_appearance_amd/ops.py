@@ -613,6 +613,18 @@ def nhwc_to_nchw(x):
     return y
 
 
+def frames_u8_to_nchw(frames_u8, out_hw=(256, 256), swap_rb=False, mean=0.5, std=0.5, out=None):
+    """uint8 HWC frames [B,H,W,3] on the device -> normalised fp32 NCHW [B,3,Ho,Wo] (demo.py:177-185 on the device)."""
+    if not (torch.is_tensor(frames_u8) and frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3):
+        raise L.SmxError("frames_u8_to_nchw: a uint8 device tensor [B,H,W,3] is expected")
+    B, H, W, _ = frames_u8.shape
+    if out is None:
+        out = torch.empty((B, 3, out_hw[0], out_hw[1]), device=frames_u8.device, dtype=torch.float32)
+    L.check(L.load().smx_frames_u8_to_nchw_f32(frames_u8.contiguous().data_ptr(), _dev(out).data_ptr(), B, H, W, out_hw[0], out_hw[1],
+                                               int(swap_rb), float(mean), float(std), _stream()), "frames_u8_to_nchw")
+    return out
+
+
 def to_uint8(x, lo=-1.0, hi=1.0):
     y = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
     L.check(L.load().smx_to_uint8_f32(_dev(x).contiguous().data_ptr(), y.data_ptr(), x.numel(), lo, hi, _stream()), "to_uint8")

@@ -245,6 +245,36 @@ def test_source_cache_is_keyed_on_content_not_on_the_pointer(nets):
     assert net_g.encode_source(buf) is not c1
 
 
+def test_frame_pipeline_host_to_host_equals_device_resident_run(nets):
+    """row N3: uint8 host frames -> FramePipeline (pinned H2D, device normalise, render, D2H on three streams) must equal
+    render_frames on the same frames converted with the reference's own host arithmetic (demo.py:180-185: x/255 then
+    (x - 0.5)/0.5 in fp32); ragged last batch; the ingest kernel itself bit-exact vs that arithmetic; and its resize branch
+    (cv2.INTER_LINEAR geometry, uint8-rounded) within 1 LSB of a float half-pixel bilinear."""
+    import torch.nn.functional as F
+    from synergize_motion_appearance_amd import driver, ops
+    from synergize_motion_appearance_amd.synth import synth_clip
+    net_g, me = nets
+    src, drv = synth_clip(11, seed=9)
+    u8 = ops.to_uint8(drv.cuda().permute(0, 2, 3, 1).contiguous(), -1.0, 1.0).cpu()          # [11,256,256,3] uint8 "decoded video"
+    ref_in = ((u8.float() / 255.0) - 0.5) / 0.5                                               # the reference's host-side arithmetic
+    x = ops.frames_u8_to_nchw(u8.cuda())
+    assert torch.equal(x.cpu(), ref_in.permute(0, 3, 1, 2))
+    assert torch.equal(ops.frames_u8_to_nchw(u8.cuda(), swap_rb=True).cpu(), ref_in.flip(-1).permute(0, 3, 1, 2))
+    st = driver.encode_source_state(net_g, me, src.cuda(), x[0:1], True)
+    want = driver.render_frames(st, x, net_g, me, True, True, batch=4)
+    pipe = driver.FramePipeline(net_g, me, batch=4)
+    got = pipe.run(st, u8)
+    assert got.dtype == torch.uint8 and not got.is_cuda and torch.equal(got, want.cpu())
+    again = torch.cat([c.clone() for _, c in pipe.stream(st, u8.numpy())])                    # numpy in, chunks out, buffers recycled
+    assert torch.equal(again, got)
+    # resize branch: 300x340 frames -> 256x256
+    big = (torch.rand((2, 300, 340, 3), generator=torch.Generator().manual_seed(3)) * 255).to(torch.uint8)
+    y = ops.frames_u8_to_nchw(big.cuda(), (256, 256))
+    ref = F.interpolate(big.permute(0, 3, 1, 2).float(), size=(256, 256), mode="bilinear", align_corners=False)
+    back = ((y.cpu() * 0.5 + 0.5) * 255.0)
+    assert float((back - back.round()).abs().max()) < 1e-3 and float((back.round() - ref).abs().max()) <= 1.0 + 1e-3
+
+
 def test_standalone_registered_archs_vs_reference():
     """KPDetector / DenseMotionNetwork / VQGANDiscriminator built by name (the reference registers them too): outputs vs
     the fixture produced by the reference's own standalone modules (tests/golden/make_golden_r2.py)."""

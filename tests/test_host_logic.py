@@ -85,8 +85,11 @@ def test_no_cpu_fallback():
     with pytest.raises(SmxError):
         net_g(torch.zeros(1, 3, 256, 256), {"deformation": torch.zeros(1, 64, 64, 2), "occlusion_map": torch.zeros(1, 1, 64, 64),
                                             "driving_kp_heatmap": torch.zeros(1, 15, 64, 64)}, w=1, inference=True)
+    with pytest.raises(SmxError):                      # the training-branch forward (N2 slice 1) has no CPU path either
+        net_g(torch.zeros(1, 3, 256, 256), {"deformation": torch.zeros(1, 64, 64, 2), "occlusion_map": torch.zeros(1, 1, 64, 64),
+                                            "driving_kp_heatmap": torch.zeros(1, 15, 64, 64)}, w=1, inference=False)
     with pytest.raises(NotImplementedError):
-        net_g(torch.zeros(1, 3, 256, 256), {}, w=1, inference=False)
+        net_g(torch.zeros(1, 3, 256, 256), {}, w=1, inference=True, visualize_app_feat=True)
     with pytest.raises(SmxError):
         ops.warp(torch.zeros(1, 32, 32, 64), torch.zeros(1, 64, 64, 2))
     src = open(os.path.join(REPO, "synergize_motion_appearance_amd", "ops.py")).read() + \

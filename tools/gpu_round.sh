@@ -14,7 +14,7 @@ import json
 try:
     j = json.loads([l for l in open("$OUT/bench_$TAG.json") if l.startswith("{")][-1])
     print("fps", j["value"], "ms/step", j["ms_per_step"], "roofline", {k: j.get("roofline", {}).get(k) for k in ("achieved", "frac", "achieved_algorithmic", "share_of_step_time")},
-          "d2h", j.get("value_incl_uint8_d2h"), "cons", j.get("batch_consistency", {}).get("max_lsb_vs_b1"), "cpu", (j.get("cpu_baseline") or {}).get("value"))
+          "pcie", j.get("value_incl_pcie"), "cons", j.get("batch_consistency", {}).get("max_lsb_vs_b1"), "cpu", (j.get("cpu_baseline") or {}).get("value"))
 except Exception as e:
     print("bench parse failed", e)
 PY
