@@ -16,7 +16,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"gemm_xcd_swizzle", "SMX_GEMM_XCD_SWIZZLE", 1},
   {"warp_rows", "SMX_WARP_ROWS", 1},            // warp: row-chunk kernel when eligible (0 = per-lane kernel)
   {"warp_reorder", "SMX_WARP_REORDER", 1},      // warp: (XCD, chunk, frame) block order
-  {"wino_epi", "SMX_WINO_EPI", -1},             // Winograd: epilogue variant
+  {"wino_epi", "SMX_WINO_EPI", 1},              // Winograd: 1 = one-pass epilogue (default, measured +11..47 % on ResBlock-form launches), 0 = two passes over the output columns
   {"conv16_tpb", "SMX_CONV16_TPB", -1},         // bf16 region-direct 3x3: tiles walked per block (reserved)
   {"attn16", "SMX_ATTN16", 1},                  // bf16 storage, d_head 32: bf16 MFMA kernel (0 = fp32 MFMA kernel on bf16 storage)
 };

@@ -31,8 +31,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int RH = 10, RW = 18;                     // staged input region (pixels)
-constexpr int RPMAX = 19, RPIX = RH * RPMAX;              // LDS row pitch 19 px: with the chunk swizzle below every
-                                                    // ds_read_b128 16-lane group hits 16 distinct 4-bank slots
+constexpr int RPMAX = 19;                                 // LDS row pitch 19 px with the chunk swizzle: every ds_read_b128 16-lane group
+                                                    // hits 16 distinct 4-bank slots (18 without the swizzle)
 constexpr int RLD = 36;                             // floats per region pixel in LDS (32 + 4 pad)
 
 struct WP {
@@ -61,9 +61,10 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 
 // NW = 32-wide N tiles per block (waves = 4 frequency rows x NW).  NW=1: 4 waves, <=168 VGPRs, 3 blocks/CU;
 // NW=2: 8 waves, <=128 VGPRs, 2 blocks/CU.
-template <bool SWZ, int NW, int ABL = 0>   // ABL: timing-only ablation mask (tools only): 2 no U loads, 4 no region staging, 16 no epilogue
+template <bool SWZ, int NW, int ABL = 0, bool EPI1 = false>   // ABL: timing-only ablation mask (tools only): 2 no U loads, 4 no region staging, 16 no epilogue; EPI1: one-pass epilogue
 __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP p) {
   constexpr int RP = SWZ ? 19 : 18;
+  constexpr int RPIX = RH * RP;                       // region pixels per LDS buffer (pitch 18 unswizzled: 3 blocks of the 4-wave variant fit 160 KiB)
   constexpr int NTHR = 256 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [2][RPIX][RLD] (reused by the epilogue)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -217,6 +218,109 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   float* zb = smem;
   float* __restrict__ Yp = p.y;
   const float* __restrict__ Rp = p.res;
+  if (EPI1) {
+    // One pass: every wave writes BOTH output columns of its frequency row (Z[0], Z[1]) -> one barrier -> each thread
+    // finishes a whole 2x2 output tile x 4 channels (was: two passes over q with four barriers).  zb2 [2 q][4 fi][32 tiles][NB].
+    constexpr int NB1 = 32 * NW, NQ1 = NB1 / 4;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int row = SWZ ? 16 * (__popc((unsigned)(rl >> 2)) & 1) + 4 * (rl >> 3) + (rl & 3) : rl;
+      zb[((0 * 4 + fi) * 32 + row) * NB1 + nh * 32 + t] = acc[0][r] + acc[1][r] + acc[2][r];
+      zb[((1 * 4 + fi) * 32 + row) * NB1 + nh * 32 + t] = acc[1][r] - acc[2][r] - acc[3][r];
+    }
+    __syncthreads();
+    const int tile = tid / NQ1, n4 = (tid % NQ1) * 4;
+    const int n = nblk * NB1 + n4;
+    float4 o[2][2];                                                  // [output row][output col q]
+    float gs4[4] = {0.f, 0.f, 0.f, 0.f}, gm2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.Cout) {
+      const bool full = n + 3 < p.Cout;
+      float bn[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < p.Cout) bn[e] = p.bias[n + e];
+      }
+      const bool vec = full && (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) &&
+                       (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0));
+      const int oy = by * 8 + 2 * (tile >> 3), ox0 = bx * 16 + 2 * (tile & 7);
+      const long long pix0 = ((long long)img * p.H + oy) * p.W + ox0;
+      float4 rr[2][2];
+      if (Rp && vec) {
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) rr[yy][q] = *reinterpret_cast<const float4*>(Rp + (pix0 + yy * p.W + q) * p.ldres + n);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 z0 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 0) * 32 + tile) * NB1 + n4);
+        const float4 z1 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 1) * 32 + tile) * NB1 + n4);
+        const float4 z2 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 2) * 32 + tile) * NB1 + n4);
+        const float4 z3 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 3) * 32 + tile) * NB1 + n4);
+        float a0[4] = {z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w};
+        float a1[4] = {z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] = w_act(a0[e] + bn[e], p.act); a1[e] = w_act(a1[e] + bn[e], p.act); }
+        o[0][q] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+        o[1][q] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+      }
+      if (vec) {
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (Rp) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
+            *reinterpret_cast<float4*>(Yp + (pix0 + yy * p.W + q) * p.ldc + n) = o[yy][q];
+          }
+      } else {
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float v[4] = {o[yy][q].x, o[yy][q].y, o[yy][q].z, o[yy][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (n + e >= p.Cout) { v[e] = 0.f; continue; }
+              if (Rp) v[e] += Rp[(pix0 + yy * p.W + q) * p.ldres + n + e];
+              Yp[(pix0 + yy * p.W + q) * p.ldc + n + e] = v[e];
+            }
+            o[yy][q] = make_float4(v[0], v[1], v[2], v[3]);
+          }
+      }
+      // Welford partial of this thread's 4 values per channel: a,b (q=0: rows 0,1), c,d (q=1)
+      const float va[4][4] = {{o[0][0].x, o[0][0].y, o[0][0].z, o[0][0].w}, {o[1][0].x, o[1][0].y, o[1][0].z, o[1][0].w},
+                              {o[0][1].x, o[0][1].y, o[0][1].z, o[0][1].w}, {o[1][1].x, o[1][1].y, o[1][1].z, o[1][1].w}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s0 = va[0][e] + va[1][e], d0 = va[0][e] - va[1][e], s1 = va[2][e] + va[3][e], d1 = va[2][e] - va[3][e], ds = s0 - s1;
+        gs4[e] = 0.25f * (s0 + s1);
+        gm2[e] = 0.5f * (d0 * d0 + d1 * d1) + 0.25f * ds * ds;
+      }
+    }
+    if (p.stats) {
+      __syncthreads();                                               // zb2 is dead: reduction buffer [32 tiles][NB][2] on top of it
+      float* red = smem;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(tile * NB1 + n4 + e) * 2] = gs4[e]; red[(tile * NB1 + n4 + e) * 2 + 1] = gm2[e]; }
+      __syncthreads();
+      if (tid < NB1 && nblk * NB1 + tid < p.Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll 8
+        for (int tl = 0; tl < 32; ++tl) { a += red[(tl * NB1 + tid) * 2]; b += red[(tl * NB1 + tid) * 2 + 1]; }
+        a *= (1.f / 32.f);
+        float c2 = 0.f;
+#pragma unroll 8
+        for (int tl = 0; tl < 32; ++tl) { const float d = red[(tl * NB1 + tid) * 2] - a; c2 += d * d; }
+        b += 4.f * c2;
+        const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
+        float* o2 = p.stats + (chunk * p.Cout + nblk * NB1 + tid) * 2;
+        o2[0] = a; o2[1] = b;
+      }
+    }
+    return;
+  }
   // GroupNorm statistics of the consumer, produced here: per channel {sum, sum^2} of what is stored
   // in Welford form ({mean, M2} of the block's 128 values per channel; see gn_partial_kernel for why not {sum, sum^2})
   float gs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gd[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -326,13 +430,16 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
   if (16LL * ((Cout + 31) / 32) * (Cin / 8) * 256 > 2147483647LL) return SMX_EINVAL;
-  const size_t lds = (size_t)2 * RPIX * RLD * sizeof(float);       // 54,720 B (>= the epilogue 32 KiB)
+  const int nw_t = smx_tune(SMX_TUNE_WINO_NW);
+  const int nw = (nw_t == 1 || nw_t == 2) ? nw_t : ((Cout % 64 == 0 && blocks * (Cout / 64) >= 1024) ? 2 : 1);
+  const int swz = smx_tune(SMX_TUNE_WINO_SWZ);
+  const int epi1 = smx_tune(SMX_TUNE_WINO_EPI) > 0 ? 1 : 0;
+  // 2 region buffers (pitch 18 px, 19 with the swizzle) -- 51,840 / 54,720 B -- or the one-pass epilogue's [2][4][32][32*NW] floats
+  size_t lds = (size_t)2 * RH * (swz ? 19 : 18) * RLD * sizeof(float);
+  if (epi1 && (size_t)2 * 4 * 32 * 32 * nw * sizeof(float) > lds) lds = (size_t)2 * 4 * 32 * 32 * nw * sizeof(float);
   // measured (profiles/r01_e_winograd_variants.txt): 8-wave blocks (N=64) win once there are >= 1024 of
   // them, 4-wave blocks (N=32, 3 per CU) otherwise; the conflict-free LDS swizzle is neutral (LDS is
   // not the limiter) and stays off by default.
-  const int swz = smx_tune(SMX_TUNE_WINO_SWZ);
-  const int nw_t = smx_tune(SMX_TUNE_WINO_NW);
-  const int nw = (nw_t == 1 || nw_t == 2) ? nw_t : ((Cout % 64 == 0 && blocks * (Cout / 64) >= 1024) ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
   const int abl = smx_tune(SMX_TUNE_WINO_ABLATE);
   if (abl && nw == 2) {
@@ -348,11 +455,17 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   }
   if (nw == 2) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
-    if (swz) SMX_LAUNCH((winograd_kernel<true, 2>), grid, dim3(512), lds, st, p);
+    if (epi1) {
+      static bool attr = false;
+      if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
+      SMX_LAUNCH((winograd_kernel<false, 2, 0, true>), grid, dim3(512), lds, st, p);
+    }
+    else if (swz) SMX_LAUNCH((winograd_kernel<true, 2>), grid, dim3(512), lds, st, p);
     else SMX_LAUNCH((winograd_kernel<false, 2>), grid, dim3(512), lds, st, p);
   } else {
     dim3 grid((unsigned)blocks, (Cout + 31) / 32);
-    if (swz) SMX_LAUNCH((winograd_kernel<true, 1>), grid, dim3(256), lds, st, p);
+    if (epi1) SMX_LAUNCH((winograd_kernel<false, 1, 0, true>), grid, dim3(256), lds, st, p);
+    else if (swz) SMX_LAUNCH((winograd_kernel<true, 1>), grid, dim3(256), lds, st, p);
     else SMX_LAUNCH((winograd_kernel<false, 1>), grid, dim3(256), lds, st, p);
   }
   return smx_launch_status();

@@ -271,6 +271,11 @@ class FramePipeline:
             raise ValueError(f"frames must be uint8 [N,{self.hw[0]},{self.hw[1]},3], got {frames.dtype} {tuple(frames.shape)}")
         N, B = frames.shape[0], self.B
         cur = torch.cuda.current_stream(self.dev)
+        # the staging buffers came from the caching allocator, whose reuse is only ordered on the stream that allocated them:
+        # work already queued on the compute stream may still be using that memory under another name, so the copy streams
+        # start behind everything queued so far
+        self.s_h2d.wait_stream(cur)
+        self.s_d2h.wait_stream(cur)
         in_free, out_ready, pending = [None, None], [None, None], None
         nb = (N + B - 1) // B
         for i in range(nb):

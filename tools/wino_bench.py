@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused Winograd kernel on the B=60 (and B=1) shapes of the step, per epilogue variant.
+usage: python tools/wino_bench.py [B]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from synergize_motion_appearance_amd import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+SHAPES = [(64, 64, 256), (128, 128, 128), (128, 64, 256), (128, 128, 256), (256, 128, 64), (128, 128, 64), (256, 256, 32), (256, 512, 32), (512, 256, 32)]
+
+
+def timed(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+print(f"B={B}  cin cout s : epi0 us (alg TF, exec frac)   epi1 us (alg TF, exec frac)   [GN loader + stats + residual, as in a ResBlock]")
+for cin, cout, s in SHAPES:
+    x = torch.randn((B, s, s, cin), device="cuda")
+    cv = ops.Conv.from_torch(torch.randn((cout, cin, 3, 3), device="cuda") / (3 * cin ** 0.5), torch.randn(cout, device="cuda") * 0.1)
+    out = torch.empty((B, s, s, cout), device="cuda")
+    res = torch.randn((B, s, s, cout), device="cuda")
+    ss = torch.rand((B, cin, 2), device="cuda")
+    fl = 2.0 * B * s * s * cout * 9 * cin
+    row = []
+    for epi in (0, 1):
+        ops.set_tuning("wino_epi", epi)
+        t = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True, res=res, want_stats=True))
+        row.append(f"{1e3 * t:8.1f} ({fl / t / 1e9:5.0f} TF, {fl * 4 / 9 / t / 1e9 / 157.3:.3f})")
+    ops.set_tuning("wino_epi", 1)
+    print(f"{cin:4d} {cout:4d} {s:4d} : " + "   ".join(row))
