@@ -61,7 +61,7 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 
 // NW = 32-wide N tiles per block (waves = 4 frequency rows x NW).  NW=1: 4 waves, <=168 VGPRs, 3 blocks/CU;
 // NW=2: 8 waves, <=128 VGPRs, 2 blocks/CU.
-template <bool SWZ, int NW, int ABL = 0, bool EPI1 = false>   // ABL: timing-only ablation mask (tools only): 2 no U loads, 4 no region staging, 16 no epilogue; EPI1: one-pass epilogue
+template <bool SWZ, int NW, int ABL = 0, bool EPI1 = false, int UD = 2>   // UD: U prefetch distance in units (2 | 3) on the 4-slot ring   // ABL: timing-only ablation mask (tools only): 2 no U loads, 4 no region staging, 16 no epilogue; EPI1: one-pass epilogue
 __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP p) {
   constexpr int RP = SWZ ? 19 : 18;
   constexpr int RPIX = RH * RP;                       // region pixels per LDS buffer (pitch 18 unswizzled: 3 blocks of the 4-wave variant fit 160 KiB)
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     return *reinterpret_cast<const float4*>(U + ((unit & 3) * ufs + (unit >> 2) * 256) + lane4);
   };
   ur[0] = uload(0); ur[1] = uload(1);
+  if (UD == 3) ur[2] = uload(2);
   __syncthreads();
   // input transform of 8-channel step `sub` for frequency row fi, this lane's (tile, 4 channels):
   // t_b = d[ra][b] +- d[rb][b];  V[i][0..3] = t0-t2, t1+t2, t2-t1, t1-t3
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   auto mfma16 = [&](const float4 (&v)[4], int unit0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (!(ABL & 2)) ur[(j + 2) & 3] = uload(unit0 + j + 2);
+      if (!(ABL & 2)) ur[(j + UD) & 3] = uload(unit0 + j + UD);   // UD = 3: the slot freed by the previous group (its MFMAs are issued)
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[j].x, acc[j], 0, 0, 0);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[j].y, acc[j], 0, 0, 0);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[j].z, acc[j], 0, 0, 0);
@@ -412,6 +413,353 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   }
 }
 
+
+// "Wide" variant for the big launches (Cout % 64 == 0): 4 waves per block, one per frequency row, each wave owning BOTH 32-wide
+// N tiles of the block's 64 output channels -- 8 accumulators (128 VGPRs) at a 256-VGPR budget, 2 waves per SIMD (2 blocks / CU).
+// Against the 8-wave block: the input transform (LDS reads + 48 VALU) and the region staging are done once per 32 MFMAs instead
+// of once per 16, the two accumulator chains of a frequency alternate on the matrix pipe (no back-to-back dependent MFMAs), a
+// barrier joins 4 waves instead of 8, and nothing spills.
+template <bool PIPE, int UD = 2>
+__global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
+  constexpr int RP = 18, RPIX = RH * RP, NTHR = 256, NI = 2, NB = 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int fi = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, t = lane & 31;
+  const int tr = t >> 3, tc = t & 7;
+  int bid = blockIdx.x;
+  const int bx = bid % p.tiles_x; bid /= p.tiles_x;
+  const int by = bid % p.tiles_y; const int img = bid / p.tiles_y;
+  const int nblk = blockIdx.y;
+  const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
+  const float* __restrict__ X = p.x + (long long)img * Hs * Ws * p.lda;
+
+  constexpr int NIT = (RH * RW * 8 + NTHR - 1) / NTHR;                 // 6
+  float4 stage[NIT];
+  auto item_geo = [&](int k, int& g, int& l, bool& gok, bool& lok) {
+    const int item = tid + NTHR * k;
+    lok = item < RH * RW * 8;
+    const int px = item >> 3, c4 = item & 7;
+    const int ry = px / RW, rx = px - ry * RW;
+    int iy = by * 8 - 1 + ry, ix = bx * 16 - 1 + rx;
+    gok = lok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    if (p.up2) { iy >>= 1; ix >>= 1; }
+    g = (iy * Ws + ix) * p.lda + c4 * 4;
+    l = (ry * RP + rx) * RLD + c4 * 4;
+  };
+  unsigned okmask = 0;                                                 // bit k: in frame, bit 8+k: inside the region
+  auto load_region = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      int g, l; bool gok, lok; item_geo(k, g, l, gok, lok);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gok) v = *reinterpret_cast<const float4*>(X + g + c0);
+      stage[k] = v;
+    }
+  };
+  auto store_region = [&](int buf, int c0) {
+    float* rb = smem + buf * RPIX * RLD;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      int g, l; bool gok, lok; item_geo(k, g, l, gok, lok);
+      if (!lok) continue;
+      float4 v = stage[k];
+      if (p.in_ss && gok) {
+        const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + ((tid + NTHR * k) & 7) * 4) * 2;
+        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+        v = make_float4(fmaf(v.x, s0.x, s0.y), fmaf(v.y, s0.z, s0.w), fmaf(v.z, s1.x, s1.y), fmaf(v.w, s1.z, s1.w));
+        if (p.in_swish) {
+          constexpr float L2E = 1.44269504088896340736f;
+          v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
+          v.y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.y));
+          v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
+          v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
+        }
+      }
+      *reinterpret_cast<float4*>(rb + l) = v;
+    }
+  };
+  (void)okmask;
+
+  const int ra = (fi == 0) ? 0 : ((fi == 2) ? 2 : 1);
+  const int rb_ = (fi == 0) ? 2 : ((fi == 1) ? 2 : ((fi == 2) ? 1 : 3));
+  const int pa = ((2 * tr + ra) * RP + 2 * tc) * RLD;
+  const int pb = ((2 * tr + rb_) * RP + 2 * tc) * RLD;
+  const float sgn = (fi == 1) ? 1.f : -1.f;
+
+  const int cs8 = p.Cin >> 3;
+  const int ufs = p.n32 * cs8 * 256;
+  const int lane4 = lane * 4;
+  const float* __restrict__ U0 = p.u + (((long long)(fi * 4) * p.n32 + min(nblk * 2, p.n32 - 1)) * cs8) * 256;
+  const float* __restrict__ U1 = p.u + (((long long)(fi * 4) * p.n32 + min(nblk * 2 + 1, p.n32 - 1)) * cs8) * 256;
+
+  f32x16 acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsl = p.Cin >> 5;
+  load_region(0); store_region(0, 0);
+  float4 ur[NI][4];
+  auto uload = [&](const float* U, int unit) -> float4 {
+    return *reinterpret_cast<const float4*>(U + ((unit & 3) * ufs + (unit >> 2) * 256) + lane4);
+  };
+  ur[0][0] = uload(U0, 0); ur[1][0] = uload(U1, 0); ur[0][1] = uload(U0, 1); ur[1][1] = uload(U1, 1);
+  if (UD == 3) { ur[0][2] = uload(U0, 2); ur[1][2] = uload(U1, 2); }
+  __syncthreads();
+  auto transform = [&](const float* rb, int sub, float4 (&v)[4]) {
+    float4 tt[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ch = (2 * sub + hh) * 4;
+      const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + ch);
+      const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + ch);
+      tt[b] = make_float4(fmaf(sgn, db.x, da.x), fmaf(sgn, db.y, da.y), fmaf(sgn, db.z, da.z), fmaf(sgn, db.w, da.w));
+    }
+    v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+  };
+  auto mfma32 = [&](const float4 (&v)[4], int unit0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ur[0][(j + UD) & 3] = uload(U0, unit0 + j + UD);              // UD = 3: the slot whose MFMAs were issued one group ago
+      ur[1][(j + UD) & 3] = uload(U1, unit0 + j + UD);
+      // the two N tiles' accumulators alternate: consecutive MFMAs never depend on each other
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[0][j].x, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[1][j].x, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[0][j].y, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[1][j].y, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[0][j].z, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[1][j].z, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[0][j].w, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[1][j].w, acc[1][j], 0, 0, 0);
+    }
+  };
+  if (!PIPE) {
+    for (int s = 0; s < nsl; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nsl) load_region((s + 1) * 32);
+      const float* rb = smem + buf * RPIX * RLD;
+#pragma unroll 1
+      for (int sub = 0; sub < 4; ++sub) {
+        float4 v[4];
+        transform(rb, sub, v);
+        __builtin_amdgcn_s_setprio(1);
+        mfma32(v, (s * 4 + sub) * 4);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      if (s + 1 < nsl) store_region(buf ^ 1, (s + 1) * 32);
+      __syncthreads();
+    }
+  } else {
+    // Software-pipelined: a wave's own VALU / LDS work (~150 instructions per 8-channel step: transform, U addressing,
+    // GroupNorm+swish of the staged region) used to sit BETWEEN its MFMA bursts, and the two waves of a SIMD run the same
+    // program in near lockstep, so the matrix pipe idled while both transformed (PMC: MFMA busy 0.55, VALU issue 13 % of wave
+    // time).  Here the transform of step k+1 is issued in four column pieces between the four 8-MFMA groups of step k
+    // (a 64-cycle f32 MFMA leaves ~15 issue slots), and the next slice's region is staged in two halves during steps 0-2
+    // (12 staging VGPRs instead of 24, which is what pays for the second A-operand buffer at the 256-VGPR budget).
+    auto col = [&](const float* rb, int sub, int b, float4& out) {     // t_b = d[ra][b] +- d[rb][b] for patch column b
+      const int ch = (2 * sub + hh) * 4;
+      const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + ch);
+      const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + ch);
+      out = make_float4(fmaf(sgn, db.x, da.x), fmaf(sgn, db.y, da.y), fmaf(sgn, db.z, da.z), fmaf(sgn, db.w, da.w));
+    };
+    auto finish = [&](float4 (&v)[4]) {                                // columns t0..t3 (in v) -> V[i][0..3] = t0-t2, t1+t2, t2-t1, t1-t3
+      const float4 t1 = v[1], t2 = v[2];
+      v[0] = f4sub(v[0], t2); v[3] = f4sub(t1, v[3]); v[1] = f4add(t1, t2); v[2] = f4sub(t2, t1);
+    };
+    auto group = [&](const float4 (&v)[4], int unit0, int j) {         // the 8 MFMAs of frequency j (+ the U prefetch two units ahead)
+      ur[0][(j + 2) & 3] = uload(U0, unit0 + j + 2);
+      ur[1][(j + 2) & 3] = uload(U1, unit0 + j + 2);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[0][j].x, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[1][j].x, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[0][j].y, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[1][j].y, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[0][j].z, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[1][j].z, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[0][j].w, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[1][j].w, acc[1][j], 0, 0, 0);
+    };
+    // one step: MFMAs of `cur` interleaved with the column pieces of the NEXT step's transform (from region buffer nrb)
+    auto step = [&](const float4 (&cur)[4], float4 (&nxt)[4], int unit0, const float* nrb, int nsub, bool have_next) {
+      __builtin_amdgcn_s_setprio(1);
+      if (have_next) col(nrb, nsub, 0, nxt[0]);
+      group(cur, unit0, 0);
+      if (have_next) col(nrb, nsub, 1, nxt[1]);
+      group(cur, unit0, 1);
+      if (have_next) col(nrb, nsub, 2, nxt[2]);
+      group(cur, unit0, 2);
+      if (have_next) col(nrb, nsub, 3, nxt[3]);
+      group(cur, unit0, 3);
+      if (have_next) finish(nxt);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    constexpr int HALF = NIT / 2;                                      // 3 items per staging half
+    float4 sth[HALF];
+    auto load_half = [&](int h, int c0) {
+#pragma unroll
+      for (int k = 0; k < HALF; ++k) {
+        int g, l; bool gok, lok; item_geo(h * HALF + k, g, l, gok, lok);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gok) v = *reinterpret_cast<const float4*>(X + g + c0);
+        sth[k] = v;
+      }
+    };
+    auto store_half = [&](int h, int buf, int c0) {
+      float* rb = smem + buf * RPIX * RLD;
+#pragma unroll
+      for (int k = 0; k < HALF; ++k) {
+        int g, l; bool gok, lok; item_geo(h * HALF + k, g, l, gok, lok);
+        if (!lok) continue;
+        float4 v = sth[k];
+        if (p.in_ss && gok) {
+          const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + ((tid + NTHR * (h * HALF + k)) & 7) * 4) * 2;
+          const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+          v = make_float4(fmaf(v.x, s0.x, s0.y), fmaf(v.y, s0.z, s0.w), fmaf(v.z, s1.x, s1.y), fmaf(v.w, s1.z, s1.w));
+          if (p.in_swish) {
+            constexpr float L2E = 1.44269504088896340736f;
+            v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
+            v.y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.y));
+            v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
+            v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
+          }
+        }
+        *reinterpret_cast<float4*>(rb + l) = v;
+      }
+    };
+    float4 va[4], vb[4];
+    { col(smem, 0, 0, va[0]); col(smem, 0, 1, va[1]); col(smem, 0, 2, va[2]); col(smem, 0, 3, va[3]); finish(va); }
+    for (int s = 0; s < nsl; ++s) {
+      const int buf = s & 1;
+      const bool more = s + 1 < nsl;
+      const float* rb = smem + buf * RPIX * RLD;
+      const float* nb = smem + (buf ^ 1) * RPIX * RLD;
+      const int u0 = s * 16;
+      if (more) load_half(0, (s + 1) * 32);
+      step(va, vb, u0, rb, 1, true);                                   // step 0 | transform of step 1
+      if (more) { store_half(0, buf ^ 1, (s + 1) * 32); load_half(1, (s + 1) * 32); }
+      step(vb, va, u0 + 4, rb, 2, true);                               // step 1 | transform of step 2
+      if (more) store_half(1, buf ^ 1, (s + 1) * 32);
+      step(va, vb, u0 + 8, rb, 3, true);                               // step 2 | transform of step 3
+      __syncthreads();                                                 // the next slice's region is complete (and nobody reads `buf` after step 3's columns, read above)
+      step(vb, va, u0 + 12, nb, 0, more);                              // step 3 | transform of the next slice's step 0
+    }
+  }
+
+  // ---- one-pass epilogue: zb2 [2 q][4 fi][32 tiles][64 n] -------------------------------------------------------------
+  float* zb = smem;
+  float* __restrict__ Yp = p.y;
+  const float* __restrict__ Rp = p.res;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      zb[((0 * 4 + fi) * 32 + row) * NB + i * 32 + t] = acc[i][0][r] + acc[i][1][r] + acc[i][2][r];
+      zb[((1 * 4 + fi) * 32 + row) * NB + i * 32 + t] = acc[i][1][r] - acc[i][2][r] - acc[i][3][r];
+    }
+  __syncthreads();
+  float gs4[2][4], gm2[2][4];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = tid + NTHR * it;                                  // 32 tiles x 16 channel quads
+    const int tile = item >> 4, n4 = (item & 15) * 4;
+    const int n = nblk * NB + n4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gs4[it][e] = 0.f; gm2[it][e] = 0.f; }
+    if (n < p.Cout) {
+      const bool full = n + 3 < p.Cout;
+      float bn[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < p.Cout) bn[e] = p.bias[n + e];
+      }
+      const bool vec = full && (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) &&
+                       (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0));
+      const int oy = by * 8 + 2 * (tile >> 3), ox0 = bx * 16 + 2 * (tile & 7);
+      const long long pix0 = ((long long)img * p.H + oy) * p.W + ox0;
+      float4 o[2][2], rr[2][2];
+      if (Rp && vec) {
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) rr[yy][q] = *reinterpret_cast<const float4*>(Rp + (pix0 + yy * p.W + q) * p.ldres + n);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 z0 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 0) * 32 + tile) * NB + n4);
+        const float4 z1 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 1) * 32 + tile) * NB + n4);
+        const float4 z2 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 2) * 32 + tile) * NB + n4);
+        const float4 z3 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 3) * 32 + tile) * NB + n4);
+        float a0[4] = {z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w};
+        float a1[4] = {z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] = w_act(a0[e] + bn[e], p.act); a1[e] = w_act(a1[e] + bn[e], p.act); }
+        o[0][q] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+        o[1][q] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+      }
+      if (vec) {
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (Rp) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
+            *reinterpret_cast<float4*>(Yp + (pix0 + yy * p.W + q) * p.ldc + n) = o[yy][q];
+          }
+      } else {
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float v[4] = {o[yy][q].x, o[yy][q].y, o[yy][q].z, o[yy][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (n + e >= p.Cout) { v[e] = 0.f; continue; }
+              if (Rp) v[e] += Rp[(pix0 + yy * p.W + q) * p.ldres + n + e];
+              Yp[(pix0 + yy * p.W + q) * p.ldc + n + e] = v[e];
+            }
+            o[yy][q] = make_float4(v[0], v[1], v[2], v[3]);
+          }
+      }
+      const float va4[4][4] = {{o[0][0].x, o[0][0].y, o[0][0].z, o[0][0].w}, {o[1][0].x, o[1][0].y, o[1][0].z, o[1][0].w},
+                               {o[0][1].x, o[0][1].y, o[0][1].z, o[0][1].w}, {o[1][1].x, o[1][1].y, o[1][1].z, o[1][1].w}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s0 = va4[0][e] + va4[1][e], d0 = va4[0][e] - va4[1][e], s1 = va4[2][e] + va4[3][e], d1 = va4[2][e] - va4[3][e], ds = s0 - s1;
+        gs4[it][e] = 0.25f * (s0 + s1);
+        gm2[it][e] = 0.5f * (d0 * d0 + d1 * d1) + 0.25f * ds * ds;
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* red = smem;                                                 // [32 tiles][64][2]
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + NTHR * it, tile = item >> 4, n4 = (item & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(tile * NB + n4 + e) * 2] = gs4[it][e]; red[(tile * NB + n4 + e) * 2 + 1] = gm2[it][e]; }
+    }
+    __syncthreads();
+    if (tid < NB && nblk * NB + tid < p.Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll 8
+      for (int tl = 0; tl < 32; ++tl) { a += red[(tl * NB + tid) * 2]; b += red[(tl * NB + tid) * 2 + 1]; }
+      a *= (1.f / 32.f);
+      float c2 = 0.f;
+#pragma unroll 8
+      for (int tl = 0; tl < 32; ++tl) { const float d = red[(tl * NB + tid) * 2] - a; c2 += d * d; }
+      b += 4.f * c2;
+      const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
+      float* o2 = p.stats + (chunk * p.Cout + nblk * NB + tid) * 2;
+      o2[0] = a; o2[1] = b;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
@@ -434,6 +782,7 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   const int nw = (nw_t == 1 || nw_t == 2) ? nw_t : ((Cout % 64 == 0 && blocks * (Cout / 64) >= 1024) ? 2 : 1);
   const int swz = smx_tune(SMX_TUNE_WINO_SWZ);
   const int epi1 = smx_tune(SMX_TUNE_WINO_EPI) > 0 ? 1 : 0;
+  const int ud = smx_tune(SMX_TUNE_WINO_UD) == 3 ? 3 : 2;
   // 2 region buffers (pitch 18 px, 19 with the swizzle) -- 51,840 / 54,720 B -- or the one-pass epilogue's [2][4][32][32*NW] floats
   size_t lds = (size_t)2 * RH * (swz ? 19 : 18) * RLD * sizeof(float);
   if (epi1 && (size_t)2 * 4 * 32 * 32 * nw * sizeof(float) > lds) lds = (size_t)2 * 4 * 32 * 32 * nw * sizeof(float);
@@ -453,18 +802,35 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
     }
     return smx_launch_status();
   }
-  if (nw == 2) {
+  const int wide = smx_tune(SMX_TUNE_WINO_WIDE);
+  if (nw == 2 && wide > 0 && !swz) {
+    dim3 grid((unsigned)blocks, (Cout + 63) / 64);
+    static bool attrw = false;
+    if (!attrw) {
+      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      attrw = true;
+    }
+    if (wide == 3) SMX_LAUNCH((winograd_wide_kernel<false, 3>), grid, dim3(256), 65536, st, p);
+    else if (wide == 2) SMX_LAUNCH(winograd_wide_kernel<true>, grid, dim3(256), 65536, st, p);
+    else SMX_LAUNCH(winograd_wide_kernel<false>, grid, dim3(256), 65536, st, p);
+  } else if (nw == 2) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
     if (epi1) {
       static bool attr = false;
       if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
-      SMX_LAUNCH((winograd_kernel<false, 2, 0, true>), grid, dim3(512), lds, st, p);
+      static bool attr3 = false;
+      if (!attr3) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr3 = true; }
+      if (ud == 3) SMX_LAUNCH((winograd_kernel<false, 2, 0, true, 3>), grid, dim3(512), lds, st, p);
+      else SMX_LAUNCH((winograd_kernel<false, 2, 0, true>), grid, dim3(512), lds, st, p);
     }
     else if (swz) SMX_LAUNCH((winograd_kernel<true, 2>), grid, dim3(512), lds, st, p);
     else SMX_LAUNCH((winograd_kernel<false, 2>), grid, dim3(512), lds, st, p);
   } else {
     dim3 grid((unsigned)blocks, (Cout + 31) / 32);
-    if (epi1) SMX_LAUNCH((winograd_kernel<false, 1, 0, true>), grid, dim3(256), lds, st, p);
+    if (epi1 && ud == 3) SMX_LAUNCH((winograd_kernel<false, 1, 0, true, 3>), grid, dim3(256), lds, st, p);
+    else if (epi1) SMX_LAUNCH((winograd_kernel<false, 1, 0, true>), grid, dim3(256), lds, st, p);
     else if (swz) SMX_LAUNCH((winograd_kernel<true, 1>), grid, dim3(256), lds, st, p);
     else SMX_LAUNCH((winograd_kernel<false, 1>), grid, dim3(256), lds, st, p);
   }

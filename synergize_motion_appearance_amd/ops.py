@@ -138,7 +138,7 @@ class Conv:
             Up = torch.zeros((16, n32 * 32, self.cin), device=g.device, dtype=torch.float32)
             Up[:, :self.cout] = U.reshape(16, self.cout, self.cin)
             Up = Up.view(16, n32, 32, self.cin // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
-            self._u = torch.cat([Up.view(-1), torch.zeros(512, device=g.device, dtype=torch.float32)])   # prefetch pad
+            self._u = torch.cat([Up.view(-1), torch.zeros(1024, device=g.device, dtype=torch.float32)])   # prefetch pad (up to 3 units of 256 floats past the end)
         return self._u
 
     @staticmethod

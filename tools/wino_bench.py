@@ -25,7 +25,7 @@ def timed(fn, n=5):
     return e0.elapsed_time(e1) / n
 
 
-print(f"B={B}  cin cout s : epi0 us (alg TF, exec frac)   epi1 us (alg TF, exec frac)   [GN loader + stats + residual, as in a ResBlock]")
+print(f"B={B}  cin cout s : 8-wave us (alg TF, exec frac)   wide us   wide+pipelined us   [GN loader + stats + residual, as in a ResBlock]")
 for cin, cout, s in SHAPES:
     x = torch.randn((B, s, s, cin), device="cuda")
     cv = ops.Conv.from_torch(torch.randn((cout, cin, 3, 3), device="cuda") / (3 * cin ** 0.5), torch.randn(cout, device="cuda") * 0.1)
@@ -34,9 +34,9 @@ for cin, cout, s in SHAPES:
     ss = torch.rand((B, cin, 2), device="cuda")
     fl = 2.0 * B * s * s * cout * 9 * cin
     row = []
-    for epi in (0, 1):
-        ops.set_tuning("wino_epi", epi)
+    for epi in (0, 1, 2):
+        ops.set_tuning("wino_wide", epi)
         t = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True, res=res, want_stats=True))
         row.append(f"{1e3 * t:8.1f} ({fl / t / 1e9:5.0f} TF, {fl * 4 / 9 / t / 1e9 / 157.3:.3f})")
-    ops.set_tuning("wino_epi", 1)
+    ops.set_tuning("wino_wide", 0)
     print(f"{cin:4d} {cout:4d} {s:4d} : " + "   ".join(row))
