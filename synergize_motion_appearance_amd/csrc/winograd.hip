@@ -418,7 +418,10 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
 // N tiles of the block's 64 output channels -- 8 accumulators (128 VGPRs) at a 256-VGPR budget, 2 waves per SIMD (2 blocks / CU).
 // Against the 8-wave block: the input transform (LDS reads + 48 VALU) and the region staging are done once per 32 MFMAs instead
 // of once per 16, the two accumulator chains of a frequency alternate on the matrix pipe (no back-to-back dependent MFMAs), a
-// barrier joins 4 waves instead of 8, and nothing spills.
+// barrier joins 4 waves instead of 8, and nothing spills.  Measured dead ends on top of it (kept out / selectable): a workgroup
+// walking several tile blocks with the next tile's region held in registers across the epilogue (99 VGPRs spilled at the
+// 256 budget), the software-pipelined transform (PIPE: hipcc clusters the pieces instead of interleaving them, -4 %), U prefetch
+// distance 3 (neutral).
 template <bool PIPE, int UD = 2>
 __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   constexpr int RP = 18, RPIX = RH * RP, NTHR = 256, NI = 2, NB = 64;
