@@ -297,11 +297,12 @@ int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, floa
 /* 3x3 / stride 1 / pad 1 convolution on the bf16 MFMA, region-direct (the configs[2] counterpart of smx_winograd_conv3x3_f32, same
  * call sites): x bf16 NHWC [B][H][W][lda] ([B][H/2][W/2][lda] with up2), w bf16 [Cout][ldw >= 9*Cin] (k = (ky*3+kx)*Cin + c),
  * y bf16 NHWC; bias fp32; res bf16 or (res_f32) fp32; in_ss / in_swish / stats_part as in the Winograd entry point, with
- * stats_part = {mean, M2} of the STORED (bf16-rounded) values per 16x16-pixel tile: [B][(H/16)*(W/16)][Cout][2].
- * H % 16 == 0, W % 16 == 0, Cin % 64 == 0. */
+ * stats_part = {mean, M2} of the STORED (bf16-rounded) values per tile_h x 16-pixel tile: [B][(H/tile_h)*(W/16)][Cout][2].
+ * tile_h = 16 (2 workgroups per CU) or 8 (3 per CU: more loads in flight for the small-C_in layers); H % tile_h == 0,
+ * W % 16 == 0, Cin % 64 == 0. */
 int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32, int ldres,
                      void* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
-                     float* stats_part, void* stream);
+                     float* stats_part, int tile_h, void* stream);
 int smx_groupnorm_swish_nhwc_bf16(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int B, int HW,
                                   int C, int groups, float eps, int swish, float* ws, void* stream);
 int smx_groupnorm_stats_bf16(const void* x, int ldx, const float* gamma, const float* beta, float* ss, int B, int HW, int C,

@@ -23,14 +23,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int TH = 16, TW = 16, RH = TH + 2, RW = TW + 2, RPX = RH * RW;   // output tile, staged region
+constexpr int TW = 16, RW = TW + 2;                                        // output tile width, staged region width
 constexpr int PIXB = 144;                                                  // bytes per region pixel / weight row in LDS (128 + 16 pad)
 constexpr int BN = 64, CS = 64;                                            // output channels per block, channels per slice
 constexpr int NT = 256;
-constexpr int REGION_B = RPX * PIXB;                                       // 46,656
 constexpr int WT_B = BN * PIXB;                                            // 9,216
 constexpr int CLD = BN + 4;
-constexpr int LDS_B = (REGION_B + 2 * WT_B) > (TH * TW * CLD * 4) ? (REGION_B + 2 * WT_B) : (TH * TW * CLD * 4);
+// TH = output tile height: 16 (wave = 64 px x 64 n, 2 blocks / CU) or 8 (wave = 32 px x 64 n, ~100 VGPRs, 3 blocks / CU = 12 waves:
+// more loads in flight per CU for the latency-bound small-C_in layers, a two-step-deep weight ring without spills)
+template <int TH> struct Geo {
+  static constexpr int RH = TH + 2, RPX = RH * RW, REGION_B = RPX * PIXB;
+  static constexpr int LDS_B = (REGION_B + 2 * WT_B) > (TH * TW * CLD * 4) ? (REGION_B + 2 * WT_B) : (TH * TW * CLD * 4);
+};
 
 struct CP {
   const bf16_t* x; const bf16_t* w; const float* bias; const void* res; bf16_t* y; float* stats; const float* in_ss;
@@ -51,7 +55,9 @@ __device__ __forceinline__ float c_act(float v, int act) {
   }
 }
 
-__global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
+template <int TH>
+__global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p) {
+  constexpr int RPX = Geo<TH>::RPX, REGION_B = Geo<TH>::REGION_B, TI = TH / 8;   // TI: 32-pixel A fragments per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Rg = smem;                       // region [RPX][PIXB]
   unsigned char* Ws = smem + REGION_B;            // weights [2][BN][PIXB]
@@ -73,7 +79,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
   // ---- region staging: RPX * 8 chunks of 16 B per slice, 256 threads -> 11 chunks per thread (the last partially) -----
   constexpr int NCH = (RPX * 8 + NT - 1) / NT;
   uint4 rreg[NCH];
-  auto load_region = [&](int c0) {
+  auto load_region = [&](int c0) __attribute__((always_inline)) {
+    // a thread's chunks all cover the same 8 channels (item & 7 == tid & 7): their GroupNorm {scale, shift} pairs are loaded once per slice
+    float4 ssv[4];
+    if (p.in_ss) {
+      const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + (tid & 7) * 8) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ssv[e] = *reinterpret_cast<const float4*>(sp + 4 * e);
+    }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int item = tid + NT * k;
@@ -88,10 +101,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
           if (p.in_ss) {
             // GroupNorm(+swish) of the producer, applied once per staged element; padding stays exactly 0
             float f[8]; unpack8(v, f);
-            const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + c8 * 8) * 2;
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-              const float4 s4 = *reinterpret_cast<const float4*>(sp + 2 * e);
+              const float4 s4 = ssv[e >> 1];
               f[e] = fmaf(f[e], s4.x, s4.y); f[e + 1] = fmaf(f[e + 1], s4.z, s4.w);
             }
             if (p.in_swish) {
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
       rreg[k] = v;
     }
   };
-  auto store_region = [&]() {
+  auto store_region = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int item = tid + NT * k;
@@ -116,29 +128,29 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
   // ---- weight tile: [BN][64 k] bf16 of (tap, slice): 64 rows x 8 chunks = 512 chunks -> 2 per thread -----------------
   uint4 wreg[2];
   const int wr0 = tid >> 3, wc8 = tid & 7;
-  auto load_w = [&](int tap, int c0) {
+  auto load_w = [&](int tap, int c0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int n = n0 + wr0 + 32 * i;
       wreg[i] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (long long)n * p.ldw + tap * p.Cin + c0 + wc8 * 8) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(Ws + buf * WT_B + (wr0 + 32 * i) * PIXB + wc8 * 16) = wreg[i];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // A operand: lane l <-> MFMA row l&31 = pixel (tile row 4*wave + 2*i + ((l&31)>>4), col l&15), k chunk (l>>5)
+  // A operand: lane l <-> MFMA row l&31 = pixel (tile row 2*TI*wave + 2*i + ((l&31)>>4), col l&15), k chunk (l>>5)
   const int arow = lane & 31, hh = lane >> 5;
-  const int abase = ((4 * wave + (arow >> 4)) * RW + (arow & 15)) * PIXB + hh * 16;      // + i*2*RW*PIXB + tap offset + kk*32
+  const int abase = ((2 * TI * wave + (arow >> 4)) * RW + (arow & 15)) * PIXB + hh * 16; // + i*2*RW*PIXB + tap offset + kk*32
   const int bbase = arow * PIXB + hh * 16;                                               // + j*32*PIXB + kk*32
 
   // one step = one (slice, tap): this step's weight tile is in Ws[step & 1]; the next one is requested at the top of the step
@@ -146,43 +158,83 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
   // weight ring -- two statically indexed register sets, loop unrolled by two -- and a multi-tile loop that holds the next
   // tile's region in registers across the epilogue both spill 32-89 VGPRs.)
   const int nsl = p.Cin / CS, nsteps = nsl * 9;
-  load_region(0); store_region();
-  load_w(0, 0); store_w(0);
-  __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
+  auto compute = [&](int step) __attribute__((always_inline)) {
     const int s = step / 9, tap = step - s * 9, buf = step & 1;
-    if (step + 1 < nsteps) { const int s1 = (step + 1) / 9; load_w(step + 1 - s1 * 9, s1 * CS); }
-    if (tap == 5 && s + 1 < nsl) load_region((s + 1) * CS);            // in flight over the last taps of this slice
     const int ky = tap / 3, kx = tap - ky * 3;
     const unsigned char* ap = Rg + abase + (ky * RW + kx) * PIXB;
     const unsigned char* bp = Ws + buf * WT_B + bbase;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[TI], bfr[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + i * 2 * RW * PIXB + kk * 32));
+      for (int i = 0; i < TI; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + i * 2 * RW * PIXB + kk * 32));
 #pragma unroll
       for (int j = 0; j < 2; ++j) bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + j * 32 * PIXB + kk * 32));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (step + 1 < nsteps) store_w(buf ^ 1);
+  };
+  load_region(0); store_region();
+  if (TH == 16) {
+    // one step = one (slice, tap): this step's weight tile is in Ws[step & 1]; the next one is requested at the top of the step
+    // and written to the other buffer at its end (a deeper ring spills at this variant's 2-waves-per-SIMD budget)
+    load_w(0, 0); store_w(0);
     __syncthreads();
-    if (tap == 8 && s + 1 < nsl) { store_region(); __syncthreads(); }   // every wave is past its last read of the old slice
+    for (int step = 0; step < nsteps; ++step) {
+      const int s = step / 9, tap = step - s * 9;
+      if (step + 1 < nsteps) { const int s1 = (step + 1) / 9; load_w(step + 1 - s1 * 9, s1 * CS); }
+      if (tap == 5 && s + 1 < nsl) load_region((s + 1) * CS);          // in flight over the last taps of this slice
+      compute(step);
+      if (step + 1 < nsteps) store_w((step & 1) ^ 1);
+      __syncthreads();
+      if (tap == 8 && s + 1 < nsl) { store_region(); __syncthreads(); } // every wave is past its last read of the old slice
+    }
+  } else {
+    // 8x16 tiles (122 VGPRs): two statically indexed weight register sets, loop unrolled by two -- the tile of step g is requested
+    // at the top of step g-2 and written to LDS at the end of step g-1, so an L2 round trip has two steps to complete
+    uint4 wa[2], wb[2];
+    auto ldw = [&](uint4 (&wr)[2], int step) __attribute__((always_inline)) {
+      const int s1 = step / 9, tap = step - s1 * 9;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = n0 + wr0 + 32 * i;
+        wr[i] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (long long)n * p.ldw + tap * p.Cin + s1 * CS + wc8 * 8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    };
+    auto stw = [&](const uint4 (&wr)[2], int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(Ws + buf * WT_B + (wr0 + 32 * i) * PIXB + wc8 * 16) = wr[i];
+    };
+    auto body = [&](int step, uint4 (&mine)[2], const uint4 (&other)[2]) __attribute__((always_inline)) {   // `mine` held this step's tile (already in LDS)
+      const int s = step / 9, tap = step - s * 9;
+      if (step + 2 < nsteps) ldw(mine, step + 2);
+      if (tap == 5 && s + 1 < nsl) load_region((s + 1) * CS);
+      compute(step);
+      if (step + 1 < nsteps) stw(other, (step & 1) ^ 1);
+      __syncthreads();
+      if (tap == 8 && s + 1 < nsl) { store_region(); __syncthreads(); }
+    };
+    ldw(wa, 0); ldw(wb, 1);
+    stw(wa, 0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; step += 2) {
+      body(step, wa, wb);
+      if (step + 1 < nsteps) body(step + 1, wb, wa);
+    }
   }
 
   // ---- epilogue: block transpose through LDS -> 16-B chunks of 8 channels ------------------------------------------------
-  float* Cs = reinterpret_cast<float*>(smem);                            // [256 px][CLD]
+  float* Cs = reinterpret_cast<float*>(smem);                            // [TH*16 px][CLD]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;                   // MFMA row -> pixel of the wave's 32-pixel group i
-        const int px = (4 * wave + 2 * i + (m >> 4)) * TW + (m & 15);
+        const int px = (2 * TI * wave + 2 * i + (m >> 4)) * TW + (m & 15);
         Cs[px * CLD + j * 32 + arow] = acc[i][j][r];
       }
   __syncthreads();
@@ -199,9 +251,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
   float piv[8], sm[8], sq[8];                                            // Welford partials of what is stored (shifted by the first value)
 #pragma unroll
   for (int e = 0; e < 8; ++e) { piv[e] = 0.f; sm[e] = 0.f; sq[e] = 0.f; }
+  constexpr int NPASS = TH * TW / 32;                                    // pixels of the tile, 32 per pass
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int px = (tid >> 3) + 32 * it;                                 // 256 pixels, 32 per pass
+  for (int it = 0; it < NPASS; ++it) {
+    const int px = (tid >> 3) + 32 * it;
     const int oy = by * TH + (px >> 4), ox = bx * TW + (px & 15);
     const long long opix = ((long long)img * p.H + oy) * p.W + ox;
     const float4 v0 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8);
@@ -250,7 +303,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float ms = sm[e] * 0.125f;
+      const float ms = sm[e] * (1.f / NPASS);
       red[((tid >> 3) * BN + cq * 8 + e) * 2] = piv[e] + ms;
       red[((tid >> 3) * BN + cq * 8 + e) * 2 + 1] = fmaxf(sq[e] - sm[e] * ms, 0.f);
     }
@@ -262,7 +315,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
       mean *= (1.f / 32.f);
       float m2 = 0.f;
 #pragma unroll 8
-      for (int t = 0; t < 32; ++t) { const float d = red[(t * BN + tid) * 2] - mean; m2 += red[(t * BN + tid) * 2 + 1] + 8.f * d * d; }
+      for (int t = 0; t < 32; ++t) { const float d = red[(t * BN + tid) * 2] - mean; m2 += red[(t * BN + tid) * 2 + 1] + (float)NPASS * d * d; }
       const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
       float* o = p.stats + (chunk * p.Cout + n0 + tid) * 2;
       o[0] = mean; o[1] = m2;
@@ -274,8 +327,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16_kernel(CP p) {
 
 extern "C" int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32,
                                 int ldres, void* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act,
-                                const float* in_ss, int in_swish, float* stats_part, void* stream) {
-  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0) return SMX_EINVAL;
+                                const float* in_ss, int in_swish, float* stats_part, int tile_h, void* stream) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (tile_h != 8 && tile_h != 16)) return SMX_EINVAL;
+  const int TH = tile_h;
   if (H % TH != 0 || W % TW != 0 || Cin % CS != 0 || lda % 8 != 0 || lda < Cin || ldc < Cout || ldw < 9 * Cin || ldw % 8 != 0) return SMX_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (in_ss && ((uintptr_t)in_ss & 15)) || (res && ldres < Cout)) return SMX_EINVAL;
   if (up2 && ((H & 1) || (W & 1))) return SMX_EINVAL;
@@ -287,9 +341,10 @@ extern "C" int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, 
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
   static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)); attr = true; }
+  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<16>::LDS_B)); attr = true; }
   p.ntiles = (int)blocks; p.tpb = 1;
   dim3 grid((unsigned)blocks, (Cout + BN - 1) / BN);
-  SMX_LAUNCH(conv3x3_bf16_kernel, grid, dim3(NT), LDS_B, (hipStream_t)stream, p);
+  if (TH == 16) SMX_LAUNCH(conv3x3_bf16_kernel<16>, grid, dim3(NT), Geo<16>::LDS_B, (hipStream_t)stream, p);
+  else SMX_LAUNCH(conv3x3_bf16_kernel<8>, grid, dim3(NT), Geo<8>::LDS_B, (hipStream_t)stream, p);
   return smx_launch_status();
 }

@@ -56,7 +56,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // A_F32: A is stored in fp32 (converted to bf16 while staging).  VEC: 8-element chunks (Cin % 8 == 0, aligned).
-template <int BM, int BN, int WGM, int WGN, bool A_F32, bool VEC>
+template <int BM, int BN, int WGM, int WGN, bool A_F32, bool VEC, bool SHORTK = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GB p) {
   constexpr int NT = 64 * WGM * WGN, RPP = NT / 8;       // 8 chunks of 16 B per row
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -108,7 +108,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GB p) {
   }
   const int Hlim = p.up2 ? 2 * p.Hin : p.Hin, Wlim = p.up2 ? 2 * p.Win : p.Win;
 
-  uint4 areg[RA], breg[RB];
   const int nslices_all = (p.K + BK - 1) / BK;
   int s_begin = 0, s_end = nslices_all;
   if (p.ksplit > 1) {
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GB p) {
     }
   };
 
-  auto load_slice = [&](int k0) {
+  auto load_into = [&](uint4 (&areg)[RA], uint4 (&breg)[RB], int k0) __attribute__((always_inline)) {
     if (VEC) {
       int l_ky = tap_ky, l_kx = tap_kx, l_c = tap_c0 + c8 * 8; bool kin = true;
       if (!p.cin_bk) {
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GB p) {
       }
     }
   };
-  auto store_slice = [&](int buf) {
+  auto store_from = [&](const uint4 (&areg)[RA], const uint4 (&breg)[RB], int buf) __attribute__((always_inline)) {
     unsigned char* as = As + buf * BM * ROWB; unsigned char* bs = Bs + buf * BN * ROWB;
 #pragma unroll
     for (int i = 0; i < RA; ++i) if (!GA || r0 + RPP * i < BM) *reinterpret_cast<uint4*>(as + (r0 + RPP * i) * ROWB + c8 * 16) = areg[i];
@@ -252,15 +251,43 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GB p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   };
-  // write-late pipeline: the loads of slice s+1 are issued before the MFMAs of slice s and written after them
-  if (nslices > 0) { load_slice(s_begin * BK); store_slice(0); }
-  __syncthreads();
-  for (int s = 0; s < nslices; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nslices) load_slice((s_begin + s + 1) * BK);
-    compute(buf);
-    if (s + 1 < nslices) store_slice(buf ^ 1);
+  if (SHORTK && nslices <= 4) {
+    // short K (<= 256: the 1x1 convolutions, projections, patch GEMMs -- most launches of the step): the whole K range of the
+    // tile is requested up front into four register sets, so the tile pays ONE memory round trip instead of one per 64-deep
+    // slice (these launches are latency-bound: 2-4 slices per tile, nothing to amortise a serialised pipeline over)
+    uint4 a0[RA], b0[RB], a1[RA], b1[RB], a2[RA], b2[RB], a3[RA], b3[RB];
+    load_into(a0, b0, s_begin * BK);
+    if (nslices > 1) load_into(a1, b1, (s_begin + 1) * BK);
+    if (nslices > 2) load_into(a2, b2, (s_begin + 2) * BK);
+    if (nslices > 3) load_into(a3, b3, (s_begin + 3) * BK);
+    store_from(a0, b0, 0);
     __syncthreads();
+    if (nslices > 1) store_from(a1, b1, 1);
+    compute(0);
+    __syncthreads();
+    if (nslices > 1) {
+      if (nslices > 2) store_from(a2, b2, 0);
+      compute(1);
+      __syncthreads();
+    }
+    if (nslices > 2) {
+      if (nslices > 3) store_from(a3, b3, 1);
+      compute(0);
+      __syncthreads();
+    }
+    if (nslices > 3) { compute(1); __syncthreads(); }
+  } else {
+    // write-late pipeline: the loads of slice s+1 are issued before the MFMAs of slice s and written after them
+    uint4 areg[RA], breg[RB];
+    if (nslices > 0) { load_into(areg, breg, s_begin * BK); store_from(areg, breg, 0); }
+    __syncthreads();
+    for (int s = 0; s < nslices; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nslices) load_into(areg, breg, (s_begin + s + 1) * BK);
+      compute(buf);
+      if (s + 1 < nslices) store_from(areg, breg, buf ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----------------------------------------------------------------------
@@ -388,7 +415,13 @@ int launch16(const GB& p, int nb, bool a_f32, bool vec, hipStream_t st) {
     if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     SMX_LAUNCH(k, grid, block, lds, st, q);                                                                         \
   } while (0)
-  if (a_f32) { if (vec) SMX_L16(true, true); else SMX_L16(true, false); }
+  const bool shortk = vec && !a_f32 && p.ksplit <= 1 && p.K <= 4 * BK;
+  if (shortk) {
+    auto k = gemm_bf16_kernel<BM, BN, WGM, WGN, false, true, true>;
+    if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMX_LAUNCH(k, grid, block, lds, st, q);
+  }
+  else if (a_f32) { if (vec) SMX_L16(true, true); else SMX_L16(true, false); }
   else { if (vec) SMX_L16(false, true); else SMX_L16(false, false); }
 #undef SMX_L16
   if (p.ksplit > 1) {
@@ -436,10 +469,10 @@ extern "C" int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream) {
   int tile = d->tile;
   if (tile == 0) {
     const long long Mt = (long long)d->M * nb;
+    // measured on the device (tools/gemm16_tune.py, B = 60 shapes): 64x64 tiles (4 waves, 4 workgroups / CU) win every
+    // short-K launch -- they are latency-bound --, 128x128 / 8 waves the long-K and very wide ones
     if (d->N <= 32) tile = 4;
-    else if (d->N <= 64) tile = Mt >= 65536 ? 2 : 3;
-    else if (d->N % 128 == 0 && Mt >= 32768) tile = 1;
-    else if (Mt >= 65536) tile = 2;
+    else if (d->N % 128 == 0 && Mt >= 32768 && (d->K >= 1024 || d->N >= 2048 || (d->K >= 256 && Mt >= 500000))) tile = 1;
     else tile = 3;
   }
   const bool af = d->a_f32 != 0;

@@ -180,6 +180,14 @@ def gemm16_raw(**kw):
 
 
 REGION3X3 = not _os.environ.get("SMX_NO_REGION3X3")
+CONV16_TILE_H = int(_os.environ.get("SMX_CONV16_TILE_H", "0"))      # 0 = auto, 8 | 16 = forced (tools / tests)
+
+
+def _conv16_tile_h(Cin, Ho):
+    """output tile height of the region-direct bf16 3x3 kernel: measured per shape on the device (tools/conv16_bench.py)"""
+    if CONV16_TILE_H in (8, 16) and Ho % CONV16_TILE_H == 0:
+        return CONV16_TILE_H
+    return 16 if Cin >= 512 else 8          # 8x16 tiles (3 workgroups / CU) win up to C_in = 256: 1.1-1.4x; 16x16 at C_in = 512
 
 
 def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss, in_swish, out_dtype, want_stats=False):
@@ -209,11 +217,12 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
         # region-direct 3x3 kernel: the input region is staged once per 64-channel slice and all nine taps read it from LDS
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1,
                 "bytes": 2.0 * B * Ho * Wo * (Cin / (4.0 if up2 else 1.0) + cv.cout * (2 if res is not None else 1))} if _PROFILE is not None else None
-        part = torch.empty((B, (Ho // 16) * (Wo // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
+        th = _conv16_tile_h(Cin, Ho)
+        part = torch.empty((B, (Ho // th) * (Wo // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
         L.check(_timed("conv3x3_bf16", meta, L.load().smx_conv3x3_bf16, a_ptr, lda, cv.w16.data_ptr(), cv.w16.shape[1],
                        None if cv.b is None else cv.b.data_ptr(), r_ptr, int(res is not None and res.dtype == torch.float32), ldr,
                        c_ptr, ldc, B, Ho, Wo, Cin, cv.cout, int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish),
-                       None if part is None else part.data_ptr(), _stream()), "smx_conv3x3_bf16")
+                       None if part is None else part.data_ptr(), th, _stream()), "smx_conv3x3_bf16")
         if part is not None:
             out._gn_part = part
         return out

@@ -165,12 +165,14 @@ R3_CASES = [(2, 64, 64, 32, 32, False, 0, None), (1, 128, 128, 64, 32, False, 3,
             (3, 64, 3 * 64, 16, 32, False, 0, None)]
 
 
+@pytest.mark.parametrize("tile_h", [16, 8])
 @pytest.mark.parametrize("case", R3_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_up{int(c[5])}_act{c[6]}_res{c[7]}" for c in R3_CASES])
-def test_conv3x3_region_direct_bf16(ops, case):
+def test_conv3x3_region_direct_bf16(ops, case, tile_h, monkeypatch):
     """the region-direct 3x3 kernel (input region staged once per 64-channel slice, nine taps read from LDS) against conv2d on
     the bf16-rounded operands, against the implicit-GEMM bf16 kernel on the same operands, through channel-slice views, with
     the fused GroupNorm+swish loader, and with the Welford partials it emits for the next GroupNorm."""
     B, Cin, Cout, H, W, up2, act, resk = case
+    monkeypatch.setattr(ops, "CONV16_TILE_H", tile_h)
     x = r16(rnd(f"r3x{case}", (B, Cin, H // (2 if up2 else 1), W // (2 if up2 else 1))))
     w = rnd(f"r3w{case}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
     b = rnd(f"r3b{case}", (Cout,), 0.1)
@@ -196,9 +198,9 @@ def test_conv3x3_region_direct_bf16(ops, case):
     assert ok, worst
     # Welford partials of the stored tile: {mean, M2} per 16x16 pixels and channel
     part = y._gn_part
-    assert part is not None and tuple(part.shape) == (B, (H // 16) * (W // 16), Cout, 2)
+    assert part is not None and tuple(part.shape) == (B, (H // tile_h) * (W // 16), Cout, 2)
     yc = y.float().cpu().double()
-    blocks = yc.view(B, H // 16, 16, W // 16, 16, Cout).permute(0, 1, 3, 5, 2, 4).reshape(B, -1, Cout, 256)
+    blocks = yc.view(B, H // tile_h, tile_h, W // 16, 16, Cout).permute(0, 1, 3, 5, 2, 4).reshape(B, -1, Cout, tile_h * 16)
     bm = blocks.mean(-1)
     assert maxabs(part[..., 0].cpu(), bm) < 5e-6 * max(1.0, float(bm.abs().max()))
     assert maxabs(part[..., 1].cpu(), ((blocks - bm[..., None]) ** 2).sum(-1)) < 1e-3

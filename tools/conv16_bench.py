@@ -34,9 +34,14 @@ for cin, cout, s in SHAPES:
     ss = torch.rand((B, cin, 2), device="cuda")
     fl = 2.0 * B * s * s * cout * 9 * cin
     by = 2.0 * B * s * s * (cin + cout)
+    ops.CONV16_TILE_H = 16
     t_r = timed(lambda: ops.conv(x, cv, out=out))
+    ops.CONV16_TILE_H = 8
+    t_8 = timed(lambda: ops.conv(x, cv, out=out))
+    t_8n = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True))
+    ops.CONV16_TILE_H = 16
     t_g = timed(lambda: ops.conv(x, cv, out=out, tile=2 if cout <= 64 else 1))
     t_n = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True))
     t_s = timed(lambda: ops.conv(x, cv, out=out, want_stats=True))
     print(f"{cin:4d} {cout:4d} {s:4d} : {1e3 * t_r:8.1f} ({fl / t_r / 1e9:6.0f} TF, {by / t_r / 1e6:6.0f} GB/s)   {1e3 * t_g:8.1f} ({fl / t_g / 1e9:6.0f} TF)   "
-          f"{1e3 * t_n:8.1f}   {1e3 * t_s:8.1f}")
+          f"{1e3 * t_n:8.1f}   {1e3 * t_s:8.1f}   | tile_h=8: {1e3 * t_8:8.1f} ({fl / t_8 / 1e9:5.0f} TF)  +GN {1e3 * t_8n:8.1f}")
