@@ -18,7 +18,7 @@ the data path.  RCCL failing to initialise is FATAL (no silent fallback); SMX_BE
 explicitly (test boxes with one device) and is reported in config.parallelism.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     the DOMINANT KERNEL ALONE (winograd_kernel): executed fp32-MFMA flops / launch time against the
+  "roofline":     the DOMINANT KERNEL ALONE (the Winograd family in fp32): executed fp32-MFMA flops / launch time against the
                   157.3 TF matrix peak (frac <= 1), the algorithmic (direct-convolution) rate as a side field, HBM
                   traffic per launch and the MFMA-busy counters from the committed rocprofv3 PMC passes,
   "kernels":      per-family breakdown incl. the HBM-bound warp kernel (algorithmic AND counter GB/s) and the VQ kernel,
@@ -294,15 +294,17 @@ def main():
             f["flops"] += meta.get("flops", 0.0)
             f["mfma_flops"] += meta.get("mfma_flops", meta.get("flops", 0.0))
             f["bytes"] += meta.get("bytes", 0.0)
-        traffic = load_profile_json("r02_traffic_pmc.json") or load_profile_json("r01_o_traffic_pmc.json")
+        sfx = "" if args.dtype == "f32" else "_bf16"
+        traffic = load_profile_json(f"r02_traffic_pmc{sfx}.json")
         tfam = (traffic or {}).get("families", {}) if B == 60 else {}
-        mfma_pmc = load_profile_json("r02_mfma_pmc.json") if B == 60 else None
+        mfma_pmc = load_profile_json(f"r02_mfma_pmc{sfx}.json") if B == 60 else None
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         dom = max((k for k in fam if fam[k]["mfma_flops"] > 0), key=lambda k: fam[k]["ms"])
         g = fam[dom]
         tf_exec = g["mfma_flops"] / (g["ms"] * 1e-3) / 1e12
         tf_alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        kname = {"winograd": "winograd_kernel<SWZ=false,NW> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
+        kname = {"winograd": "winograd_wide_kernel / winograd_kernel<..> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
+                 "conv3x3_bf16": "conv3x3_bf16_kernel<TH> (region-direct 3x3/s1/p1 convolution, v_mfma_f32_32x32x16_bf16)",
                  "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x2_f32)",
                  "gemm_bf16": "gemm_bf16_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom)
         if dom.startswith("attention"):
@@ -312,9 +314,11 @@ def main():
             "frac": round(tf_exec / peak, 4),
             "traffic": round(tfam[dom]["hbm_bytes_per_launch"]) if dom in tfam else None,
             "achieved_algorithmic": round(tf_alg, 2),
-            "note": "achieved/frac = flops the matrix cores EXECUTE in this kernel (2*M*N*16/4*Cin per launch for F(2x2,3x3): 16 multiplies per "
-                    "2x2 output tile and channel) / its summed launch time; achieved_algorithmic = the direct convolution's 2*M*N*9*Cin over "
-                    "the same time (2.25x the executed rate by construction, not a utilisation)",
+            "note": ("achieved/frac = flops the matrix cores EXECUTE in this kernel (2*M*N*16/4*Cin per launch for F(2x2,3x3): 16 multiplies per "
+                     "2x2 output tile and channel) / its summed launch time; achieved_algorithmic = the direct convolution's 2*M*N*9*Cin over "
+                     "the same time (2.25x the executed rate by construction, not a utilisation)") if dom == "winograd" else
+                    ("achieved = 2*M*N*K of the launches / their summed time (executed == algorithmic: a direct convolution); in bf16 no layer of "
+                     "this network is MFMA-bound -- see kernels.*.algorithmic_GBps for the byte side"),
             "launches_per_step": g["calls"] // nprof, "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
             "share_of_step_time": round(g["ms"] / nprof / step_ms, 3),
             "method": f"HIP events around every launch on the launch stream, {nprof} instrumented steps after the timed region"}
@@ -322,7 +326,10 @@ def main():
             roof["traffic_note"] = ("HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of the guide), from separate rocprofv3 --pmc "
                                     "passes of this command at B=60 committed under profiles/ (not measured in this run)")
         if mfma_pmc and dom in mfma_pmc.get("kernels", {}):
-            roof["mfma_pmc"] = dict(mfma_pmc["kernels"][dom], source="profiles/r02_mfma_pmc.json (rocprofv3 --pmc pass of this command, B=60)")
+            roof["mfma_pmc"] = dict(mfma_pmc["kernels"][dom], source=f"profiles/r02_mfma_pmc{sfx}.json (rocprofv3 --pmc pass of this command, B=60; "
+                                                                         "all launches of the family, the B=1 source-encoder ones included)")
+            if dom == "winograd" and "winograd_wide" in mfma_pmc["kernels"]:
+                roof["mfma_pmc_b60_launches"] = mfma_pmc["kernels"]["winograd_wide"]          # the wide kernel = the B=60 launches alone
         result["roofline"] = roof
         conv_ms = sum(fam[k]["ms"] for k in ("winograd", "gemm_conv") if k in fam)
         conv_fl = sum(fam[k]["flops"] for k in ("winograd", "gemm_conv") if k in fam)

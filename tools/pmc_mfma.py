@@ -18,8 +18,8 @@ import sys
 
 SIMDS, XCDS, SPEC_GHZ = 1024, 8, 2.4
 PEAK = {"F32": 157.3, "BF16": 2500.0}
-FAMILIES = (("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("attn_mfma", "attention_mfma"),
-            ("attn_flash", "attention_flash"), ("vq_kernel", "vq"))
+FAMILIES = (("winograd_wide_kernel", "winograd"), ("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"),
+            ("conv3x3_bf16_kernel", "conv3x3_bf16"), ("attn_mfma16", "attention_mfma16"), ("attn_mfma", "attention_mfma"), ("vq_kernel", "vq"))
 
 
 def family(name):
@@ -36,7 +36,8 @@ def variants(name):
         return []
     out = [fam]
     if fam == "winograd":
-        out.append("winograd_nw2" if "winograd_kernel<false, 2" in name or "winograd_kernel<true, 2" in name else "winograd_nw1")
+        out.append("winograd_wide" if "winograd_wide_kernel" in name else
+                   "winograd_nw2" if "winograd_kernel<false, 2" in name or "winograd_kernel<true, 2" in name else "winograd_nw1")
     return out
 
 

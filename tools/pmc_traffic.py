@@ -22,7 +22,7 @@ def load(d, counter):
 
 
 def family(name):
-    for key, fam in (("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("attn_", "attention"),
+    for key, fam in (("winograd_", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("conv3x3_bf16", "conv3x3_bf16"), ("attn_", "attention"),
                      ("warp_", "warp"), ("gn_", "groupnorm"), ("layernorm", "layernorm")):
         if key in name:
             return fam
