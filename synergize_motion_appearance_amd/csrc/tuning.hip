@@ -21,6 +21,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"attn16", "SMX_ATTN16", 1},                  // bf16 storage, d_head 32: bf16 MFMA kernel (0 = fp32 MFMA kernel on bf16 storage)
   {"wino_ud", "SMX_WINO_UD", 2},                // Winograd: U-fragment prefetch distance in units (2 | 3) on the 4-slot register ring
   {"wino_wide", "SMX_WINO_WIDE", 1},            // Winograd big launches: 1 = 4-wave "wide" blocks, 64 n per wave (default: +5..13 % per launch), 0 = 8-wave blocks, 2 = wide + software-pipelined transform (measured 4 % slower), 3 = wide + U prefetch distance 3 (neutral)
+  {"wino_nt", "SMX_WINO_NT", 0},                // wide Winograd epilogue: non-temporal residual loads / output stores
 };
 bool g_init = false;
 void init_once() {

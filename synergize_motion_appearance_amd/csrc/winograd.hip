@@ -23,16 +23,22 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "smx.h"
 #include "smx_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// streaming (read-once / write-once) global accesses: keep the residual and the output from evicting U and the input halo from L2
+__device__ __forceinline__ float4 ld_stream(const float* p) { const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st_stream(float* p, float4 v) { f32x4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w; __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(p)); }
 
 namespace {
 
 constexpr int RH = 10, RW = 18;                     // staged input region (pixels)
 constexpr int RPMAX = 19;                                 // LDS row pitch 19 px with the chunk swizzle: every ds_read_b128 16-lane group
                                                     // hits 16 distinct 4-bank slots (18 without the swizzle)
+constexpr int WIDE_LDS = 2 * 4 * 32 * 68 * 4;         // the wide kernel's epilogue exchange [2 q][4 fi][32 tiles][pitch 68] floats
 constexpr int RLD = 36;                             // floats per region pixel in LDS (32 + 4 pad)
 
 struct WP {
@@ -43,8 +49,10 @@ struct WP {
   int B, H, W, Cin, Cout, up2, act;
   int tiles_y, tiles_x;          // blocks per image along y / x
   int n32;                       // ceil(Cout/32) (U is packed for n32*32 rows)
+  int nt;                        // wide kernel: non-temporal residual loads / output stores
 };
 
+__device__ __forceinline__ bool smx_nt_flag(const struct WP& p);
 __device__ __forceinline__ float w_act(float v, int act) {
   switch (act) {
     case SMX_ACT_RELU: return v > 0.f ? v : 0.f;
@@ -56,6 +64,7 @@ __device__ __forceinline__ float w_act(float v, int act) {
   }
 }
 
+__device__ __forceinline__ bool smx_nt_flag(const WP& p) { return p.nt != 0; }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
@@ -422,12 +431,20 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
 // walking several tile blocks with the next tile's region held in registers across the epilogue (99 VGPRs spilled at the
 // 256 budget), the software-pipelined transform (PIPE: hipcc clusters the pieces instead of interleaving them, -4 %), U prefetch
 // distance 3 (neutral).
-template <bool PIPE, int UD = 2>
+template <bool PIPE, int UD = 2, int ABL = 0, bool FLAGS = false>   // ABL (timing-only, tools): 1 no transform, 2 no U loads, 4 no region staging after the first slice, 8 no barriers, 16 no epilogue
 __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
-  constexpr int RP = 18, RPIX = RH * RP, NTHR = 256, NI = 2, NB = 64;
+  constexpr int RP = 18, RPIX = RH * RP, NTHR = 256, NI = 2, NB = 64, ZS = 68;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int fi = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ABL & 32 (tools/wino_trace.py): per-wave s_memtime stamps of the block's phases, written over the statistics output
+  unsigned stamp[28];
+  if (ABL & 32) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) stamp[k] = 0u;
+  }
+  auto mark = [&](int k) __attribute__((always_inline)) { if (ABL & 32) stamp[k] = (unsigned)__builtin_readcyclecounter(); };
+  mark(0);
   const int hh = lane >> 5, t = lane & 31;
   const int tr = t >> 3, tc = t & 7;
   int bid = blockIdx.x;
@@ -451,7 +468,16 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
     l = (ry * RP + rx) * RLD + c4 * 4;
   };
   unsigned okmask = 0;                                                 // bit k: in frame, bit 8+k: inside the region
-  auto load_region = [&](int c0) {
+  // GroupNorm scale/shift of this thread's channel quad (item & 7 == tid & 7 for every item): fetched WITH the region, one
+  // pair per slice, and applied branch-free -- the per-item `if (in frame) { load ss; ... }` this replaces serialised six
+  // L2 round trips per staged slice (3.4k of a 30k-cycle slice, tools/wino_trace.py)
+  float4 ssa = make_float4(1.f, 0.f, 1.f, 0.f), ssb = ssa;
+  const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
+  auto load_region = [&](int c0) __attribute__((always_inline)) {
+    if (loader) {
+      const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + (tid & 7) * 4) * 2;
+      ssa = *reinterpret_cast<const float4*>(sp); ssb = *reinterpret_cast<const float4*>(sp + 4);
+    }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       int g, l; bool gok, lok; item_geo(k, g, l, gok, lok);
@@ -460,27 +486,31 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
       stage[k] = v;
     }
   };
-  auto store_region = [&](int buf, int c0) {
-    float* rb = smem + buf * RPIX * RLD;
+  auto store_items = [&](float* rb, auto mode) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode)::value;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       int g, l; bool gok, lok; item_geo(k, g, l, gok, lok);
-      if (!lok) continue;
       float4 v = stage[k];
-      if (p.in_ss && gok) {
-        const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + ((tid + NTHR * k) & 7) * 4) * 2;
-        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-        v = make_float4(fmaf(v.x, s0.x, s0.y), fmaf(v.y, s0.z, s0.w), fmaf(v.z, s1.x, s1.y), fmaf(v.w, s1.z, s1.w));
-        if (p.in_swish) {
+      if (MODE >= 1) {
+        v = make_float4(fmaf(v.x, ssa.x, ssa.y), fmaf(v.y, ssa.z, ssa.w), fmaf(v.z, ssb.x, ssb.y), fmaf(v.w, ssb.z, ssb.w));
+        if (MODE == 2) {
           constexpr float L2E = 1.44269504088896340736f;
           v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
           v.y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.y));
           v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
           v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
         }
+        v.x = gok ? v.x : 0.f; v.y = gok ? v.y : 0.f; v.z = gok ? v.z : 0.f; v.w = gok ? v.w : 0.f;   // the conv's zero padding
       }
-      *reinterpret_cast<float4*>(rb + l) = v;
+      if (lok) *reinterpret_cast<float4*>(rb + l) = v;
     }
+  };
+  auto store_region = [&](int buf, int) __attribute__((always_inline)) {
+    float* rb = smem + buf * RPIX * RLD;
+    if (loader == 2) store_items(rb, std::integral_constant<int, 2>{});
+    else if (loader == 1) store_items(rb, std::integral_constant<int, 1>{});
+    else store_items(rb, std::integral_constant<int, 0>{});
   };
   (void)okmask;
 
@@ -505,14 +535,17 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nsl = p.Cin >> 5;
-  load_region(0); store_region(0, 0);
+  load_region(0); mark(24); store_region(0, 0); mark(25);
   float4 ur[NI][4];
   auto uload = [&](const float* U, int unit) -> float4 {
     return *reinterpret_cast<const float4*>(U + ((unit & 3) * ufs + (unit >> 2) * 256) + lane4);
   };
   ur[0][0] = uload(U0, 0); ur[1][0] = uload(U1, 0); ur[0][1] = uload(U0, 1); ur[1][1] = uload(U1, 1);
   if (UD == 3) { ur[0][2] = uload(U0, 2); ur[1][2] = uload(U1, 2); }
+  if (FLAGS && tid < 2) reinterpret_cast<int*>(smem + 2 * RPIX * RLD)[tid] = 0;
+  mark(1);
   __syncthreads();
+  mark(2);
   auto transform = [&](const float* rb, int sub, float4 (&v)[4]) {
     float4 tt[4];
 #pragma unroll
@@ -527,35 +560,90 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   auto mfma32 = [&](const float4 (&v)[4], int unit0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      ur[0][(j + UD) & 3] = uload(U0, unit0 + j + UD);              // UD = 3: the slot whose MFMAs were issued one group ago
-      ur[1][(j + UD) & 3] = uload(U1, unit0 + j + UD);
-      // the two N tiles' accumulators alternate: consecutive MFMAs never depend on each other
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[0][j].x, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[1][j].x, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[0][j].y, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[1][j].y, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[0][j].z, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[1][j].z, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[0][j].w, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[1][j].w, acc[1][j], 0, 0, 0);
+      if (!(ABL & 2)) {
+        ur[0][(j + UD) & 3] = uload(U0, unit0 + j + UD);            // UD = 3: the slot whose MFMAs were issued one group ago
+        ur[1][(j + UD) & 3] = uload(U1, unit0 + j + UD);
+      }
+      // A = U, B = V: the accumulator tile is [n][tile], so a lane holds 4 CONSECUTIVE channels per register quad and the
+      // epilogue moves it through LDS with 16 ds_write_b128 instead of 64 ds_write_b32.  The two N tiles' accumulators
+      // alternate: consecutive MFMAs never depend on each other
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].x, v[j].x, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].x, v[j].x, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].y, v[j].y, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].y, v[j].y, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].z, v[j].z, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].z, v[j].z, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].w, v[j].w, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].w, v[j].w, acc[1][j], 0, 0, 0);
     }
   };
-  if (!PIPE) {
+  if (!PIPE && FLAGS) {
+    // No rendezvous in the main loop: the slice barrier is replaced by two LDS counters (regions produced / slices consumed,
+    // one increment per wave), the next region is stored at mid-slice, and a wave only waits for the counter it needs --
+    // a fast wave runs up to half a slice ahead of the slowest instead of idling its SIMD's matrix pipe at every barrier.
+    volatile int* cnt = reinterpret_cast<volatile int*>(smem + 2 * RPIX * RLD);   // [0] produced, [1] consumed
+    auto signal = [&](int which) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(cnt) + which, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_for = [&](int which, int target) {
+      while (__builtin_amdgcn_readfirstlane(cnt[which]) < target) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    };
+    if (nsl > 1) load_region(32);
     for (int s = 0; s < nsl; ++s) {
       const int buf = s & 1;
-      if (s + 1 < nsl) load_region((s + 1) * 32);
       const float* rb = smem + buf * RPIX * RLD;
 #pragma unroll 1
-      for (int sub = 0; sub < 4; ++sub) {
+      for (int sub = 0; sub < 2; ++sub) {
         float4 v[4];
         transform(rb, sub, v);
         __builtin_amdgcn_s_setprio(1);
         mfma32(v, (s * 4 + sub) * 4);
         __builtin_amdgcn_s_setprio(0);
       }
-      if (s + 1 < nsl) store_region(buf ^ 1, (s + 1) * 32);
-      __syncthreads();
+      if (s + 1 < nsl) {
+        if (s > 0) wait_for(1, 4 * s);                                 // everyone has finished reading slice s-1 (this buffer)
+        store_region(buf ^ 1, (s + 1) * 32);
+        signal(0);
+        if (s + 2 < nsl) load_region((s + 2) * 32);
+      }
+#pragma unroll 1
+      for (int sub = 2; sub < 4; ++sub) {
+        float4 v[4];
+        transform(rb, sub, v);
+        __builtin_amdgcn_s_setprio(1);
+        mfma32(v, (s * 4 + sub) * 4);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      if (s + 1 < nsl) {
+        signal(1);
+        wait_for(0, 4 * (s + 1));                                      // region s+1 is complete
+      }
     }
+  } else if (!PIPE) {
+    float4 vconst[4] = {make_float4(1.f, 2.f, 3.f, 4.f), make_float4(1.f, 2.f, 3.f, 4.f), make_float4(1.f, 2.f, 3.f, 4.f), make_float4(1.f, 2.f, 3.f, 4.f)};
+    for (int s = 0; s < nsl; ++s) {
+      const int buf = (ABL & 4) ? 0 : (s & 1);
+      if (!(ABL & 4) && s + 1 < nsl) load_region((s + 1) * 32);
+      const float* rb = smem + buf * RPIX * RLD;
+#pragma unroll 1
+      for (int sub = 0; sub < 4; ++sub) {
+        float4 v[4];
+        if (ABL & 1) { v[0] = vconst[0]; v[1] = vconst[1]; v[2] = vconst[2]; v[3] = vconst[3]; }
+        else transform(rb, sub, v);
+        __builtin_amdgcn_s_setprio(1);
+        mfma32(v, (s * 4 + sub) * 4);
+        __builtin_amdgcn_s_setprio(0);
+        if ((ABL & 32) && s == 1) { if (sub == 0) mark(15); else if (sub == 1) mark(16); else if (sub == 2) mark(17); }
+      }
+      if ((ABL & 32) && s < 4) { if (s == 0) mark(3); else if (s == 1) mark(6); else if (s == 2) mark(9); else mark(12); }
+      if (!(ABL & 4) && s + 1 < nsl) store_region(buf ^ 1, (s + 1) * 32);
+      if ((ABL & 32) && s < 4) { if (s == 0) mark(4); else if (s == 1) mark(7); else if (s == 2) mark(10); else mark(13); }
+      if (!(ABL & 8)) __syncthreads();
+      if ((ABL & 32) && s < 4) { if (s == 0) mark(5); else if (s == 1) mark(8); else if (s == 2) mark(11); else mark(14); }
+    }
+    if (ABL & 16) { if (acc[0][0][0] + acc[1][1][1] + acc[0][2][2] + acc[1][3][3] + acc[1][0][4] + acc[0][1][5] + acc[1][2][6] + acc[0][3][7] == 123.456f) p.y[0] = 1.f; return; }
   } else {
     // Software-pipelined: a wave's own VALU / LDS work (~150 instructions per 8-channel step: transform, U addressing,
     // GroupNorm+swish of the staged region) used to sit BETWEEN its MFMA bursts, and the two waves of a SIMD run the same
@@ -576,14 +664,14 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
     auto group = [&](const float4 (&v)[4], int unit0, int j) {         // the 8 MFMAs of frequency j (+ the U prefetch two units ahead)
       ur[0][(j + 2) & 3] = uload(U0, unit0 + j + 2);
       ur[1][(j + 2) & 3] = uload(U1, unit0 + j + 2);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[0][j].x, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[1][j].x, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[0][j].y, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[1][j].y, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[0][j].z, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[1][j].z, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[0][j].w, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[1][j].w, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].x, v[j].x, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].x, v[j].x, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].y, v[j].y, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].y, v[j].y, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].z, v[j].z, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].z, v[j].z, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].w, v[j].w, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].w, v[j].w, acc[1][j], 0, 0, 0);
     };
     // one step: MFMAs of `cur` interleaved with the column pieces of the NEXT step's transform (from region buffer nrb)
     auto step = [&](const float4 (&cur)[4], float4 (&nxt)[4], int unit0, const float* nrb, int nsub, bool have_next) {
@@ -651,21 +739,100 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
     }
   }
 
-  // ---- one-pass epilogue: zb2 [2 q][4 fi][32 tiles][64 n] -------------------------------------------------------------
+  // ---- one-pass epilogue: zb2 [2 q][4 fi][32 tiles][64 n (pitch 68)] -------------------------------------------------------------
   float* zb = smem;
   float* __restrict__ Yp = p.y;
   const float* __restrict__ Rp = p.res;
   __syncthreads();
+  mark(18);
+  // lane (t, hh) holds tile t, channels i*32 + 8g + 4hh + (0..3) in registers 4g..4g+3; rows are ZS = 68 floats apart so the
+  // eight lanes of a 128 B LDS beat hit distinct banks
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      zb[((0 * 4 + fi) * 32 + row) * NB + i * 32 + t] = acc[i][0][r] + acc[i][1][r] + acc[i][2][r];
-      zb[((1 * 4 + fi) * 32 + row) * NB + i * 32 + t] = acc[i][1][r] - acc[i][2][r] - acc[i][3][r];
+    for (int g = 0; g < 4; ++g) {
+      float4 q0, q1;
+      q0.x = acc[i][0][4 * g + 0] + acc[i][1][4 * g + 0] + acc[i][2][4 * g + 0]; q1.x = acc[i][1][4 * g + 0] - acc[i][2][4 * g + 0] - acc[i][3][4 * g + 0];
+      q0.y = acc[i][0][4 * g + 1] + acc[i][1][4 * g + 1] + acc[i][2][4 * g + 1]; q1.y = acc[i][1][4 * g + 1] - acc[i][2][4 * g + 1] - acc[i][3][4 * g + 1];
+      q0.z = acc[i][0][4 * g + 2] + acc[i][1][4 * g + 2] + acc[i][2][4 * g + 2]; q1.z = acc[i][1][4 * g + 2] - acc[i][2][4 * g + 2] - acc[i][3][4 * g + 2];
+      q0.w = acc[i][0][4 * g + 3] + acc[i][1][4 * g + 3] + acc[i][2][4 * g + 3]; q1.w = acc[i][1][4 * g + 3] - acc[i][2][4 * g + 3] - acc[i][3][4 * g + 3];
+      *reinterpret_cast<float4*>(zb + ((0 * 4 + fi) * 32 + t) * ZS + i * 32 + 8 * g + 4 * hh) = q0;
+      *reinterpret_cast<float4*>(zb + ((1 * 4 + fi) * 32 + t) * ZS + i * 32 + 8 * g + 4 * hh) = q1;
     }
+  mark(19);
   __syncthreads();
+  mark(20);
   float gs4[2][4], gm2[2][4];
+  // Cout % 64 == 0 on this path, so every thread's channel quad is complete; the two items of a thread (tiles t and t + 16)
+  // share it.  Fast path (16 B-aligned rows, the only one the engines produce): both items' residual tiles are requested
+  // before anything waits (a load queued behind the first item's stores waits for their write acknowledgements -- one vmcnt
+  // on gfx9), the bias is one float4, and the activation is resolved once per block, not per value.
+  const int n4q = (tid & 15) * 4, nq = nblk * NB + n4q;
+  const bool NT = smx_nt_flag(p);
+  const bool vec_all = (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) && (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0)) &&
+                       (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (p.Cout % NB == 0);
+  if (vec_all) {
+    float4 rr[2][2][2];
+    long long pix[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int tile = (tid >> 4) + 16 * it;
+      pix[it] = ((long long)img * p.H + by * 8 + 2 * (tile >> 3)) * p.W + bx * 16 + 2 * (tile & 7);
+      if (Rp) {
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) rr[it][yy][q] = NT ? ld_stream(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq) : *reinterpret_cast<const float4*>(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq);
+      }
+    }
+    const float4 bq = p.bias ? *reinterpret_cast<const float4*>(p.bias + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bn[4] = {bq.x, bq.y, bq.z, bq.w};
+    auto items = [&](auto mode) __attribute__((always_inline)) {
+      constexpr int MODE = decltype(mode)::value;                      // 0 identity, 1 relu / leaky relu (slope form), 2 generic
+      const float slope = p.act == SMX_ACT_RELU ? 0.f : 0.2f;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int tile = (tid >> 4) + 16 * it;
+        float4 o[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float4 z0 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 0) * 32 + tile) * ZS + n4q);
+          const float4 z1 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 1) * 32 + tile) * ZS + n4q);
+          const float4 z2 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 2) * 32 + tile) * ZS + n4q);
+          const float4 z3 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 3) * 32 + tile) * ZS + n4q);
+          float a0[4] = {z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w};
+          float a1[4] = {z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a0[e] += bn[e]; a1[e] += bn[e];
+            if (MODE == 1) { a0[e] = fmaxf(a0[e], 0.f) + slope * fminf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f) + slope * fminf(a1[e], 0.f); }
+            if (MODE == 2) { a0[e] = w_act(a0[e], p.act); a1[e] = w_act(a1[e], p.act); }
+          }
+          o[0][q] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+          o[1][q] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        }
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (Rp) { o[yy][q].x += rr[it][yy][q].x; o[yy][q].y += rr[it][yy][q].y; o[yy][q].z += rr[it][yy][q].z; o[yy][q].w += rr[it][yy][q].w; }
+            if (NT) st_stream(Yp + (pix[it] + yy * p.W + q) * p.ldc + nq, o[yy][q]);
+            else *reinterpret_cast<float4*>(Yp + (pix[it] + yy * p.W + q) * p.ldc + nq) = o[yy][q];
+          }
+        const float va4[4][4] = {{o[0][0].x, o[0][0].y, o[0][0].z, o[0][0].w}, {o[1][0].x, o[1][0].y, o[1][0].z, o[1][0].w},
+                                 {o[0][1].x, o[0][1].y, o[0][1].z, o[0][1].w}, {o[1][1].x, o[1][1].y, o[1][1].z, o[1][1].w}};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float s0 = va4[0][e] + va4[1][e], d0 = va4[0][e] - va4[1][e], s1 = va4[2][e] + va4[3][e], d1 = va4[2][e] - va4[3][e], ds = s0 - s1;
+          gs4[it][e] = 0.25f * (s0 + s1);
+          gm2[it][e] = 0.5f * (d0 * d0 + d1 * d1) + 0.25f * ds * ds;
+        }
+      }
+    };
+    if (p.act == SMX_ACT_NONE) items(std::integral_constant<int, 0>{});
+    else if (p.act == SMX_ACT_RELU || p.act == SMX_ACT_LRELU02) items(std::integral_constant<int, 1>{});
+    else items(std::integral_constant<int, 2>{});
+  } else
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int item = tid + NTHR * it;                                  // 32 tiles x 16 channel quads
@@ -693,10 +860,10 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const float4 z0 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 0) * 32 + tile) * NB + n4);
-        const float4 z1 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 1) * 32 + tile) * NB + n4);
-        const float4 z2 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 2) * 32 + tile) * NB + n4);
-        const float4 z3 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 3) * 32 + tile) * NB + n4);
+        const float4 z0 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 0) * 32 + tile) * ZS + n4);
+        const float4 z1 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 1) * 32 + tile) * ZS + n4);
+        const float4 z2 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 2) * 32 + tile) * ZS + n4);
+        const float4 z3 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 3) * 32 + tile) * ZS + n4);
         float a0[4] = {z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w};
         float a1[4] = {z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w};
 #pragma unroll
@@ -737,6 +904,7 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
       }
     }
   }
+  mark(21);
   if (p.stats) {
     __syncthreads();
     float* red = smem;                                                 // [32 tiles][64][2]
@@ -758,7 +926,19 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
       b += 4.f * c2;
       const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
       float* o2 = p.stats + (chunk * p.Cout + nblk * NB + tid) * 2;
-      o2[0] = a; o2[1] = b;
+      if (!(ABL & 32)) { o2[0] = a; o2[1] = b; }
+    }
+    if (ABL & 32) {
+      mark(22);
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      stamp[23] = hw;
+      const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
+      unsigned* tr = reinterpret_cast<unsigned*>(p.stats + (chunk * p.Cout + nblk * NB) * 2) + fi * 32;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 28; ++k) tr[k] = stamp[k];
+      }
     }
   }
 }
@@ -777,7 +957,7 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   p.x = x; p.u = u_packed; p.bias = bias; p.res = res; p.y = y; p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0;
   p.in_ss = in_ss; p.in_swish = in_swish; p.stats = stats_part;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
-  p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32;
+  p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32; p.nt = smx_tune(SMX_TUNE_WINO_NT);
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
   if (16LL * ((Cout + 31) / 32) * (Cin / 8) * 256 > 2147483647LL) return SMX_EINVAL;
@@ -793,8 +973,9 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   // them, 4-wave blocks (N=32, 3 per CU) otherwise; the conflict-free LDS swizzle is neutral (LDS is
   // not the limiter) and stays off by default.
   hipStream_t st = (hipStream_t)stream;
+  const int wide = smx_tune(SMX_TUNE_WINO_WIDE);
   const int abl = smx_tune(SMX_TUNE_WINO_ABLATE);
-  if (abl && nw == 2) {
+  if (abl && nw == 2 && wide <= 0) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
     switch (abl) {
       case 2: SMX_LAUNCH((winograd_kernel<false, 2, 2>), grid, dim3(512), lds, st, p); break;
@@ -805,26 +986,42 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
     }
     return smx_launch_status();
   }
-  const int wide = smx_tune(SMX_TUNE_WINO_WIDE);
   if (nw == 2 && wide > 0 && !swz) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
     static bool attrw = false;
     if (!attrw) {
-      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-      SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
+      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
+      SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
       attrw = true;
     }
-    if (wide == 3) SMX_LAUNCH((winograd_wide_kernel<false, 3>), grid, dim3(256), 65536, st, p);
-    else if (wide == 2) SMX_LAUNCH(winograd_wide_kernel<true>, grid, dim3(256), 65536, st, p);
-    else SMX_LAUNCH(winograd_wide_kernel<false>, grid, dim3(256), 65536, st, p);
+    if (abl) {
+#define SMX_WABL(A) do { SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<false, 2, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); \
+                         SMX_LAUNCH((winograd_wide_kernel<false, 2, A>), grid, dim3(256), wide == 5 ? 98304 : WIDE_LDS, st, p); } while (0)
+      switch (abl) {
+        case 1: SMX_WABL(1); break; case 2: SMX_WABL(2); break; case 4: SMX_WABL(4); break; case 8: SMX_WABL(8); break;
+        case 16: SMX_WABL(16); break; case 7: SMX_WABL(7); break; case 32: SMX_WABL(32); break; default: SMX_WABL(31); break;
+      }
+#undef SMX_WABL
+    }
+    else if (wide == 4) {
+      SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<false, 2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
+      SMX_LAUNCH((winograd_wide_kernel<false, 2, 0, true>), grid, dim3(256), WIDE_LDS, st, p);
+    }
+    else if (wide == 5) {   // timing experiment: same kernel, one block per CU (LDS request > half the CU's)
+      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+      SMX_LAUNCH(winograd_wide_kernel<false>, grid, dim3(256), 98304, st, p);
+    }
+    else if (wide == 3) SMX_LAUNCH((winograd_wide_kernel<false, 3>), grid, dim3(256), WIDE_LDS, st, p);
+    else if (wide == 2) SMX_LAUNCH(winograd_wide_kernel<true>, grid, dim3(256), WIDE_LDS, st, p);
+    else SMX_LAUNCH(winograd_wide_kernel<false>, grid, dim3(256), WIDE_LDS, st, p);
   } else if (nw == 2) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
     if (epi1) {
       static bool attr = false;
-      if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
+      if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS)); attr = true; }
       static bool attr3 = false;
-      if (!attr3) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr3 = true; }
+      if (!attr3) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS)); attr3 = true; }
       if (ud == 3) SMX_LAUNCH((winograd_kernel<false, 2, 0, true, 3>), grid, dim3(512), lds, st, p);
       else SMX_LAUNCH((winograd_kernel<false, 2, 0, true>), grid, dim3(512), lds, st, p);
     }

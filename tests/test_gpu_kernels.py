@@ -122,8 +122,8 @@ def tuning(ops):
         ops.set_tuning(name, old)
 
 
-@pytest.mark.parametrize("nw,swz,epi", [(-1, 0, 0), (1, 0, 0), (2, 0, 0), (1, 1, 0), (2, 1, 0), (1, 0, 1), (2, 0, 1), (2, 0, 11), (2, 0, 12)],
-                         ids=["auto", "nw1", "nw2", "nw1_swz", "nw2_swz", "nw1_epi1", "nw2_epi1", "nw2_wide", "nw2_wide_pipelined"])
+@pytest.mark.parametrize("nw,swz,epi", [(-1, 0, 0), (1, 0, 0), (2, 0, 0), (1, 1, 0), (2, 1, 0), (1, 0, 1), (2, 0, 1), (2, 0, 11), (2, 0, 12), (2, 0, 14)],
+                         ids=["auto", "nw1", "nw2", "nw1_swz", "nw2_swz", "nw1_epi1", "nw2_epi1", "nw2_wide", "nw2_wide_pipelined", "nw2_wide_flags"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_H{c[3]}_up{int(c[4])}_act{c[5]}_res{int(c[6])}" for c in WINO_CASES])
 def test_winograd_conv3x3(ops, case, nw, swz, epi, tuning):
     """fused Winograd F(2x2,3x3) == F.conv2d (3x3, s1, p1); also through channel-slice operands.  Every block
@@ -133,7 +133,7 @@ def test_winograd_conv3x3(ops, case, nw, swz, epi, tuning):
     tuning("wino_nw", nw)
     tuning("wino_swz", swz)
     tuning("wino_epi", epi % 10)
-    tuning("wino_wide", epi // 10 * (epi % 10))          # 11 -> wide, 12 -> wide + software-pipelined transform
+    tuning("wino_wide", epi // 10 * (epi % 10))          # 11 -> wide, 12 -> wide + software-pipelined transform, 14 -> wide + LDS-counter slice sync
     x = rnd(f"wx{case}", (B, Cin, H, H))
     w = rnd(f"ww{case}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
     b = rnd(f"wb{case}", (Cout,), 0.1)
@@ -174,7 +174,7 @@ def test_winograd_fused_groupnorm_loader(ops):
 
 @pytest.mark.parametrize("B,C,Co,H,W,act,res", [(2, 64, 64, 32, 32, 0, True), (3, 128, 128, 16, 32, 3, False), (1, 32, 96, 64, 64, 0, True),
                                                  (2, 64, 126, 8, 16, 1, False)])
-@pytest.mark.parametrize("epi", [0, 1, 11, 12], ids=["two_pass_epilogue", "one_pass_epilogue", "wide_blocks", "wide_blocks_pipelined"])
+@pytest.mark.parametrize("epi", [0, 1, 11, 12, 14], ids=["two_pass_epilogue", "one_pass_epilogue", "wide_blocks", "wide_blocks_pipelined", "wide_blocks_flags"])
 def test_winograd_epilogue_emits_groupnorm_partials(ops, B, C, Co, H, W, act, res, epi, monkeypatch, tuning):
     """want_stats: the conv's epilogue emits per-block {mean, M2} of what it stores (after bias, activation,
     residual); groupnorm_stats on the tagged output is then a finalize only and must equal the two-pass
