@@ -16,11 +16,11 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"gemm_xcd_swizzle", "SMX_GEMM_XCD_SWIZZLE", 1},
   {"warp_rows", "SMX_WARP_ROWS", 1},            // warp: row-chunk kernel when eligible (0 = per-lane kernel)
   {"warp_reorder", "SMX_WARP_REORDER", 1},      // warp: (XCD, chunk, frame) block order
-  {"wino_epi", "SMX_WINO_EPI", 1},              // Winograd: 1 = one-pass epilogue (default, measured +11..47 % on ResBlock-form launches), 0 = two passes over the output columns
+  {"wino_epi", "SMX_WINO_EPI", 1},              // (retired: the one-pass epilogue is the only one)
   {"conv16_tpb", "SMX_CONV16_TPB", -1},         // bf16 region-direct 3x3: tiles walked per block (reserved)
   {"attn16", "SMX_ATTN16", 1},                  // bf16 storage, d_head 32: bf16 MFMA kernel (0 = fp32 MFMA kernel on bf16 storage)
-  {"wino_ud", "SMX_WINO_UD", 2},                // Winograd: U-fragment prefetch distance in units (2 | 3) on the 4-slot register ring
-  {"wino_wide", "SMX_WINO_WIDE", 1},            // Winograd big launches: 1 = 4-wave "wide" blocks, 64 n per wave (default: +5..13 % per launch), 0 = 8-wave blocks, 2 = wide + software-pipelined transform (measured 4 % slower), 3 = wide + U prefetch distance 3 (neutral)
+  {"wino_ud", "SMX_WINO_UD", 2},                // (retired: U prefetch distance 3 measured neutral)
+  {"wino_wide", "SMX_WINO_WIDE", 1},            // Winograd big launches: 1 = 4-wave "wide" blocks, 64 n per wave (default), 0 = 8-wave blocks, 5 = wide at one block per CU (tools)
   {"wino_nt", "SMX_WINO_NT", 0},                // wide Winograd epilogue: non-temporal residual loads / output stores
 };
 bool g_init = false;

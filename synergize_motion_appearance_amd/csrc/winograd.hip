@@ -68,22 +68,21 @@ __device__ __forceinline__ bool smx_nt_flag(const WP& p) { return p.nt != 0; }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-// NW = 32-wide N tiles per block (waves = 4 frequency rows x NW).  NW=1: 4 waves, <=168 VGPRs, 3 blocks/CU;
-// NW=2: 8 waves, <=128 VGPRs, 2 blocks/CU.
-template <bool SWZ, int NW, int ABL = 0, bool EPI1 = false, int UD = 2>   // UD: U prefetch distance in units (2 | 3) on the 4-slot ring   // ABL: timing-only ablation mask (tools only): 2 no U loads, 4 no region staging, 16 no epilogue; EPI1: one-pass epilogue
+// NW = 32-wide N tiles per block (waves = 4 frequency rows x NW).  NW=1: 4 waves, <=168 VGPRs, 3 blocks/CU (the small
+// launches: B=1, Cout not a multiple of 64); NW=2: 8 waves, <=128 VGPRs, 2 blocks/CU (kept selectable: wino_wide=0).
+// ABL: timing-only ablation mask (tools only): 2 no U loads, 4 no region staging, 16 no epilogue.
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP p) {
-  constexpr int RP = SWZ ? 19 : 18;
-  constexpr int RPIX = RH * RP;                       // region pixels per LDS buffer (pitch 18 unswizzled: 3 blocks of the 4-wave variant fit 160 KiB)
+  constexpr int RP = 18;
+  constexpr int RPIX = RH * RP;                       // region pixels per LDS buffer (pitch 18: 3 blocks of the 4-wave variant fit 160 KiB)
   constexpr int NTHR = 256 * NW;
+  constexpr int NB = 32 * NW, NQ = NB / 4, ZS = NB + 4;               // output channels per block, channel quads, exchange pitch
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [2][RPIX][RLD] (reused by the epilogue)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform -> SGPR addressing below
   const int fi = wave / NW, nh = wave % NW;                         // frequency row, N tile within the block
-  // lane -> tile map chosen so that each hardware ds_read_b128 lane group ({0-3,12-15,20-27},
-  // {4-11,16-19,28-31}) holds two complete tile rows: tile = 16*parity(q) + 4*(q>>1) + (t&3), q = t>>2
   const int hh = lane >> 5, t = lane & 31;
-  const int tile_of_lane = SWZ ? 16 * (__popc((unsigned)(t >> 2)) & 1) + 4 * (t >> 3) + (t & 3) : t;
-  const int tr = tile_of_lane >> 3, tc = tile_of_lane & 7;
+  const int tr = t >> 3, tc = t & 7;
   // block -> (image, tile-block y, tile-block x), N block
   int bid = blockIdx.x;
   const int bx = bid % p.tiles_x; bid /= p.tiles_x;
@@ -92,7 +91,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
   const float* __restrict__ X = p.x + (long long)img * Hs * Ws * p.lda;
 
-  // ---- region staging: RPIX x 8 float4 per 32-channel slice, NTHR threads -> 3 items max ----
+  // ---- region staging: RPIX x 8 float4 per 32-channel slice, NTHR threads -> 6 / 3 items ----
   constexpr int NIT = (RH * RW * 8 + NTHR - 1) / NTHR;
   int goff[NIT]; int loff[NIT]; bool gok[NIT], lok[NIT];     // element offsets fit 32 bits (checked on the host)
 #pragma unroll
@@ -105,12 +104,20 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     gok[k] = lok[k] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     if (p.up2) { iy >>= 1; ix >>= 1; }
     goff[k] = (iy * Ws + ix) * p.lda + c4 * 4;
-    loff[k] = (ry * RP + rx) * RLD + ((SWZ ? (c4 ^ ((rx >> 1) & 1)) : c4) * 4);      // XOR swizzle of the 16-B chunk
+    loff[k] = (ry * RP + rx) * RLD + c4 * 4;
   }
   float4 stage[NIT];
-  // load_region only ISSUES the global loads (consumed a whole slice of MFMAs later);
-  // store_region applies the fused GroupNorm(+swish) and writes LDS.
-  auto load_region = [&](int c0) {
+  // load_region only ISSUES the global loads (consumed a whole slice of MFMAs later) -- the region AND the GroupNorm
+  // scale/shift pair of this thread's channel quad (item & 7 == tid & 7 for every item); store_region applies the fused
+  // GroupNorm(+swish) branch-free and writes LDS.  (A per-item `if (in frame) { load ss; ...}` serialised one L2 round
+  // trip per item: 3.4k of a 30k-cycle slice in the wide kernel's trace.)
+  float4 ssa = make_float4(1.f, 0.f, 1.f, 0.f), ssb = ssa;
+  const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
+  auto load_region = [&](int c0) __attribute__((always_inline)) {
+    if (loader) {
+      const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + (tid & 7) * 4) * 2;
+      ssa = *reinterpret_cast<const float4*>(sp); ssb = *reinterpret_cast<const float4*>(sp + 4);
+    }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -118,19 +125,16 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
       stage[k] = v;
     }
   };
-  auto store_region = [&](int buf, int c0) {
-    float* rb = smem + buf * RPIX * RLD;
+  auto store_items = [&](float* rb, auto mode) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode)::value;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      if (!lok[k]) continue;
       float4 v = stage[k];
-      if (p.in_ss && gok[k]) {
+      if (MODE >= 1) {
         // GroupNorm(+swish) of the producer folded into the loader: each input element is normalised
         // once per staged region instead of in a separate read+write pass; padding stays exactly 0
-        const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + ((tid + NTHR * k) & 7) * 4) * 2;
-        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-        v = make_float4(fmaf(v.x, s0.x, s0.y), fmaf(v.y, s0.z, s0.w), fmaf(v.z, s1.x, s1.y), fmaf(v.w, s1.z, s1.w));
-        if (p.in_swish) {
+        v = make_float4(fmaf(v.x, ssa.x, ssa.y), fmaf(v.y, ssa.z, ssa.w), fmaf(v.z, ssb.x, ssb.y), fmaf(v.w, ssb.z, ssb.w));
+        if (MODE == 2) {
           // swish = v * rcp(1 + 2^(-v*log2e)): v_exp_f32 + v_rcp_f32 (1 ulp each) keep the loader light
           constexpr float L2E = 1.44269504088896340736f;
           v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
@@ -138,18 +142,24 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
           v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
           v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
         }
+        v.x = gok[k] ? v.x : 0.f; v.y = gok[k] ? v.y : 0.f; v.z = gok[k] ? v.z : 0.f; v.w = gok[k] ? v.w : 0.f;
       }
-      *reinterpret_cast<float4*>(rb + loff[k]) = v;
+      if (lok[k]) *reinterpret_cast<float4*>(rb + loff[k]) = v;
     }
+  };
+  auto store_region = [&](int buf) __attribute__((always_inline)) {
+    float* rb = smem + buf * RPIX * RLD;
+    if (loader == 2) store_items(rb, std::integral_constant<int, 2>{});
+    else if (loader == 1) store_items(rb, std::integral_constant<int, 1>{});
+    else store_items(rb, std::integral_constant<int, 0>{});
   };
 
   // which two patch rows frequency row fi needs: B^T rows (0:[d0-d2] 1:[d1+d2] 2:[d2-d1] 3:[d1-d3])
   const int ra = (fi == 0) ? 0 : ((fi == 2) ? 2 : 1);
   const int rb_ = (fi == 0) ? 2 : ((fi == 1) ? 2 : ((fi == 2) ? 1 : 3));
-  const bool plus = (fi == 1);
   const int pa = ((2 * tr + ra) * RP + 2 * tc) * RLD;               // patch row a, col 0 (chunk added per read)
   const int pb = ((2 * tr + rb_) * RP + 2 * tc) * RLD;
-  const int par = SWZ ? (tc & 1) : 0;                                           // swizzle parity of patch columns 0,1 (2,3: flipped)
+  const float sgn = (fi == 1) ? 1.f : -1.f;
 
   // U fragments: [f][n32][Cin/8][64 lanes][4] (+ one padded step at the end so the 2-unit prefetch
   // never needs a predicate); wave-uniform bases (SGPR) + lane*16 B
@@ -167,8 +177,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int nsl = p.Cin >> 5;
-  const float sgn = plus ? 1.f : -1.f;
-  load_region(0); store_region(0, 0);
+  load_region(0); store_region(0);
   // U ring: slot j holds the fragment of the unit with frequency j; prefetch distance = 2 units
   // (= 8 MFMAs of this wave, ~4x that in wall time with 4 waves per SIMD) hides the L2 latency.
   float4 ur[4];
@@ -176,7 +185,6 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     return *reinterpret_cast<const float4*>(U + ((unit & 3) * ufs + (unit >> 2) * 256) + lane4);
   };
   ur[0] = uload(0); ur[1] = uload(1);
-  if (UD == 3) ur[2] = uload(2);
   __syncthreads();
   // input transform of 8-channel step `sub` for frequency row fi, this lane's (tile, 4 channels):
   // t_b = d[ra][b] +- d[rb][b];  V[i][0..3] = t0-t2, t1+t2, t2-t1, t1-t3
@@ -184,26 +192,30 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     float4 tt[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int ch = (SWZ ? ((2 * sub + hh) ^ (par ^ (b >> 1))) : (2 * sub + hh)) * 4;
+      const int ch = (2 * sub + hh) * 4;
       const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + ch);
       const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + ch);
       tt[b] = make_float4(fmaf(sgn, db.x, da.x), fmaf(sgn, db.y, da.y), fmaf(sgn, db.z, da.z), fmaf(sgn, db.w, da.w));
     }
     v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
   };
+  // A = U, B = V: the accumulator tile is [n][tile] -- a lane holds 4 consecutive channels per register quad, which the
+  // epilogue moves through LDS as ds_write_b128
   auto mfma16 = [&](const float4 (&v)[4], int unit0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (!(ABL & 2)) ur[(j + UD) & 3] = uload(unit0 + j + UD);   // UD = 3: the slot freed by the previous group (its MFMAs are issued)
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, ur[j].x, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, ur[j].y, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, ur[j].z, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, ur[j].w, acc[j], 0, 0, 0);
+      if (!(ABL & 2)) ur[(j + 2) & 3] = uload(unit0 + j + 2);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[j].x, v[j].x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[j].y, v[j].y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[j].z, v[j].z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[j].w, v[j].w, acc[j], 0, 0, 0);
     }
   };
+  // the next region's global loads go out at the END of a slice (after the staged one went to LDS): vmcnt retires in order,
+  // so a U fragment requested after them cannot be consumed before they land
+  if (!(ABL & 4) && nsl > 1) load_region(32);
   for (int s = 0; s < nsl; ++s) {
     const int buf = s & 1;
-    if (!(ABL & 4) && s + 1 < nsl) load_region((s + 1) * 32);
     const float* rb = smem + buf * RPIX * RLD;
     // (a hand-unrolled variant that put the transform of step sub+1 in the same basic block as the
     //  MFMAs of step sub measured 15-20% SLOWER under hipcc's scheduling -- kept simple.)
@@ -211,213 +223,135 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     for (int sub = 0; sub < 4; ++sub) {
       float4 v[4];
       transform(rb, sub, v);
-      // a wave inside its MFMA burst outranks the co-resident waves that are in their transform / staging
-      // segment (VALU + LDS): measured +2.5 % end to end (levels 1-3 alike)
       __builtin_amdgcn_s_setprio(1);
       mfma16(v, (s * 4 + sub) * 4);
       __builtin_amdgcn_s_setprio(0);
     }
-    if (!(ABL & 4) && s + 1 < nsl) store_region(buf ^ 1, (s + 1) * 32);
+    if (!(ABL & 4) && s + 1 < nsl) { store_region(buf ^ 1); if (s + 2 < nsl) load_region((s + 2) * 32); }
     __syncthreads();
   }
   if (ABL & 16) { if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 123.456f) p.y[0] = 1.f; return; }
 
   // ---- epilogue: Y = A^T M A.  In-register: Z_i[q] = sum_j M[i][j] A[j][q] ------------------
   //   A^T = [[1,1,1,0],[0,1,-1,-1]]  =>  Z[0] = M0+M1+M2 ;  Z[1] = M1-M2-M3
-  // Cross-row: Y[0][q] = Z_0+Z_1+Z_2 ; Y[1][q] = Z_1-Z_2-Z_3  (via LDS zb[4][32 tiles][64 n])
+  // Cross-row: Y[0][q] = Z_0+Z_1+Z_2 ; Y[1][q] = Z_1-Z_2-Z_3.  One pass: every wave writes BOTH output columns of its
+  // frequency row -> one barrier -> each thread finishes a whole 2x2 output tile x 4 channels.
+  // Exchange zb [2 q][4 fi][32 tiles][NB n, pitch NB + 4]: lane (t, hh) holds tile t, channels 8g + 4hh + (0..3) in
+  // registers 4g..4g+3.
   float* zb = smem;
   float* __restrict__ Yp = p.y;
   const float* __restrict__ Rp = p.res;
-  if (EPI1) {
-    // One pass: every wave writes BOTH output columns of its frequency row (Z[0], Z[1]) -> one barrier -> each thread
-    // finishes a whole 2x2 output tile x 4 channels (was: two passes over q with four barriers).  zb2 [2 q][4 fi][32 tiles][NB].
-    constexpr int NB1 = 32 * NW, NQ1 = NB1 / 4;
-    __syncthreads();
+  __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const int row = SWZ ? 16 * (__popc((unsigned)(rl >> 2)) & 1) + 4 * (rl >> 3) + (rl & 3) : rl;
-      zb[((0 * 4 + fi) * 32 + row) * NB1 + nh * 32 + t] = acc[0][r] + acc[1][r] + acc[2][r];
-      zb[((1 * 4 + fi) * 32 + row) * NB1 + nh * 32 + t] = acc[1][r] - acc[2][r] - acc[3][r];
-    }
-    __syncthreads();
-    const int tile = tid / NQ1, n4 = (tid % NQ1) * 4;
-    const int n = nblk * NB1 + n4;
-    float4 o[2][2];                                                  // [output row][output col q]
-    float gs4[4] = {0.f, 0.f, 0.f, 0.f}, gm2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n < p.Cout) {
-      const bool full = n + 3 < p.Cout;
-      float bn[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
+  for (int g = 0; g < 4; ++g) {
+    float4 q0, q1;
+    q0.x = acc[0][4 * g + 0] + acc[1][4 * g + 0] + acc[2][4 * g + 0]; q1.x = acc[1][4 * g + 0] - acc[2][4 * g + 0] - acc[3][4 * g + 0];
+    q0.y = acc[0][4 * g + 1] + acc[1][4 * g + 1] + acc[2][4 * g + 1]; q1.y = acc[1][4 * g + 1] - acc[2][4 * g + 1] - acc[3][4 * g + 1];
+    q0.z = acc[0][4 * g + 2] + acc[1][4 * g + 2] + acc[2][4 * g + 2]; q1.z = acc[1][4 * g + 2] - acc[2][4 * g + 2] - acc[3][4 * g + 2];
+    q0.w = acc[0][4 * g + 3] + acc[1][4 * g + 3] + acc[2][4 * g + 3]; q1.w = acc[1][4 * g + 3] - acc[2][4 * g + 3] - acc[3][4 * g + 3];
+    *reinterpret_cast<float4*>(zb + ((0 * 4 + fi) * 32 + t) * ZS + nh * 32 + 8 * g + 4 * hh) = q0;
+    *reinterpret_cast<float4*>(zb + ((1 * 4 + fi) * 32 + t) * ZS + nh * 32 + 8 * g + 4 * hh) = q1;
+  }
+  const int tile = tid / NQ, n4 = (tid % NQ) * 4;
+  const int n = nblk * NB + n4;
+  const bool full = n + 3 < p.Cout;
+  const bool vec = full && (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) &&
+                   (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0));
+  const int oy = by * 8 + 2 * (tile >> 3), ox0 = bx * 16 + 2 * (tile & 7);
+  const long long pix0 = ((long long)img * p.H + oy) * p.W + ox0;
+  float4 rr[2][2];
+  if (Rp && vec) {                                                   // requested before the barrier: the residual's latency hides under it
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (n + e < p.Cout) bn[e] = p.bias[n + e];
-      }
-      const bool vec = full && (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) &&
-                       (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0));
-      const int oy = by * 8 + 2 * (tile >> 3), ox0 = bx * 16 + 2 * (tile & 7);
-      const long long pix0 = ((long long)img * p.H + oy) * p.W + ox0;
-      float4 rr[2][2];
-      if (Rp && vec) {
+    for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
-        for (int yy = 0; yy < 2; ++yy)
+      for (int q = 0; q < 2; ++q) rr[yy][q] = *reinterpret_cast<const float4*>(Rp + (pix0 + yy * p.W + q) * p.ldres + n);
+  }
+  float bn[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && n < p.Cout) {
 #pragma unroll
-          for (int q = 0; q < 2; ++q) rr[yy][q] = *reinterpret_cast<const float4*>(Rp + (pix0 + yy * p.W + q) * p.ldres + n);
-      }
+    for (int e = 0; e < 4; ++e) if (n + e < p.Cout) bn[e] = p.bias[n + e];
+  }
+  __syncthreads();
+  float4 o[2][2];                                                    // [output row][output col q]
+  float gs4[4] = {0.f, 0.f, 0.f, 0.f}, gm2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < p.Cout) {
+    // the activation is resolved once per block (0 identity, 1 relu / leaky relu in slope form, 2 generic), not per value
+    auto finish = [&](auto mode) __attribute__((always_inline)) {
+      constexpr int MODE = decltype(mode)::value;
+      const float slope = p.act == SMX_ACT_RELU ? 0.f : 0.2f;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const float4 z0 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 0) * 32 + tile) * NB1 + n4);
-        const float4 z1 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 1) * 32 + tile) * NB1 + n4);
-        const float4 z2 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 2) * 32 + tile) * NB1 + n4);
-        const float4 z3 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 3) * 32 + tile) * NB1 + n4);
+        const float4 z0 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 0) * 32 + tile) * ZS + n4);
+        const float4 z1 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 1) * 32 + tile) * ZS + n4);
+        const float4 z2 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 2) * 32 + tile) * ZS + n4);
+        const float4 z3 = *reinterpret_cast<const float4*>(zb + ((q * 4 + 3) * 32 + tile) * ZS + n4);
         float a0[4] = {z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w};
         float a1[4] = {z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a0[e] = w_act(a0[e] + bn[e], p.act); a1[e] = w_act(a1[e] + bn[e], p.act); }
+        for (int e = 0; e < 4; ++e) {
+          a0[e] += bn[e]; a1[e] += bn[e];
+          if (MODE == 1) { a0[e] = fmaxf(a0[e], 0.f) + slope * fminf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f) + slope * fminf(a1[e], 0.f); }
+          if (MODE == 2) { a0[e] = w_act(a0[e], p.act); a1[e] = w_act(a1[e], p.act); }
+        }
         o[0][q] = make_float4(a0[0], a0[1], a0[2], a0[3]);
         o[1][q] = make_float4(a1[0], a1[1], a1[2], a1[3]);
       }
-      if (vec) {
+    };
+    if (p.act == SMX_ACT_NONE) finish(std::integral_constant<int, 0>{});
+    else if (p.act == SMX_ACT_RELU || p.act == SMX_ACT_LRELU02) finish(std::integral_constant<int, 1>{});
+    else finish(std::integral_constant<int, 2>{});
+    if (vec) {
 #pragma unroll
-        for (int yy = 0; yy < 2; ++yy)
+      for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            if (Rp) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
-            *reinterpret_cast<float4*>(Yp + (pix0 + yy * p.W + q) * p.ldc + n) = o[yy][q];
-          }
-      } else {
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            float v[4] = {o[yy][q].x, o[yy][q].y, o[yy][q].z, o[yy][q].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (n + e >= p.Cout) { v[e] = 0.f; continue; }
-              if (Rp) v[e] += Rp[(pix0 + yy * p.W + q) * p.ldres + n + e];
-              Yp[(pix0 + yy * p.W + q) * p.ldc + n + e] = v[e];
-            }
-            o[yy][q] = make_float4(v[0], v[1], v[2], v[3]);
-          }
-      }
-      // Welford partial of this thread's 4 values per channel: a,b (q=0: rows 0,1), c,d (q=1)
-      const float va[4][4] = {{o[0][0].x, o[0][0].y, o[0][0].z, o[0][0].w}, {o[1][0].x, o[1][0].y, o[1][0].z, o[1][0].w},
-                              {o[0][1].x, o[0][1].y, o[0][1].z, o[0][1].w}, {o[1][1].x, o[1][1].y, o[1][1].z, o[1][1].w}};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float s0 = va[0][e] + va[1][e], d0 = va[0][e] - va[1][e], s1 = va[2][e] + va[3][e], d1 = va[2][e] - va[3][e], ds = s0 - s1;
-        gs4[e] = 0.25f * (s0 + s1);
-        gm2[e] = 0.5f * (d0 * d0 + d1 * d1) + 0.25f * ds * ds;
-      }
-    }
-    if (p.stats) {
-      __syncthreads();                                               // zb2 is dead: reduction buffer [32 tiles][NB][2] on top of it
-      float* red = smem;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { red[(tile * NB1 + n4 + e) * 2] = gs4[e]; red[(tile * NB1 + n4 + e) * 2 + 1] = gm2[e]; }
-      __syncthreads();
-      if (tid < NB1 && nblk * NB1 + tid < p.Cout) {
-        float a = 0.f, b = 0.f;
-#pragma unroll 8
-        for (int tl = 0; tl < 32; ++tl) { a += red[(tl * NB1 + tid) * 2]; b += red[(tl * NB1 + tid) * 2 + 1]; }
-        a *= (1.f / 32.f);
-        float c2 = 0.f;
-#pragma unroll 8
-        for (int tl = 0; tl < 32; ++tl) { const float d = red[(tl * NB1 + tid) * 2] - a; c2 += d * d; }
-        b += 4.f * c2;
-        const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
-        float* o2 = p.stats + (chunk * p.Cout + nblk * NB1 + tid) * 2;
-        o2[0] = a; o2[1] = b;
-      }
-    }
-    return;
-  }
-  // GroupNorm statistics of the consumer, produced here: per channel {sum, sum^2} of what is stored
-  // in Welford form ({mean, M2} of the block's 128 values per channel; see gn_partial_kernel for why not {sum, sum^2})
-  float gs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gd[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  constexpr int NB = 32 * NW, NQ = NB / 4;
-  for (int q = 0; q < 2; ++q) {
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;               // MFMA row = lane that supplied the A row
-      const int row = SWZ ? 16 * (__popc((unsigned)(rl >> 2)) & 1) + 4 * (rl >> 3) + (rl & 3) : rl;   // -> its tile
-      const float z = q == 0 ? (acc[0][r] + acc[1][r] + acc[2][r]) : (acc[1][r] - acc[2][r] - acc[3][r]);
-      zb[(fi * 32 + row) * (32 * NW) + nh * 32 + t] = z;
-    }
-    __syncthreads();
-    // 32 tiles x (32*NW / 4) channel quads = NTHR items: one float4 column group per thread
-    {
-      const int tile = tid / NQ, n4 = (tid % NQ) * 4;
-      const int n = nblk * NB + n4;
-      if (n < p.Cout) {
-        const float4 z0 = *reinterpret_cast<const float4*>(zb + (0 * 32 + tile) * NB + n4);
-        const float4 z1 = *reinterpret_cast<const float4*>(zb + (1 * 32 + tile) * NB + n4);
-        const float4 z2 = *reinterpret_cast<const float4*>(zb + (2 * 32 + tile) * NB + n4);
-        const float4 z3 = *reinterpret_cast<const float4*>(zb + (3 * 32 + tile) * NB + n4);
-        const bool full = n + 3 < p.Cout;
-        float bn[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < p.Cout) bn[e] = p.bias[n + e];
+        for (int q = 0; q < 2; ++q) {
+          if (Rp) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
+          *reinterpret_cast<float4*>(Yp + (pix0 + yy * p.W + q) * p.ldc + n) = o[yy][q];
         }
-        const bool vec = full && (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) &&
-                         (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0));
-        const int oy = by * 8 + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7) + q;
-        const long long pix0 = ((long long)img * p.H + oy) * p.W + ox;
-        float o0[4] = {z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w};
-        float o1[4] = {z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w};
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o0[e] = w_act(o0[e] + bn[e], p.act); o1[e] = w_act(o1[e] + bn[e], p.act); }
-        if (vec) {
-          if (Rp) {
-            const float4 r0 = *reinterpret_cast<const float4*>(Rp + pix0 * p.ldres + n);
-            const float4 r1 = *reinterpret_cast<const float4*>(Rp + (pix0 + p.W) * p.ldres + n);
-            o0[0] += r0.x; o0[1] += r0.y; o0[2] += r0.z; o0[3] += r0.w;
-            o1[0] += r1.x; o1[1] += r1.y; o1[2] += r1.z; o1[3] += r1.w;
-          }
-          *reinterpret_cast<float4*>(Yp + pix0 * p.ldc + n) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-          *reinterpret_cast<float4*>(Yp + (pix0 + p.W) * p.ldc + n) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-        } else {
+      for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float v[4] = {o[yy][q].x, o[yy][q].y, o[yy][q].z, o[yy][q].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (n + e >= p.Cout) { o0[e] = 0.f; o1[e] = 0.f; continue; }
-            if (Rp) { o0[e] += Rp[pix0 * p.ldres + n + e]; o1[e] += Rp[(pix0 + p.W) * p.ldres + n + e]; }
-            Yp[pix0 * p.ldc + n + e] = o0[e];
-            Yp[(pix0 + p.W) * p.ldc + n + e] = o1[e];
+            if (n + e >= p.Cout) { v[e] = 0.f; continue; }
+            if (Rp) v[e] += Rp[(pix0 + yy * p.W + q) * p.ldres + n + e];
+            Yp[(pix0 + yy * p.W + q) * p.ldc + n + e] = v[e];
           }
+          o[yy][q] = make_float4(v[0], v[1], v[2], v[3]);
         }
+    }
+    // GroupNorm statistics of the consumer, produced here in Welford form ({mean, M2} of what is stored; see
+    // gn_partial_kernel for why not {sum, sum^2}): this thread's 4 values per channel: a,b (q=0: rows 0,1), c,d (q=1)
+    const float va[4][4] = {{o[0][0].x, o[0][0].y, o[0][0].z, o[0][0].w}, {o[1][0].x, o[1][0].y, o[1][0].z, o[1][0].w},
+                            {o[0][1].x, o[0][1].y, o[0][1].z, o[0][1].w}, {o[1][1].x, o[1][1].y, o[1][1].z, o[1][1].w}};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { gs[q][e] = o0[e] + o1[e]; gd[q][e] = o0[e] - o1[e]; }
-      }
+    for (int e = 0; e < 4; ++e) {
+      const float s0 = va[0][e] + va[1][e], d0 = va[0][e] - va[1][e], s1 = va[2][e] + va[3][e], d1 = va[2][e] - va[3][e], ds = s0 - s1;
+      gs4[e] = 0.25f * (s0 + s1);
+      gm2[e] = 0.5f * (d0 * d0 + d1 * d1) + 0.25f * ds * ds;
     }
   }
   if (p.stats) {
-    // block reduction over the 32 tiles (zb's first 4*32*NB floats are still being read by slow waves of
-    // the last q pass: the reduction buffer sits behind them)
-    float* red = smem + 4 * 32 * NB;                               // [32 tiles][NB][2]
-    {
-      const int tile = tid / NQ, n4 = (tid % NQ) * 4;
+    __syncthreads();                                                 // the exchange is dead: reduction buffer [32 tiles][NB][2] on top of it
+    float* red = smem;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // this thread's 4 values a,b (q=0), c,d (q=1): mean = (a+b+c+d)/4, M2 = ((a-b)^2 + (c-d)^2)/2 + ((a+b)-(c+d))^2/4
-        const float ds = gs[0][e] - gs[1][e];
-        red[(tile * NB + n4 + e) * 2] = 0.25f * (gs[0][e] + gs[1][e]);
-        red[(tile * NB + n4 + e) * 2 + 1] = 0.5f * (gd[0][e] * gd[0][e] + gd[1][e] * gd[1][e]) + 0.25f * ds * ds;
-      }
-    }
+    for (int e = 0; e < 4; ++e) { red[(tile * NB + n4 + e) * 2] = gs4[e]; red[(tile * NB + n4 + e) * 2 + 1] = gm2[e]; }
     __syncthreads();
     if (tid < NB && nblk * NB + tid < p.Cout) {
       float a = 0.f, b = 0.f;
 #pragma unroll 8
       for (int tl = 0; tl < 32; ++tl) { a += red[(tl * NB + tid) * 2]; b += red[(tl * NB + tid) * 2 + 1]; }
-      a *= (1.f / 32.f);                                           // block mean (32 threads x 4 values each)
+      a *= (1.f / 32.f);
       float c2 = 0.f;
 #pragma unroll 8
       for (int tl = 0; tl < 32; ++tl) { const float d = red[(tl * NB + tid) * 2] - a; c2 += d * d; }
       b += 4.f * c2;
       const long long chunk = ((long long)img * p.tiles_y + by) * p.tiles_x + bx;
-      float* o = p.stats + (chunk * p.Cout + nblk * NB + tid) * 2;
-      o[0] = a; o[1] = b;
+      float* o2 = p.stats + (chunk * p.Cout + nblk * NB + tid) * 2;
+      o2[0] = a; o2[1] = b;
     }
   }
 }
@@ -431,7 +365,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
 // walking several tile blocks with the next tile's region held in registers across the epilogue (99 VGPRs spilled at the
 // 256 budget), the software-pipelined transform (PIPE: hipcc clusters the pieces instead of interleaving them, -4 %), U prefetch
 // distance 3 (neutral).
-template <bool PIPE, int UD = 2, int ABL = 0, bool FLAGS = false>   // ABL (timing-only, tools): 1 no transform, 2 no U loads, 4 no region staging after the first slice, 8 no barriers, 16 no epilogue
+template <int ABL = 0>   // ABL (timing-only, tools): 1 no transform, 2 no U loads, 4 no region staging after the first slice, 8 no barriers, 16 no epilogue
 __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   constexpr int RP = 18, RPIX = RH * RP, NTHR = 256, NI = 2, NB = 64, ZS = 68;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -527,25 +461,11 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   const float* __restrict__ U1 = p.u + (((long long)(fi * 4) * p.n32 + min(nblk * 2 + 1, p.n32 - 1)) * cs8) * 256;
 
   f32x16 acc[NI][4];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int nsl = p.Cin >> 5;
-  load_region(0); mark(24); store_region(0, 0); mark(25);
   float4 ur[NI][4];
   auto uload = [&](const float* U, int unit) -> float4 {
     return *reinterpret_cast<const float4*>(U + ((unit & 3) * ufs + (unit >> 2) * 256) + lane4);
   };
-  ur[0][0] = uload(U0, 0); ur[1][0] = uload(U1, 0); ur[0][1] = uload(U0, 1); ur[1][1] = uload(U1, 1);
-  if (UD == 3) { ur[0][2] = uload(U0, 2); ur[1][2] = uload(U1, 2); }
-  if (FLAGS && tid < 2) reinterpret_cast<int*>(smem + 2 * RPIX * RLD)[tid] = 0;
-  mark(1);
-  __syncthreads();
-  mark(2);
   auto transform = [&](const float* rb, int sub, float4 (&v)[4]) {
     float4 tt[4];
 #pragma unroll
@@ -561,8 +481,8 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (!(ABL & 2)) {
-        ur[0][(j + UD) & 3] = uload(U0, unit0 + j + UD);            // UD = 3: the slot whose MFMAs were issued one group ago
-        ur[1][(j + UD) & 3] = uload(U1, unit0 + j + UD);
+        ur[0][(j + 2) & 3] = uload(U0, unit0 + j + 2);                // two units (16 MFMAs) ahead on the 4-slot ring
+        ur[1][(j + 2) & 3] = uload(U1, unit0 + j + 2);
       }
       // A = U, B = V: the accumulator tile is [n][tile], so a lane holds 4 CONSECUTIVE channels per register quad and the
       // epilogue moves it through LDS with 16 ds_write_b128 instead of 64 ds_write_b32.  The two N tiles' accumulators
@@ -577,55 +497,26 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
       acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].w, v[j].w, acc[1][j], 0, 0, 0);
     }
   };
-  if (!PIPE && FLAGS) {
-    // No rendezvous in the main loop: the slice barrier is replaced by two LDS counters (regions produced / slices consumed,
-    // one increment per wave), the next region is stored at mid-slice, and a wave only waits for the counter it needs --
-    // a fast wave runs up to half a slice ahead of the slowest instead of idling its SIMD's matrix pipe at every barrier.
-    volatile int* cnt = reinterpret_cast<volatile int*>(smem + 2 * RPIX * RLD);   // [0] produced, [1] consumed
-    auto signal = [&](int which) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(cnt) + which, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto wait_for = [&](int which, int target) {
-      while (__builtin_amdgcn_readfirstlane(cnt[which]) < target) __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory");
-    };
-    if (nsl > 1) load_region(32);
-    for (int s = 0; s < nsl; ++s) {
-      const int buf = s & 1;
-      const float* rb = smem + buf * RPIX * RLD;
-#pragma unroll 1
-      for (int sub = 0; sub < 2; ++sub) {
-        float4 v[4];
-        transform(rb, sub, v);
-        __builtin_amdgcn_s_setprio(1);
-        mfma32(v, (s * 4 + sub) * 4);
-        __builtin_amdgcn_s_setprio(0);
-      }
-      if (s + 1 < nsl) {
-        if (s > 0) wait_for(1, 4 * s);                                 // everyone has finished reading slice s-1 (this buffer)
-        store_region(buf ^ 1, (s + 1) * 32);
-        signal(0);
-        if (s + 2 < nsl) load_region((s + 2) * 32);
-      }
-#pragma unroll 1
-      for (int sub = 2; sub < 4; ++sub) {
-        float4 v[4];
-        transform(rb, sub, v);
-        __builtin_amdgcn_s_setprio(1);
-        mfma32(v, (s * 4 + sub) * 4);
-        __builtin_amdgcn_s_setprio(0);
-      }
-      if (s + 1 < nsl) {
-        signal(1);
-        wait_for(0, 4 * (s + 1));                                      // region s+1 is complete
-      }
-    }
-  } else if (!PIPE) {
+  load_region(0); mark(24);
+  store_region(0, 0); mark(25);
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  ur[0][0] = uload(U0, 0); ur[1][0] = uload(U1, 0); ur[0][1] = uload(U0, 1); ur[1][1] = uload(U1, 1);
+  mark(1);
+  __syncthreads();
+  mark(2);
+  {
     float4 vconst[4] = {make_float4(1.f, 2.f, 3.f, 4.f), make_float4(1.f, 2.f, 3.f, 4.f), make_float4(1.f, 2.f, 3.f, 4.f), make_float4(1.f, 2.f, 3.f, 4.f)};
+    // the next region's global loads are issued at the END of a slice (right after the staged one went to LDS), not at the
+    // start of the next: vmcnt retires in order, so a U fragment requested after them cannot be consumed before they land,
+    // and issued ahead of the barrier + transform their HBM latency overlaps time the wave spends without MFMAs anyway
+    if (!(ABL & 4) && nsl > 1) load_region(32);
     for (int s = 0; s < nsl; ++s) {
       const int buf = (ABL & 4) ? 0 : (s & 1);
-      if (!(ABL & 4) && s + 1 < nsl) load_region((s + 1) * 32);
       const float* rb = smem + buf * RPIX * RLD;
 #pragma unroll 1
       for (int sub = 0; sub < 4; ++sub) {
@@ -638,105 +529,12 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
         if ((ABL & 32) && s == 1) { if (sub == 0) mark(15); else if (sub == 1) mark(16); else if (sub == 2) mark(17); }
       }
       if ((ABL & 32) && s < 4) { if (s == 0) mark(3); else if (s == 1) mark(6); else if (s == 2) mark(9); else mark(12); }
-      if (!(ABL & 4) && s + 1 < nsl) store_region(buf ^ 1, (s + 1) * 32);
+      if (!(ABL & 4) && s + 1 < nsl) { store_region(buf ^ 1, (s + 1) * 32); if (s + 2 < nsl) load_region((s + 2) * 32); }
       if ((ABL & 32) && s < 4) { if (s == 0) mark(4); else if (s == 1) mark(7); else if (s == 2) mark(10); else mark(13); }
       if (!(ABL & 8)) __syncthreads();
       if ((ABL & 32) && s < 4) { if (s == 0) mark(5); else if (s == 1) mark(8); else if (s == 2) mark(11); else mark(14); }
     }
     if (ABL & 16) { if (acc[0][0][0] + acc[1][1][1] + acc[0][2][2] + acc[1][3][3] + acc[1][0][4] + acc[0][1][5] + acc[1][2][6] + acc[0][3][7] == 123.456f) p.y[0] = 1.f; return; }
-  } else {
-    // Software-pipelined: a wave's own VALU / LDS work (~150 instructions per 8-channel step: transform, U addressing,
-    // GroupNorm+swish of the staged region) used to sit BETWEEN its MFMA bursts, and the two waves of a SIMD run the same
-    // program in near lockstep, so the matrix pipe idled while both transformed (PMC: MFMA busy 0.55, VALU issue 13 % of wave
-    // time).  Here the transform of step k+1 is issued in four column pieces between the four 8-MFMA groups of step k
-    // (a 64-cycle f32 MFMA leaves ~15 issue slots), and the next slice's region is staged in two halves during steps 0-2
-    // (12 staging VGPRs instead of 24, which is what pays for the second A-operand buffer at the 256-VGPR budget).
-    auto col = [&](const float* rb, int sub, int b, float4& out) {     // t_b = d[ra][b] +- d[rb][b] for patch column b
-      const int ch = (2 * sub + hh) * 4;
-      const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + ch);
-      const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + ch);
-      out = make_float4(fmaf(sgn, db.x, da.x), fmaf(sgn, db.y, da.y), fmaf(sgn, db.z, da.z), fmaf(sgn, db.w, da.w));
-    };
-    auto finish = [&](float4 (&v)[4]) {                                // columns t0..t3 (in v) -> V[i][0..3] = t0-t2, t1+t2, t2-t1, t1-t3
-      const float4 t1 = v[1], t2 = v[2];
-      v[0] = f4sub(v[0], t2); v[3] = f4sub(t1, v[3]); v[1] = f4add(t1, t2); v[2] = f4sub(t2, t1);
-    };
-    auto group = [&](const float4 (&v)[4], int unit0, int j) {         // the 8 MFMAs of frequency j (+ the U prefetch two units ahead)
-      ur[0][(j + 2) & 3] = uload(U0, unit0 + j + 2);
-      ur[1][(j + 2) & 3] = uload(U1, unit0 + j + 2);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].x, v[j].x, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].x, v[j].x, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].y, v[j].y, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].y, v[j].y, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].z, v[j].z, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].z, v[j].z, acc[1][j], 0, 0, 0);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[0][j].w, v[j].w, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[1][j].w, v[j].w, acc[1][j], 0, 0, 0);
-    };
-    // one step: MFMAs of `cur` interleaved with the column pieces of the NEXT step's transform (from region buffer nrb)
-    auto step = [&](const float4 (&cur)[4], float4 (&nxt)[4], int unit0, const float* nrb, int nsub, bool have_next) {
-      __builtin_amdgcn_s_setprio(1);
-      if (have_next) col(nrb, nsub, 0, nxt[0]);
-      group(cur, unit0, 0);
-      if (have_next) col(nrb, nsub, 1, nxt[1]);
-      group(cur, unit0, 1);
-      if (have_next) col(nrb, nsub, 2, nxt[2]);
-      group(cur, unit0, 2);
-      if (have_next) col(nrb, nsub, 3, nxt[3]);
-      group(cur, unit0, 3);
-      if (have_next) finish(nxt);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    constexpr int HALF = NIT / 2;                                      // 3 items per staging half
-    float4 sth[HALF];
-    auto load_half = [&](int h, int c0) {
-#pragma unroll
-      for (int k = 0; k < HALF; ++k) {
-        int g, l; bool gok, lok; item_geo(h * HALF + k, g, l, gok, lok);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gok) v = *reinterpret_cast<const float4*>(X + g + c0);
-        sth[k] = v;
-      }
-    };
-    auto store_half = [&](int h, int buf, int c0) {
-      float* rb = smem + buf * RPIX * RLD;
-#pragma unroll
-      for (int k = 0; k < HALF; ++k) {
-        int g, l; bool gok, lok; item_geo(h * HALF + k, g, l, gok, lok);
-        if (!lok) continue;
-        float4 v = sth[k];
-        if (p.in_ss && gok) {
-          const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + ((tid + NTHR * (h * HALF + k)) & 7) * 4) * 2;
-          const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-          v = make_float4(fmaf(v.x, s0.x, s0.y), fmaf(v.y, s0.z, s0.w), fmaf(v.z, s1.x, s1.y), fmaf(v.w, s1.z, s1.w));
-          if (p.in_swish) {
-            constexpr float L2E = 1.44269504088896340736f;
-            v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
-            v.y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.y));
-            v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
-            v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
-          }
-        }
-        *reinterpret_cast<float4*>(rb + l) = v;
-      }
-    };
-    float4 va[4], vb[4];
-    { col(smem, 0, 0, va[0]); col(smem, 0, 1, va[1]); col(smem, 0, 2, va[2]); col(smem, 0, 3, va[3]); finish(va); }
-    for (int s = 0; s < nsl; ++s) {
-      const int buf = s & 1;
-      const bool more = s + 1 < nsl;
-      const float* rb = smem + buf * RPIX * RLD;
-      const float* nb = smem + (buf ^ 1) * RPIX * RLD;
-      const int u0 = s * 16;
-      if (more) load_half(0, (s + 1) * 32);
-      step(va, vb, u0, rb, 1, true);                                   // step 0 | transform of step 1
-      if (more) { store_half(0, buf ^ 1, (s + 1) * 32); load_half(1, (s + 1) * 32); }
-      step(vb, va, u0 + 4, rb, 2, true);                               // step 1 | transform of step 2
-      if (more) store_half(1, buf ^ 1, (s + 1) * 32);
-      step(va, vb, u0 + 8, rb, 3, true);                               // step 2 | transform of step 3
-      __syncthreads();                                                 // the next slice's region is complete (and nobody reads `buf` after step 3's columns, read above)
-      step(vb, va, u0 + 12, nb, 0, more);                              // step 3 | transform of the next slice's step 0
-    }
   }
 
   // ---- one-pass epilogue: zb2 [2 q][4 fi][32 tiles][64 n (pitch 68)] -------------------------------------------------------------
@@ -963,76 +761,37 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
   if (16LL * ((Cout + 31) / 32) * (Cin / 8) * 256 > 2147483647LL) return SMX_EINVAL;
   const int nw_t = smx_tune(SMX_TUNE_WINO_NW);
   const int nw = (nw_t == 1 || nw_t == 2) ? nw_t : ((Cout % 64 == 0 && blocks * (Cout / 64) >= 1024) ? 2 : 1);
-  const int swz = smx_tune(SMX_TUNE_WINO_SWZ);
-  const int epi1 = smx_tune(SMX_TUNE_WINO_EPI) > 0 ? 1 : 0;
-  const int ud = smx_tune(SMX_TUNE_WINO_UD) == 3 ? 3 : 2;
-  // 2 region buffers (pitch 18 px, 19 with the swizzle) -- 51,840 / 54,720 B -- or the one-pass epilogue's [2][4][32][32*NW] floats
-  size_t lds = (size_t)2 * RH * (swz ? 19 : 18) * RLD * sizeof(float);
-  if (epi1 && (size_t)2 * 4 * 32 * 32 * nw * sizeof(float) > lds) lds = (size_t)2 * 4 * 32 * 32 * nw * sizeof(float);
-  // measured (profiles/r01_e_winograd_variants.txt): 8-wave blocks (N=64) win once there are >= 1024 of
-  // them, 4-wave blocks (N=32, 3 per CU) otherwise; the conflict-free LDS swizzle is neutral (LDS is
-  // not the limiter) and stays off by default.
+  // 2 region buffers (pitch 18 px: 51,840 B) or the epilogue exchange [2 q][4 fi][32 tiles][pitch 32*NW + 4] floats
+  const size_t lds_region = (size_t)2 * RH * 18 * RLD * sizeof(float);
+  const size_t lds = nw == 2 ? (size_t)WIDE_LDS : lds_region;
+  // measured (profiles/r01_e_winograd_variants.txt, r02_j): 64-channel blocks win once there are >= 1024 of them -- the
+  // 4-wave "wide" form (one wave per frequency row, both N tiles) over the 8-wave form by 5-13 % -- and 4-wave N=32 blocks
+  // (3 per CU) otherwise.
   hipStream_t st = (hipStream_t)stream;
   const int wide = smx_tune(SMX_TUNE_WINO_WIDE);
   const int abl = smx_tune(SMX_TUNE_WINO_ABLATE);
-  if (abl && nw == 2 && wide <= 0) {
+  if (nw == 2 && wide > 0) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
+    const size_t wlds = wide == 5 ? 98304 : WIDE_LDS;          // wide == 5 (tools): the same kernel at one block per CU
+#define SMX_WABL(A) do { SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); \
+                         SMX_LAUNCH((winograd_wide_kernel<A>), grid, dim3(256), wlds, st, p); } while (0)
     switch (abl) {
-      case 2: SMX_LAUNCH((winograd_kernel<false, 2, 2>), grid, dim3(512), lds, st, p); break;
-      case 4: SMX_LAUNCH((winograd_kernel<false, 2, 4>), grid, dim3(512), lds, st, p); break;
-      case 6: SMX_LAUNCH((winograd_kernel<false, 2, 6>), grid, dim3(512), lds, st, p); break;
-      case 16: SMX_LAUNCH((winograd_kernel<false, 2, 16>), grid, dim3(512), lds, st, p); break;
-      default: SMX_LAUNCH((winograd_kernel<false, 2, 22>), grid, dim3(512), lds, st, p); break;
+      case 0: SMX_WABL(0); break;
+      case 1: SMX_WABL(1); break; case 2: SMX_WABL(2); break; case 4: SMX_WABL(4); break; case 8: SMX_WABL(8); break;
+      case 16: SMX_WABL(16); break; case 7: SMX_WABL(7); break; case 32: SMX_WABL(32); break; default: SMX_WABL(31); break;
     }
-    return smx_launch_status();
-  }
-  if (nw == 2 && wide > 0 && !swz) {
-    dim3 grid((unsigned)blocks, (Cout + 63) / 64);
-    static bool attrw = false;
-    if (!attrw) {
-      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
-      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
-      SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
-      attrw = true;
-    }
-    if (abl) {
-#define SMX_WABL(A) do { SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<false, 2, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); \
-                         SMX_LAUNCH((winograd_wide_kernel<false, 2, A>), grid, dim3(256), wide == 5 ? 98304 : WIDE_LDS, st, p); } while (0)
-      switch (abl) {
-        case 1: SMX_WABL(1); break; case 2: SMX_WABL(2); break; case 4: SMX_WABL(4); break; case 8: SMX_WABL(8); break;
-        case 16: SMX_WABL(16); break; case 7: SMX_WABL(7); break; case 32: SMX_WABL(32); break; default: SMX_WABL(31); break;
-      }
 #undef SMX_WABL
-    }
-    else if (wide == 4) {
-      SMX_HIP(hipFuncSetAttribute((const void*)(winograd_wide_kernel<false, 2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
-      SMX_LAUNCH((winograd_wide_kernel<false, 2, 0, true>), grid, dim3(256), WIDE_LDS, st, p);
-    }
-    else if (wide == 5) {   // timing experiment: same kernel, one block per CU (LDS request > half the CU's)
-      SMX_HIP(hipFuncSetAttribute((const void*)winograd_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-      SMX_LAUNCH(winograd_wide_kernel<false>, grid, dim3(256), 98304, st, p);
-    }
-    else if (wide == 3) SMX_LAUNCH((winograd_wide_kernel<false, 3>), grid, dim3(256), WIDE_LDS, st, p);
-    else if (wide == 2) SMX_LAUNCH(winograd_wide_kernel<true>, grid, dim3(256), WIDE_LDS, st, p);
-    else SMX_LAUNCH(winograd_wide_kernel<false>, grid, dim3(256), WIDE_LDS, st, p);
   } else if (nw == 2) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
-    if (epi1) {
-      static bool attr = false;
-      if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS)); attr = true; }
-      static bool attr3 = false;
-      if (!attr3) { SMX_HIP(hipFuncSetAttribute((const void*)winograd_kernel<false, 2, 0, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS)); attr3 = true; }
-      if (ud == 3) SMX_LAUNCH((winograd_kernel<false, 2, 0, true, 3>), grid, dim3(512), lds, st, p);
-      else SMX_LAUNCH((winograd_kernel<false, 2, 0, true>), grid, dim3(512), lds, st, p);
+#define SMX_W8(A) do { SMX_HIP(hipFuncSetAttribute((const void*)(winograd_kernel<2, A>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS)); \
+                       SMX_LAUNCH((winograd_kernel<2, A>), grid, dim3(512), lds, st, p); } while (0)
+    switch (abl) {
+      case 0: SMX_W8(0); break; case 2: SMX_W8(2); break; case 4: SMX_W8(4); break; case 16: SMX_W8(16); break; default: SMX_W8(22); break;
     }
-    else if (swz) SMX_LAUNCH((winograd_kernel<true, 2>), grid, dim3(512), lds, st, p);
-    else SMX_LAUNCH((winograd_kernel<false, 2>), grid, dim3(512), lds, st, p);
+#undef SMX_W8
   } else {
     dim3 grid((unsigned)blocks, (Cout + 31) / 32);
-    if (epi1 && ud == 3) SMX_LAUNCH((winograd_kernel<false, 1, 0, true, 3>), grid, dim3(256), lds, st, p);
-    else if (epi1) SMX_LAUNCH((winograd_kernel<false, 1, 0, true>), grid, dim3(256), lds, st, p);
-    else if (swz) SMX_LAUNCH((winograd_kernel<true, 1>), grid, dim3(256), lds, st, p);
-    else SMX_LAUNCH((winograd_kernel<false, 1>), grid, dim3(256), lds, st, p);
+    SMX_LAUNCH((winograd_kernel<1>), grid, dim3(256), lds, st, p);
   }
   return smx_launch_status();
 }

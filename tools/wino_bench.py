@@ -25,7 +25,7 @@ def timed(fn, n=5):
     return e0.elapsed_time(e1) / n
 
 
-print(f"B={B}  cin cout s : wide us (exec frac) | no transform | no U loads | no region staging | no barriers | no epilogue | 1+2+4 | all off   [GN loader + stats + residual, as in a ResBlock]")
+print(f"B={B}  cin cout s : wide blocks us (executed MFMA fraction of 157.3 TF) | other block shapes   [GN loader + stats + residual, as in a ResBlock]")
 for cin, cout, s in SHAPES:
     x = torch.randn((B, s, s, cin), device="cuda")
     cv = ops.Conv.from_torch(torch.randn((cout, cin, 3, 3), device="cuda") / (3 * cin ** 0.5), torch.randn(cout, device="cuda") * 0.1)
@@ -40,11 +40,13 @@ for cin, cout, s in SHAPES:
         t = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True, res=res, want_stats=True))
         row.append(f"{1e3 * t:7.1f} ({fl * 4 / 9 / t / 1e9 / 157.3:.3f})")
     ops.set_tuning("wino_ablate", 0)
-    for name, val in (("wino_nt", 1), ("wino_wide", 3)):
-        ops.set_tuning(name, val)
-        t = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True, res=res, want_stats=True))
-        row.append(f"{name}={val}: {1e3 * t:7.1f} ({fl * 4 / 9 / t / 1e9 / 157.3:.3f})")
-        ops.set_tuning("wino_nt", 0)
-        ops.set_tuning("wino_wide", 1)
+    ops.set_tuning("wino_nw", 1)
+    t = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True, res=res, want_stats=True))
+    row.append(f"N=32 blocks: {1e3 * t:7.1f} ({fl * 4 / 9 / t / 1e9 / 157.3:.3f})")
+    ops.set_tuning("wino_nw", 2)
+    ops.set_tuning("wino_wide", 0)
+    t = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True, res=res, want_stats=True))
+    row.append(f"8-wave N=64 blocks: {1e3 * t:7.1f} ({fl * 4 / 9 / t / 1e9 / 157.3:.3f})")
+    ops.set_tuning("wino_nw", -1)
     ops.set_tuning("wino_wide", 1)
     print(f"{cin:4d} {cout:4d} {s:4d} : " + "   ".join(row))
