@@ -361,10 +361,20 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
 // N tiles of the block's 64 output channels -- 8 accumulators (128 VGPRs) at a 256-VGPR budget, 2 waves per SIMD (2 blocks / CU).
 // Against the 8-wave block: the input transform (LDS reads + 48 VALU) and the region staging are done once per 32 MFMAs instead
 // of once per 16, the two accumulator chains of a frequency alternate on the matrix pipe (no back-to-back dependent MFMAs), a
-// barrier joins 4 waves instead of 8, and nothing spills.  Measured dead ends on top of it (kept out / selectable): a workgroup
-// walking several tile blocks with the next tile's region held in registers across the epilogue (99 VGPRs spilled at the
-// 256 budget), the software-pipelined transform (PIPE: hipcc clusters the pieces instead of interleaving them, -4 %), U prefetch
-// distance 3 (neutral).
+// barrier joins 4 waves instead of 8, and nothing spills.
+//
+// Where its time goes (profiles/r02_j_winograd_phases.txt; B=60, 128->128 @ 256x256, executed MFMA fraction 0.60 of 157.3 TF):
+// a bare MFMA loop of the same shape runs at 0.89 (the sustained clock under matrix load); two waves share each SIMD's
+// matrix pipe and a wave spends ~38 % of its life outside the MFMA loop -- prologue 13 % (entry, first region's HBM round
+// trip, GN+swish, LDS store), staging 7 %, epilogue 15 %, barriers 3 % -- during which its partner has the pipe to itself
+// but, alone, keeps it only ~60 % busy (U fragments from L2 and the transform are exposed without a second wave).  Removing
+// single phases (timing-only builds) moves the fraction by: transform +0.035, U loads +0.044, staging +0.064, epilogue
+// +0.063, barriers +0.01; all of them 0.89.  One block per CU: 0.43.
+// What was tried on top and measured no better (removed; numbers in DESIGN.md section 4): software-pipelined transform
+// (-4 %), U prefetch distance 3 on a 4-slot ring (neutral), slice barrier replaced by LDS produce/consume counters (-4 %),
+// s_setprio levels (no effect either way), non-temporal residual/output accesses (neutral), a workgroup walking several
+// tile blocks with the next block's first slice staged before a two-pass epilogue (prologue hidden, -6 %: the partner
+// wave was already using that time), a previous block warming L2 for the next one (-1 %).
 template <int ABL = 0>   // ABL (timing-only, tools): 1 no transform, 2 no U loads, 4 no region staging after the first slice, 8 no barriers, 16 no epilogue
 __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   constexpr int RP = 18, RPIX = RH * RP, NTHR = 256, NI = 2, NB = 64, ZS = 68;
@@ -541,6 +551,29 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   float* zb = smem;
   float* __restrict__ Yp = p.y;
   const float* __restrict__ Rp = p.res;
+  // the residual tiles of both items (and the bias) are requested BEFORE the accumulators go through LDS: their HBM round trip
+  // (3-4k cycles under load) overlaps the two barriers and the exchange instead of following them
+  const int n4q = (tid & 15) * 4, nq = nblk * NB + n4q;
+  const bool NT = smx_nt_flag(p);
+  const bool vec_all = (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) && (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0)) &&
+                       (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (p.Cout % NB == 0);
+  float4 rr[2][2][2];
+  long long pix[2];
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec_all) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int tile = (tid >> 4) + 16 * it;
+      pix[it] = ((long long)img * p.H + by * 8 + 2 * (tile >> 3)) * p.W + bx * 16 + 2 * (tile & 7);
+      if (Rp) {
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) rr[it][yy][q] = NT ? ld_stream(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq) : *reinterpret_cast<const float4*>(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq);
+      }
+    }
+    if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + nq);
+  }
   __syncthreads();
   mark(18);
   // lane (t, hh) holds tile t, channels i*32 + 8g + 4hh + (0..3) in registers 4g..4g+3; rows are ZS = 68 floats apart so the
@@ -565,25 +598,7 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   // share it.  Fast path (16 B-aligned rows, the only one the engines produce): both items' residual tiles are requested
   // before anything waits (a load queued behind the first item's stores waits for their write acknowledgements -- one vmcnt
   // on gfx9), the bias is one float4, and the activation is resolved once per block, not per value.
-  const int n4q = (tid & 15) * 4, nq = nblk * NB + n4q;
-  const bool NT = smx_nt_flag(p);
-  const bool vec_all = (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) && (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0)) &&
-                       (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (p.Cout % NB == 0);
   if (vec_all) {
-    float4 rr[2][2][2];
-    long long pix[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int tile = (tid >> 4) + 16 * it;
-      pix[it] = ((long long)img * p.H + by * 8 + 2 * (tile >> 3)) * p.W + bx * 16 + 2 * (tile & 7);
-      if (Rp) {
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) rr[it][yy][q] = NT ? ld_stream(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq) : *reinterpret_cast<const float4*>(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq);
-      }
-    }
-    const float4 bq = p.bias ? *reinterpret_cast<const float4*>(p.bias + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float bn[4] = {bq.x, bq.y, bq.z, bq.w};
     auto items = [&](auto mode) __attribute__((always_inline)) {
       constexpr int MODE = decltype(mode)::value;                      // 0 identity, 1 relu / leaky relu (slope form), 2 generic
