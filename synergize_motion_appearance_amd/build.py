@@ -11,7 +11,9 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libsmx.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment",
+# -amdgpu-mfma-vgpr-form: MFMA results go to architectural VGPRs (gfx90a+ unified file) instead of AccVGPRs, so the VALU code
+# that consumes accumulators (softmax on S, O rescale, Winograd / GEMM epilogues) needs no v_accvgpr_read/write copies
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-mllvm", "-amdgpu-mfma-vgpr-form",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 
 

@@ -14,8 +14,8 @@
 //   sit in lane l^32), so the row max / sum are 15 in-register ops + ONE wavefront shuffle, the
 //   O rescale is a lane-local scalar, and P feeds the second MFMA with no transpose or LDS trip
 //   (the k-pairing of the MFMA is free: A and B fragments just have to agree).
-// d_head = 4 (motion, E=32): matrix cores would be 8x padded -> VALU kernel, one query per
-//   lane, keys/values broadcast from LDS, 8 keys per online-softmax step.
+// d_head = 4 (motion, E=32): the 32x32 MFMAs would be 8x padded; the 16-block 4x4x1 MFMA fits exactly
+//   (attn_mfma4_kernel below); the VALU kernel (one query per lane, keys/values broadcast from LDS) stays selectable.
 // Fully masked rows give NaN exactly like the reference (0/0).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -340,6 +340,102 @@ __global__ __launch_bounds__(256) void attn_valu4_kernel(AP<T> p) {
   }
 }
 
+
+// d_head = 4 on the matrix pipe: v_mfma_f32_4x4x1_16B_f32 computes 16 independent 4x4 (K = 1) outer products per
+// instruction -- block = lane / 4.  With the products swapped the way the d_head = 32 kernel does it,
+//     S^T block [4 keys][4 queries]  = sum_d K[key][d] * Q[query][d]    (A = K column d, B = this lane's q.d)
+//     O^T block [4 d][4 queries]    += V^T[d][key] * P^T[key][query]    (A = V row of the key, B = this lane's p)
+// lane l owns query l in BOTH results (block b covers queries 4b..4b+3 = its own 4 lanes; every block is fed the same
+// 4 keys), so scores, softmax statistics and the output accumulators are lane-local: no shuffles.  The 8 FMAs per
+// (query, key) leave the VALU, which is left with the softmax itself (max, sub, v_exp_f32, sum, rescale) -- the
+// VALU kernel spent ~70 issue cycles per key and wave, this one ~36 with the matrix pipe (16) running beside it.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <typename T, bool MASK>
+__global__ __launch_bounds__(256) void attn_mfma4_kernel(AP<T> p) {
+  extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+  float4* Ks = smem4;                                            // [S] key-major: K[key][0..3]
+  float* Vt = reinterpret_cast<float*>(smem4 + p.S);             // [4][S] d-major
+  float* Mf = reinterpret_cast<float*>(smem4 + 2 * p.S);         // [S] (MASK) 0 / -inf per key: the score accumulators START from it
+  float* part = Mf + (MASK ? p.S : 0);                           // [4][64][6]
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l4 = lane & 3;
+  const int qrow = blockIdx.x * 64 + lane;
+  float4 q = St<T>::ld4(p.q + b * p.q_bs + (long long)qrow * p.ldq + h * 4);
+  { const float sc = p.scale * 1.44269504088896340736f; q = make_float4(q.x * sc, q.y * sc, q.z * sc, q.w * sc); }
+  const T* K = p.k + b * p.k_bs + h * 4;
+  const T* V = p.v + b * p.v_bs + h * 4;
+  const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
+  for (int i = threadIdx.x; i < p.S; i += 256) {
+    Ks[i] = St<T>::ld4(K + (long long)i * p.ldk);
+    const float4 v = St<T>::ld4(V + (long long)i * p.ldv);
+    Vt[i] = v.x; Vt[p.S + i] = v.y; Vt[2 * p.S + i] = v.z; Vt[3 * p.S + i] = v.w;
+    if (MASK) Mf[i] = M[i] ? -INFINITY : 0.f;
+  }
+  __syncthreads();
+  float m = -INFINITY, l = 0.f;
+  f32x4m acc[4];                                                 // 4 independent chains (key e of every 4-key block)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  const int per = p.S >> 2, g0 = wave * per;
+  const float* vrow = Vt + l4 * p.S;
+  for (int g = g0; g < g0 + per; g += 16) {
+    f32x4m s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 kf = Ks[g + 4 * c + l4];                      // A: K[key g+4c+(lane&3)][0..3]
+      f32x4m c0 = f32x4m{0.f, 0.f, 0.f, 0.f};
+      if (MASK) { const float4 mf = *reinterpret_cast<const float4*>(Mf + g + 4 * c); c0 = f32x4m{mf.x, mf.y, mf.z, mf.w}; }
+      s[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(kf.x, q.x, c0, 0, 0, 0);
+      s[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(kf.y, q.y, s[c], 0, 0, 0);
+      s[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(kf.z, q.z, s[c], 0, 0, 0);
+      s[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(kf.w, q.w, s[c], 0, 0, 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tmax = fmaxf(tmax, s[c][i]);
+    }
+    const float m_new = fmaxf(m, tmax);
+    if (MASK && m_new == -INFINITY) continue;                    // every key so far masked (per lane: keep the state)
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[c][i] = __builtin_amdgcn_exp2f(s[c][i] - m_new); ps += s[c][i]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] *= alpha;
+    l = l * alpha + ps; m = m_new;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 vf = *reinterpret_cast<const float4*>(vrow + g + 4 * c);       // A: V[key g+4c+e][d = lane&3], e = 0..3
+      acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(vf.x, s[c][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(vf.y, s[c][1], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(vf.z, s[c][2], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(vf.w, s[c][3], acc[3], 0, 0, 0);
+    }
+  }
+  const f32x4m a4 = acc[0] + acc[1] + acc[2] + acc[3];
+  float* pp = part + (wave * 64 + lane) * 6;
+  pp[0] = m; pp[1] = l; pp[2] = a4[0]; pp[3] = a4[1]; pp[4] = a4[2]; pp[5] = a4[3];
+  __syncthreads();
+  if (wave == 0) {
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, part[(w * 64 + lane) * 6]);
+    float ll = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* q6 = part + (w * 64 + lane) * 6;
+      const float f = (q6[0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(q6[0] - mm);
+      ll += q6[1] * f; a.x += q6[2] * f; a.y += q6[3] * f; a.z += q6[4] * f; a.w += q6[5] * f;
+    }
+    // ll == 0 (every key masked) -> 0/0 = NaN like the reference
+    St<T>::st4(p.o + b * p.o_bs + (long long)qrow * p.ldo + h * 4, make_float4(a.x / ll, a.y / ll, a.z / ll, a.w / ll));
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -354,7 +450,11 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
   if (dh == 4) {
     if (L % 64 || S % 32 || S > 2048) return SMX_EINVAL;
     const size_t lds = (size_t)S * 33 + 4 * 64 * 6 * sizeof(float);
-    SMX_LAUNCH(attn_valu4_kernel<T>, dim3(L / 64, B * H), dim3(256), lds, st, p);
+    if (smx_tune(SMX_TUNE_ATTN4_MFMA) && S % 64 == 0) {
+      if (key_mask) SMX_LAUNCH((attn_mfma4_kernel<T, true>), dim3(L / 64, B * H), dim3(256), (size_t)S * 36 + 4 * 64 * 6 * sizeof(float), st, p);
+      else SMX_LAUNCH((attn_mfma4_kernel<T, false>), dim3(L / 64, B * H), dim3(256), (size_t)S * 32 + 4 * 64 * 6 * sizeof(float), st, p);
+    }
+    else SMX_LAUNCH(attn_valu4_kernel<T>, dim3(L / 64, B * H), dim3(256), lds, st, p);
   } else if (dh == 32 || dh == 64) {
     if (L % 128 || S % 32) return SMX_EINVAL;
     if (dh == 32 && sizeof(T) == 2 && S % 64 == 0 && smx_tune(SMX_TUNE_ATTN16)) {

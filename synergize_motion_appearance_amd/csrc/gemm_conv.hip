@@ -13,6 +13,7 @@
 //
 // Tile configs (256 threads = 4 waves): 128x128, 128x64, 128x32, 64x128, 64x64.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 #include "smx.h"
@@ -272,47 +273,69 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
   const int mrow0 = tile_m * BM + wm * WTM + 4 * (lane >> 5);
   if (!p.d2s_p) {
     // plain store.  Two phases so that every residual / row-bias load of the tile is in flight
-    // before the first use (one s_waitcnt per tile column instead of one per element).
+    // before the first use (one s_waitcnt per tile column instead of one per element).  The activation and the
+    // tile-inside-the-matrix test are resolved once per block (MODE: 0 identity, 1 relu / leaky relu in slope form,
+    // 2 generic; FULL: no per-element bounds tests) -- a per-value `switch (p.act)` compiles to scalar branches around
+    // every one of the 16*TM*TN values.
+    auto store_tile = [&](auto mode, auto fulltag) __attribute__((always_inline)) {
+      constexpr int MODE = decltype(mode)::value;
+      constexpr bool FULL = decltype(fulltag)::value;
+      const float slope = p.act == SMX_ACT_RELU ? 0.f : 0.2f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = tile_n * BN + wn * WTN + j * 32 + (lane & 31);
-      const bool nok = n < p.N;
-      const float bn = (nok && p.bias && !p.bias_per_row) ? p.bias[n] : 0.f;
-      float rv[TM][16];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-          float t = 0.f;
-          if (nok && m < p.M) {
-            if (R) t = R[(long long)m * p.ldres + n];
-          }
-          rv[i][r] = t;
-        }
-      float rb[TM][16];
-      if (p.bias && p.bias_per_row) {
+      for (int j = 0; j < TN; ++j) {
+        const int n = tile_n * BN + wn * WTN + j * 32 + (lane & 31);
+        const bool nok = FULL || n < p.N;
+        const float bn = (nok && p.bias && !p.bias_per_row) ? p.bias[n] : 0.f;
+        float rv[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-            rb[i][r] = m < p.M ? p.bias[m] : 0.f;
+            float t = 0.f;
+            if (R && nok && (FULL || m < p.M)) t = R[(long long)m * p.ldres + n];
+            rv[i][r] = t;
           }
-      } else {
+        float rb[TM][16];
+        if (p.bias && p.bias_per_row) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+              rb[i][r] = (FULL || m < p.M) ? p.bias[m] : 0.f;
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rb[i][r] = bn;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rb[i][r] = bn;
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+            float v = p.alpha * acc[i][j][r] + rb[i][r];
+            if (MODE == 1) v = fmaxf(v, 0.f) + slope * fminf(v, 0.f);
+            if (MODE == 2) v = apply_act(v, p.act);
+            if (MODE == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+            v += rv[i][r];
+            if (nok && (FULL || m < p.M)) C[(long long)m * p.ldc + n] = v;
+          }
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-          const float v = apply_act(p.alpha * acc[i][j][r] + rb[i][r], p.act) + rv[i][r];
-          if (nok && m < p.M) C[(long long)m * p.ldc + n] = v;
-        }
+    };
+    const bool full = (tile_m * BM + BM <= p.M) && (tile_n * BN + BN <= p.N);
+    const int amode = p.act == SMX_ACT_NONE ? 0 : ((p.act == SMX_ACT_RELU || p.act == SMX_ACT_LRELU02) ? 1 : (p.act == SMX_ACT_GELU ? 3 : 2));
+    if (full) {
+      if (amode == 0) store_tile(std::integral_constant<int, 0>{}, std::true_type{});
+      else if (amode == 1) store_tile(std::integral_constant<int, 1>{}, std::true_type{});
+      else if (amode == 3) store_tile(std::integral_constant<int, 3>{}, std::true_type{});
+      else store_tile(std::integral_constant<int, 2>{}, std::true_type{});
+    } else {
+      if (amode == 0) store_tile(std::integral_constant<int, 0>{}, std::false_type{});
+      else if (amode == 1) store_tile(std::integral_constant<int, 1>{}, std::false_type{});
+      else store_tile(std::integral_constant<int, 2>{}, std::false_type{});
     }
     return;
   }
