@@ -127,6 +127,15 @@ int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, con
                              const float* res, int ldres, float* y, int ldc, int B, int H, int W,
                              int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
                              float* stats_part, void* stream);
+/* The same convolution with the SFT modulation of Fuse_sft_block (archs/appmotioncodebook_arch.py:49-51,
+ * `out = dec_feat + w * (dec_feat * scale + shift)`) as its epilogue: x is the shift branch's hidden
+ * activation, the convolution IS `shift`, and y = dec + w * (dec * scale + conv(x)) -- the separate
+ * smx_sft_combine_f32 pass (4 tensor streams) disappears.  dec / scale NHWC with row strides lddec /
+ * ldscale; 16 B-aligned rows, Cout % 4 == 0. */
+int smx_winograd_conv3x3_sft_f32(const float* x, int lda, const float* u_packed, const float* bias,
+                                 const float* dec, int lddec, const float* scale, int ldscale, float w,
+                                 float* y, int ldc, int B, int H, int W, int Cin, int Cout,
+                                 float* stats_part, void* stream);
 /* in_ss != NULL: the GroupNorm(+swish, if in_swish) that precedes the conv in ResBlock
  * (archs/vqgan_arch.py:183-188) is applied by the region loader: x*in_ss[b][c][0] + in_ss[b][c][1],
  * with in_ss from smx_groupnorm_stats_f32 -- the separate normalise read+write pass disappears.

@@ -50,6 +50,7 @@ struct WP {
   int tiles_y, tiles_x;          // blocks per image along y / x
   int n32;                       // ceil(Cout/32) (U is packed for n32*32 rows)
   int nt;                        // wide kernel: non-temporal residual loads / output stores
+  const float* mul; int ldmul; float sft_w;   // SFT epilogue (Fuse_sft_block, appmotioncodebook_arch.py:49-51): y = res + sft_w * (res * mul + conv)
 };
 
 __device__ __forceinline__ bool smx_nt_flag(const struct WP& p);
@@ -259,12 +260,16 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
                    (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0));
   const int oy = by * 8 + 2 * (tile >> 3), ox0 = bx * 16 + 2 * (tile & 7);
   const long long pix0 = ((long long)img * p.H + oy) * p.W + ox0;
-  float4 rr[2][2];
+  float4 rr[2][2], mm[2][2];
+  const float* __restrict__ Mp = p.mul;                              // SFT epilogue (host guarantees res, 16 B-aligned rows, full channel quads)
   if (Rp && vec) {                                                   // requested before the barrier: the residual's latency hides under it
 #pragma unroll
     for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) rr[yy][q] = *reinterpret_cast<const float4*>(Rp + (pix0 + yy * p.W + q) * p.ldres + n);
+      for (int q = 0; q < 2; ++q) {
+        rr[yy][q] = *reinterpret_cast<const float4*>(Rp + (pix0 + yy * p.W + q) * p.ldres + n);
+        if (Mp) mm[yy][q] = *reinterpret_cast<const float4*>(Mp + (pix0 + yy * p.W + q) * p.ldmul + n);
+      }
   }
   float bn[4] = {0.f, 0.f, 0.f, 0.f};
   if (p.bias && n < p.Cout) {
@@ -305,7 +310,12 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
       for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          if (Rp) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
+          if (Mp) {
+            const float4 r4 = rr[yy][q], m4 = mm[yy][q];
+            o[yy][q] = make_float4(r4.x + p.sft_w * (r4.x * m4.x + o[yy][q].x), r4.y + p.sft_w * (r4.y * m4.y + o[yy][q].y),
+                                   r4.z + p.sft_w * (r4.z * m4.z + o[yy][q].z), r4.w + p.sft_w * (r4.w * m4.w + o[yy][q].w));
+          }
+          else if (Rp) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
           *reinterpret_cast<float4*>(Yp + (pix0 + yy * p.W + q) * p.ldc + n) = o[yy][q];
         }
     } else {
@@ -557,9 +567,10 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   const bool NT = smx_nt_flag(p);
   const bool vec_all = (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) && (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0)) &&
                        (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (p.Cout % NB == 0);
-  float4 rr[2][2][2];
+  float4 rr[2][2][2], mm[2][2][2];
   long long pix[2];
   float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* __restrict__ Mp = p.mul;                              // SFT epilogue (host guarantees res + the fast-path layout)
   if (vec_all) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -569,7 +580,10 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
 #pragma unroll
         for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
-          for (int q = 0; q < 2; ++q) rr[it][yy][q] = NT ? ld_stream(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq) : *reinterpret_cast<const float4*>(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq);
+          for (int q = 0; q < 2; ++q) {
+            rr[it][yy][q] = NT ? ld_stream(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq) : *reinterpret_cast<const float4*>(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq);
+            if (Mp) mm[it][yy][q] = *reinterpret_cast<const float4*>(Mp + (pix[it] + yy * p.W + q) * p.ldmul + nq);
+          }
       }
     }
     if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + nq);
@@ -628,7 +642,12 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
         for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            if (Rp) { o[yy][q].x += rr[it][yy][q].x; o[yy][q].y += rr[it][yy][q].y; o[yy][q].z += rr[it][yy][q].z; o[yy][q].w += rr[it][yy][q].w; }
+            if (Mp) {
+              const float4 r4 = rr[it][yy][q], m4 = mm[it][yy][q];
+              o[yy][q] = make_float4(r4.x + p.sft_w * (r4.x * m4.x + o[yy][q].x), r4.y + p.sft_w * (r4.y * m4.y + o[yy][q].y),
+                                     r4.z + p.sft_w * (r4.z * m4.z + o[yy][q].z), r4.w + p.sft_w * (r4.w * m4.w + o[yy][q].w));
+            }
+            else if (Rp) { o[yy][q].x += rr[it][yy][q].x; o[yy][q].y += rr[it][yy][q].y; o[yy][q].z += rr[it][yy][q].z; o[yy][q].w += rr[it][yy][q].w; }
             if (NT) st_stream(Yp + (pix[it] + yy * p.W + q) * p.ldc + nq, o[yy][q]);
             else *reinterpret_cast<float4*>(Yp + (pix[it] + yy * p.W + q) * p.ldc + nq) = o[yy][q];
           }
@@ -758,17 +777,21 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
 
 }  // namespace
 
-extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
-                                        const float* res, int ldres, float* y, int ldc, int B, int H, int W,
-                                        int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
-                                        float* stats_part, void* stream) {
+static int winograd_launch(const float* x, int lda, const float* u_packed, const float* bias,
+                           const float* res, int ldres, const float* mul, int ldmul, float sft_w, float* y, int ldc, int B, int H, int W,
+                           int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
+                           float* stats_part, void* stream) {
   if (!x || !u_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0) return SMX_EINVAL;
+  if (mul) {   // SFT epilogue: only the vector store path implements it
+    if (!res || Cout % 4 || ldc % 4 || ldres % 4 || ldmul % 4 || ldmul < Cout || act != SMX_ACT_NONE) return SMX_EINVAL;
+    if ((((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)mul)) & 15 || (bias && (((uintptr_t)bias) & 15))) return SMX_EINVAL;
+  }
   if (in_ss && (((uintptr_t)in_ss) & 15)) return SMX_EINVAL;
   if (H % 8 != 0 || W % 16 != 0 || Cin % 32 != 0 || lda % 4 != 0 || lda < Cin || ldc < Cout) return SMX_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)u_packed & 15) || (res && ldres < Cout)) return SMX_EINVAL;
   WP p;
   p.x = x; p.u = u_packed; p.bias = bias; p.res = res; p.y = y; p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0;
-  p.in_ss = in_ss; p.in_swish = in_swish; p.stats = stats_part;
+  p.in_ss = in_ss; p.in_swish = in_swish; p.stats = stats_part; p.mul = mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
   p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32; p.nt = smx_tune(SMX_TUNE_WINO_NT);
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
@@ -809,4 +832,18 @@ extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_
     SMX_LAUNCH((winograd_kernel<1>), grid, dim3(256), lds, st, p);
   }
   return smx_launch_status();
+}
+
+extern "C" int smx_winograd_conv3x3_f32(const float* x, int lda, const float* u_packed, const float* bias,
+                                        const float* res, int ldres, float* y, int ldc, int B, int H, int W,
+                                        int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
+                                        float* stats_part, void* stream) {
+  return winograd_launch(x, lda, u_packed, bias, res, ldres, nullptr, 0, 0.f, y, ldc, B, H, W, Cin, Cout, up2, act, in_ss, in_swish, stats_part, stream);
+}
+
+extern "C" int smx_winograd_conv3x3_sft_f32(const float* x, int lda, const float* u_packed, const float* bias,
+                                            const float* dec, int lddec, const float* scale, int ldscale, float w,
+                                            float* y, int ldc, int B, int H, int W, int Cin, int Cout, float* stats_part, void* stream) {
+  if (!dec || !scale) return SMX_EINVAL;
+  return winograd_launch(x, lda, u_packed, bias, dec, lddec, scale, ldscale, w, y, ldc, B, H, W, Cin, Cout, 0, SMX_ACT_NONE, nullptr, 0, stats_part, stream);
 }

@@ -402,8 +402,7 @@ class NetGEngine:
         e = f["res"](cat)
         ss = ops.conv(e, f["ss0"], act=ACT_LRELU02)                           # [.., 2C] = [scale.0 | shift.0]
         scale = ops.conv(ss[..., :C], f["scale2"])
-        shift = ops.conv(ss[..., C:], f["shift2"])
-        x = ops.sft_combine(dec, scale, shift, w)
+        x = ops.conv_sft(ss[..., C:], f["shift2"], dec, scale, w)             # dec + w * (dec * scale + shift): shift2's epilogue
         return ops.conv(enc, f["ms"], res=x, want_stats=True)                 # x + fuse_ms(enc)
 
     def forward(self, cache, deformation, occ64, heat_nhwc, w=1.0, train=False):

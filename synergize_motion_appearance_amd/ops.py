@@ -578,6 +578,31 @@ def sft_combine(dec, scale, shift, w=1.0):
     return out
 
 
+def conv_sft(x, cv, dec, scale, w=1.0):
+    """Fuse_sft_block's modulation with the shift branch's last conv folded in (archs/appmotioncodebook_arch.py:49-51):
+    dec + w * (dec * scale + conv3x3(x)).  fp32 + Winograd-eligible shapes run it as the conv's epilogue
+    (smx_winograd_conv3x3_sft_f32); anything else is the conv followed by sft_combine."""
+    B, H, W, Cin = x.shape
+    fused = (WINOGRAD and x.dtype == torch.float32 and dec.dtype == torch.float32 and scale.dtype == torch.float32
+             and cv.kh == 3 and cv.kw == 3 and Cin == cv.cin and Cin % 32 == 0 and H % 8 == 0 and W % 16 == 0 and cv.cout % 4 == 0
+             and tuple(dec.shape) == (B, H, W, cv.cout) and tuple(scale.shape) == (B, H, W, cv.cout))
+    if fused:
+        a_ptr, lda = _pix(x, "conv_sft input")
+        d_ptr, ldd = _pix(dec, "conv_sft dec")
+        s_ptr, lds_ = _pix(scale, "conv_sft scale")
+        fused = (lda % 4 == 0 and ldd % 4 == 0 and lds_ % 4 == 0 and (a_ptr | d_ptr | s_ptr) % 16 == 0
+                 and (cv.b is None or cv.b.data_ptr() % 16 == 0))
+    if not fused:
+        return sft_combine(dec, scale, conv(x, cv), w)
+    out = torch.empty((B, H, W, cv.cout), device=x.device, dtype=torch.float32)
+    meta = {"flops": 2.0 * B * H * W * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * H * W * cv.cout * 4 * Cin,
+            "M": B * H * W, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1} if _PROFILE is not None else None
+    L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_sft_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
+                   None if cv.b is None else cv.b.data_ptr(), d_ptr, ldd, s_ptr, lds_, float(w), out.data_ptr(), cv.cout,
+                   B, H, W, Cin, cv.cout, None, _stream()), "smx_winograd_conv3x3_sft_f32")
+    return out
+
+
 def fingerprint(x):
     """(sum, weighted sum) of a small device tensor as a host tuple -- a content key for the source caches
     (one tiny launch + an 8-byte D2H copy)."""

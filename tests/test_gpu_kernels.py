@@ -670,3 +670,26 @@ def test_vq_ties_and_ragged(ops):
     bad = got != ref
     if bad.any():   # tie-aware: a differing index must be distance-equivalent within fp32 noise
         assert float((d[bad, got[bad]] - d[bad, ref[bad]]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("B,C,H,W,nw", [(2, 64, 32, 32, 1), (2, 64, 32, 32, 2), (3, 128, 16, 32, 2), (1, 96, 8, 16, 1)])
+def test_conv_sft_epilogue_equals_conv_then_sft_combine(ops, B, C, H, W, nw, tuning):
+    """Fuse_sft_block's `dec + w * (dec * scale + shift)` as the epilogue of the shift branch's 3x3 conv
+    (smx_winograd_conv3x3_sft_f32), on both Winograd block shapes and with the operands being channel slices of
+    wider buffers (ss = [scale.0 | shift.0], cat = [enc | dec]) as in the engine -- against F.conv2d + the formula."""
+    tuning("wino_nw", nw)
+    tuning("wino_wide", 1)
+    ss = rnd(f"cs{C}{H}", (B, H, W, 2 * C))
+    cat = rnd(f"cc{C}{H}", (B, H, W, 2 * C))
+    scale = rnd(f"cq{C}{H}", (B, H, W, C))
+    w = rnd(f"cw{C}", (C, C, 3, 3), 1.0 / math.sqrt(9 * C))
+    b = rnd(f"cb{C}", (C,), 0.1)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    ssd, catd = ss.cuda(), cat.cuda()
+    y = ops.conv_sft(ssd[..., C:], cv, catd[..., C:], scale.cuda(), 0.7)
+    shift = F.conv2d(ss[..., C:].permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    dec = cat[..., C:]
+    assert maxabs(y.cpu(), dec + 0.7 * (dec * scale + shift)) < 2e-5
+    # and it is the same value the unfused pair produces (identical conv, one rounding of the modulation)
+    ref = ops.sft_combine(catd[..., C:], scale.cuda(), ops.conv(ssd[..., C:], cv), 0.7)
+    assert maxabs(y, ref) < 2e-6
