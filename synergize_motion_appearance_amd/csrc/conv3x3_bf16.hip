@@ -15,6 +15,7 @@
 // LDS: region 18*18 px * 144 B = 46.7 KB + 2 x 9.2 KB weights (the epilogue's 256 x 68 fp32 tile reuses it: 69.6 KB) -> 2 blocks / CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "smx.h"
 #include "smx_common.h"
 #include "bf16.h"
@@ -79,51 +80,65 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   // ---- region staging: RPX * 8 chunks of 16 B per slice, 256 threads -> 11 chunks per thread (the last partially) -----
   constexpr int NCH = (RPX * 8 + NT - 1) / NT;
   uint4 rreg[NCH];
+  // load_region only ISSUES the global loads -- the region chunks and, once per slice, the GroupNorm {scale, shift} pairs of
+  // this thread's 8 channels (item & 7 == tid & 7 for all its chunks); store_region, three taps later, applies the fused
+  // GroupNorm(+swish) branch-free and writes LDS.  (Normalising right after the load made every wave sit out the region's
+  // HBM round trip in the middle of the tap loop.)
+  float4 ssv[4];
+  const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
+  auto chunk_ok = [&](int k, long long& g) __attribute__((always_inline)) -> bool {
+    const int item = tid + NT * k;
+    const int px = item >> 3, c8 = item & 7;
+    const int ry = px / RW, rx = px - ry * RW;
+    int iy = by * TH - 1 + ry, ix = bx * TW - 1 + rx;
+    const bool ok = item < RPX * 8 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    if (p.up2) { iy >>= 1; ix >>= 1; }
+    g = ((long long)iy * Ws_ + ix) * p.lda + c8 * 8;
+    return ok;
+  };
   auto load_region = [&](int c0) __attribute__((always_inline)) {
-    // a thread's chunks all cover the same 8 channels (item & 7 == tid & 7): their GroupNorm {scale, shift} pairs are loaded once per slice
-    float4 ssv[4];
-    if (p.in_ss) {
+    if (loader) {
       const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + (tid & 7) * 8) * 2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ssv[e] = *reinterpret_cast<const float4*>(sp + 4 * e);
     }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      const int item = tid + NT * k;
+      long long g; const bool ok = chunk_ok(k, g);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (item < RPX * 8) {
-        const int px = item >> 3, c8 = item & 7;
-        const int ry = px / RW, rx = px - ry * RW;
-        int iy = by * TH - 1 + ry, ix = bx * TW - 1 + rx;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-          if (p.up2) { iy >>= 1; ix >>= 1; }
-          v = *reinterpret_cast<const uint4*>(X + ((long long)iy * Ws_ + ix) * p.lda + c0 + c8 * 8);
-          if (p.in_ss) {
-            // GroupNorm(+swish) of the producer, applied once per staged element; padding stays exactly 0
-            float f[8]; unpack8(v, f);
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-              const float4 s4 = ssv[e >> 1];
-              f[e] = fmaf(f[e], s4.x, s4.y); f[e + 1] = fmaf(f[e + 1], s4.z, s4.w);
-            }
-            if (p.in_swish) {
-              constexpr float L2E = 1.44269504088896340736f;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) f[e] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * f[e]));
-            }
-            v = pack8(f);
-          }
-        }
-      }
+      if (ok) v = *reinterpret_cast<const uint4*>(X + g + c0);
       rreg[k] = v;
     }
   };
-  auto store_region = [&]() __attribute__((always_inline)) {
+  auto store_items = [&](auto mode) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode)::value;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int item = tid + NT * k;
-      if (item < RPX * 8) *reinterpret_cast<uint4*>(Rg + (item >> 3) * PIXB + (item & 7) * 16) = rreg[k];
+      uint4 v = rreg[k];
+      if (MODE >= 1) {
+        long long g; const bool ok = chunk_ok(k, g);
+        float f[8]; unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float4 s4 = ssv[e >> 1];
+          f[e] = fmaf(f[e], s4.x, s4.y); f[e + 1] = fmaf(f[e + 1], s4.z, s4.w);
+        }
+        if (MODE == 2) {
+          constexpr float L2E = 1.44269504088896340736f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * f[e]));
+        }
+        v = pack8(f);
+        if (!ok) v = make_uint4(0u, 0u, 0u, 0u);                          // the conv's zero padding stays exactly 0
+      }
+      if (item < RPX * 8) *reinterpret_cast<uint4*>(Rg + (item >> 3) * PIXB + (item & 7) * 16) = v;
     }
+  };
+  auto store_region = [&]() __attribute__((always_inline)) {
+    if (loader == 2) store_items(std::integral_constant<int, 2>{});
+    else if (loader == 1) store_items(std::integral_constant<int, 1>{});
+    else store_items(std::integral_constant<int, 0>{});
   };
   // ---- weight tile: [BN][64 k] bf16 of (tap, slice): 64 rows x 8 chunks = 512 chunks -> 2 per thread -----------------
   uint4 wreg[2];
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // A = weights: the tile is [n][pixel]
     }
   };
   load_region(0); store_region();
@@ -225,78 +240,108 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
     }
   }
 
-  // ---- epilogue: block transpose through LDS -> 16-B chunks of 8 channels ------------------------------------------------
+  // ---- epilogue: block exchange through LDS -> 16-B chunks of 8 channels ---------------------------------------------------
+  // The accumulator tile is [n][pixel] (A = weights): lane (pixel = l&31, hh) holds channels 8g + 4hh + (0..3) of its pixel in
+  // registers 4g..4g+3, so the exchange is 4 ds_write_b128 per tile (pitch 68 floats: conflict-free) instead of 16 ds_write_b32.
   float* Cs = reinterpret_cast<float*>(smem);                            // [TH*16 px][CLD]
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;                   // MFMA row -> pixel of the wave's 32-pixel group i
-        const int px = (2 * TI * wave + 2 * i + (m >> 4)) * TW + (m & 15);
-        Cs[px * CLD + j * 32 + arow] = acc[i][j][r];
-      }
-  __syncthreads();
   const int cq = tid & 7;                                                // this thread's 8-channel chunk (same for all its pixels)
   const int nc = n0 + cq * 8;
-  float bv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = (p.bias && nc + e < p.Cout) ? p.bias[nc + e] : 0.f;
   const bool full = nc + 7 < p.Cout;
   const bool al = (p.ldc % 8 == 0) && ((((uintptr_t)p.y) & 15) == 0) &&
                   (!p.res || (p.res_f32 ? ((p.ldres % 4 == 0) && ((((uintptr_t)p.res) & 15) == 0)) : ((p.ldres % 8 == 0) && ((((uintptr_t)p.res) & 15) == 0))));
   const bf16_t* __restrict__ R16 = reinterpret_cast<const bf16_t*>(p.res);
   const float* __restrict__ R32 = reinterpret_cast<const float*>(p.res);
+  constexpr int NPASS = TH * TW / 32;                                    // pixels of the tile, 32 per pass
+  // a bf16 residual is requested for ALL passes before the accumulators go through LDS: one HBM round trip overlapped with the
+  // exchange instead of NPASS of them in sequence behind it
+  const bool pre = p.res && !p.res_f32 && full && al;
+  uint4 rq[NPASS];
+  if (pre) {
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int px = (tid >> 3) + 32 * it;
+      const long long opix = ((long long)img * p.H + by * TH + (px >> 4)) * p.W + bx * TW + (px & 15);
+      rq[it] = *reinterpret_cast<const uint4*>(R16 + opix * p.ldres + nc);
+    }
+  }
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = (p.bias && nc + e < p.Cout) ? p.bias[nc + e] : 0.f;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int px = (2 * TI * wave + 2 * i + (arow >> 4)) * TW + (arow & 15);
+        *reinterpret_cast<float4*>(Cs + px * CLD + j * 32 + 8 * g + 4 * hh) =
+            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+  __syncthreads();
   float piv[8], sm[8], sq[8];                                            // Welford partials of what is stored (shifted by the first value)
 #pragma unroll
   for (int e = 0; e < 8; ++e) { piv[e] = 0.f; sm[e] = 0.f; sq[e] = 0.f; }
-  constexpr int NPASS = TH * TW / 32;                                    // pixels of the tile, 32 per pass
+  // the activation is resolved once per block (0 identity, 1 relu / leaky relu in slope form, 2 generic), not per value
+  auto passes = [&](auto mode) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode)::value;
+    const float slope = p.act == SMX_ACT_RELU ? 0.f : 0.2f;
 #pragma unroll
-  for (int it = 0; it < NPASS; ++it) {
-    const int px = (tid >> 3) + 32 * it;
-    const int oy = by * TH + (px >> 4), ox = bx * TW + (px & 15);
-    const long long opix = ((long long)img * p.H + oy) * p.W + ox;
-    const float4 v0 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8 + 4);
-    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = c_act(v[e] + bv[e], p.act);
-    if (nc < p.Cout) {
-      if (full && al) {
-        if (p.res) {
-          if (p.res_f32) {
-            const float4 q0 = *reinterpret_cast<const float4*>(R32 + opix * p.ldres + nc), q1 = *reinterpret_cast<const float4*>(R32 + opix * p.ldres + nc + 4);
-            v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
-          } else {
-            float q[8]; unpack8(*reinterpret_cast<const uint4*>(R16 + opix * p.ldres + nc), q);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += q[e];
-          }
-        }
-        const uint4 pk = pack8(v);
-        *reinterpret_cast<uint4*>(p.y + opix * p.ldc + nc) = pk;
-        if (p.stats) unpack8(pk, v);                                     // statistics of the values as STORED (bf16-rounded)
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (nc + e >= p.Cout) { v[e] = 0.f; continue; }
-          if (p.res) v[e] += p.res_f32 ? R32[opix * p.ldres + nc + e] : bf2f(R16[opix * p.ldres + nc + e]);
-          const bf16_t h = f2bf(v[e]);
-          p.y[opix * p.ldc + nc + e] = h;
-          v[e] = bf2f(h);
-        }
-      }
-    }
-    if (p.stats) {
+    for (int it = 0; it < NPASS; ++it) {
+      const int px = (tid >> 3) + 32 * it;
+      const int oy = by * TH + (px >> 4), ox = bx * TW + (px & 15);
+      const long long opix = ((long long)img * p.H + oy) * p.W + ox;
+      const float4 v0 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        if (it == 0) piv[e] = v[e];
-        const float d = v[e] - piv[e];
-        sm[e] += d; sq[e] += d * d;
+        v[e] += bv[e];
+        if (MODE == 1) v[e] = fmaxf(v[e], 0.f) + slope * fminf(v[e], 0.f);
+        if (MODE == 2) v[e] = c_act(v[e], p.act);
+      }
+      if (nc < p.Cout) {
+        if (full && al) {
+          if (pre) {
+            float q[8]; unpack8(rq[it], q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += q[e];
+          } else if (p.res) {
+            if (p.res_f32) {
+              const float4 q0 = *reinterpret_cast<const float4*>(R32 + opix * p.ldres + nc), q1 = *reinterpret_cast<const float4*>(R32 + opix * p.ldres + nc + 4);
+              v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+            } else {
+              float q[8]; unpack8(*reinterpret_cast<const uint4*>(R16 + opix * p.ldres + nc), q);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += q[e];
+            }
+          }
+          const uint4 pk = pack8(v);
+          *reinterpret_cast<uint4*>(p.y + opix * p.ldc + nc) = pk;
+          if (p.stats) unpack8(pk, v);                                   // statistics of the values as STORED (bf16-rounded)
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (nc + e >= p.Cout) { v[e] = 0.f; continue; }
+            if (p.res) v[e] += p.res_f32 ? R32[opix * p.ldres + nc + e] : bf2f(R16[opix * p.ldres + nc + e]);
+            const bf16_t h = f2bf(v[e]);
+            p.y[opix * p.ldc + nc + e] = h;
+            v[e] = bf2f(h);
+          }
+        }
+      }
+      if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (it == 0) piv[e] = v[e];
+          const float d = v[e] - piv[e];
+          sm[e] += d; sq[e] += d * d;
+        }
       }
     }
-  }
+  };
+  if (p.act == SMX_ACT_NONE) passes(std::integral_constant<int, 0>{});
+  else if (p.act == SMX_ACT_RELU || p.act == SMX_ACT_LRELU02) passes(std::integral_constant<int, 1>{});
+  else passes(std::integral_constant<int, 2>{});
   if (p.stats) {
     // per channel: Chan-merge the 32 threads (8 values each) that share this channel chunk
     __syncthreads();                                                     // Cs is dead: reuse as [32 threads][64 ch][2]

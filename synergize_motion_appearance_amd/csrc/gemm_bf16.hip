@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "smx.h"
 #include "smx_common.h"
 #include "bf16.h"
@@ -329,6 +330,66 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GB p) {
   const bool vec_c = p.d2s_p ? (p.d2s_c % 8 == 0) : true;
   const bool al_c = (p.ldc % 8 == 0) && ((((uintptr_t)p.c) & 15) == 0) && (c_goff % 8 == 0);
   const bool al_r = !p.res || ((p.ldres % 8 == 0) && ((((uintptr_t)p.res) & 15) == 0) && (r_goff % 8 == 0));
+  // Fast path (plain NHWC store, aligned rows, tile inside N -- the engines' layers): this thread's chunk column is the same
+  // for all its rows (NT % CPR == 0), so the bias vector is loaded once, the activation is resolved once per block, and a bf16
+  // residual is requested for ALL of the thread's rows before the first is used (the rolled loop below issued one dependent
+  // HBM round trip per row, 8 in sequence for a 128-row tile).
+  static_assert(NT % CPR == 0 && (BM * CPR) % NT == 0, "epilogue mapping");
+  constexpr int ITER = BM * CPR / NT, RSTEP = NT / CPR;
+  if (!p.d2s_p && al_c && al_r && tile_n * BN + BN <= p.N && !p.bias_per_row) {
+    const int cq = tid % CPR, row0 = tid / CPR;
+    const int n0 = tile_n * BN + cq * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + e] : 0.f;
+    const bool pre = p.res && !p.res_f32;
+    uint4 rq[ITER];
+    if (pre) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int m = tile_m * BM + row0 + RSTEP * it;
+        rq[it] = m < p.M ? *reinterpret_cast<const uint4*>(R16 + (long long)m * p.ldres + n0) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    auto rows = [&](auto mode) __attribute__((always_inline)) {
+      constexpr int MODE = decltype(mode)::value;           // 0 identity, 1 relu / leaky relu (slope form), 2 generic, 3 gelu
+      const float slope = p.act == SMX_ACT_RELU ? 0.f : 0.2f;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int row = row0 + RSTEP * it, m = tile_m * BM + row;
+        if (m >= p.M) continue;
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cq * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cq * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = p.alpha * v[e] + bv[e];
+          if (MODE == 1) v[e] = fmaxf(v[e], 0.f) + slope * fminf(v[e], 0.f);
+          if (MODE == 2) v[e] = apply_act(v[e], p.act);
+          if (MODE == 3) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+        }
+        if (pre) {
+          float q[8]; unpack8(rq[it], q);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += q[e];
+        } else if (p.res) {
+          const float4 q0 = *reinterpret_cast<const float4*>(R32 + (long long)m * p.ldres + n0), q1 = *reinterpret_cast<const float4*>(R32 + (long long)m * p.ldres + n0 + 4);
+          v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+        }
+        if (p.c_f32) {
+          *reinterpret_cast<float4*>(C32 + (long long)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(C32 + (long long)m * p.ldc + n0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *reinterpret_cast<uint4*>(C16 + (long long)m * p.ldc + n0) = pack8(v);
+        }
+      }
+    };
+    if (p.act == SMX_ACT_NONE) rows(std::integral_constant<int, 0>{});
+    else if (p.act == SMX_ACT_RELU || p.act == SMX_ACT_LRELU02) rows(std::integral_constant<int, 1>{});
+    else if (p.act == SMX_ACT_GELU) rows(std::integral_constant<int, 3>{});
+    else rows(std::integral_constant<int, 2>{});
+    return;
+  }
   for (int ch = tid; ch < BM * CPR; ch += NT) {
     const int row = ch / CPR, cq = ch - row * CPR;
     const int m = tile_m * BM + row, n0 = tile_n * BN + cq * 8;

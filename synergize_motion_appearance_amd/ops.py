@@ -183,11 +183,13 @@ REGION3X3 = not _os.environ.get("SMX_NO_REGION3X3")
 CONV16_TILE_H = int(_os.environ.get("SMX_CONV16_TILE_H", "0"))      # 0 = auto, 8 | 16 = forced (tools / tests)
 
 
-def _conv16_tile_h(Cin, Ho):
-    """output tile height of the region-direct bf16 3x3 kernel: measured per shape on the device (tools/conv16_bench.py)"""
+def _conv16_tile_h(Cin, Ho, nblk16=0):
+    """output tile height of the region-direct bf16 3x3 kernel (measured per shape, tools/conv16_bench.py): 16x16 tiles (2 workgroups
+    per CU) once the launch has >= 1024 of them -- 5-15 % over 8x16 tiles at every B=60 shape since the loader normalises at store
+    time -- and 8x16 tiles (3 per CU, twice the workgroups) for the small launches."""
     if CONV16_TILE_H in (8, 16) and Ho % CONV16_TILE_H == 0:
         return CONV16_TILE_H
-    return 16 if Cin >= 512 else 8          # 8x16 tiles (3 workgroups / CU) win up to C_in = 256: 1.1-1.4x; 16x16 at C_in = 512
+    return 16 if (Ho % 16 == 0 and (nblk16 >= 1024 or Cin >= 512)) else 8
 
 
 def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss, in_swish, out_dtype, want_stats=False):
@@ -217,7 +219,7 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
         # region-direct 3x3 kernel: the input region is staged once per 64-channel slice and all nine taps read it from LDS
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1,
                 "bytes": 2.0 * B * Ho * Wo * (Cin / (4.0 if up2 else 1.0) + cv.cout * (2 if res is not None else 1))} if _PROFILE is not None else None
-        th = _conv16_tile_h(Cin, Ho)
+        th = _conv16_tile_h(Cin, Ho, B * (Ho // 16) * (Wo // 16) * ((cv.cout + 63) // 64))
         part = torch.empty((B, (Ho // th) * (Wo // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
         L.check(_timed("conv3x3_bf16", meta, L.load().smx_conv3x3_bf16, a_ptr, lda, cv.w16.data_ptr(), cv.w16.shape[1],
                        None if cv.b is None else cv.b.data_ptr(), r_ptr, int(res is not None and res.dtype == torch.float32), ldr,
