@@ -39,9 +39,10 @@ enum { SMX_ACT_NONE = 0, SMX_ACT_RELU = 1, SMX_ACT_LRELU02 = 2, SMX_ACT_SWISH = 
 const char* smx_version(void);
 
 /* Launch-selection knobs (tests / tuning tools; the defaults are the device-tuned choices).  Names: "wino_nw"
- * (1|2 N tiles per Winograd block, -1 auto), "wino_swz", "wino_ablate", "wino_epi", "gemm_variant",
- * "gemm_xcd_swizzle", "warp_rows", "warp_reorder", "attn16" (bf16 storage, d_head 32: 1 = bf16 MFMA kernel, 0 = fp32 MFMA kernel).  Initialised once from the SMX_* environment; the launch paths
- * read the table, never the environment.  Returns SMX_EINVAL for an unknown name. */
+ * (1|2 N tiles per Winograd block, -1 auto), "wino_wide" (64-channel blocks: 1 = 4 waves x 64 n, 0 = 8 waves), "wino_ablate" /
+ * "wino_nt" (tools), "gemm_variant", "gemm_xcd_swizzle", "warp_rows", "warp_reorder", "attn16" (bf16 storage, d_head 32: 1 = bf16
+ * MFMA kernel, 0 = fp32 MFMA kernel), "attn4_mfma" (d_head 4: 1 = 4x4x1 MFMA kernel, 0 = VALU kernel).  Initialised once from the
+ * SMX_* environment; the launch paths read the table, never the environment.  Returns SMX_EINVAL for an unknown name. */
 int smx_set_tuning(const char* name, int value);
 int smx_get_tuning(const char* name, int* value);
 

@@ -10,16 +10,12 @@ namespace {
 struct Knob { const char* name; const char* env; int value; };
 Knob g_knobs[SMX_TUNE_COUNT] = {
   {"wino_nw", "SMX_WINO_NW", -1},               // Winograd: 32-wide N tiles per block (1 | 2)
-  {"wino_swz", "SMX_WINO_SWZ", 0},              // Winograd: conflict-free LDS swizzle
   {"wino_ablate", "SMX_WINO_ABLATE", 0},        // Winograd: timing-only ablation mask (tools)
   {"gemm_variant", "SMX_GEMM_VARIANT", 3},      // implicit GEMM: bit0 store-early pipeline, bit1 s_setprio
   {"gemm_xcd_swizzle", "SMX_GEMM_XCD_SWIZZLE", 1},
   {"warp_rows", "SMX_WARP_ROWS", 1},            // warp: row-chunk kernel when eligible (0 = per-lane kernel)
   {"warp_reorder", "SMX_WARP_REORDER", 1},      // warp: (XCD, chunk, frame) block order
-  {"wino_epi", "SMX_WINO_EPI", 1},              // (retired: the one-pass epilogue is the only one)
-  {"conv16_tpb", "SMX_CONV16_TPB", -1},         // bf16 region-direct 3x3: tiles walked per block (reserved)
   {"attn16", "SMX_ATTN16", 1},                  // bf16 storage, d_head 32: bf16 MFMA kernel (0 = fp32 MFMA kernel on bf16 storage)
-  {"wino_ud", "SMX_WINO_UD", 2},                // (retired: U prefetch distance 3 measured neutral)
   {"wino_wide", "SMX_WINO_WIDE", 1},            // Winograd big launches: 1 = 4-wave "wide" blocks, 64 n per wave (default), 0 = 8-wave blocks, 5 = wide at one block per CU (tools)
   {"wino_nt", "SMX_WINO_NT", 0},                // wide Winograd epilogue: non-temporal residual loads / output stores
   {"attn4_mfma", "SMX_ATTN4_MFMA", 1},          // d_head 4 attention: 1 = 4x4x1 (16-block) MFMA kernel, 0 = VALU kernel
