@@ -313,6 +313,11 @@ int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, floa
 int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32, int ldres,
                      void* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
                      float* stats_part, int tile_h, void* stream);
+/* The bf16 counterpart of smx_winograd_conv3x3_sft_f32: y = dec + w * (dec * scale + conv3x3(x)) as the convolution's epilogue
+ * (Fuse_sft_block, archs/appmotioncodebook_arch.py:49-51); dec / scale / y bf16 NHWC with 16 B-aligned rows, Cout % 8 == 0. */
+int smx_conv3x3_sft_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* dec, int lddec,
+                         const void* scale, int ldscale, float sft_w, void* y, int ldc, int B, int H, int W, int Cin, int Cout,
+                         int tile_h, void* stream);
 int smx_groupnorm_swish_nhwc_bf16(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int B, int HW,
                                   int C, int groups, float eps, int swish, float* ws, void* stream);
 int smx_groupnorm_stats_bf16(const void* x, int ldx, const float* gamma, const float* beta, float* ss, int B, int HW, int C,

@@ -40,6 +40,7 @@ template <int TH> struct Geo {
 struct CP {
   const bf16_t* x; const bf16_t* w; const float* bias; const void* res; bf16_t* y; float* stats; const float* in_ss;
   int in_swish, res_f32;
+  const bf16_t* mul; int ldmul; float sft_w;   // SFT epilogue: y = res + sft_w * (res * mul + conv)  (bf16 res / mul, 16 B-aligned rows)
   int lda, ldc, ldres, ldw;
   int B, H, W, Cin, Cout, up2, act;
   int tiles_y, tiles_x, ntiles, tpb;
@@ -255,13 +256,15 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   // a bf16 residual is requested for ALL passes before the accumulators go through LDS: one HBM round trip overlapped with the
   // exchange instead of NPASS of them in sequence behind it
   const bool pre = p.res && !p.res_f32 && full && al;
-  uint4 rq[NPASS];
+  const bool sft = pre && p.mul;                                         // the launcher only passes mul with the fast-path layout
+  uint4 rq[NPASS], mq[NPASS];
   if (pre) {
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
       const int px = (tid >> 3) + 32 * it;
       const long long opix = ((long long)img * p.H + by * TH + (px >> 4)) * p.W + bx * TW + (px & 15);
       rq[it] = *reinterpret_cast<const uint4*>(R16 + opix * p.ldres + nc);
+      if (sft) mq[it] = *reinterpret_cast<const uint4*>(p.mul + opix * p.ldmul + nc);
     }
   }
   float bv[8];
@@ -301,7 +304,11 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
       }
       if (nc < p.Cout) {
         if (full && al) {
-          if (pre) {
+          if (sft) {
+            float q[8], m[8]; unpack8(rq[it], q); unpack8(mq[it], m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = q[e] + p.sft_w * (q[e] * m[e] + v[e]);
+          } else if (pre) {
             float q[8]; unpack8(rq[it], q);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += q[e];
@@ -370,16 +377,19 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
 
 }  // namespace
 
-extern "C" int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32,
-                                int ldres, void* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act,
-                                const float* in_ss, int in_swish, float* stats_part, int tile_h, void* stream) {
+static int conv3x3_bf16_launch(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32,
+                               int ldres, const void* mul, int ldmul, float sft_w, void* y, int ldc, int B, int H, int W, int Cin, int Cout,
+                               int up2, int act, const float* in_ss, int in_swish, float* stats_part, int tile_h, void* stream) {
   if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (tile_h != 8 && tile_h != 16)) return SMX_EINVAL;
+  if (mul && (!res || res_f32 || Cout % 8 || ldc % 8 || ldres % 8 || ldmul % 8 || ldmul < Cout || act != SMX_ACT_NONE ||
+              ((((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)mul)) & 15))) return SMX_EINVAL;
   const int TH = tile_h;
   if (H % TH != 0 || W % TW != 0 || Cin % CS != 0 || lda % 8 != 0 || lda < Cin || ldc < Cout || ldw < 9 * Cin || ldw % 8 != 0) return SMX_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (in_ss && ((uintptr_t)in_ss & 15)) || (res && ldres < Cout)) return SMX_EINVAL;
   if (up2 && ((H & 1) || (W & 1))) return SMX_EINVAL;
   CP p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = bias; p.res = res; p.res_f32 = res_f32; p.y = (bf16_t*)y; p.stats = stats_part;
+  p.mul = (const bf16_t*)mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
   p.in_ss = in_ss; p.in_swish = in_swish; p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0; p.ldw = ldw;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
   p.tiles_y = H / TH; p.tiles_x = W / TW;
@@ -392,4 +402,19 @@ extern "C" int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, 
   if (TH == 16) SMX_LAUNCH(conv3x3_bf16_kernel<16>, grid, dim3(NT), Geo<16>::LDS_B, (hipStream_t)stream, p);
   else SMX_LAUNCH(conv3x3_bf16_kernel<8>, grid, dim3(NT), Geo<8>::LDS_B, (hipStream_t)stream, p);
   return smx_launch_status();
+}
+
+extern "C" int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32,
+                                int ldres, void* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act,
+                                const float* in_ss, int in_swish, float* stats_part, int tile_h, void* stream) {
+  return conv3x3_bf16_launch(x, lda, w, ldw, bias, res, res_f32, ldres, nullptr, 0, 0.f, y, ldc, B, H, W, Cin, Cout, up2, act, in_ss, in_swish,
+                             stats_part, tile_h, stream);
+}
+
+extern "C" int smx_conv3x3_sft_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* dec, int lddec,
+                                    const void* scale, int ldscale, float sft_w, void* y, int ldc, int B, int H, int W, int Cin, int Cout,
+                                    int tile_h, void* stream) {
+  if (!dec || !scale) return SMX_EINVAL;
+  return conv3x3_bf16_launch(x, lda, w, ldw, bias, dec, 0, lddec, scale, ldscale, sft_w, y, ldc, B, H, W, Cin, Cout, 0, SMX_ACT_NONE, nullptr, 0,
+                             nullptr, tile_h, stream);
 }

@@ -101,6 +101,7 @@ SIGNATURES = {
     "smx_frames_u8_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "smx_to_uint8_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
     "smx_conv3x3_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "smx_conv3x3_sft_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_groupnorm_swish_nhwc_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
     "smx_groupnorm_stats_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
     "smx_groupnorm_apply_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -594,6 +594,21 @@ def conv_sft(x, cv, dec, scale, w=1.0):
         s_ptr, lds_ = _pix(scale, "conv_sft scale")
         fused = (lda % 4 == 0 and ldd % 4 == 0 and lds_ % 4 == 0 and (a_ptr | d_ptr | s_ptr) % 16 == 0
                  and (cv.b is None or cv.b.data_ptr() % 16 == 0))
+    if (not fused and REGION3X3 and x.dtype == BF16 and dec.dtype == BF16 and scale.dtype == BF16 and cv.kh == 3 and cv.kw == 3
+            and Cin == cv.cin and Cin % 64 == 0 and H % 8 == 0 and W % 16 == 0 and cv.cout % 8 == 0
+            and tuple(dec.shape) == (B, H, W, cv.cout) and tuple(scale.shape) == (B, H, W, cv.cout)):
+        a_ptr, lda = _pix(x, "conv_sft input")
+        d_ptr, ldd = _pix(dec, "conv_sft dec")
+        s_ptr, lds_ = _pix(scale, "conv_sft scale")
+        if lda % 8 == 0 and ldd % 8 == 0 and lds_ % 8 == 0 and (a_ptr | d_ptr | s_ptr) % 16 == 0:
+            out = torch.empty((B, H, W, cv.cout), device=x.device, dtype=BF16)
+            th = _conv16_tile_h(Cin, H, B * (H // 16) * (W // 16) * ((cv.cout + 63) // 64))
+            meta = {"flops": 2.0 * B * H * W * cv.cout * 9 * Cin, "M": B * H * W, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1,
+                    "bytes": 2.0 * B * H * W * (Cin + 3 * cv.cout)} if _PROFILE is not None else None
+            L.check(_timed("conv3x3_bf16", meta, L.load().smx_conv3x3_sft_bf16, a_ptr, lda, cv.w16.data_ptr(), cv.w16.shape[1],
+                           None if cv.b is None else cv.b.data_ptr(), d_ptr, ldd, s_ptr, lds_, float(w), out.data_ptr(), cv.cout,
+                           B, H, W, Cin, cv.cout, th, _stream()), "smx_conv3x3_sft_bf16")
+            return out
     if not fused:
         return sft_combine(dec, scale, conv(x, cv), w)
     out = torch.empty((B, H, W, cv.cout), device=x.device, dtype=torch.float32)

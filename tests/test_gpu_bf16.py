@@ -458,3 +458,25 @@ def test_bf16_batched_driver_and_packed_state_roundtrip(nets16):
     rmax = float(golden("autocast_bf16.npz")["err_out_netg_only"][0])
     rmean = float(golden("autocast_bf16.npz")["err_out_netg_only"][1])
     assert float(d.mean()) < 1.5 * rmean * 127.5 and float(d.max()) <= rmax * 127.5, (float(d.mean()), float(d.max()))
+
+
+@pytest.mark.parametrize("B,C,H,W,tile_h", [(2, 64, 32, 32, 16), (2, 128, 16, 32, 8), (1, 64, 16, 16, 8)])
+def test_conv_sft_epilogue_bf16(ops, B, C, H, W, tile_h, monkeypatch):
+    """Fuse_sft_block's `dec + w * (dec * scale + shift)` as the epilogue of the shift branch's 3x3 conv on the bf16 region kernel
+    (smx_conv3x3_sft_bf16), operands being channel slices of wider bf16 buffers as in the engine: against conv2d + the formula in
+    fp32 on the bf16-rounded operands (one rounding of the result), and it must not run a separate sft_combine pass."""
+    monkeypatch.setattr(ops, "CONV16_TILE_H", tile_h)
+    ss = r16(rnd(f"bs{C}{H}", (B, H, W, 2 * C)))
+    cat = r16(rnd(f"bc{C}{H}", (B, H, W, 2 * C)))
+    scale = r16(rnd(f"bq{C}{H}", (B, H, W, C)))
+    w = rnd(f"bw{C}", (C, C, 3, 3), 1.0 / math.sqrt(9 * C))
+    b = rnd(f"bb{C}", (C,), 0.1)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    ssd, catd = ss.cuda().to(BF), cat.cuda().to(BF)
+    with ops.profile() as rec:
+        y = ops.conv_sft(ssd[..., C:], cv, catd[..., C:], scale.cuda().to(BF), 0.7)
+    assert [r[0] for r in rec.rows] == ["conv3x3_bf16"] and y.dtype == BF
+    shift = F.conv2d(ss[..., C:].permute(0, 3, 1, 2).double(), r16(w).double(), b.double(), padding=1).permute(0, 2, 3, 1).float()
+    dec = cat[..., C:]
+    ok, worst = close16(y.float().cpu(), dec + 0.7 * (dec * scale + shift), ulps=1.0)
+    assert ok, worst
