@@ -57,12 +57,21 @@ __device__ __forceinline__ float c_act(float v, int act) {
   }
 }
 
-template <int TH>
+// SLAB (the big launches, 16x16 tiles): 32-channel slices with ALL NINE taps' weights of the slice in LDS -- one staging phase
+// (region + 9 x [64 n][32 k] weights, 72 KB single-buffered) and two barriers per 72 MFMAs per wave.  The per-step trace of the
+// tap-streaming form (one [64 n][64 k] weight tile, one barrier, one store/load phase per tap = per 16 MFMAs) read: compute
+// 1.25k cycles, weight store / next request / barrier 1.05k, loop overhead 0.35k per step -- the matrix pipe idled through more
+// than half of every step, and neither deeper weight prefetch, nor skipping the barriers, nor pipelining the LDS reads moved it.
+template <int TH, bool SLAB = false>
 __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p) {
-  constexpr int RPX = Geo<TH>::RPX, REGION_B = Geo<TH>::REGION_B, TI = TH / 8;   // TI: 32-pixel A fragments per wave
+  constexpr int RPX = Geo<TH>::RPX, TI = TH / 8;                                 // TI: 32-pixel A fragments per wave
+  constexpr int CSL = SLAB ? 32 : CS;                                            // channels per staged slice
+  constexpr int PB = SLAB ? 80 : PIXB;                                           // bytes per region pixel / weight row in LDS (data + 16 pad)
+  constexpr int CPP = CSL / 8, CPPL = SLAB ? 2 : 3;                              // 16-B chunks per pixel (and its log2)
+  constexpr int REGION_B = RPX * PB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Rg = smem;                       // region [RPX][PIXB]
-  unsigned char* Ws = smem + REGION_B;            // weights [2][BN][PIXB]
+  unsigned char* Rg = smem;                       // region [RPX][PB]
+  unsigned char* Ws = smem + REGION_B;            // weights [2][BN][PIXB]  (SLAB: [9 taps][BN][PB])
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware order: block b runs on XCD b%8; give each XCD a contiguous range of (image, tile) so neighbouring tiles'
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   const bf16_t* __restrict__ X = p.x + (long long)img * Hs * Ws_ * p.lda;
 
   // ---- region staging: RPX * 8 chunks of 16 B per slice, 256 threads -> 11 chunks per thread (the last partially) -----
-  constexpr int NCH = (RPX * 8 + NT - 1) / NT;
+  constexpr int NCH = (RPX * CPP + NT - 1) / NT;
   uint4 rreg[NCH];
   // load_region only ISSUES the global loads -- the region chunks and, once per slice, the GroupNorm {scale, shift} pairs of
   // this thread's 8 channels (item & 7 == tid & 7 for all its chunks); store_region, three taps later, applies the fused
@@ -89,17 +98,17 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
   auto chunk_ok = [&](int k, long long& g) __attribute__((always_inline)) -> bool {
     const int item = tid + NT * k;
-    const int px = item >> 3, c8 = item & 7;
+    const int px = item >> CPPL, c8 = item & (CPP - 1);
     const int ry = px / RW, rx = px - ry * RW;
     int iy = by * TH - 1 + ry, ix = bx * TW - 1 + rx;
-    const bool ok = item < RPX * 8 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const bool ok = item < RPX * CPP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     if (p.up2) { iy >>= 1; ix >>= 1; }
     g = ((long long)iy * Ws_ + ix) * p.lda + c8 * 8;
     return ok;
   };
   auto load_region = [&](int c0) __attribute__((always_inline)) {
     if (loader) {
-      const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + (tid & 7) * 8) * 2;
+      const float* sp = p.in_ss + ((long long)img * p.Cin + c0 + (tid & (CPP - 1)) * 8) * 2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ssv[e] = *reinterpret_cast<const float4*>(sp + 4 * e);
     }
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
         v = pack8(f);
         if (!ok) v = make_uint4(0u, 0u, 0u, 0u);                          // the conv's zero padding stays exactly 0
       }
-      if (item < RPX * 8) *reinterpret_cast<uint4*>(Rg + (item >> 3) * PIXB + (item & 7) * 16) = v;
+      if (item < RPX * CPP) *reinterpret_cast<uint4*>(Rg + (item >> CPPL) * PB + (item & (CPP - 1)) * 16) = v;
     }
   };
   auto store_region = [&]() __attribute__((always_inline)) {
@@ -166,8 +175,8 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
 
   // A operand: lane l <-> MFMA row l&31 = pixel (tile row 2*TI*wave + 2*i + ((l&31)>>4), col l&15), k chunk (l>>5)
   const int arow = lane & 31, hh = lane >> 5;
-  const int abase = ((2 * TI * wave + (arow >> 4)) * RW + (arow & 15)) * PIXB + hh * 16; // + i*2*RW*PIXB + tap offset + kk*32
-  const int bbase = arow * PIXB + hh * 16;                                               // + j*32*PIXB + kk*32
+  const int abase = ((2 * TI * wave + (arow >> 4)) * RW + (arow & 15)) * PB + hh * 16;   // + i*2*RW*PB + tap offset + kk*32
+  const int bbase = arow * PB + hh * 16;                                                 // + j*32*PB + kk*32
 
   // one step = one (slice, tap): this step's weight tile is in Ws[step & 1]; the next one is requested at the top of the step
   // and written to the other buffer at its end.  (Measured dead ends at the 256-VGPR / 2-waves-per-SIMD budget: a two-step-deep
@@ -192,6 +201,51 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // A = weights: the tile is [n][pixel]
     }
   };
+  if (SLAB) {
+    constexpr int NWC = 9 * BN * CPP / NT;                               // 9 weight chunks per thread per slice
+    uint4 wq[NWC];
+    auto load_wslab = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < NWC; ++k) {
+        const int item = tid + NT * k, row = item >> CPPL, c4 = item & (CPP - 1);     // row = tap * 64 + n
+        const int n = n0 + (row & 63);
+        wq[k] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (long long)n * p.ldw + (row >> 6) * p.Cin + c0 + c4 * 8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    };
+    auto store_wslab = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < NWC; ++k) {
+        const int item = tid + NT * k;
+        *reinterpret_cast<uint4*>(Ws + (item >> CPPL) * PB + (item & (CPP - 1)) * 16) = wq[k];
+      }
+    };
+    const int nsl32 = p.Cin / CSL;
+    load_wslab(0); load_region(0);
+    store_wslab(); store_region();
+    __syncthreads();
+    for (int s = 0; s < nsl32; ++s) {
+      if (s + 1 < nsl32) { load_wslab((s + 1) * CSL); load_region((s + 1) * CSL); }   // in flight over the slice's 72 MFMAs
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const unsigned char* ap = Rg + abase + ((tap / 3) * RW + (tap % 3)) * PB;
+        const unsigned char* bp = Ws + tap * BN * PB + bbase;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 af[TI], bfr[2];
+#pragma unroll
+          for (int i = 0; i < TI; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + i * 2 * RW * PB + kk * 32));
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + j * 32 * PB + kk * 32));
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();                                                   // every wave is past its last read of this slice
+      if (s + 1 < nsl32) { store_wslab(); store_region(); __syncthreads(); }
+    }
+  } else {
   load_region(0); store_region();
   if (TH == 16) {
     // one step = one (slice, tap): this step's weight tile is in Ws[step & 1]; the next one is requested at the top of the step
@@ -240,6 +294,8 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
       if (step + 1 < nsteps) body(step + 1, wb, wa);
     }
   }
+
+  }   // !SLAB
 
   // ---- epilogue: block exchange through LDS -> 16-B chunks of 8 channels ---------------------------------------------------
   // The accumulator tile is [n][pixel] (A = weights): lane (pixel = l&31, hh) holds channels 8g + 4hh + (0..3) of its pixel in
@@ -399,7 +455,13 @@ static int conv3x3_bf16_launch(const void* x, int lda, const void* w, int ldw, c
   if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<16>::LDS_B)); attr = true; }
   p.ntiles = (int)blocks; p.tpb = 1;
   dim3 grid((unsigned)blocks, (Cout + BN - 1) / BN);
-  if (TH == 16) SMX_LAUNCH(conv3x3_bf16_kernel<16>, grid, dim3(NT), Geo<16>::LDS_B, (hipStream_t)stream, p);
+  constexpr int SLAB_LDS = Geo<16>::RPX * 80 + 9 * BN * 80;            // 72,000 B (>= the 69,632 B epilogue exchange)
+  if (TH == 16 && Cin % 32 == 0 && smx_tune(SMX_TUNE_CONV16_SLAB)) {
+    static bool attr2 = false;
+    if (!attr2) { SMX_HIP(hipFuncSetAttribute((const void*)(conv3x3_bf16_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS)); attr2 = true; }
+    SMX_LAUNCH((conv3x3_bf16_kernel<16, true>), grid, dim3(NT), SLAB_LDS, (hipStream_t)stream, p);
+  }
+  else if (TH == 16) SMX_LAUNCH(conv3x3_bf16_kernel<16>, grid, dim3(NT), Geo<16>::LDS_B, (hipStream_t)stream, p);
   else SMX_LAUNCH(conv3x3_bf16_kernel<8>, grid, dim3(NT), Geo<8>::LDS_B, (hipStream_t)stream, p);
   return smx_launch_status();
 }

@@ -165,13 +165,15 @@ R3_CASES = [(2, 64, 64, 32, 32, False, 0, None), (1, 128, 128, 64, 32, False, 3,
             (3, 64, 3 * 64, 16, 32, False, 0, None)]
 
 
-@pytest.mark.parametrize("tile_h", [16, 8])
+@pytest.mark.parametrize("tile_h", [16, 116, 8], ids=["16x16_slab", "16x16_per_tap", "8x16"])
 @pytest.mark.parametrize("case", R3_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_up{int(c[5])}_act{c[6]}_res{c[7]}" for c in R3_CASES])
 def test_conv3x3_region_direct_bf16(ops, case, tile_h, monkeypatch):
     """the region-direct 3x3 kernel (input region staged once per 64-channel slice, nine taps read from LDS) against conv2d on
     the bf16-rounded operands, against the implicit-GEMM bf16 kernel on the same operands, through channel-slice views, with
     the fused GroupNorm+swish loader, and with the Welford partials it emits for the next GroupNorm."""
     B, Cin, Cout, H, W, up2, act, resk = case
+    ops.set_tuning("conv16_slab", 0 if tile_h > 100 else 1)     # 16x16 tiles: all nine taps' weights of a 32-channel slice in LDS | one tile per tap
+    tile_h %= 100
     monkeypatch.setattr(ops, "CONV16_TILE_H", tile_h)
     x = r16(rnd(f"r3x{case}", (B, Cin, H // (2 if up2 else 1), W // (2 if up2 else 1))))
     w = rnd(f"r3w{case}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
