@@ -531,7 +531,9 @@ extern "C" int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream) {
   if (tile == 0) {
     const long long Mt = (long long)d->M * nb;
     // measured on the device (tools/gemm16_tune.py, B = 60 shapes): 64x64 tiles (4 waves, 4 workgroups / CU) win every
-    // short-K launch -- they are latency-bound --, 128x128 / 8 waves the long-K and very wide ones
+    // short-K launch -- they are latency-bound --, 128x128 / 8 waves the long-K and very wide ones.  (128x128 / 4 waves, tile 7,
+    // wins the isolated 1x1 sweep by 8-18 % but loses in the pipeline's own launches -- GELU / fp32-out epilogues, N = 2048-4096:
+    // +0.5 ms per step -- and stays selectable only.)
     if (d->N <= 32) tile = 4;
     else if (d->N % 128 == 0 && Mt >= 32768 && (d->K >= 1024 || d->N >= 2048 || (d->K >= 256 && Mt >= 500000))) tile = 1;
     else tile = 3;
@@ -544,6 +546,7 @@ extern "C" int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream) {
     case 4: return launch16<128, 32, 4, 1>(p, (int)nb, af, vec, st);    // 4 waves, N <= 32
     case 5: return launch16<64, 128, 2, 2>(p, (int)nb, af, vec, st);    // 4 waves, 32x64 per wave
     case 6: return launch16<256, 64, 8, 1>(p, (int)nb, af, vec, st);    // 8 waves, 32x64 per wave
+    case 7: return launch16<128, 128, 2, 2>(p, (int)nb, af, vec, st);   // 4 waves, 64x64 per wave (16 MFMAs per wave per 64-deep slice)
     default: return SMX_EINVAL;
   }
 }

@@ -78,6 +78,8 @@ GEMM16_CASES = [
     (2, 64, 32, 16, 3, 1, None, None, False, 0, 4, False, False, "tile4 N=32"),
     (1, 64, 128, 32, 3, 1, None, None, False, 0, 5, False, False, "tile5"),
     (1, 64, 64, 32, 3, 1, None, None, False, 0, 6, False, False, "tile6"),
+    (2, 128, 128, 32, 3, 1, None, None, False, 1, 7, False, False, "tile7 128x128 / 4 waves relu"),
+    (2, 256, 256, 32, 1, 1, None, None, False, 4, 7, False, True, "tile7 1x1 short K gelu fp32 out"),
     (2, 32, 32, 64, 3, 2, (0, 0), (32, 32), False, 0, 0, False, False, "stride 2 pad(0,1,0,1), Cin=32 (chunks inside a 64-slice)"),
     (2, 64, 64, 16, 3, 1, None, None, True, 0, 0, False, False, "nearest x2 folded"),
     (2, 256, 192, 32, 1, 1, None, None, False, 1, 0, False, False, "1x1 256->192 relu"),

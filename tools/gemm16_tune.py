@@ -27,11 +27,11 @@ def timed(fn, n=8):
     return e0.elapsed_time(e1) / n
 
 
-print("M N K : auto us | tile1 128x128/8w  tile2 128x64/4w  tile3 64x64/4w  tile4 128x32  tile5 64x128  tile6 256x64/8w   (GB/s of the best)")
+print("M N K : auto us | tile1 128x128/8w  tile2 128x64/4w  tile3 64x64/4w  tile4 128x32  tile5 64x128  tile6 256x64/8w  tile7 128x128/4w   (GB/s of the best)")
 for M, N, K in SHAPES:
     x = torch.randn((1, M // 256, 256, K), device="cuda").to(BF)
     cv = ops.Conv.from_torch(torch.randn((N, K, 1, 1), device="cuda") / K ** 0.5, torch.randn(N, device="cuda") * 0.1)
     out = torch.empty((1, M // 256, 256, N), device="cuda", dtype=BF)
-    ts = [timed(lambda t=t: ops.conv(x, cv, out=out, tile=t)) for t in (0, 1, 2, 3, 4, 5, 6)]
+    ts = [timed(lambda t=t: ops.conv(x, cv, out=out, tile=t)) for t in (0, 1, 2, 3, 4, 5, 6, 7)]
     best = min(ts[1:])
     print(f"{M:8d} {N:5d} {K:5d} : {1e3 * ts[0]:7.1f} | " + " ".join(f"{1e3 * t:7.1f}" for t in ts[1:]) + f"   best tile {ts.index(best)}  {2.0 * M * (N + K) / best / 1e6:6.0f} GB/s {2.0 * M * N * K / best / 1e9:5.0f} TF")
