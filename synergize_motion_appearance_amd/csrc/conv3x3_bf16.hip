@@ -96,14 +96,14 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   // HBM round trip in the middle of the tap loop.)
   float4 ssv[4];
   const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
-  auto chunk_ok = [&](int k, long long& g) __attribute__((always_inline)) -> bool {
+  auto chunk_ok = [&](int k, int& g) __attribute__((always_inline)) -> bool {   // in-image offsets fit 32 bits (launcher check)
     const int item = tid + NT * k;
     const int px = item >> CPPL, c8 = item & (CPP - 1);
     const int ry = px / RW, rx = px - ry * RW;
     int iy = by * TH - 1 + ry, ix = bx * TW - 1 + rx;
     const bool ok = item < RPX * CPP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     if (p.up2) { iy >>= 1; ix >>= 1; }
-    g = ((long long)iy * Ws_ + ix) * p.lda + c8 * 8;
+    g = (iy * Ws_ + ix) * p.lda + c8 * 8;
     return ok;
   };
   auto load_region = [&](int c0) __attribute__((always_inline)) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
     }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      long long g; const bool ok = chunk_ok(k, g);
+      int g; const bool ok = chunk_ok(k, g);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (ok) v = *reinterpret_cast<const uint4*>(X + g + c0);
       rreg[k] = v;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
       const int item = tid + NT * k;
       uint4 v = rreg[k];
       if (MODE >= 1) {
-        long long g; const bool ok = chunk_ok(k, g);
+        int g; const bool ok = chunk_ok(k, g);
         float f[8]; unpack8(v, f);
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int n = n0 + wr0 + 32 * i;
-      wreg[i] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (long long)n * p.ldw + tap * p.Cin + c0 + wc8 * 8) : make_uint4(0u, 0u, 0u, 0u);
+      wreg[i] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (n * p.ldw + tap * p.Cin + c0 + wc8 * 8)) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   auto store_w = [&](int buf) __attribute__((always_inline)) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
       for (int k = 0; k < NWC; ++k) {
         const int item = tid + NT * k, row = item >> CPPL, c4 = item & (CPP - 1);     // row = tap * 64 + n
         const int n = n0 + (row & 63);
-        wq[k] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (long long)n * p.ldw + (row >> 6) * p.Cin + c0 + c4 * 8) : make_uint4(0u, 0u, 0u, 0u);
+        wq[k] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (n * p.ldw + (row >> 6) * p.Cin + c0 + c4 * 8)) : make_uint4(0u, 0u, 0u, 0u);
       }
     };
     auto store_wslab = [&]() __attribute__((always_inline)) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int n = n0 + wr0 + 32 * i;
-        wr[i] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (long long)n * p.ldw + tap * p.Cin + s1 * CS + wc8 * 8) : make_uint4(0u, 0u, 0u, 0u);
+        wr[i] = n < p.Cout ? *reinterpret_cast<const uint4*>(p.w + (n * p.ldw + tap * p.Cin + s1 * CS + wc8 * 8)) : make_uint4(0u, 0u, 0u, 0u);
       }
     };
     auto stw = [&](const uint4 (&wr)[2], int buf) __attribute__((always_inline)) {
@@ -306,8 +306,12 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   const bool full = nc + 7 < p.Cout;
   const bool al = (p.ldc % 8 == 0) && ((((uintptr_t)p.y) & 15) == 0) &&
                   (!p.res || (p.res_f32 ? ((p.ldres % 4 == 0) && ((((uintptr_t)p.res) & 15) == 0)) : ((p.ldres % 8 == 0) && ((((uintptr_t)p.res) & 15) == 0))));
-  const bf16_t* __restrict__ R16 = reinterpret_cast<const bf16_t*>(p.res);
-  const float* __restrict__ R32 = reinterpret_cast<const float*>(p.res);
+  // per-image bases (64-bit once, wave-uniform); per-value offsets are 32-bit (H*W*ld < 2^31, launcher check)
+  const long long ipix = (long long)img * p.H * p.W;
+  const bf16_t* __restrict__ R16 = reinterpret_cast<const bf16_t*>(p.res) + ipix * p.ldres;
+  const float* __restrict__ R32 = reinterpret_cast<const float*>(p.res) + ipix * p.ldres;
+  const bf16_t* __restrict__ M16 = p.mul + ipix * p.ldmul;
+  bf16_t* __restrict__ Y16 = p.y + ipix * p.ldc;
   constexpr int NPASS = TH * TW / 32;                                    // pixels of the tile, 32 per pass
   // a bf16 residual is requested for ALL passes before the accumulators go through LDS: one HBM round trip overlapped with the
   // exchange instead of NPASS of them in sequence behind it
@@ -318,9 +322,9 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
       const int px = (tid >> 3) + 32 * it;
-      const long long opix = ((long long)img * p.H + by * TH + (px >> 4)) * p.W + bx * TW + (px & 15);
+      const int opix = (by * TH + (px >> 4)) * p.W + bx * TW + (px & 15);
       rq[it] = *reinterpret_cast<const uint4*>(R16 + opix * p.ldres + nc);
-      if (sft) mq[it] = *reinterpret_cast<const uint4*>(p.mul + opix * p.ldmul + nc);
+      if (sft) mq[it] = *reinterpret_cast<const uint4*>(M16 + opix * p.ldmul + nc);
     }
   }
   float bv[8];
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
     for (int it = 0; it < NPASS; ++it) {
       const int px = (tid >> 3) + 32 * it;
       const int oy = by * TH + (px >> 4), ox = bx * TW + (px & 15);
-      const long long opix = ((long long)img * p.H + oy) * p.W + ox;
+      const int opix = oy * p.W + ox;
       const float4 v0 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8);
       const float4 v1 = *reinterpret_cast<const float4*>(Cs + px * CLD + cq * 8 + 4);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
             }
           }
           const uint4 pk = pack8(v);
-          *reinterpret_cast<uint4*>(p.y + opix * p.ldc + nc) = pk;
+          *reinterpret_cast<uint4*>(Y16 + opix * p.ldc + nc) = pk;
           if (p.stats) unpack8(pk, v);                                   // statistics of the values as STORED (bf16-rounded)
         } else {
 #pragma unroll
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
             if (nc + e >= p.Cout) { v[e] = 0.f; continue; }
             if (p.res) v[e] += p.res_f32 ? R32[opix * p.ldres + nc + e] : bf2f(R16[opix * p.ldres + nc + e]);
             const bf16_t h = f2bf(v[e]);
-            p.y[opix * p.ldc + nc + e] = h;
+            Y16[opix * p.ldc + nc + e] = h;
             v[e] = bf2f(h);
           }
         }
@@ -451,6 +455,8 @@ static int conv3x3_bf16_launch(const void* x, int lda, const void* w, int ldw, c
   p.tiles_y = H / TH; p.tiles_x = W / TW;
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
+  if ((long long)H * W * ldc > 2147483647LL || (long long)H * W * (res ? ldres : 0) > 2147483647LL || (long long)H * W * (mul ? ldmul : 0) > 2147483647LL ||
+      (long long)Cout * ldw > 2147483647LL) return SMX_EINVAL;
   static bool attr = false;
   if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<16>::LDS_B)); attr = true; }
   p.ntiles = (int)blocks; p.tpb = 1;

@@ -568,21 +568,24 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   const bool vec_all = (p.ldc % 4 == 0) && ((((uintptr_t)Yp) & 15) == 0) && (!Rp || (p.ldres % 4 == 0 && (((uintptr_t)Rp) & 15) == 0)) &&
                        (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (p.Cout % NB == 0);
   float4 rr[2][2][2], mm[2][2][2];
-  long long pix[2];
-  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+  int pix[2];                                                        // in-image pixel index: per-image bases are 64-bit once (SGPRs), the
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);                       // per-value offsets 32-bit (H*W*ld < 2^31, checked by the launcher)
   const float* __restrict__ Mp = p.mul;                              // SFT epilogue (host guarantees res + the fast-path layout)
+  float* __restrict__ Yi = Yp + (long long)img * p.H * p.W * p.ldc;
+  const float* __restrict__ Ri = Rp ? Rp + (long long)img * p.H * p.W * p.ldres : nullptr;
+  const float* __restrict__ Mi = Mp ? Mp + (long long)img * p.H * p.W * p.ldmul : nullptr;
   if (vec_all) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int tile = (tid >> 4) + 16 * it;
-      pix[it] = ((long long)img * p.H + by * 8 + 2 * (tile >> 3)) * p.W + bx * 16 + 2 * (tile & 7);
+      pix[it] = (by * 8 + 2 * (tile >> 3)) * p.W + bx * 16 + 2 * (tile & 7);
       if (Rp) {
 #pragma unroll
         for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            rr[it][yy][q] = NT ? ld_stream(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq) : *reinterpret_cast<const float4*>(Rp + (pix[it] + yy * p.W + q) * p.ldres + nq);
-            if (Mp) mm[it][yy][q] = *reinterpret_cast<const float4*>(Mp + (pix[it] + yy * p.W + q) * p.ldmul + nq);
+            rr[it][yy][q] = NT ? ld_stream(Ri + (pix[it] + yy * p.W + q) * p.ldres + nq) : *reinterpret_cast<const float4*>(Ri + (pix[it] + yy * p.W + q) * p.ldres + nq);
+            if (Mp) mm[it][yy][q] = *reinterpret_cast<const float4*>(Mi + (pix[it] + yy * p.W + q) * p.ldmul + nq);
           }
       }
     }
@@ -648,8 +651,8 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
                                      r4.z + p.sft_w * (r4.z * m4.z + o[yy][q].z), r4.w + p.sft_w * (r4.w * m4.w + o[yy][q].w));
             }
             else if (Rp) { o[yy][q].x += rr[it][yy][q].x; o[yy][q].y += rr[it][yy][q].y; o[yy][q].z += rr[it][yy][q].z; o[yy][q].w += rr[it][yy][q].w; }
-            if (NT) st_stream(Yp + (pix[it] + yy * p.W + q) * p.ldc + nq, o[yy][q]);
-            else *reinterpret_cast<float4*>(Yp + (pix[it] + yy * p.W + q) * p.ldc + nq) = o[yy][q];
+            if (NT) st_stream(Yi + (pix[it] + yy * p.W + q) * p.ldc + nq, o[yy][q]);
+            else *reinterpret_cast<float4*>(Yi + (pix[it] + yy * p.W + q) * p.ldc + nq) = o[yy][q];
           }
         const float va4[4][4] = {{o[0][0].x, o[0][0].y, o[0][0].z, o[0][0].w}, {o[1][0].x, o[1][0].y, o[1][0].z, o[1][0].w},
                                  {o[0][1].x, o[0][1].y, o[0][1].z, o[0][1].w}, {o[1][1].x, o[1][1].y, o[1][1].z, o[1][1].w}};
@@ -796,6 +799,7 @@ static int winograd_launch(const float* x, int lda, const float* u_packed, const
   p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32; p.nt = smx_tune(SMX_TUNE_WINO_NT);
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
+  if ((long long)H * W * ldc > 2147483647LL || (long long)H * W * (res ? ldres : 0) > 2147483647LL || (long long)H * W * (mul ? ldmul : 0) > 2147483647LL) return SMX_EINVAL;
   if (16LL * ((Cout + 31) / 32) * (Cin / 8) * 256 > 2147483647LL) return SMX_EINVAL;
   const int nw_t = smx_tune(SMX_TUNE_WINO_NW);
   const int nw = (nw_t == 1 || nw_t == 2) ? nw_t : ((Cout % 64 == 0 && blocks * (Cout / 64) >= 1024) ? 2 : 1);
