@@ -693,3 +693,56 @@ def test_conv_sft_epilogue_equals_conv_then_sft_combine(ops, B, C, H, W, nw, tun
     # and it is the same value the unfused pair produces (identical conv, one rounding of the modulation)
     ref = ops.sft_combine(catd[..., C:], scale.cuda(), ops.conv(ssd[..., C:], cv), 0.7)
     assert maxabs(y, ref) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------
+# Size-independent properties AT THE BENCHMARK'S SIZES (B = 60 frames of 256x256: the oracle / F.conv2d on CPU are too slow
+# there, and these are the launches that pick the big-block kernel variants by themselves)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Cin,Cout,s", [(64, 64, 256), (128, 128, 128), (256, 512, 32)])
+def test_full_size_conv_linearity_and_locality(ops, Cin, Cout, s):
+    """B = 60 launches of the fused Winograd kernel (wide blocks selected by the launcher itself):
+    conv(a x + y) == a conv(x) + conv(y) - bias-free part (linearity), a zero input gives exactly the bias, and an
+    impulse in one frame leaves every other frame untouched (frames never mix)."""
+    B = 60
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn((B, s, s, Cin), device="cuda", generator=g)
+    y = torch.randn((B, s, s, Cin), device="cuda", generator=g)
+    cv = ops.Conv.from_torch(torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) / (3 * Cin ** 0.5), torch.randn(Cout, device="cuda", generator=g) * 0.1)
+    with ops.profile() as rec:
+        cx = ops.conv(x, cv)
+    assert [r[0] for r in rec.rows] == ["gemm_conv"] and rec.rows[0][1].get("wino") == 1
+    cy, cz = ops.conv(y, cv), ops.conv(torch.zeros_like(x), cv)
+    assert float((cz - cv.b.view(1, 1, 1, -1)).abs().max()) == 0.0                      # exact: every product is 0
+    lin = ops.conv(2.0 * x + y, cv)
+    err = float((lin - (2.0 * (cx - cz) + (cy - cz) + cz)).abs().max())
+    assert err < 5e-5 * max(1.0, float(cx.abs().max())), err
+    imp = torch.zeros_like(x)
+    imp[17, s // 2, s // 2, 3] = 1.0
+    ci = ops.conv(imp, cv) - cz
+    assert float(ci[:17].abs().max()) == 0.0 and float(ci[18:].abs().max()) == 0.0      # other frames: bias only
+    lit = ci[17].abs().amax(-1) > 0
+    assert int(lit.sum()) == 9 and bool(lit[s // 2 - 1:s // 2 + 2, s // 2 - 1:s // 2 + 2].all())   # exactly the 3x3 support
+
+
+def test_full_size_attention_and_vq_invariants(ops):
+    """B = 60: attention with all keys equal returns V's mean regardless of the queries (d_head 4 MFMA kernel and d_head 32);
+    a one-hot-dominant key returns its value row; VQ of codebook rows returns their own indices (idempotence) at N = 61,440."""
+    B, H, N = 60, 8, 1024
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for dh in (4, 32):
+        E = H * dh
+        q = torch.randn((B, N, E), device="cuda", generator=g)
+        k = torch.zeros((B, 256, E), device="cuda")
+        v = torch.randn((B, 256, E), device="cuda", generator=g)
+        o = ops.attention(q, k, v, H, dh, 256)
+        assert float((o - v.mean(1, keepdim=True)).abs().max()) < 2e-6
+        k2 = torch.zeros((B, 256, E), device="cuda")
+        k2[:, 77] = 100.0                                                         # score of query 0 (all ones) with key 77: 100 * sqrt(d_head) >= 200
+        q[:, 0] = 1.0
+        o2 = ops.attention(q, k2, v, H, dh, 256)
+        assert float((o2[:, 0] - v[:, 77]).abs().max()) < 1e-3
+    cb = torch.randn((1024, 256), device="cuda", generator=g)
+    idx = torch.randint(0, 1024, (B * 1024,), device="cuda", generator=g)
+    got, zq, dmin, _ = ops.vq_nearest(cb[idx].contiguous(), cb, 1024)
+    assert torch.equal(got.view(-1), idx) and torch.equal(zq, cb[idx]) and float(dmin.abs().max()) < 1e-3
