@@ -91,9 +91,10 @@ def imwrite(img, file_path, params=None, auto_mkdir=True):
     return True
 
 
-def mimsave(visualizations, file_path, auto_mkdir=True):
+def mimsave(visualizations, file_path, auto_mkdir=True, fps=None):
     """list of RGB uint8 frames -> video file (reference `mimsave`, img_util.py:157-173 =
-    imageio.mimwrite). Without imageio the frames are written as `<file_path>.frames/%06d.png`."""
+    imageio.mimwrite; `fps` as demo.py:222 passes it). Without imageio the frames are written as
+    `<file_path>.frames/%06d.png` and that folder's path is returned."""
     import os
     if auto_mkdir:
         os.makedirs(os.path.abspath(os.path.dirname(file_path)), exist_ok=True)
@@ -107,7 +108,7 @@ def mimsave(visualizations, file_path, auto_mkdir=True):
             with open(os.path.join(d, f"{i:06d}.png"), "wb") as f:
                 f.write(encode_png(np.asarray(fr)))
         return d
-    return imageio.mimwrite(file_path, visualizations)
+    return imageio.mimwrite(file_path, visualizations, **({} if fps is None else {"fps": fps}))
 
 
 def resize_linear(img, size):

@@ -334,3 +334,44 @@ def test_graft_entry_build_then_smoke_in_a_fresh_process():
                        text=True, timeout=600, cwd=repo)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "smoke: one 256x256 frame" in r.stdout
+
+
+def test_demo_entry_from_png_folder_end_to_end(nets, tmp_path):
+    """`basicsr/demo.py` with the reference's command line: checkpoints named in the yml, a PNG source, a folder of PNG driving
+    frames, --relative --adapt_scale --best_frame: the frames it writes are exactly what `animate_batched` renders from the
+    same uint8 inputs (anchor semantics = the reference's backward/forward splice, demo.py:205-216), and --visual_video
+    holds [source | driving | result] panels."""
+    import importlib.util
+    from synergize_motion_appearance_amd import ops
+    from synergize_motion_appearance_amd.driver import animate_batched
+    from synergize_motion_appearance_amd.png import encode_png, decode_png
+    net_g, me = nets
+    src, drv = clip()
+    to_u8 = lambda t: ((t.clamp(-1, 1) + 1) * 127.5).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous().numpy()
+    s8, d8 = to_u8(src[None])[0], to_u8(drv)
+    (tmp_path / "source.png").write_bytes(encode_png(s8))
+    os.makedirs(tmp_path / "drv")
+    for i, f in enumerate(d8):
+        (tmp_path / "drv" / f"{i:03d}.png").write_bytes(encode_png(f))
+    torch.save({"params_ema": {"module." + k: v.cpu() for k, v in net_g.state_dict().items()}}, tmp_path / "g.pth")
+    torch.save({"params": {k: v.cpu() for k, v in me.state_dict().items()}}, tmp_path / "m.pth")
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/test.yml")))
+    cfg["path"] = {"pretrain_network_g": str(tmp_path / "g.pth"), "param_key_g": "params_ema", "strict_load_g": True,
+                   "pretrain_network_motion_estimator": str(tmp_path / "m.pth"), "strict_load_motion_estimator": True}
+    yaml.safe_dump(cfg, open(tmp_path / "demo.yml", "w"))
+    spec = importlib.util.spec_from_file_location("smx_demo", os.path.join(REPO, "basicsr", "demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    out = demo.main(["--config", str(tmp_path / "demo.yml"), "--source_image", str(tmp_path / "source.png"), "--driving_video", str(tmp_path / "drv"),
+                     "--result_video", str(tmp_path / "res.mp4"), "--visual_video", str(tmp_path / "vis.mp4"), "--relative", "--adapt_scale",
+                     "--best_frame", "3", "--batch", "4"])
+    assert out.shape == (drv.shape[0], 256, 256, 3) and out.dtype == np.uint8
+    norm = lambda a: ops.frames_u8_to_nchw(torch.from_numpy(a).cuda(), (256, 256))
+    ref = animate_batched(norm(s8[None])[0], norm(d8), net_g, me, True, True, batch=4, anchor_idx=3).cpu().numpy()
+    assert np.array_equal(out, ref)                                # same kernels at the same batch size: identical bytes
+    written = sorted(os.listdir(str(tmp_path / "res.mp4") + ".frames")) if os.path.isdir(str(tmp_path / "res.mp4") + ".frames") else None
+    if written is not None:                                        # no imageio here: PNG frames beside the requested name
+        assert len(written) == drv.shape[0]
+        assert np.array_equal(decode_png(open(os.path.join(str(tmp_path / "res.mp4") + ".frames", written[2]), "rb").read()), out[2])
+        vis = decode_png(open(os.path.join(str(tmp_path / "vis.mp4") + ".frames", written[2]), "rb").read())
+        assert vis.shape == (256, 768, 3) and np.array_equal(vis[:, 512:], out[2]) and np.array_equal(vis[:, 256:512], d8[2]) and np.array_equal(vis[:, :256], s8)

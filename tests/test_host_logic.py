@@ -218,3 +218,40 @@ def test_standalone_registered_names_have_the_reference_checkpoint_layout():
         build_network(STANDALONE_OPTS["KPDetector"]).eval()(torch.zeros(1, 3, 256, 256))
     with pytest.raises(NotImplementedError):
         build_network(STANDALONE_OPTS["VQGANDiscriminator"])(torch.zeros(1, 3, 64, 64))      # train mode = SURVEY row N2
+
+
+def test_demo_entry_command_line_readers_and_refusals(tmp_path):
+    """basicsr/demo.py: the reference's flags parse (demo.py:136-160), a PNG-folder clip and a PNG source are read as uint8 RGB,
+    a DataParallel-style checkpoint loads strictly (demo.py:58-71), and what the path cannot do is refused loudly: --cpu
+    (no CPU fallback), --find_best_frame without an index (needs face_alignment)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("smx_demo", os.path.join(os.path.dirname(HERE), "basicsr", "demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    o = demo.cli(["--config", "c.yml", "--source_image", "s.png", "--driving_video", "d", "--result_video", "r.mp4", "--relative",
+                  "--adapt_scale", "--best_frame", "2", "--visual_video", "v.mp4"])
+    assert (o.relative, o.adapt_scale, o.best_frame, o.visual_video, o.find_best_frame, o.cpu, o.audio) == (True, True, 2, "v.mp4", False, False, False)
+    d = demo.cli(["--config", "c.yml"])
+    assert (d.source_image, d.driving_video, d.result_video, d.relative, d.adapt_scale) == ("source.png", "driving.mp4", "result.mp4", False, False)
+    from synergize_motion_appearance_amd.png import encode_png
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (3, 20, 24, 3), dtype=np.uint8)
+    os.makedirs(tmp_path / "clip")
+    for i, f in enumerate(frames):
+        (tmp_path / "clip" / f"{i:04d}.png").write_bytes(encode_png(f))
+    (tmp_path / "gray.png").write_bytes(encode_png(frames[0, :, :, 0]))
+    clip, fps = demo.read_clip(str(tmp_path / "clip"))
+    assert clip.dtype == np.uint8 and np.array_equal(clip, frames) and fps == demo.DEFAULT_FPS
+    g = demo.read_rgb(str(tmp_path / "gray.png"))
+    assert g.shape == (20, 24, 3) and np.array_equal(g[..., 1], frames[0, :, :, 0])
+    os.makedirs(tmp_path / "empty")
+    with pytest.raises(RuntimeError):
+        demo.read_clip(str(tmp_path / "empty"))                # a folder without frames
+    lin = torch.nn.Linear(3, 2)
+    torch.save({"params_ema": {"module." + k: v for k, v in lin.state_dict().items()}}, tmp_path / "ck.pth")
+    lin2 = demo.load_checkpoint(torch.nn.Linear(3, 2), str(tmp_path / "ck.pth"), True, "params_ema")
+    assert all(torch.equal(a, b) for a, b in zip(lin.state_dict().values(), lin2.state_dict().values()))
+    with pytest.raises(SystemExit, match="no CPU mode"):
+        demo.main(["--config", os.path.join(os.path.dirname(HERE), "options", "test.yml"), "--cpu"])
+    with pytest.raises(SystemExit, match="face_alignment"):
+        demo.main(["--config", os.path.join(os.path.dirname(HERE), "options", "test.yml"), "--find_best_frame"])
