@@ -7,12 +7,15 @@
 //     region is staged once into LDS (GroupNorm(+swish) of the producer and the nearest-x2 upsampling folded into the
 //     staging pass) and ALL NINE taps read their MFMA A operands straight out of it: im2col never exists, not even in LDS
 //     (the implicit-GEMM kernel stages 9 shifted copies: 9x the global->LDS traffic for the same bytes);
-//   * only the weights stream per tap: a [64 n][64 k] bf16 tile (8 KB) per (slice, tap), double buffered, one barrier per tap;
+//   * weights: the big launches (16x16 tiles, SLAB) keep ALL NINE taps' [64 n][32 k] tiles of a 32-channel slice in LDS -- one staging
+//     phase and two barriers per 72 MFMAs per wave; the small ones (8x16 tiles, 3 blocks / CU) stream a [64 n][64 k] tile per tap,
+//     double buffered, one barrier per tap;
 //   * 4 waves, each 64 pixels x 64 channels (2 x 2 MFMA tiles of 32x32x16): 1 KB of LDS reads per MFMA;
 //   * the epilogue transposes the accumulators through LDS and stores 16-B chunks of 8 channels (bias / activation / residual
 //     fused) and can emit the Welford partials {mean, M2} of the stored tile for the NEXT GroupNorm (stats_part), so a
 //     ResBlock's activations are read by the convolutions only.
-// LDS: region 18*18 px * 144 B = 46.7 KB + 2 x 9.2 KB weights (the epilogue's 256 x 68 fp32 tile reuses it: 69.6 KB) -> 2 blocks / CU.
+// LDS: SLAB 18*18 px * 80 B + 9 * 64 * 80 B = 72 KB (the epilogue's 256 x 68 fp32 tile reuses it) -> 2 blocks / CU; per-tap form:
+// region 46.7 KB (25.9 KB at 8x16) + 2 x 9.2 KB weights.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>

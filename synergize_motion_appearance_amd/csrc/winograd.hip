@@ -5,8 +5,11 @@
 // of 36: 2.25x fewer MFMA passes than the direct implicit GEMM, at fp32 accuracy (transform
 // coefficients are 0, +-1, +-1/2).  Everything is fused -- no transformed tensor touches HBM:
 //
-//   * a block owns 32 output tiles (4x8 tiles = 8x16 output pixels of one image) x 64 output
-//     channels and ALL 16 Winograd frequencies; 8 waves = 4 frequency rows i x 2 N-halves;
+//   * a block owns 32 output tiles (4x8 tiles = 8x16 output pixels of one image) x 32 or 64 output
+//     channels and ALL 16 Winograd frequencies.  Three block shapes: `winograd_wide_kernel` (the big
+//     launches: 4 waves = 4 frequency rows, each wave BOTH 32-wide N tiles, 256-VGPR budget),
+//     `winograd_kernel<1>` (4 waves, N = 32, 3 blocks / CU: small launches and C_out % 64 != 0),
+//     `winograd_kernel<2>` (8 waves = 4 frequency rows x 2 N tiles: selectable, superseded by wide);
 //   * per 32-channel slice the raw 10x18-pixel input region is staged ONCE, coalesced, into LDS
 //     (double buffered, one barrier per slice = 64 MFMAs per wave per barrier);
 //   * the input transform is wave-private and register-resident: lane l owns tile (l&31) and
@@ -15,8 +18,9 @@
 //     forms V[i][0..3] with 8 float4 add/subs; no transpose, no second LDS trip;
 //   * U = G g G^T is precomputed at weight-pack time and stored fragment-ordered
 //     ([f][n/32][c/8][lane][4]), so a wave's B fragment is one fully coalesced 1 KiB load;
-//   * epilogue: Z_i = M_i. A (in registers), cross-frequency-row sum through LDS, then bias /
-//     activation / residual and coalesced NHWC stores.
+//   * epilogue: Z_i = M_i. A (in registers), ONE cross-frequency-row exchange through LDS (accumulators are
+//     [n][tile], so it is ds_write_b128), then bias / activation / residual (or the SFT modulation) and
+//     coalesced NHWC float4 stores; optionally the Welford partials of the stored tile for the next GroupNorm.
 // Optional virtual nearest-x2 upsampling of the input (Upsample blocks) is folded into the region
 // loader.  Replaces the same reference call sites as smx_gemm_conv_f32 for eligible layers.
 #include <hip/hip_runtime.h>
