@@ -331,8 +331,9 @@ def main():
             if dom == "winograd" and "winograd_wide" in mfma_pmc["kernels"]:
                 roof["mfma_pmc_b60_launches"] = mfma_pmc["kernels"]["winograd_wide"]          # the wide kernel = the B=60 launches alone
         result["roofline"] = roof
-        conv_ms = sum(fam[k]["ms"] for k in ("winograd", "gemm_conv") if k in fam)
-        conv_fl = sum(fam[k]["flops"] for k in ("winograd", "gemm_conv") if k in fam)
+        mm = ("winograd", "gemm_conv", "gemm_bf16", "conv3x3_bf16")          # every convolution / GEMM family of either dtype
+        conv_ms = max(sum(fam[k]["ms"] for k in mm if k in fam), 1e-9)
+        conv_fl = sum(fam[k]["flops"] for k in mm if k in fam)
         result["conv_gemm_family"] = {"algorithmic_gflop_per_frame": round(conv_fl / nprof / B / 1e9, 2),
                                       "share_of_step_time": round(conv_ms / nprof / step_ms, 3),
                                       "algorithmic_TFLOPs": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
