@@ -44,6 +44,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfm
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
 CLIP = 300                       # frames of the driving clip (BASELINE.json configs[1])
+PROFILE_TAG = "r03"              # profiles/<tag>_{traffic,mfma}_pmc[_bf16].json: the committed counter summaries this run quotes
 
 
 def build_nets(device):
@@ -58,41 +59,69 @@ def build_nets(device):
     return net_g.to(device).eval(), me.to(device).eval(), Pg, Pm
 
 
+def _pin_process_to(cpus):
+    """taskset-style: confine EVERY thread of this process (the OpenMP / ATen pool threads already exist) to `cpus`;
+    returns the previous per-thread masks so the caller can restore them."""
+    prev = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            prev[int(tid)] = os.sched_getaffinity(int(tid))
+            os.sched_setaffinity(int(tid), cpus)
+        except OSError:
+            pass
+    return prev
+
+
 def cpu_baseline(Pg, Pm, src, drv, frames=20, warmup=2, threads=None):
     """SURVEY 8(d) protocol: the oracle port of demo.make_animation (B=1, sequential), warm-up 2 frames, MEDIAN of
-    >= 20 per-frame times; once as the reference runs it (source re-encoded every frame, demo.py:130) and once with
-    the source encoder cached; host core count and thread count printed."""
+    >= 20 per-frame times (p10 / p90 beside it); once as the reference runs it (source re-encoded every
+    frame, demo.py:130) and once with the source encoder cached; host core count and thread count printed.  The process is
+    confined to `cores` CPUs for the duration (one thread per CPU): on a shared 256-CPU host the unpinned pool migrated
+    between sockets and the figure moved 0.77-1.25 fps between runs."""
     from oracle import reenact_oracle as O
     host = os.cpu_count() or 1
-    cores = threads or min(host, 32)       # torch CPU convolutions stop scaling (and thrash) far below 256 threads
+    allowed = sorted(os.sched_getaffinity(0))
+    cores = min(threads or 32, len(allowed))   # torch CPU convolutions stop scaling (and thrash) far below 256 threads
+    cpus = set(allowed[:cores])
+    prev = _pin_process_to(cpus)
     torch.set_num_threads(cores)
-    with torch.no_grad():
-        s = src.unsqueeze(0)
-        kp_s = O.kp_detector(Pm, s)
-        kp_0 = O.kp_detector(Pm, drv[0:1])
-        enc = O.encode_source(Pg, s)
+    try:
+        with torch.no_grad():
+            s = src.unsqueeze(0)
+            kp_s = O.kp_detector(Pm, s)
+            kp_0 = O.kp_detector(Pm, drv[0:1])
+            enc = O.encode_source(Pg, s)
 
-        def one(t, cached):
-            kp_d = O.kp_detector(Pm, drv[t:t + 1])
-            kp_n = O.normalize_kp(kp_s, kp_d, kp_0, True, True, True)
-            dm = O.dense_motion(Pm, s, kp_n, kp_s)
-            return O.tensor2img(O.netg_forward(Pg, s, dm, enc=enc if cached else None)["out"])
+            def one(t, cached):
+                kp_d = O.kp_detector(Pm, drv[t:t + 1])
+                kp_n = O.normalize_kp(kp_s, kp_d, kp_0, True, True, True)
+                dm = O.dense_motion(Pm, s, kp_n, kp_s)
+                return O.tensor2img(O.netg_forward(Pg, s, dm, enc=enc if cached else None)["out"])
 
-        def run(cached):
-            for t in range(warmup):
-                one(t, cached)
-            ts = []
-            for t in range(frames):
-                t0 = time.perf_counter()
-                one((warmup + t) % drv.shape[0], cached)
-                ts.append(time.perf_counter() - t0)
-            return ts
-        t_ref, t_cached = run(False), run(True)
-    med, medc = statistics.median(t_ref), statistics.median(t_cached)
-    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "host_cpu_count": host, "kind": "port",
-            "value_cached_encoder": round(1.0 / medc, 4),
-            "sample": f"median of {frames} per-frame times after {warmup} warm-up frames of the same 256x256 clip, B=1 sequential, "
-                      f"torch CPU fp32, {cores} threads on a {host}-CPU host; value: source re-encoded per frame "
+            def run(cached):
+                for t in range(warmup):
+                    one(t, cached)
+                ts = []
+                for t in range(frames):
+                    t0 = time.perf_counter()
+                    one((warmup + t) % drv.shape[0], cached)
+                    ts.append(time.perf_counter() - t0)
+                return ts
+            t_ref, t_cached = run(False), run(True)
+    finally:
+        for tid, mask in prev.items():
+            try:
+                os.sched_setaffinity(tid, mask)
+            except OSError:
+                pass
+    a, c = summarise_cpu_times(t_ref), summarise_cpu_times(t_cached)
+    return {"value": round(1.0 / a["median_s"], 4), "unit": "frames/s", "cores": cores, "host_cpu_count": host, "kind": "port",
+            "value_p10_p90": [round(1.0 / a["p90_s"], 4), round(1.0 / a["p10_s"], 4)],
+            "value_cached_encoder": round(1.0 / c["median_s"], 4),
+            "value_cached_encoder_p10_p90": [round(1.0 / c["p90_s"], 4), round(1.0 / c["p10_s"], 4)],
+            "pinned_cpus": f"{min(cpus)}-{max(cpus)}",
+            "sample": f"median (p10/p90 beside it) of {frames} per-frame times after {warmup} warm-up frames of the same 256x256 clip, B=1 sequential, "
+                      f"torch CPU fp32, {cores} threads confined to {cores} CPUs of a {host}-CPU host; value: source re-encoded per frame "
                       f"(demo.py:117-131 semantics), value_cached_encoder: source encoder computed once; "
                       f"{sum(t_ref) + sum(t_cached):.1f} s of timed CPU work"}
 
@@ -123,51 +152,29 @@ def load_profile_json(name):
     return json.load(open(p)) if os.path.exists(p) else None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=60, help="driving frames per step per GPU (frames in flight); 5 steps x 60 = the 300-frame clip")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32: BASELINE configs[1] (headline); bf16: configs[2] storage/MFMA dtype")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-d2h", action="store_true")
-    ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")
-    args = ap.parse_args()
+def summarise_cpu_times(ts):
+    ts = sorted(ts)
+    q = lambda f: ts[min(len(ts) - 1, max(0, int(round(f * (len(ts) - 1)))))]   # noqa: E731
+    return {"median_s": statistics.median(ts), "p10_s": q(0.1), "p90_s": q(0.9)}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the HIP path)"
-    one_device = bool(os.environ.get("SMX_BENCH_ONE_DEVICE"))   # test knob: exercise the N>1 control flow on a 1-GPU box
-    if one_device:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist, collective = (None, None) if world == 1 else init_distributed(rank, world, dev)
 
-    from synergize_motion_appearance_amd import ops, driver
-    from synergize_motion_appearance_amd.synth import synth_clip
-
-    net_g, me, Pg, Pm = build_nets(dev)
-    if args.dtype == "bf16":
-        net_g.set_compute_dtype("bf16")
-        me.set_compute_dtype("bf16")
+def render_leg(args, dtype, world, rank, dev, dist, collective, net_g, me, drv, my_sources, n_src):
+    """one measured leg in `dtype` storage: prologue + W warm-up steps, then barrier | prologue + K steps | barrier, max over ranks;
+    followed by the B=1 re-render check of the last timed batch.  -> dict with the timing, the states and the step closure."""
+    from synergize_motion_appearance_amd import driver
     B, K, W = args.batch, args.steps, args.warmup
-    # N sources (seeds 123, 124, ...), one driving clip shared by all of them (device resident before timing)
-    src_cpu, drv_cpu = synth_clip(CLIP, seed=123)
-    drv = drv_cpu.to(dev)
-    n_src = world
-    my_sources = {j: (src_cpu if j == 0 else synth_clip(1, seed=123 + j)[0]).unsqueeze(0).to(dev) for j in range(n_src) if j % world == rank}
+    net_g.set_compute_dtype(dtype)
+    me.set_compute_dtype(dtype)
     total_units = n_src * CLIP
+    strong = bool(args.strong)
 
     def segments(step_idx):
-        """this rank's B units of the global window `step_idx` -> [(source j, frames tensor)] (views of the clip where contiguous)."""
-        a, b = driver.shard_frames(world * B, rank, world)
-        u0, segs = step_idx * world * B + a, []
+        """this rank's units of the global window `step_idx` -> [(source j, frames tensor)] (views of the clip where contiguous).
+        weak (default): the window is world*B consecutive (source, frame) units, B per rank.  strong: the window is B frames
+        of ONE source (the 300-frame clip), B/world per rank (config 2 -> 8 GPUs, 37/38 frames per GPU)."""
+        win = B if strong else world * B
+        a, b = driver.shard_frames(win, rank, world)
+        u0, segs = step_idx * win + a, []
         n = b - a
         while n > 0:
             u = u0 % total_units
@@ -181,13 +188,15 @@ def main():
     states = {}
 
     def prologue():
-        """frame-invariant work of the job: every source is encoded once, by its owner (+ one RCCL broadcast each for N>1)."""
-        for j in range(n_src):
-            if world > 1:
-                owner = j % world
-                states[j] = driver.broadcast_source_state(net_g, me, my_sources.get(j), drv[0:1] if owner == rank else None, True,
-                                                          src=owner, device=dev)
-            else:
+        """frame-invariant work of the job: every source is encoded once, by its owner.  N>1: each rank encodes the sources it
+        owns FIRST, then all broadcasts are issued asynchronously and waited for together (driver.broadcast_source_states) -- no
+        host synchronisation between sources, the hull ratio stays on the device."""
+        if world > 1:
+            owners = {j: j % world for j in range(n_src)}
+            owned = {j: (my_sources[j], drv[0:1]) for j in my_sources}
+            states.update(driver.broadcast_source_states(net_g, me, owned, owners, True, device=dev))
+        else:
+            for j in range(n_src):
                 states[j] = driver.encode_source_state(net_g, me, my_sources[j], drv[0:1], True)
 
     def step(segs):
@@ -208,161 +217,151 @@ def main():
     prologue()
     for i in range(K):
         out = step(work[W + i])
+    torch.cuda.synchronize()
+    my_dt = time.perf_counter() - t0                       # this rank's own time (before the closing barrier): stragglers show here
     barrier()
     dt = time.perf_counter() - t0
+    rank_times = [my_dt]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if collective == "RCCL" else "cpu")
+        cdev = dev if collective == "RCCL" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert out.shape == (B, 256, 256, 3) and out.dtype == torch.uint8
-    fps = world * K * B / dt
+        mine = torch.tensor([my_dt], dtype=torch.float64, device=cdev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        rank_times = [float(x.item()) for x in allt]
+    n_mine = sum(fr.shape[0] for _, fr in work[W + K - 1])
+    assert out.shape == (n_mine, 256, 256, 3) and out.dtype == torch.uint8
+    frames_total = (K * B) if strong else (world * K * B)
+    fps = frames_total / dt
 
     # the benchmark's own batch, checked: first / middle / last frame of the last timed batch re-rendered at B=1
-    (j_last, fr_last) = work[W + K - 1][-1]
-    off = B - fr_last.shape[0]
-    picks = sorted({0, fr_last.shape[0] // 2, fr_last.shape[0] - 1})
-    worst, ndiff, ntot, dsum = 0, 0, 0, 0.0
-    for i in picks:
-        one = driver.render_frames(states[j_last], fr_last[i:i + 1], net_g, me, True, True, batch=1)
-        d = (one[0].int() - out[off + i].int()).abs()
-        worst, ndiff, ntot, dsum = max(worst, int(d.max())), ndiff + int((d > 0).sum()), ntot + d.numel(), dsum + float(d.sum())
-    consistency = {"frames_checked": len(picks), "max_lsb_vs_b1": worst, "mean_lsb_vs_b1": round(dsum / ntot, 5), "bytes_differing": ndiff,
-                   "bytes": ntot, "what": f"frames {picks} of the last timed batch (B={B}) re-rendered one at a time; uint8 outputs compared"}
-    # fp32: another batch size only reorders fp32 sums (<= 1 LSB).  bf16 storage: a reordered sum can round to the other
-    # neighbour (2^-8) and the flip propagates through ~100 layers, so two bf16 evaluations are as far from each other as
-    # each is from fp32; the bar there is the reference-under-autocast error (tests/golden/autocast_bf16.npz: mean 0.0078,
-    # max 0.33 on [-1,1] = 1.0 / 42 LSB): mean < 1.5 LSB, worst pixel <= 42 LSB
-    bad = worst > 1 if args.dtype == "f32" else (dsum / ntot >= 1.5 or worst > 42)
-    if bad:
-        raise SystemExit(f"[bench] batch consistency FAILED: B={B} output differs from B=1 by {worst} LSB (mean {dsum / ntot:.3f})")
+    consistency = None
+    if not args.no_consistency:
+        (j_last, fr_last) = work[W + K - 1][-1]
+        off = n_mine - fr_last.shape[0]
+        picks = sorted({0, fr_last.shape[0] // 2, fr_last.shape[0] - 1})
+        worst, ndiff, ntot, dsum = 0, 0, 0, 0.0
+        for i in picks:
+            one = driver.render_frames(states[j_last], fr_last[i:i + 1], net_g, me, True, True, batch=1)
+            d = (one[0].int() - out[off + i].int()).abs()
+            worst, ndiff, ntot, dsum = max(worst, int(d.max())), ndiff + int((d > 0).sum()), ntot + d.numel(), dsum + float(d.sum())
+        consistency = {"frames_checked": len(picks), "max_lsb_vs_b1": worst, "mean_lsb_vs_b1": round(dsum / ntot, 5), "bytes_differing": ndiff,
+                       "bytes": ntot, "what": f"frames {picks} of the last timed batch (B={n_mine}) re-rendered one at a time; uint8 outputs compared"}
+        # fp32: another batch size only reorders fp32 sums (<= 1 LSB).  bf16 storage: a reordered sum can round to the other
+        # neighbour (2^-8) and the flip propagates through ~100 layers, so two bf16 evaluations are as far from each other as
+        # each is from fp32; the bar there is the reference-under-autocast error (tests/golden/autocast_bf16.npz: mean 0.0078,
+        # max 0.33 on [-1,1] = 1.0 / 42 LSB): mean < 1.5 LSB, worst pixel <= 42 LSB
+        bad = worst > 1 if dtype == "f32" else (dsum / ntot >= 1.5 or worst > 42)
+        if bad:
+            raise SystemExit(f"[bench] batch consistency FAILED ({dtype}): B={n_mine} output differs from B=1 by {worst} LSB (mean {dsum / ntot:.3f})")
+    return {"dt": dt, "fps": fps, "frames_total": frames_total, "rank_times": rank_times, "consistency": consistency, "states": states,
+            "work": work, "step": step, "total_units": total_units}
 
-    dname = {"f32": "f32", "bf16": "bf16"}[args.dtype]
-    cfg_ix = 1 if (world == 1 and args.dtype == "f32") else 2
-    result = {
-        "metric": "reenactment frames/sec at 256x256", "value": round(fps, 3), "unit": "frames/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
-        "config": {"workload": (f"BASELINE.json configs[{cfg_ix}]: 256x256, {n_src} source(s) x 300-frame driving clip, {dname}, options/test.yml, "
-                                "name-keyed random-init weights"), "frames_per_step": B, "frames_total": world * K * B,
-                   "sources": n_src,
-                   "parallelism": (f"{n_src} sources x {CLIP} frames = {total_units} (source, frame) units; each step's window of {world * B} "
-                                   f"units sharded x{world} (driver.shard_frames); one {collective} broadcast per source of its packed "
-                                   f"frame-invariant state ({4 * driver.cache_numel(net_g.engine().adt) / 1e6:.1f} MB) from the owner rank, inside the timed region")
-                   if world > 1 else "1 GPU",
-                   "relative": True, "adapt_movement_scale": True, "output": "uint8 HWC frames in HBM"},
-        "batch_consistency": consistency,
-    }
-    if one_device:
-        result["config"]["one_device_test_knob"] = True
 
-    # ---- PCIe-inclusive figures (SURVEY 8d config 2: "separately incl. uint8 D2H"; row N3): the same K steps through
-    # driver.FramePipeline -- uint8 frames from pinned host memory (1 B/sample H2D), resize/normalise on the device, render,
-    # uint8 frames back to pinned host memory; H2D of batch i+1 and D2H of batch i-1 overlap the compute of batch i.  Never `value`.
-    if rank == 0 and not args.no_d2h:
-        j0 = work[W][0][0]
-        u8 = ops.to_uint8(drv.permute(0, 2, 3, 1).contiguous(), -1.0, 1.0).cpu()            # the clip as a decoder would deliver it
-        reps = (K * B + CLIP - 1) // CLIP
-        host_in = (u8 if reps == 1 else u8.repeat(reps, 1, 1, 1))[:K * B].contiguous().pin_memory()
-        host_out = torch.empty((K * B, 256, 256, 3), dtype=torch.uint8).pin_memory()
-        pipe = driver.FramePipeline(net_g, me, batch=B)
-        pipe.run(states[j0], host_in[:B], host_out[:B])                                    # warm the staging path
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        pipe.run(states[j0], host_in, host_out)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        result["value_incl_pcie"] = round(K * B / dt2, 3)
-        result["value_incl_pcie_note"] = ("this rank's frames/s host-to-host: uint8 frames H2D from pinned memory (196,608 B/frame), uint8 -> fp32 "
-                                          "normalisation on the device, render, uint8 frames D2H to pinned memory, copies overlapped with compute on "
-                                          "separate streams (driver.FramePipeline); source state already resident; per GPU")
-    if dist is not None:
-        dist.barrier()
-
-    if rank == 0 and not args.no_roofline:
-        nprof = min(K, 3)
-        with ops.profile() as rec:
-            for i in range(nprof):
-                step(work[W + i])
-        step_ms = 1e3 * dt / K
-        fam = {}
-        for name, meta, ms in rec.rows:
-            meta = meta or {}
-            key = "winograd" if meta.get("wino") else name
-            f = fam.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "mfma_flops": 0.0})
-            f["calls"] += 1
-            f["ms"] += ms
-            f["flops"] += meta.get("flops", 0.0)
-            f["mfma_flops"] += meta.get("mfma_flops", meta.get("flops", 0.0))
-            f["bytes"] += meta.get("bytes", 0.0)
-        sfx = "" if args.dtype == "f32" else "_bf16"
-        traffic = load_profile_json(f"r02_traffic_pmc{sfx}.json")
-        tfam = (traffic or {}).get("families", {}) if B == 60 else {}
-        mfma_pmc = load_profile_json(f"r02_mfma_pmc{sfx}.json") if B == 60 else None
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        dom = max((k for k in fam if fam[k]["mfma_flops"] > 0), key=lambda k: fam[k]["ms"])
-        g = fam[dom]
-        tf_exec = g["mfma_flops"] / (g["ms"] * 1e-3) / 1e12
-        tf_alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        kname = {"winograd": "winograd_wide_kernel / winograd_kernel<..> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
-                 "conv3x3_bf16": "conv3x3_bf16_kernel<TH> (region-direct 3x3/s1/p1 convolution, v_mfma_f32_32x32x16_bf16)",
-                 "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x2_f32)",
-                 "gemm_bf16": "gemm_bf16_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom)
-        if dom.startswith("attention"):
-            peak = PEAK_F32_MFMA_TFLOPS                      # the attention cores run on the fp32 MFMA in both storage modes
-        roof = {
-            "kernel": kname, "bound": "mfma", "achieved": round(tf_exec, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(tf_exec / peak, 4),
-            "traffic": round(tfam[dom]["hbm_bytes_per_launch"]) if dom in tfam else None,
-            "achieved_algorithmic": round(tf_alg, 2),
-            "note": ("achieved/frac = flops the matrix cores EXECUTE in this kernel (2*M*N*16/4*Cin per launch for F(2x2,3x3): 16 multiplies per "
-                     "2x2 output tile and channel) / its summed launch time; achieved_algorithmic = the direct convolution's 2*M*N*9*Cin over "
-                     "the same time (2.25x the executed rate by construction, not a utilisation)") if dom == "winograd" else
-                    ("achieved = 2*M*N*K of the launches / their summed time (executed == algorithmic: a direct convolution); in bf16 no layer of "
-                     "this network is MFMA-bound -- see kernels.*.algorithmic_GBps for the byte side"),
-            "launches_per_step": g["calls"] // nprof, "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
-            "share_of_step_time": round(g["ms"] / nprof / step_ms, 3),
-            "method": f"HIP events around every launch on the launch stream, {nprof} instrumented steps after the timed region"}
-        if dom in tfam:
-            roof["traffic_note"] = ("HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of the guide), from separate rocprofv3 --pmc "
-                                    "passes of this command at B=60 committed under profiles/ (not measured in this run)")
-        if mfma_pmc and dom in mfma_pmc.get("kernels", {}):
-            roof["mfma_pmc"] = dict(mfma_pmc["kernels"][dom], source=f"profiles/r02_mfma_pmc{sfx}.json (rocprofv3 --pmc pass of this command, B=60; "
-                                                                         "all launches of the family, the B=1 source-encoder ones included)")
-            if dom == "winograd" and "winograd_wide" in mfma_pmc["kernels"]:
-                roof["mfma_pmc_b60_launches"] = mfma_pmc["kernels"]["winograd_wide"]          # the wide kernel = the B=60 launches alone
-        result["roofline"] = roof
-        mm = ("winograd", "gemm_conv", "gemm_bf16", "conv3x3_bf16")          # every convolution / GEMM family of either dtype
-        conv_ms = max(sum(fam[k]["ms"] for k in mm if k in fam), 1e-9)
-        conv_fl = sum(fam[k]["flops"] for k in mm if k in fam)
-        result["conv_gemm_family"] = {"algorithmic_gflop_per_frame": round(conv_fl / nprof / B / 1e9, 2),
-                                      "share_of_step_time": round(conv_ms / nprof / step_ms, 3),
-                                      "algorithmic_TFLOPs": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
-        kern = {}
-        for name, f in fam.items():
-            e = {"calls_per_step": f["calls"] // nprof, "ms_per_step": round(f["ms"] / nprof, 3)}
-            avg_s = f["ms"] * 1e-3 / f["calls"]
-            if f["bytes"]:
-                e["algorithmic_GBps"] = round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)
-                e["hbm_frac_algorithmic"] = round(e["algorithmic_GBps"] / PEAK_HBM_GBS, 4)
-            if f["flops"]:
-                e["TFLOPs_algorithmic"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
-            if f["mfma_flops"] and f["mfma_flops"] != f["flops"]:
-                e["TFLOPs_executed"] = round(f["mfma_flops"] / (f["ms"] * 1e-3) / 1e12, 2)
-            pf = "attention" if name.startswith("attention") else name
-            if pf in tfam and not name.startswith("attention"):
-                e["pmc_hbm_bytes_per_launch"] = round(tfam[pf]["hbm_bytes_per_launch"])
-                e["pmc_hbm_GBps"] = round(tfam[pf]["hbm_bytes_per_launch"] / avg_s / 1e9, 1)
-                e["hbm_frac_pmc"] = round(e["pmc_hbm_GBps"] / PEAK_HBM_GBS, 4)
-            kern[name] = e
-        if "warp" in kern:
-            kern["warp"]["note"] = ("algorithmic = SURVEY 8(d) bytes (every frame charged a source read + output write + flow + occlusion); pmc = "
-                                    "what reaches HBM (the broadcast source stays in L2/MALL, the output stream is compulsory)")
-        # warp by scale (A7) and the VQ kernel (A12)
-        for s in (32, 64, 128, 256):
-            rows = [(m, ms) for n, m, ms in rec.rows if n == "warp" and m["s"] == s]
-            if rows:
-                by, ms = sum(m["bytes"] for m, _ in rows), sum(x for _, x in rows)
-                kern[f"warp_s{s}"] = {"algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 1), "avg_launch_us": round(1e3 * ms / len(rows), 2)}
+def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
+    """instrumented pass (HIP events around every launch on the launch stream) over min(K,3) steps of the leg just timed
+    -> (roofline dict of the dominant kernel, conv/GEMM family summary, per-family kernel table)."""
+    from synergize_motion_appearance_amd import ops
+    B, K, W = args.batch, args.steps, args.warmup
+    step, work, dt = leg["step"], leg["work"], leg["dt"]
+    nprof = min(K, 3)
+    with ops.profile() as rec:
+        for i in range(nprof):
+            step(work[W + i])
+    step_ms = 1e3 * dt / K
+    fam = {}
+    for name, meta, ms in rec.rows:
+        meta = meta or {}
+        key = ("winograd_wide" if meta.get("wide") else "winograd_nw1") if meta.get("wino") else name
+        f = fam.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "mfma_flops": 0.0})
+        f["calls"] += 1
+        f["ms"] += ms
+        f["flops"] += meta.get("flops", 0.0)
+        f["mfma_flops"] += meta.get("mfma_flops", meta.get("flops", 0.0))
+        f["bytes"] += meta.get("bytes", 0.0)
+    wino = [fam[k] for k in ("winograd_wide", "winograd_nw1") if k in fam]
+    if wino:                                               # the family as a whole (both block shapes), next to its two members
+        fam["winograd"] = {k: sum(w[k] for w in wino) for k in wino[0]}
+    sfx = "" if dtype == "f32" else "_bf16"
+    traffic = load_profile_json(f"{PROFILE_TAG}_traffic_pmc{sfx}.json")
+    tfam = (traffic or {}).get("families", {}) if B == 60 else {}
+    mfma_pmc = load_profile_json(f"{PROFILE_TAG}_mfma_pmc{sfx}.json") if B == 60 else None
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    dom = max((k for k in fam if fam[k]["mfma_flops"] > 0 and k not in ("winograd_wide", "winograd_nw1")), key=lambda k: fam[k]["ms"])
+    g = fam[dom]
+    tf_exec = g["mfma_flops"] / (g["ms"] * 1e-3) / 1e12
+    tf_alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    kname = {"winograd": "winograd_wide_kernel / winograd_kernel<..> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
+             "conv3x3_bf16": "conv3x3_bf16_kernel<TH> (region-direct 3x3/s1/p1 convolution, v_mfma_f32_32x32x16_bf16)",
+             "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x2_f32)",
+             "gemm_bf16": "gemm_bf16_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom)
+    if dom.startswith("attention"):
+        peak = PEAK_F32_MFMA_TFLOPS                      # the attention cores run on the fp32 MFMA in both storage modes
+    # traffic: the B=60 launches of the dominant kernel ALONE (the wide block shape for the Winograd family), paired with the
+    # event-timed duration of exactly those launches
+    tkey = "winograd_wide" if (dom == "winograd" and "winograd_wide" in tfam and "winograd_wide" in fam) else dom
+    roof = {
+        "kernel": kname, "bound": "mfma", "achieved": round(tf_exec, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(tf_exec / peak, 4),
+        "traffic": round(tfam[tkey]["hbm_bytes_per_launch"]) if tkey in tfam else None,
+        "achieved_algorithmic": round(tf_alg, 2),
+        "note": ("achieved/frac = flops the matrix cores EXECUTE in this kernel (2*M*N*16/4*Cin per launch for F(2x2,3x3): 16 multiplies per "
+                 "2x2 output tile and channel) / its summed launch time; achieved_algorithmic = the direct convolution's 2*M*N*9*Cin over "
+                 "the same time (2.25x the executed rate by construction, not a utilisation)") if dom == "winograd" else
+                ("achieved = 2*M*N*K of the launches / their summed time (executed == algorithmic: a direct convolution); in bf16 no layer of "
+                 "this network is MFMA-bound -- see kernels.*.algorithmic_GBps for the byte side"),
+        "launches_per_step": g["calls"] // nprof, "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
+        "share_of_step_time": round(g["ms"] / nprof / step_ms, 3),
+        "method": f"HIP events around every launch on the launch stream, {nprof} instrumented steps after the timed region"}
+    if tkey in tfam:
+        tl = fam[tkey]
+        roof["traffic_launches"] = tkey
+        roof["traffic_GBps"] = round(tfam[tkey]["hbm_bytes_per_launch"] / (tl["ms"] * 1e-3 / tl["calls"]) / 1e9, 1)
+        roof["traffic_note"] = (f"HBM-side bytes per launch of the `{tkey}` launches only (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of the guide), from "
+                                f"separate rocprofv3 --pmc passes of `bench.py --profile-only` at B=60 committed under profiles/{PROFILE_TAG}_traffic_pmc{sfx}.json "
+                                "(not measured in this run); traffic_GBps pairs it with this run's event-timed duration of the same launches")
+    if mfma_pmc and dom in mfma_pmc.get("kernels", {}):
+        roof["mfma_pmc"] = dict(mfma_pmc["kernels"][dom], source=f"profiles/{PROFILE_TAG}_mfma_pmc{sfx}.json (rocprofv3 --pmc pass of this command, B=60; "
+                                                                     "all launches of the family, the B=1 source-encoder ones included)")
+        if dom == "winograd" and "winograd_wide" in mfma_pmc["kernels"]:
+            roof["mfma_pmc_b60_launches"] = mfma_pmc["kernels"]["winograd_wide"]          # the wide kernel = the B=60 launches alone
+    mm = ("winograd", "gemm_conv", "gemm_bf16", "conv3x3_bf16")          # every convolution / GEMM family of either dtype
+    conv_ms = max(sum(fam[k]["ms"] for k in mm if k in fam), 1e-9)
+    conv_fl = sum(fam[k]["flops"] for k in mm if k in fam)
+    conv_family = {"algorithmic_gflop_per_frame": round(conv_fl / nprof / B / 1e9, 2),
+                   "share_of_step_time": round(conv_ms / nprof / step_ms, 3),
+                   "algorithmic_TFLOPs": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
+    kern = {}
+    for name, f in fam.items():
+        e = {"calls_per_step": f["calls"] // nprof, "ms_per_step": round(f["ms"] / nprof, 3)}
+        avg_s = f["ms"] * 1e-3 / f["calls"]
+        if f["bytes"]:
+            e["algorithmic_GBps"] = round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)
+            e["hbm_frac_algorithmic"] = round(e["algorithmic_GBps"] / PEAK_HBM_GBS, 4)
+        if f["flops"]:
+            e["TFLOPs_algorithmic"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
+        if f["mfma_flops"] and f["mfma_flops"] != f["flops"]:
+            e["TFLOPs_executed"] = round(f["mfma_flops"] / (f["ms"] * 1e-3) / 1e12, 2)
+        pf = "attention" if name.startswith("attention") else name
+        if pf in tfam and not name.startswith("attention") and name != "winograd":
+            # the counter summary holds the B=60 launches only (bench.py --profile-only skips the B=1 re-render check; the B=1
+            # source-encoder launches are separated by block shape / grid size in tools/pmc_traffic.py)
+            e["pmc_hbm_bytes_per_launch"] = round(tfam[pf]["hbm_bytes_per_launch"])
+            e["pmc_hbm_GBps"] = round(tfam[pf]["hbm_bytes_per_launch"] / avg_s / 1e9, 1)
+            e["hbm_frac_pmc"] = round(e["pmc_hbm_GBps"] / PEAK_HBM_GBS, 4)
+        kern[name] = e
+    if "warp" in kern:
+        kern["warp"]["note"] = ("algorithmic = SURVEY 8(d) bytes (every frame charged a source read + output write + flow + occlusion); pmc = "
+                                "what reaches HBM (the broadcast source stays in L2/MALL, the output stream is compulsory)")
+    # warp by scale (A7) and the VQ kernel (A12)
+    for s in (32, 64, 128, 256):
+        rows = [(m, ms) for n, m, ms in rec.rows if n == "warp" and m["s"] == s]
+        if rows:
+            by, ms = sum(m["bytes"] for m, _ in rows), sum(x for _, x in rows)
+            kern[f"warp_s{s}"] = {"algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 1), "avg_launch_us": round(1e3 * ms / len(rows), 2)}
+    if with_vq:
         for D, key in ((256, "quantize_app"), (32, "quantize_motion")):
             z = torch.randn(B * 4 * 1024, D, device=dev)
             cb = Pg[f"{key}.embedding.weight"].to(dev)
@@ -375,21 +374,144 @@ def main():
             kern[f"vq_D{D}_K1024_N{z.shape[0]}"] = {"avg_launch_us": round(1e3 * ms, 2),
                                                     "algorithmic_GBps": round(m["bytes"] / (ms * 1e-3) / 1e9, 1),
                                                     "TFLOPs": round(m["flops"] / (ms * 1e-3) / 1e12, 2)}
-        result["kernels"] = kern
-        if args.dump_shapes:
-            tab = {}
-            for n, m, ms in rec.rows:
-                if n not in ("gemm_conv", "gemm_bf16", "conv3x3_bf16"):
-                    continue
-                key = (m["M"], m["N"], m["K"], m["nb"], m["k"], int(bool(m.get("wino"))))
-                t = tab.setdefault(key, [0, 0.0, m["flops"]])
-                t[0] += 1
-                t[1] += ms
-            rows = sorted(((k, v) for k, v in tab.items()), key=lambda kv: -kv[1][1])
-            with open(args.dump_shapes, "w") as f:
-                f.write("M N K nb ksize winograd calls/step ms/step TFLOPs(algorithmic)\n")
-                for (M_, N_, K_, nb_, ks_, wn_), (c, ms, fl) in rows:
-                    f.write(f"{M_} {N_} {K_} {nb_} {ks_} {wn_} {c / nprof:.1f} {ms / nprof:.3f} {fl * c / (ms * 1e-3) / 1e12:.1f}\n")
+    if args.dump_shapes:
+        tab = {}
+        for n, m, ms in rec.rows:
+            if n not in ("gemm_conv", "gemm_bf16", "conv3x3_bf16"):
+                continue
+            key = (m["M"], m["N"], m["K"], m["nb"], m["k"], int(bool(m.get("wino"))))
+            t = tab.setdefault(key, [0, 0.0, m["flops"]])
+            t[0] += 1
+            t[1] += ms
+        rows = sorted(((k, v) for k, v in tab.items()), key=lambda kv: -kv[1][1])
+        with open(args.dump_shapes + ("" if dtype == "f32" else ".bf16"), "w") as f:
+            f.write("M N K nb ksize winograd calls/step ms/step TFLOPs(algorithmic)\n")
+            for (M_, N_, K_, nb_, ks_, wn_), (c, ms, fl) in rows:
+                f.write(f"{M_} {N_} {K_} {nb_} {ks_} {wn_} {c / nprof:.1f} {ms / nprof:.3f} {fl * c / (ms * 1e-3) / 1e12:.1f}\n")
+    return roof, conv_family, kern
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=60, help="driving frames per step per GPU (frames in flight); 5 steps x 60 = the 300-frame clip")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32: BASELINE configs[1] (headline); bf16: configs[2] storage/MFMA dtype")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the 300 frames of ONE source, each step's B frames sharded over the N ranks "
+                                                           "(SURVEY 8e config 2 -> 8 GPUs: 37/38 frames per GPU); default is weak scaling (N sources)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-d2h", action="store_true")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="N=1 fp32 runs append a configs[2] (bf16) sub-record by default; skip it")
+    ap.add_argument("--no-consistency", action="store_true", help="skip the B=1 re-render check (profiling runs: keeps B=1 launches out of the counters)")
+    ap.add_argument("--profile-only", action="store_true", help="the command the rocprofv3 passes wrap: timed steps only (no B=1 re-renders, "
+                                                                 "no roofline / PCIe / CPU / bf16 legs)")
+    ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")
+    args = ap.parse_args()
+    if args.profile_only:
+        args.no_cpu_baseline = args.no_roofline = args.no_d2h = args.no_bf16_leg = args.no_consistency = True
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the HIP path)"
+    one_device = bool(os.environ.get("SMX_BENCH_ONE_DEVICE"))   # test knob: exercise the N>1 control flow on a 1-GPU box
+    if one_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist, collective = (None, None) if world == 1 else init_distributed(rank, world, dev)
+
+    from synergize_motion_appearance_amd import ops, driver
+    from synergize_motion_appearance_amd.synth import synth_clip
+
+    net_g, me, Pg, Pm = build_nets(dev)
+    B, K, W = args.batch, args.steps, args.warmup
+    # N sources (seeds 123, 124, ...), one driving clip shared by all of them (device resident before timing); --strong: ONE source
+    src_cpu, drv_cpu = synth_clip(CLIP, seed=123)
+    drv = drv_cpu.to(dev)
+    n_src = 1 if args.strong else world
+    my_sources = {j: (src_cpu if j == 0 else synth_clip(1, seed=123 + j)[0]).unsqueeze(0).to(dev) for j in range(n_src) if j % world == rank}
+
+    leg = render_leg(args, args.dtype, world, rank, dev, dist, collective, net_g, me, drv, my_sources, n_src)
+    dt, fps = leg["dt"], leg["fps"]
+    dname = args.dtype
+    cfg_ix = 1 if (world == 1 and args.dtype == "f32") else 2
+    rt = leg["rank_times"]
+    result = {
+        "metric": "reenactment frames/sec at 256x256", "value": round(fps, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 3),
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "config": {"workload": (f"BASELINE.json configs[{cfg_ix}]: 256x256, {n_src} source(s) x 300-frame driving clip, {dname}, options/test.yml, "
+                                "name-keyed random-init weights"), "frames_per_step": B, "frames_total": leg["frames_total"],
+                   "sources": n_src,
+                   "parallelism": ((f"strong scaling: ONE source x {CLIP} frames; each step's {B} frames sharded x{world} (driver.shard_frames, "
+                                    f"{B // world}-{(B + world - 1) // world} per rank)" if args.strong else
+                                    f"{n_src} sources x {CLIP} frames = {leg['total_units']} (source, frame) units; each step's window of {world * B} "
+                                    f"units sharded x{world} (driver.shard_frames)") +
+                                   f"; one {collective} broadcast per source of its packed frame-invariant state "
+                                   f"({4 * driver.cache_numel(net_g.engine().adt) / 1e6:.1f} MB) from the owner rank, inside the timed region: every rank "
+                                   "encodes the sources it owns first, then all broadcasts are issued async and waited together")
+                   if world > 1 else "1 GPU",
+                   "relative": True, "adapt_movement_scale": True, "output": "uint8 HWC frames in HBM"},
+        "rank_times_s": {"max": round(max(rt), 4), "min": round(min(rt), 4), "per_rank": [round(x, 4) for x in rt],
+                         "what": "each rank's own wall time for the timed region (prologue + K steps, device-synchronised) before the closing barrier"},
+    }
+    if leg["consistency"] is not None:
+        result["batch_consistency"] = leg["consistency"]
+    if one_device:
+        result["config"]["one_device_test_knob"] = True
+
+    # ---- PCIe-inclusive figures (SURVEY 8d config 2: "separately incl. uint8 D2H"; row N3): the same K steps through
+    # driver.FramePipeline -- uint8 frames from pinned host memory (1 B/sample H2D), resize/normalise on the device, render,
+    # uint8 frames back to pinned host memory; H2D of batch i+1 and D2H of batch i-1 overlap the compute of batch i.  Never `value`.
+    if rank == 0 and not args.no_d2h:
+        j0 = leg["work"][W][0][0]
+        u8 = ops.to_uint8(drv.permute(0, 2, 3, 1).contiguous(), -1.0, 1.0).cpu()            # the clip as a decoder would deliver it
+        reps = (K * B + CLIP - 1) // CLIP
+        host_in = (u8 if reps == 1 else u8.repeat(reps, 1, 1, 1))[:K * B].contiguous().pin_memory()
+        host_out = torch.empty((K * B, 256, 256, 3), dtype=torch.uint8).pin_memory()
+        pipe = driver.FramePipeline(net_g, me, batch=B)
+        pipe.run(leg["states"][j0], host_in[:B], host_out[:B])                             # warm the staging path
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pipe.run(leg["states"][j0], host_in, host_out)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        result["value_incl_pcie"] = round(K * B / dt2, 3)
+        result["value_incl_pcie_note"] = ("this rank's frames/s host-to-host: uint8 frames H2D from pinned memory (196,608 B/frame), uint8 -> fp32 "
+                                          "normalisation on the device, render, uint8 frames D2H to pinned memory, copies overlapped with compute on "
+                                          "separate streams (driver.FramePipeline); source state already resident; per GPU")
+        del pipe, host_in, host_out
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0 and not args.no_roofline:
+        roof, conv_family, kern = roofline_leg(args, args.dtype, leg, dev, Pg)
+        result["roofline"], result["conv_gemm_family"], result["kernels"] = roof, conv_family, kern
+
+    # ---- BASELINE configs[2] beside the fp32 headline: the same clip in bf16 storage / bf16 MFMA on this GPU (the 8-source x 8-GPU
+    # form of configs[2] is `--gpus 8 --dtype bf16`); an extra key, never `value`
+    if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_bf16_leg:
+        leg = None                                             # drop the fp32 states before the bf16 engines are packed
+        torch.cuda.empty_cache()
+        leg16 = render_leg(args, "bf16", world, rank, dev, dist, collective, net_g, me, drv, my_sources, n_src)
+        sub = {"workload": "BASELINE.json configs[2] on ONE GPU: 256x256, 1 source x 300-frame clip, bf16 NHWC storage + v_mfma_f32_32x32x16_bf16 "
+                           "(fp32 accumulate; keypoints / flows / normalisation statistics / softmax / output image fp32)",
+               "value": round(leg16["fps"], 3), "unit": "frames/s", "dtype": "bf16", "steps": K, "warmup": W,
+               "ms_per_step": round(1e3 * leg16["dt"] / K, 3), "batch_consistency": leg16["consistency"],
+               "tolerance": "tests/test_gpu_bf16.py: within 1.25x of the reference's own CPU-autocast(bf16) error (tests/golden/autocast_bf16.npz)"}
+        if not args.no_roofline:
+            r16, c16, k16 = roofline_leg(args, "bf16", leg16, dev, Pg, with_vq=False)
+            sub["roofline"], sub["conv_gemm_family"] = r16, c16
+            sub["kernels"] = {k: v for k, v in k16.items() if k.startswith(("warp", "conv3x3_bf16", "gemm_bf16", "attention"))}
+        result["configs2_bf16"] = sub
+        leg16 = None
+        net_g.set_compute_dtype("f32")
+        me.set_compute_dtype("f32")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(Pg, Pm, src_cpu, drv_cpu)

@@ -237,6 +237,11 @@ int smx_kp_head_f32(const float* logits, int ldl, const float* jmaps, int ldj, f
 int smx_normalize_kp_f32(const float* kpd_value, const float* kpd_jac, const float* kp0_value, const float* kp0_jac,
                          const float* kps_value, const float* kps_jac, float* out_value, float* out_jac,
                          int B, int K, float scale, int rel_move, int rel_jac, void* stream);
+/* same, with the hull ratio read from device memory (one float; NaN = no adaptation, i.e. 1): the N>1 path receives it inside
+ * the broadcast source state and never brings it to the host. */
+int smx_normalize_kp_dscale_f32(const float* kpd_value, const float* kpd_jac, const float* kp0_value, const float* kp0_jac,
+                                const float* kps_value, const float* kps_jac, float* out_value, float* out_jac,
+                                int B, int K, const float* scale_dev, int rel_move, int rel_jac, void* stream);
 
 /* A4-A6: heatmaps + sparse motions + 16 sparse warps fused (archs/dense_motion_arch.py:65-116).
  * src NHWC [Bs][H][W][3] (Bs = 1 broadcasts); kp value [B][K][2], jacobian [B][K][4].
@@ -270,10 +275,11 @@ int smx_motion_ignore_f32(const float* flow, uint8_t* ignore, int B, int Hf, int
  * channel slice (row stride ld_dec floats) of the [enc|dec] concat buffer, the others are dense */
 int smx_sft_combine_f32(const float* dec, int ld_dec, const float* scale, const float* shift, float* out, float w,
                         int64_t P, int C, void* stream);
-/* content fingerprint {sum x_i, sum x_i w_i} (fixed pseudo-random weights, deterministic) of n floats -> out2[2]:
- * the host layer keys its frame-invariant source caches on it (the reference recomputes the source encoding every
+/* content fingerprint of n floats -> out16 = two uint64 (8-byte aligned): order-independent sums of per-element 64-bit
+ * avalanche hashes of (raw bit pattern, index), so ANY bit change of any element changes the key.
+ * The host layer keys its frame-invariant source caches on it (the reference recomputes the source encoding every
  * frame, demo.py:130; a pointer-based key would miss raw-pointer rewrites of a reused buffer) */
-int smx_fingerprint_f32(const float* x, int64_t n, float* out2, void* stream);
+int smx_fingerprint_f32(const float* x, int64_t n, void* out16, void* stream);
 /* y = a + b (n elements) */
 int smx_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
 /* copy a channel slice: y[.., 0:C] (ld ldy) = x[.., 0:C] (ld ldx) over P pixels */
@@ -294,10 +300,13 @@ int smx_to_uint8_f32(const float* x, uint8_t* y, int64_t n, float lo, float hi, 
  * A12: VectorQuantizer.forward (archs/vqgan_arch.py:33-93), fused: d = |z|^2 + |e|^2 - 2 z.e
  * over the first Ks rows, first-minimum argmin, gather, z_q = z + (e - z).
  * z tokens [N][D]; codebook [Ks..][D]; idx int64 [N]; zq [N][D]; dmin [N] (min distance, optional);
- * sqerr: one float, += sum (zq-z)^2 (optional; zero it first).
+ * sqerr: one float, = sum (zq-z)^2 (optional; written, not accumulated), computed WITHOUT atomics: per-block partials in
+ * sq_ws (smx_vq_ws_floats(N) floats, required with sqerr) summed in a fixed order -> the codebook loss is bit-reproducible.
+ * z, codebook, zq 16-byte aligned.
  * ------------------------------------------------------------------------------------- */
+int64_t smx_vq_ws_floats(int N);
 int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, float* zq, float* dmin,
-                       float* sqerr, int N, int D, int Ks, void* stream);
+                       float* sqerr, float* sq_ws, int N, int D, int Ks, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * BASELINE configs[2]: bf16 STORAGE variants (activation pointers are raw 16-bit bfloat16, void* here; every

@@ -29,6 +29,8 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    """SMX_TOOLS=1 in the environment adds -DSMX_TOOLS: the timing-only ablation / trace instantiations of the Winograd kernels
+    (tools/wino_bench.py, tools/wino_trace.py); the shipped library rejects a non-zero `wino_ablate` instead."""
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
     headers = [os.path.join(REPO, "include", "smx.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -37,7 +39,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + (["-DSMX_TOOLS"] if os.environ.get("SMX_TOOLS") else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

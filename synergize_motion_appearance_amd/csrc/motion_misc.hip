@@ -133,9 +133,10 @@ __global__ __launch_bounds__(256) void mask_deformation_kernel(const float* __re
 __global__ void normalize_kp_kernel(const float* __restrict__ dv, const float* __restrict__ dj, const float* __restrict__ iv,
                                     const float* __restrict__ ij, const float* __restrict__ sv, const float* __restrict__ sj,
                                     float* __restrict__ ov, float* __restrict__ oj, int B, int K, float scale,
-                                    int rel_move, int rel_jac) {
+                                    const float* __restrict__ scale_dev, int rel_move, int rel_jac) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * K) return;
+  if (scale_dev) { const float sd = *scale_dev; scale = sd == sd ? sd : 1.f; }   // device-resident hull ratio (NaN = "no adaptation")
   const int k = t % K;
   float vx = dv[t * 2], vy = dv[t * 2 + 1];
   float j0 = dj[t * 4], j1 = dj[t * 4 + 1], j2 = dj[t * 4 + 2], j3 = dj[t * 4 + 3];
@@ -283,7 +284,17 @@ extern "C" int smx_normalize_kp_f32(const float* kpd_value, const float* kpd_jac
   if (!kpd_value || !kpd_jac || !out_value || !out_jac || B <= 0 || K <= 0) return SMX_EINVAL;
   if (rel_move && (!kp0_value || !kps_value || (rel_jac && (!kp0_jac || !kps_jac)))) return SMX_EINVAL;
   SMX_LAUNCH(normalize_kp_kernel, dim3(smx_cdiv((long long)B * K, 128)), dim3(128), 0, (hipStream_t)stream, kpd_value, kpd_jac,
-                     kp0_value, kp0_jac, kps_value, kps_jac, out_value, out_jac, B, K, scale, rel_move, rel_jac);
+                     kp0_value, kp0_jac, kps_value, kps_jac, out_value, out_jac, B, K, scale, (const float*)nullptr, rel_move, rel_jac);
+  return smx_launch_status();
+}
+
+extern "C" int smx_normalize_kp_dscale_f32(const float* kpd_value, const float* kpd_jac, const float* kp0_value, const float* kp0_jac,
+                                           const float* kps_value, const float* kps_jac, float* out_value, float* out_jac,
+                                           int B, int K, const float* scale_dev, int rel_move, int rel_jac, void* stream) {
+  if (!kpd_value || !kpd_jac || !out_value || !out_jac || !scale_dev || B <= 0 || K <= 0) return SMX_EINVAL;
+  if (rel_move && (!kp0_value || !kps_value || (rel_jac && (!kp0_jac || !kps_jac)))) return SMX_EINVAL;
+  SMX_LAUNCH(normalize_kp_kernel, dim3(smx_cdiv((long long)B * K, 128)), dim3(128), 0, (hipStream_t)stream, kpd_value, kpd_jac,
+                     kp0_value, kp0_jac, kps_value, kps_jac, out_value, out_jac, B, K, 1.f, scale_dev, rel_move, rel_jac);
   return smx_launch_status();
 }
 
@@ -350,15 +361,24 @@ extern "C" int smx_sft_combine_bf16(const void* dec, int ld_dec, const void* sca
   return smx_launch_status();
 }
 
-// content fingerprint of a small tensor (cache keys on the host side): {sum x_i, sum x_i * w_i} with fixed
-// pseudo-random weights w_i in [0,1); one block, fixed reduction order -> deterministic for equal contents
-__global__ __launch_bounds__(1024) void fingerprint_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
-  __shared__ double red[2][1024];
-  double a = 0.0, b = 0.0;
+// content fingerprint of a small tensor (cache keys on the host side): two 64-bit hashes of the RAW BIT PATTERNS,
+// h_k = sum_i mix64(bits_i, i, seed_k) (mod 2^64) -- a commutative sum of per-element avalanche hashes, so the reduction
+// order is irrelevant and any single-bit change of any element changes the key (the fp32 {sum, weighted sum} it replaces
+// could not see perturbations below the resolution of a sum over ~196k values)
+__device__ inline unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(1024) void fingerprint_kernel(const float* __restrict__ x, long long n, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long red[2][1024];
+  unsigned long long a = 0ULL, b = 0ULL;
   for (long long i = threadIdx.x; i < n; i += 1024) {
-    const float v = x[i];
-    const unsigned h = ((unsigned)i * 2654435761u) >> 8;
-    a += v; b += (double)v * (double)(h & 0xffffu) * (1.0 / 65536.0);
+    const unsigned long long v = (unsigned long long)__float_as_uint(x[i]);
+    const unsigned long long k = (v << 32) ^ (unsigned long long)i;
+    a += mix64(k + 0x9e3779b97f4a7c15ULL);
+    b += mix64(k ^ 0xd6e8feb86659fd93ULL);
   }
   red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
   __syncthreads();
@@ -366,12 +386,12 @@ __global__ __launch_bounds__(1024) void fingerprint_kernel(const float* __restri
     if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[0] = (float)red[0][0]; out[1] = (float)red[1][0]; }
+  if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
 }
 
-extern "C" int smx_fingerprint_f32(const float* x, int64_t n, float* out2, void* stream) {
-  if (!x || !out2 || n <= 0) return SMX_EINVAL;
-  SMX_LAUNCH(fingerprint_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long long)n, out2);
+extern "C" int smx_fingerprint_f32(const float* x, int64_t n, void* out16, void* stream) {
+  if (!x || !out16 || n <= 0 || (((uintptr_t)out16) & 7)) return SMX_EINVAL;
+  SMX_LAUNCH(fingerprint_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long long)n, (unsigned long long*)out16);
   return smx_launch_status();
 }
 

@@ -6,7 +6,9 @@
 // running (min, index) lives in registers in the MFMA C layout, the L2 reduction over the
 // codebook axis finishes with wavefront shuffles, and nothing but z, the codebook, the
 // indices and z_q touches HBM.  z fragments stay in registers for the whole codebook sweep;
-// code tiles (32 x D) are staged in LDS (row stride D+4 dwords: conflict-free ds_read_b128).
+// code tiles (32 x D) are double-buffered in LDS (row stride D+4 dwords: conflict-free ds_read_b128),
+// the next tile prefetched into registers across the current tile's MFMAs (one barrier per tile);
+// sum (z_q - z)^2 leaves as per-block partials summed in a fixed order (bit-reproducible loss).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -20,14 +22,20 @@ namespace {
 template <int D>
 __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                  int64_t* __restrict__ idx_out, float* __restrict__ zq,
-                                                 float* __restrict__ dmin_out, float* __restrict__ sqerr, int N, int Ks) {
-  constexpr int LD = D + 4, KS = D / 8, CT = 64;     // 64 codes staged per barrier pair (two 32-wide MFMA tiles)
+                                                 float* __restrict__ dmin_out, float* __restrict__ sq_part, int N, int Ks) {
+  // 32 codes per tile, two LDS buffers: the next tile's global loads are issued BEFORE the current tile's MFMAs and land in
+  // registers while the matrix pipe works; they go to the other buffer afterwards -> ONE barrier per tile and no exposed
+  // HBM/L2 round trip (the single-buffered form had a load -> barrier -> compute -> barrier sequence per 64 codes)
+  constexpr int LD = D + 4, KS = D / 8, CT = 32;
+  constexpr int PF = CT * (D / 4) / 256;               // float4 per thread per tile (D=256: 8, D=32: 1)
+  static_assert(CT * (D / 4) % 256 == 0, "tile must split evenly over the block");
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* cs = sm;                       // [CT][LD] code tile
-  float* ee = sm + CT * LD;             // [Ks rounded up to CT] all code norms, computed once per block
+  float* cs = sm;                       // [2][CT][LD] code tiles
+  float* ee = sm + 2 * CT * LD;         // [Ks rounded up to CT] all code norms, computed once per block
   const int ks_pad = (Ks + CT - 1) / CT * CT;
   float* zzs = ee + ks_pad;             // [4][32] token norms per wave
   int* bis = reinterpret_cast<int*>(zzs + 128);   // [4][32] best index per wave
+  float* wsum = reinterpret_cast<float*>(bis + 128);   // [4] per-wave squared error
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * 128 + wave * 32;
   const int myrow = row0 + (lane & 31);
@@ -52,6 +60,25 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
     if (part == 0) ee[code] = s;
   }
+  float4 pf[PF];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int i = threadIdx.x + q * 256;
+      const int r = i / (D / 4), c4 = i % (D / 4); const int code = t * CT + r;
+      pf[q] = code < Ks ? *reinterpret_cast<const float4*>(cb + (long long)code * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int i = threadIdx.x + q * 256;
+      const int r = i / (D / 4), c4 = i % (D / 4);
+      *reinterpret_cast<float4*>(cs + (buf * CT + r) * LD + c4 * 4) = pf[q];
+    }
+  };
+  fetch(0);
+  stash(0);
   __syncthreads();
   float zzr[16];
 #pragma unroll
@@ -63,38 +90,30 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
 
   const int ntiles = ks_pad / CT;
   for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();                    // previous tile fully consumed
-    for (int i = threadIdx.x; i < CT * (D / 4); i += 256) {
-      const int r = i / (D / 4), c4 = i % (D / 4); const int code = t * CT + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (code < Ks) v = *reinterpret_cast<const float4*>(cb + (long long)code * D + c4 * 4);
-      *reinterpret_cast<float4*>(cs + r * LD + c4 * 4) = v;
+    if (t + 1 < ntiles) fetch(t + 1);                  // in flight during this tile's MFMAs
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* bp = cs + ((t & 1) * CT + (lane & 31)) * LD + (lane >> 5) * 4;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const float4 bf = *reinterpret_cast<const float4*>(bp + kk * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf.w, acc, 0, 0, 0);
     }
+    const int code = t * CT + (lane & 31);
+    if (code < Ks) {
+      const float e2 = ee[code];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = (zzr[r] + e2) - 2.f * acc[r];
+        if (d < bestd[r]) { bestd[r] = d; besti[r] = code; }
+      }
+    }
+    if (t + 1 < ntiles) stash((t + 1) & 1);            // the buffer tile t-1 used: every wave passed the barrier that ended t-1
     __syncthreads();
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* bp = cs + (h2 * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        const float4 bf = *reinterpret_cast<const float4*>(bp + kk * 8);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf.w, acc, 0, 0, 0);
-      }
-      const int code = t * CT + h2 * 32 + (lane & 31);
-      if (code < Ks) {
-        const float e2 = ee[code];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d = (zzr[r] + e2) - 2.f * acc[r];
-          if (d < bestd[r]) { bestd[r] = d; besti[r] = code; }
-        }
-      }
-    }
   }
   // reduce over the 32 code lanes (same lane>>5 half): smaller d, ties -> smaller index
 #pragma unroll
@@ -115,44 +134,68 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
     }
   }
   __syncthreads();
-  // gather: z_q = z + (e[idx] - z)  (straight-through form, vqgan_arch.py:76)
+  // gather: z_q = z + (e[idx] - z)  (straight-through form, vqgan_arch.py:76); 16 B per lane, D/4 lanes per token
+  constexpr int LPR = D / 4, RPI = 64 / LPR;           // lanes per row, rows per iteration (D=256: 64 / 1, D=32: 8 / 8)
   float err = 0.f;
-  for (int r = 0; r < 32; ++r) {
+#pragma unroll 4
+  for (int r = lane / LPR; r < 32; r += RPI) {
     const int row = row0 + r; if (row >= N) break;
-    const float* e = cb + (long long)bis[wave * 32 + r] * D;
-    for (int c = lane; c < D; c += 64) {
-      const float zv = z[(long long)row * D + c];
-      const float df = e[c] - zv;
-      if (zq) zq[(long long)row * D + c] = zv + df;
-      err += df * df;
-    }
+    const int c = (lane % LPR) * 4;
+    const float4 e = *reinterpret_cast<const float4*>(cb + (long long)bis[wave * 32 + r] * D + c);
+    const float4 zv = *reinterpret_cast<const float4*>(z + (long long)row * D + c);
+    const float4 df = make_float4(e.x - zv.x, e.y - zv.y, e.z - zv.z, e.w - zv.w);
+    if (zq) *reinterpret_cast<float4*>(zq + (long long)row * D + c) = make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w);
+    err += (df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w);
   }
-  if (sqerr) {
+  if (sq_part) {
+    // deterministic: fixed shuffle tree per wave, the block's four waves added in order, one partial per block; the host-visible
+    // scalar is the fixed-order sum of the partials (vq_finalize_kernel) -- no atomics, bit-reproducible run to run
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) err += __shfl_xor(err, o, 64);
-    if (lane == 0) atomicAdd(sqerr, err);
+    if (lane == 0) wsum[wave] = err;
+    __syncthreads();
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   }
 }
 
+// sqerr = sum of the per-block partials in a FIXED order (one block: strided per-thread sums, then a fixed LDS tree)
+__global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ sqerr) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *sqerr = red[0];
+}
+
 template <int D>
-int launch_vq(const float* z, const float* cb, int64_t* idx, float* zq, float* dmin, float* sqerr, int N, int Ks, hipStream_t st) {
-  const size_t lds = (size_t)(64 * (D + 4) + (Ks + 63) / 64 * 64 + 128 + 128) * sizeof(float);
+int launch_vq(const float* z, const float* cb, int64_t* idx, float* zq, float* dmin, float* sqerr, float* sq_ws, int N, int Ks, hipStream_t st) {
+  const size_t lds = (size_t)(2 * 32 * (D + 4) + (Ks + 31) / 32 * 32 + 128 + 128 + 4) * sizeof(float);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vq_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  SMX_LAUNCH(vq_kernel<D>, dim3(smx_cdiv(N, 128)), dim3(256), lds, st, z, cb, idx, zq, dmin, sqerr, N, Ks);
+  const int nblk = smx_cdiv(N, 128);
+  SMX_LAUNCH(vq_kernel<D>, dim3(nblk), dim3(256), lds, st, z, cb, idx, zq, dmin, sqerr ? sq_ws : nullptr, N, Ks);
+  if (sqerr) SMX_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, sq_ws, nblk, sqerr);
   return smx_launch_status();
 }
 
 }  // namespace
 
+extern "C" int64_t smx_vq_ws_floats(int N) { return N > 0 ? (int64_t)smx_cdiv(N, 128) : 0; }
+
 extern "C" int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, float* zq, float* dmin,
-                                  float* sqerr, int N, int D, int Ks, void* stream) {
-  if (!z || !codebook || !idx || N <= 0 || Ks <= 0) return SMX_EINVAL;
+                                  float* sqerr, float* sq_ws, int N, int D, int Ks, void* stream) {
+  if (!z || !codebook || !idx || N <= 0 || Ks <= 0 || (sqerr && !sq_ws)) return SMX_EINVAL;
+  if ((((uintptr_t)z) | ((uintptr_t)codebook) | ((uintptr_t)zq)) & 15) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   switch (D) {
-    case 32: return launch_vq<32>(z, codebook, idx, zq, dmin, sqerr, N, Ks, st);
-    case 64: return launch_vq<64>(z, codebook, idx, zq, dmin, sqerr, N, Ks, st);
-    case 128: return launch_vq<128>(z, codebook, idx, zq, dmin, sqerr, N, Ks, st);
-    case 256: return launch_vq<256>(z, codebook, idx, zq, dmin, sqerr, N, Ks, st);
+    case 32: return launch_vq<32>(z, codebook, idx, zq, dmin, sqerr, sq_ws, N, Ks, st);
+    case 64: return launch_vq<64>(z, codebook, idx, zq, dmin, sqerr, sq_ws, N, Ks, st);
+    case 128: return launch_vq<128>(z, codebook, idx, zq, dmin, sqerr, sq_ws, N, Ks, st);
+    case 256: return launch_vq<256>(z, codebook, idx, zq, dmin, sqerr, sq_ws, N, Ks, st);
     default: return SMX_EINVAL;
   }
 }

@@ -28,6 +28,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <mutex>
 #include "smx.h"
 #include "smx_common.h"
 
@@ -816,6 +817,30 @@ static int winograd_launch(const float* x, int lda, const float* u_packed, const
   hipStream_t st = (hipStream_t)stream;
   const int wide = smx_tune(SMX_TUNE_WINO_WIDE);
   const int abl = smx_tune(SMX_TUNE_WINO_ABLATE);
+#ifndef SMX_TOOLS
+  // the timing-only ablation / trace instantiations (they skip loads or barriers, or overwrite the GroupNorm partials with
+  // cycle stamps: WRONG results by design) exist only in the tools build (-DSMX_TOOLS, tools/wino_bench.py / wino_trace.py)
+  if (abl != 0) return SMX_EINVAL;
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_err = hipFuncSetAttribute((const void*)(winograd_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    if (attr_err == hipSuccess)
+      attr_err = hipFuncSetAttribute((const void*)(winograd_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+  });
+  if (attr_err != hipSuccess) return SMX_ELAUNCH;
+  if (nw == 2 && wide > 0) {
+    dim3 grid((unsigned)blocks, (Cout + 63) / 64);
+    const size_t wlds = wide == 5 ? 98304 : WIDE_LDS;          // wide == 5 (tools): the same kernel at one block per CU
+    SMX_LAUNCH((winograd_wide_kernel<0>), grid, dim3(256), wlds, st, p);
+  } else if (nw == 2) {
+    dim3 grid((unsigned)blocks, (Cout + 63) / 64);
+    SMX_LAUNCH((winograd_kernel<2, 0>), grid, dim3(512), lds, st, p);
+  } else {
+    dim3 grid((unsigned)blocks, (Cout + 31) / 32);
+    SMX_LAUNCH((winograd_kernel<1>), grid, dim3(256), lds, st, p);
+  }
+#else
   if (nw == 2 && wide > 0) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
     const size_t wlds = wide == 5 ? 98304 : WIDE_LDS;          // wide == 5 (tools): the same kernel at one block per CU
@@ -839,6 +864,7 @@ static int winograd_launch(const float* x, int lda, const float* u_packed, const
     dim3 grid((unsigned)blocks, (Cout + 31) / 32);
     SMX_LAUNCH((winograd_kernel<1>), grid, dim3(256), lds, st, p);
   }
+#endif
   return smx_launch_status();
 }
 

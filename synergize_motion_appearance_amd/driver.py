@@ -34,12 +34,16 @@ def normalize_kp(kp_source, kp_driving, kp_driving_initial, adapt_movement_scale
     else:
         s = 1
     kp_new = {k: v for k, v in kp_driving.items()}       # every key of kp_driving survives (demo.py:34)
-    if (use_relative_movement and kp_driving["value"].is_cuda and kp_source["value"].shape[0] == 1
-            and kp_driving_initial["value"].shape[0] == 1):
+    fast = (use_relative_movement and kp_driving["value"].is_cuda and kp_source["value"].shape[0] == 1
+            and kp_driving_initial["value"].shape[0] == 1)
+    if fast:
         # device tensors, ONE source and ONE initial frame (the kernel indexes row 0 of both): one small HIP kernel
-        # for the whole batch (no ATen matmul / inverse on the path); batched initial keypoints take the torch path
+        # for the whole batch (no ATen matmul / inverse on the path); batched initial keypoints take the torch path.
+        # `s` may be a one-float device tensor (a broadcast state's hull ratio, NaN = none): read on the device
         kp_new.update(ops.normalize_kp(kp_driving, kp_driving_initial, kp_source, s, True, use_relative_jacobian))
         return kp_new
+    if torch.is_tensor(s):
+        s = torch.where(torch.isnan(s), torch.ones_like(s), s)          # NaN encodes "none" (pack_source_state)
     if use_relative_movement:
         kp_new["value"] = (kp_driving["value"] - kp_driving_initial["value"]) * s + kp_source["value"]
         if use_relative_jacobian:
@@ -116,17 +120,45 @@ def unpack_source_state(flat: torch.Tensor, dtype=torch.float32) -> SourceState:
         kps.append({"value": flat[off:off + _KP_VALUE].view(1, 15, 2),
                     "jacobian": flat[off + _KP_VALUE:off + _KP_VALUE + _KP_JAC].view(1, 15, 2, 2)})
         off += _KP_VALUE + _KP_JAC
-    scale = float(flat[off].item())
-    return SourceState(SourceCache(feats, 1), src64, kps[0], kps[1], None if scale != scale else scale, flat)
+    # the hull ratio stays where it arrived (a one-float view of the packed buffer, NaN = none): the normalize_kp kernel reads it
+    # from device memory, so unpacking costs no host synchronisation and N broadcasts can be in flight at once
+    return SourceState(SourceCache(feats, 1), src64, kps[0], kps[1], flat[off:off + 1], flat)
 
 
-def broadcast_flat(flat_or_none, device, src=0, group=None, dtype=torch.float32):
-    """rank `src` passes the packed state, the others None; everyone returns the broadcast buffer.
+def broadcast_flat(flat_or_none, device, src=0, group=None, dtype=torch.float32, async_op=False):
+    """rank `src` (a GLOBAL rank, as torch.distributed.broadcast reads it) passes the packed state, the others None;
+    everyone returns the broadcast buffer -- or (buffer, work handle) with async_op=True.
     torch.distributed broadcast == RCCL over xGMI on the GPU box (gloo in the CPU tests)."""
     import torch.distributed as dist
     buf = flat_or_none if dist.get_rank() == src else torch.empty(cache_numel(dtype), device=device, dtype=torch.float32)
-    dist.broadcast(buf, src=src, group=group)
-    return buf
+    if dist.get_rank() == src and buf is None:
+        raise ValueError(f"broadcast_flat: rank {src} is the source of this broadcast and must pass the packed state")
+    work = dist.broadcast(buf, src=src, group=group, async_op=async_op)
+    return (buf, work) if async_op else buf
+
+
+def broadcast_source_states(net_g, motion_estimator, owned, owners, adapt_movement_scale=True, device=None, group=None):
+    """the frame-invariant state of SEVERAL sources, each encoded by its owner rank: `owners[j]` = global owner rank of source j,
+    `owned[j]` = (source, initial_frame) on the owner.  Every rank first encodes ALL the sources it owns, then all the
+    broadcasts are issued back to back (async) and waited for together -- the encodes of different owners overlap each
+    other and the N transfers pipeline, instead of N x (encode -> broadcast -> host sync) in sequence.  -> {j: SourceState}"""
+    import torch.distributed as dist
+    me = dist.get_rank()
+    adt = net_g.engine().adt
+    flats = {}
+    for j, owner in owners.items():
+        if owner == me:
+            st = encode_source_state(net_g, motion_estimator, owned[j][0], owned[j][1], adapt_movement_scale)
+            flats[j] = pack_source_state(st.cache, st.src64, st.kp_source, st.kp_initial, st.scale)
+            device = flats[j].device
+    if device is None:
+        device = next(net_g.parameters()).device
+    pending = [(j,) + broadcast_flat(flats.get(j), device, owner, group, adt, async_op=True) for j, owner in sorted(owners.items())]
+    out = {}
+    for j, buf, work in pending:
+        work.wait()
+        out[j] = unpack_source_state(buf, adt)
+    return out
 
 
 def encode_source_state(net_g, motion_estimator, source, initial_frame=None, adapt_movement_scale=True) -> SourceState:
@@ -143,8 +175,8 @@ def encode_source_state(net_g, motion_estimator, source, initial_frame=None, ada
 
 def broadcast_source_state(net_g, motion_estimator, source=None, initial_frame=None, adapt_movement_scale=True,
                            src=0, device=None, group=None) -> SourceState:
-    """rank `src` encodes the source once (`source` / `initial_frame` are only read there); every rank receives the
-    frame-invariant state with ONE broadcast of 28.4 MB -- the only collective on the data path."""
+    """rank `src` (GLOBAL rank) encodes the source once (`source` / `initial_frame` are only read there); every rank receives
+    the frame-invariant state with ONE broadcast of 28.4 MB -- the only collective on the data path."""
     import torch.distributed as dist
     flat = None
     if dist.get_rank() == src:
@@ -163,6 +195,11 @@ def render_frames(state: SourceState, frames, net_g, motion_estimator, relative=
     / fp32 NCHW [n,3,H,W] / both."""
     eng_g, eng_m = net_g.engine(), motion_estimator.engine()
     u8, fl = [], []
+    if frames.shape[0] == 0:       # an empty shard (fewer frames than ranks): typed empty results, so collectives still line up
+        H, W = frames.shape[-2:]
+        r8 = torch.empty((0, H, W, 3), device=frames.device, dtype=torch.uint8)
+        rf = torch.empty((0, 3, H, W), device=frames.device, dtype=torch.float32)
+        return r8 if want == "uint8" else rf if want == "float" else (r8, rf)
     for i in range(0, frames.shape[0], batch):
         kp_d = eng_m.estimate_kp(frames[i:i + batch].float())
         kp_n = normalize_kp(state.kp_source, kp_d, state.kp_initial, adapt_movement_scale, relative, relative, state.scale)
@@ -184,14 +221,19 @@ def animate_sharded(source, driving, net_g, motion_estimator, relative=True, ada
     source (+ the anchor frame's keypoints and the hull scale) and broadcasts the packed state once; every rank
     renders its contiguous `shard_frames` block of `driving` [N,3,H,W] -- no other collective on the data path.
     gather=True: the uint8 frames are collected on `root` in clip order (returns [N,H,W,3] there, None elsewhere);
-    gather=False: returns ((start, stop), frames_of_this_rank)."""
+    gather=False: returns ((start, stop), frames_of_this_rank).
+    `root` is a rank OF `group` (group-local, like `rank` below); it is converted once to the global rank that
+    torch.distributed's broadcast / gather expect, so a strict subgroup (e.g. global ranks 4-7, root=0 -> global 4) works."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if rank < 0:
+        raise ValueError("animate_sharded: this process is not a member of `group`")
+    groot = root if group is None else dist.get_global_rank(group, root)
     dev = driving.device
     need0 = relative or adapt_movement_scale
     state = broadcast_source_state(net_g, motion_estimator, source if rank == root else None,
                                    driving[anchor_idx:anchor_idx + 1] if (rank == root and need0) else None,
-                                   adapt_movement_scale, src=root, device=dev, group=group)
+                                   adapt_movement_scale, src=groot, device=dev, group=group)
     n = driving.shape[0]
     a, b = shard_frames(n, rank, world)
     mine = render_frames(state, driving[a:b], net_g, motion_estimator, relative, adapt_movement_scale, batch)
@@ -203,7 +245,7 @@ def animate_sharded(source, driving, net_g, motion_estimator, relative=True, ada
     if dist.get_backend(group) == "gloo":            # gloo has no device gather: stage the uint8 frames through the host
         pad = pad.cpu()
     parts = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
-    dist.gather(pad, parts, dst=root, group=group)
+    dist.gather(pad, parts, dst=groot, group=group)
     return torch.cat([p[:k] for p, k in zip(parts, sizes)]).to(dev) if rank == root else None
 
 

@@ -66,7 +66,9 @@ class _Attn:
         vt = torch.empty((B, Cc, N), device=x.device, dtype=x.dtype)          # V^T = Wv . hn^T + bv
         ops.gemm_nt(self.wv, hn, vt, M=Cc, N=N, K=Cc, lda=Cc, ldb=Cc, ldc=N, nb0=B, bt_bs=(N * Cc, 0),
                     c_bs=(Cc * N, 0), bias=self.bv, bias_per_row=True)
-        s = torch.empty((B, N, N), device=x.device, dtype=x.dtype)
+        # logits and probabilities stay fp32 in both storage modes (bf16 path: c_f32 store, fp32 softmax, a_f32 operand converted
+        # while staging): raw q.k sums over C = 256 lose too much in 8 mantissa bits before the softmax
+        s = torch.empty((B, N, N), device=x.device, dtype=torch.float32)
         ops.gemm_nt(qk, qk, s, M=N, N=N, K=Cc, lda=2 * Cc, ldb=2 * Cc, ldc=N, nb0=B, a_bs=(N * 2 * Cc, 0),
                     bt_bs=(N * 2 * Cc, 0), c_bs=(N * N, 0), bt_off=Cc)
         ops.softmax_rows(s, N, float(int(Cc) ** (-0.5)))

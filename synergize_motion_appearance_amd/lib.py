@@ -87,6 +87,7 @@ SIGNATURES = {
     "smx_antialias_down_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_kp_head_f32": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
     "smx_normalize_kp_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _p]),
+    "smx_normalize_kp_dscale_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _p]),
     "smx_sparse_motion_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p]),
     "smx_mask_deformation_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smx_flow_to_residual_f32": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -118,7 +119,8 @@ SIGNATURES = {
     "smx_convert_slice": (_i, [_p, _i, _i, _p, _i, _i, _i64, _i, _p]),
     "smx_nchw_to_nhwc_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "smx_nhwc_to_nchw_bf16": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
-    "smx_vq_nearest_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "smx_vq_ws_floats": (_i64, [_i]),
+    "smx_vq_nearest_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 
 _lib = None

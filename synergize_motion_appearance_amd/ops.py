@@ -246,6 +246,12 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
     return out
 
 
+def _wino_wide(B, H, W, cout):
+    """mirror of winograd_launch's block-shape rule (csrc/winograd.hip): 64-channel 'wide' blocks once >= 1024 of them exist --
+    in this pipeline exactly the B=60 launches of the big layers; used to label profile rows only."""
+    return int(cout % 64 == 0 and B * (H // 8) * (W // 16) * (cout // 64) >= 1024)
+
+
 def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None,
          d2s=None, tile=0, in_ss=None, in_swish=False, want_stats=False, mfma16=False, out_dtype=None):
     """y = act(conv(x) + bias) [+ res].  x [B,H,W,Cin] (slice ok) -> out [B,Ho,Wo,Cout] (slice ok).
@@ -290,7 +296,8 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
             and (Ho, Wo) == (He, We) and Cin % 32 == 0 and He % 8 == 0 and We % 16 == 0
             and lda % 4 == 0 and a_ptr % 16 == 0):
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * Ho * Wo * cv.cout * 4 * Cin,
-                "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1} if _PROFILE is not None else None
+                "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1,
+                "wide": _wino_wide(B, He, We, cv.cout)} if _PROFILE is not None else None
         part = torch.empty((B, (He // 8) * (We // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
         L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                        None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,
@@ -504,14 +511,22 @@ def kp_head(logits, jmaps, K, temperature):
 
 
 def normalize_kp(kp_d, kp_0, kp_s, scale, rel_move, rel_jac):
-    """device version of demo.py:24-44 for a batch of driving keypoints against one source / initial frame."""
+    """device version of demo.py:24-44 for a batch of driving keypoints against one source / initial frame.
+    scale: host float, or a one-element device tensor (the hull ratio as it arrives inside a broadcast source state:
+    read by the kernel, never synchronised to the host; NaN there means "no adaptation")."""
     v, j = _dev(kp_d["value"]).contiguous(), _dev(kp_d["jacobian"]).contiguous()
     B, K = v.shape[0], v.shape[1]
     ov, oj = torch.empty_like(v), torch.empty_like(j)
     ptr = lambda d, k: None if d is None else _dev(d[k]).contiguous().data_ptr()
-    L.check(L.load().smx_normalize_kp_f32(v.data_ptr(), j.data_ptr(), ptr(kp_0, "value"), ptr(kp_0, "jacobian"), ptr(kp_s, "value"),
-                                          ptr(kp_s, "jacobian"), ov.data_ptr(), oj.data_ptr(), B, K, float(scale), int(rel_move),
-                                          int(rel_jac), _stream()), "normalize_kp")
+    if torch.is_tensor(scale):
+        _dev(scale, "normalize_kp scale")
+        L.check(L.load().smx_normalize_kp_dscale_f32(v.data_ptr(), j.data_ptr(), ptr(kp_0, "value"), ptr(kp_0, "jacobian"), ptr(kp_s, "value"),
+                                                     ptr(kp_s, "jacobian"), ov.data_ptr(), oj.data_ptr(), B, K, scale.data_ptr(), int(rel_move),
+                                                     int(rel_jac), _stream()), "normalize_kp")
+    else:
+        L.check(L.load().smx_normalize_kp_f32(v.data_ptr(), j.data_ptr(), ptr(kp_0, "value"), ptr(kp_0, "jacobian"), ptr(kp_s, "value"),
+                                              ptr(kp_s, "jacobian"), ov.data_ptr(), oj.data_ptr(), B, K, float(scale), int(rel_move),
+                                              int(rel_jac), _stream()), "normalize_kp")
     return {"value": ov, "jacobian": oj}
 
 
@@ -613,7 +628,7 @@ def conv_sft(x, cv, dec, scale, w=1.0):
         return sft_combine(dec, scale, conv(x, cv), w)
     out = torch.empty((B, H, W, cv.cout), device=x.device, dtype=torch.float32)
     meta = {"flops": 2.0 * B * H * W * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * H * W * cv.cout * 4 * Cin,
-            "M": B * H * W, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1} if _PROFILE is not None else None
+            "M": B * H * W, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1, "wide": _wino_wide(B, H, W, cv.cout)} if _PROFILE is not None else None
     L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_sft_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                    None if cv.b is None else cv.b.data_ptr(), d_ptr, ldd, s_ptr, lds_, float(w), out.data_ptr(), cv.cout,
                    B, H, W, Cin, cv.cout, None, _stream()), "smx_winograd_conv3x3_sft_f32")
@@ -621,10 +636,10 @@ def conv_sft(x, cv, dec, scale, w=1.0):
 
 
 def fingerprint(x):
-    """(sum, weighted sum) of a small device tensor as a host tuple -- a content key for the source caches
-    (one tiny launch + an 8-byte D2H copy)."""
+    """two 64-bit content hashes (raw bit patterns) of a small device tensor as a host tuple -- a content key for the source
+    caches (one tiny launch + a 16-byte D2H copy)."""
     xc = _dev(x).contiguous()
-    out = torch.empty((2,), device=x.device, dtype=torch.float32)
+    out = torch.empty((2,), device=x.device, dtype=torch.int64)
     L.check(L.load().smx_fingerprint_f32(xc.data_ptr(), xc.numel(), out.data_ptr(), _stream()), "fingerprint")
     return tuple(out.tolist())
 
@@ -689,10 +704,11 @@ def vq_nearest(z_tokens, codebook, Ks, want_zq=True):
     idx = torch.empty((N,), device=z_tokens.device, dtype=torch.int64)
     zq = torch.empty_like(z_tokens) if want_zq else None
     dmin = torch.empty((N,), device=z_tokens.device, dtype=torch.float32)
-    sq = torch.zeros((1,), device=z_tokens.device, dtype=torch.float32)
+    sq = torch.empty((1,), device=z_tokens.device, dtype=torch.float32)
+    ws = torch.empty((int(L.load().smx_vq_ws_floats(N)),), device=z_tokens.device, dtype=torch.float32)   # per-block partials (no atomics)
     meta = {"bytes": 8.0 * N * D + 4.0 * Ks * D + 8.0 * N, "flops": 2.0 * N * Ks * D}
     L.check(_timed("vq", meta, L.load().smx_vq_nearest_f32, z_tokens.contiguous().data_ptr(), codebook.contiguous().data_ptr(),
-                   idx.data_ptr(), None if zq is None else zq.data_ptr(), dmin.data_ptr(), sq.data_ptr(), N, D, Ks,
+                   idx.data_ptr(), None if zq is None else zq.data_ptr(), dmin.data_ptr(), sq.data_ptr(), ws.data_ptr(), N, D, Ks,
                    _stream()), "vq_nearest")
     return idx, zq, dmin, sq
 

@@ -746,3 +746,38 @@ def test_full_size_attention_and_vq_invariants(ops):
     idx = torch.randint(0, 1024, (B * 1024,), device="cuda", generator=g)
     got, zq, dmin, _ = ops.vq_nearest(cb[idx].contiguous(), cb, 1024)
     assert torch.equal(got.view(-1), idx) and torch.equal(zq, cb[idx]) and float(dmin.abs().max()) < 1e-3
+
+
+def test_vq_loss_is_bit_reproducible_and_full_size(ops):
+    """round-3: sum (z_q - z)^2 leaves the kernel as per-block partials summed in a fixed order (no atomics): two runs on
+    the same inputs give the SAME bits; at the bench's size (N = 245,760 tokens) the result still equals the fp64 sum of the
+    gathered rows to fp32 accuracy, and every index is the reference expression's argmin (tie-aware)."""
+    for D, K, N in ((256, 1024, 60 * 4 * 1024), (32, 768, 4096 + 37)):
+        z = rnd(f"vqrep_z{D}", (N, D)).cuda()
+        cb = rnd(f"vqrep_cb{D}", (K, D)).cuda()
+        a = ops.vq_nearest(z, cb, K)
+        b = ops.vq_nearest(z, cb, K)
+        assert torch.equal(a[3], b[3]) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        e = cb[a[0]]
+        ref = float(((e.double() - z.double()) ** 2).sum())
+        assert abs(float(a[3]) - ref) < 2e-6 * ref
+        assert torch.equal(a[1], z + (e - z))
+        sub = slice(0, 4096)
+        d = (z[sub] ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * z[sub] @ cb.t()
+        best = d.min(1).values
+        got = d.gather(1, a[0][sub].view(-1, 1)).view(-1)
+        assert float((got - best).max()) < 1e-3
+
+
+def test_fingerprint_sees_single_bit_changes(ops):
+    """the source-cache key hashes raw bit patterns -- equal contents in another buffer give the same key, a 1-ulp
+    change of one element (far below the resolution of an fp32 sum over 196k values) gives a different one."""
+    x = rnd("fp_src", (1, 3, 256, 256)).cuda()
+    k0 = ops.fingerprint(x)
+    assert ops.fingerprint(x.clone()) == k0
+    y = x.clone()
+    y.view(-1)[123457] = torch.nextafter(y.view(-1)[123457], torch.tensor(10.0, device="cuda"))
+    assert ops.fingerprint(y) != k0
+    y2 = x.clone()
+    y2.view(-1)[[5, 6]] = y2.view(-1)[[6, 5]]            # a permutation of two unequal elements changes it too
+    assert ops.fingerprint(y2) != k0

@@ -81,23 +81,34 @@ def test_two_ranks_one_device_sharded_animation_equals_single_rank():
     assert r0["frac_diff"] < 0.01, r0                     # rounding ties only
 
 
-def test_bench_two_ranks_control_flow_on_one_device(tmp_path):
+@pytest.mark.parametrize("extra,scaling", [((), "weak"), (("--dtype", "bf16"), "weak"), (("--strong",), "strong")])
+def test_bench_two_ranks_control_flow_on_one_device(tmp_path, extra, scaling):
     """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), both ranks on
-    the one device of this box: the N>1 branch (per-source owner encodes, state broadcast, window sharding) executes and
-    prints a well-formed line.  The number is NOT a scaling measurement (two ranks share one GPU)."""
+    the one device of this box: the N>1 branch (owners encode first, async state broadcasts, window sharding) executes and
+    prints a well-formed line -- in fp32, in bf16 (BASELINE configs[2] is the bf16 multi-GPU config: the broadcast carries
+    raw bf16 bits) and in the strong-scaling form (ONE source, each step's frames split over the ranks).
+    The number is NOT a scaling measurement (two ranks share one GPU)."""
     assert torch.cuda.is_available(), "needs an MI355X"
     env = dict(os.environ, SMX_BENCH_ONE_DEVICE="1", SMX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "6", "--no-cpu-baseline", "--no-roofline"]
+           "--batch", "6", "--no-cpu-baseline", "--no-roofline", *extra]
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
-    assert j["config"]["frames_total"] == 2 * 2 * 6 and j["config"]["sources"] == 2
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == scaling and j["value"] > 0
+    if scaling == "weak":
+        assert j["config"]["frames_total"] == 2 * 2 * 6 and j["config"]["sources"] == 2
+    else:
+        assert j["config"]["frames_total"] == 2 * 6 and j["config"]["sources"] == 1
+    assert j["dtype"] == ("bf16" if "bf16" in extra else "f32")
     assert "gloo" in j["config"]["parallelism"] and j["config"]["one_device_test_knob"] is True
-    assert j["batch_consistency"]["max_lsb_vs_b1"] <= 1
+    assert len(j["rank_times_s"]["per_rank"]) == 2 and j["rank_times_s"]["max"] >= j["rank_times_s"]["min"] > 0
+    if "bf16" in extra:
+        assert j["batch_consistency"]["mean_lsb_vs_b1"] < 1.5
+    else:
+        assert j["batch_consistency"]["max_lsb_vs_b1"] <= 1
 
 
 def test_bench_refuses_a_silent_backend_fallback():

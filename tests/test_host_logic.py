@@ -170,9 +170,19 @@ def test_source_state_pack_roundtrip():
     assert all(torch.equal(st.cache.feats[s], feats[s]) for s in feats) and torch.equal(st.src64, src64)
     assert torch.equal(st.kp_source["value"], kp["value"]) and torch.equal(st.kp_source["jacobian"], kp["jacobian"])
     assert torch.equal(st.kp_initial["value"], kp0["value"]) and torch.equal(st.kp_initial["jacobian"], kp0["jacobian"])
-    assert st.scale == 1.25
-    # no initial frame / no adapt scale (relative=False, adapt_movement_scale=False): scale survives as None
-    assert driver.unpack_source_state(driver.pack_source_state(SourceCache(feats, 1), src64, kp, None, None)).scale is None
+    # the hull ratio stays a one-float VIEW of the packed buffer (read by the normalize_kp kernel on the device: unpacking
+    # never synchronises with the host, so N broadcasts can be in flight)
+    assert torch.is_tensor(st.scale) and st.scale.shape == (1,) and float(st.scale) == 1.25
+    assert st.scale.data_ptr() == flat[-1:].data_ptr()
+    # no initial frame / no adapt scale (relative=False, adapt_movement_scale=False): travels as NaN, which normalize_kp reads as 1
+    none = driver.unpack_source_state(driver.pack_source_state(SourceCache(feats, 1), src64, kp, None, None))
+    assert bool(torch.isnan(none.scale).all())
+    kp_d = {"value": synth_input("cvd", (2, 15, 2)), "jacobian": synth_input("cjd", (2, 15, 2, 2))}
+    a = driver.normalize_kp(kp, kp_d, kp0, True, True, False, scale=none.scale)
+    b = driver.normalize_kp(kp, kp_d, kp0, True, True, False, scale=1.0)
+    c = driver.normalize_kp(kp, kp_d, kp0, True, True, False, scale=st.scale)
+    assert torch.equal(a["value"], b["value"])
+    assert torch.allclose(c["value"], (kp_d["value"] - kp0["value"]) * 1.25 + kp["value"])
 
 
 def test_normalize_kp_keeps_extra_keys_and_batched_initial_takes_the_torch_path():

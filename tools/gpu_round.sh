@@ -19,7 +19,7 @@ except Exception as e:
     print("bench parse failed", e)
 PY
 head -12 $OUT/shapes_$TAG.txt
-BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-d2h $@"
+BENCH="python $PWD/bench.py --steps 2 --warmup 1 --profile-only $@"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_$TAG; timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o run --output-format csv -- $BENCH > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
 if [ "$PMC" = "pmc" ]; then

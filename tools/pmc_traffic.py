@@ -21,6 +21,16 @@ def load(d, counter):
     return agg
 
 
+def variant(name):
+    """finer key beside the family: the Winograd block shapes separately -- the 4-wave 'wide' block is what the B=60 launches of the
+    big layers run, `winograd_kernel<1>` the B=1 source-encoder / small launches (same split as tools/pmc_mfma.py)."""
+    if "winograd_wide_kernel" in name:
+        return "winograd_wide"
+    if "winograd_kernel" in name:
+        return "winograd_nw1" if ("<1" in name or "<false, 1" in name) else "winograd_nw2"
+    return None
+
+
 def family(name):
     for key, fam in (("winograd_", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("conv3x3_bf16", "conv3x3_bf16"), ("attn_", "attention"),
                      ("warp_", "warp"), ("gn_", "groupnorm"), ("layernorm", "layernorm")):
@@ -33,15 +43,15 @@ def main(fetch_dir, write_dir, out):
     fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     fams = collections.defaultdict(lambda: {"launches": 0, "fetch_kb_raw": 0.0, "write_kb": 0.0, "wlaunches": 0})
     for name, vals in fe.items():
-        fam = family(name)
-        if fam:
-            fams[fam]["launches"] += len(vals)
-            fams[fam]["fetch_kb_raw"] += sum(vals)
+        for fam in (family(name), variant(name)):
+            if fam:
+                fams[fam]["launches"] += len(vals)
+                fams[fam]["fetch_kb_raw"] += sum(vals)
     for name, vals in wr.items():
-        fam = family(name)
-        if fam:
-            fams[fam]["write_kb"] += sum(vals)
-            fams[fam]["wlaunches"] += len(vals)
+        for fam in (family(name), variant(name)):
+            if fam:
+                fams[fam]["write_kb"] += sum(vals)
+                fams[fam]["wlaunches"] += len(vals)
     res = {}
     for fam, v in fams.items():
         n = max(v["launches"], 1)
@@ -54,7 +64,9 @@ def main(fetch_dir, write_dir, out):
         res["conv_gemm_family"] = {"launches_profiled": nl,
                                    "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in conv.values()) / nl}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 "
-                         "--no-cpu-baseline --no-roofline`; FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B)",
+                         "--profile-only` (timed steps only: no B=1 re-render check, so every warp / attention / layernorm launch is a B=60 "
+                         "launch; the B=1 source-encoder convolutions are separated by block shape: winograd_wide = the B=60 launches); "
+                         "FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B)",
                "families": res}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
