@@ -351,6 +351,95 @@ int smx_convert_slice(const void* x, int x_dtype, int ldx, void* y, int y_dtype,
 int smx_nchw_to_nhwc_bf16(const float* x, void* y, int ldy, int B, int C, int H, int W, void* stream);   /* fp32 NCHW -> bf16 NHWC */
 int smx_nhwc_to_nchw_bf16(const void* x, int ldx, float* y, int B, int C, int H, int W, void* stream);   /* bf16 NHWC -> fp32 NCHW */
 
+/* =======================================================================================
+ * TRAINING STEP (BASELINE configs[4]): backward kernels of the hot path and the optimiser side.
+ * Reference: models/appmotioncomp_model.py:294-434 (optimize_parameters -> l_g_total.backward() + Adam steps + EMA);
+ * what torch.autograd dispatches there (convolution_backward, native_group_norm_backward, native_layer_norm_backward,
+ * grid_sampler_2d_backward, upsample_bilinear2d_backward, _softmax_backward_data, bmm, index / scatter of the quantiser)
+ * is replaced by the entry points below.  All fp32; pointers are device pointers; no allocation, no sync.
+ * ===================================================================================== */
+
+/* ---- convolution / Linear / batched GEMM (csrc/train_gemm.hip) ----
+ * The DATA gradient needs no kernel of its own: it is a forward convolution of dY with the packed, tap-flipped, transposed
+ * weights (smx_pack_weight_f32 mode 1) through smx_gemm_conv_f32 -- `up2 = 2` in the descriptor zero-inserts the input x2,
+ * which makes the data gradient of the stride-2 Downsample (archs/vqgan_arch.py:144-153) a stride-1 launch.
+ * WEIGHT gradient: dW[co][(ky,kx,ci)] = sum_m dY[m][co] X~[m][(ky,kx,ci)], m over the nb x (B*Ho*Wo) output pixels, X~ the implicit
+ * im2col of x (zero pad, stride, up2 = nearest x2).  ws: smx_wgrad_ws_floats(...) floats (also returns the pixel split to pass).
+ * out layout 0: OIHW parameter; 1: row-major out[co*ldo + k] (Linear / batched C); 2: transposed out[k*ldo + co].
+ * accumulate: out += alpha * dW (a .grad that already holds another call site's contribution), else out = alpha * dW. */
+int64_t smx_wgrad_ws_floats(int nb, int M, int Cout, int K, int* msplit_out);
+int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
+                  int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
+                  float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha, void* stream);
+/* out[c] (+)= alpha * sum_p x[p*ld + c]  (bias gradients); ws: smx_colsum_ws_floats(P, C) floats; two fixed-order stages */
+int64_t smx_colsum_ws_floats(int64_t P, int C);
+int smx_colsum_f32(const float* x, int ld, int64_t P, int C, float* ws, float* out, int accumulate, float alpha, void* stream);
+int smx_partial_reduce_f32(const float* part, int nchunk, int C, float* out, int accumulate, float alpha, void* stream);
+/* parameter (OIHW, or Linear [out][in] with kh = kw = 1) -> mode 0: [Cout][(ky,kx,ci)] (forward operand);
+ * mode 1: [Cin][(kh-1-ky, kw-1-kx, co)] (data-gradient operand) */
+int smx_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int kh, int kw, int mode, void* stream);
+/* batched y[g][c][r] = x[g][r][c] */
+int smx_transpose_f32(const float* x, int ldx, int64_t x_bs, float* y, int ldy, int64_t y_bs, int nb, int R, int C, void* stream);
+/* y = act(x) as its own pass (training keeps the pre-activation of GELU / swish / sigmoid for the backward) */
+int smx_act_f32(const float* x, int ldx, float* y, int ldy, int64_t P, int C, int act, void* stream);
+/* gx = g * act'(.): ref = the activation's OUTPUT for RELU / LRELU02 / SIGMOID, its INPUT for SWISH / GELU; P x C with row strides */
+int smx_act_bwd_f32(const float* g, int ldg, const float* ref, int ldr, float* gx, int ldo, int64_t P, int C, int act, void* stream);
+/* y[.., :C] += alpha * x[.., :C] over P pixels (gradient accumulation into channel slices) */
+int smx_axpy_slice_f32(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float alpha, void* stream);
+
+/* ---- normalisation / softmax (csrc/norm_softmax.hip) ---- */
+/* GroupNorm statistics for training: ss as smx_groupnorm_stats_f32 plus mr [B][groups][2] = {mean, rstd} saved for the backward */
+int smx_groupnorm_stats_train_f32(const float* x, int ldx, const float* gamma, const float* beta, float* ss, float* mr,
+                                  int B, int HW, int C, int groups, float eps, float* ws, void* stream);
+/* z = act(GN(x)) backward (native_group_norm_backward + the swish): dx; dgamma / dbeta ACCUMULATED.
+ * ws: smx_groupnorm_ws_floats(B, HW, C) + 2*B*groups floats */
+int smx_groupnorm_bwd_f32(const float* x, int ldx, const float* dz, int ldz, const float* ss, const float* mr, const float* gamma,
+                          float* dx, int ldo, float* dgamma, float* dbeta, int B, int HW, int C, int groups, int swish, float* ws, void* stream);
+/* LayerNorm(+pos) backward: gy / gypos = gradients of LN(x) and LN(x)+pos (either may be null); dgamma / dbeta / dpos ACCUMULATED */
+int64_t smx_layernorm_bwd_ws_floats(int T, int E);
+int smx_layernorm_bwd_f32(const float* x, const float* gamma, const float* gy, const float* gypos, float* dx, float* dgamma, float* dbeta,
+                          float* dpos, int T, int E, int npos, float eps, float* ws, void* stream);
+/* out[i] += sum_b g[b*per + i] */
+int smx_batch_sum_f32(const float* g, float* out, int B, int64_t per, void* stream);
+/* in place on dP: dS = scale * P * (dP - rowsum(dP * P))  (AttnBlock, archs/vqgan_arch.py:242-245) */
+int smx_softmax_rows_bwd_f32(const float* P, float* dP, int64_t R, int S, float scale, void* stream);
+
+/* ---- multi-head attention core backward (csrc/train_attn.hip), flash style: P recomputed from q, k and row statistics ----
+ * layouts as smx_attention_f32; o / d_o [B][L][H*dh] dense; k_bs = v_bs = 0: context shared by the batch (dk / dv batch-summed,
+ * fixed order); dq [B][L][H*dh]; dk, dv [B or 1][S][H*dh]; stats: B*H*L*3 floats scratch; dh in {4, 32} */
+int smx_attention_bwd_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs, const float* v, int ldv, int64_t v_bs,
+                          const float* o, const float* d_o, const uint8_t* key_mask, float* dq, float* dk, float* dv, float* stats,
+                          int B, int H, int L, int S, int dh, float scale, void* stream);
+
+/* ---- HBM-bound stages + optimiser (csrc/train_misc.hip) ---- */
+/* A7 backward (grid_sampler_2d_backward fused with the flow / occlusion resize): dfeat += (atomics; pre-zeroed; may be null),
+ * gsm [B][H][W][3] = {d gx, d gy, d occ_s} at the feature resolution (may be null; bring to the flow grid with smx_resize_ac_bwd_f32) */
+int smx_warp_bwd_f32(const float* feat, int feat_batch, const float* flow, const float* occ, const float* g, float* dfeat, float* gsm,
+                     int B, int H, int W, int C, int Hf, int Wf, void* stream);
+/* adjoint of smx_resize_bilinear_ac_nhwc_f32: dx [B][Hin][Win][ldx] += (atomics) from g [B][Hout][Wout][ldg] */
+int smx_resize_ac_bwd_f32(const float* g, int ldg, float* dx, int ldx, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream);
+/* y[b][h][w][(p1*p+p2)*C + c] = x[b][h*p+p1][w*p+p2][c]: the un-patchify store's inverse (x [B][Ho*p][Wo*p][ldx], y dense [B][Ho][Wo][p*p*C]) */
+int smx_space_to_depth_f32(const float* x, int ldx, float* y, int B, int Ho, int Wo, int C, int p, void* stream);
+/* A12 backward (archs/vqgan_arch.py:60-76): dz = g_zq + g_loss*2*beta/numel*(z-e); dcodebook[idx] += g_loss*2/numel*(e-z) (atomics);
+ * g_zq may be null; g_loss: one device float (d total / d this quantiser's loss) or null */
+int smx_vq_bwd_f32(const float* z, const float* codebook, const int64_t* idx, const float* g_zq, const float* g_loss, float beta,
+                   float* dz, float* dcodebook, int64_t N, int D, void* stream);
+/* smx_flow_occ_update_f32 backward: d_flow = g_mcom; d_r = {g_mcom / ((H-1)/2), g_occ*occ*(1-occ)}; d_occ_prev = g_occ*occ*(1-occ) */
+int smx_flow_occ_update_bwd_f32(const float* g_mcom, const float* g_occ, const float* occ, float* d_flow, float* d_r, float* d_occ_prev,
+                                int B, int H, int W, void* stream);
+int smx_sft_combine_bwd_f32(const float* g, const float* dec, int ld_dec, const float* scale, float* d_dec, float* d_scale, float* d_shift,
+                            float w, int64_t P, int C, void* stream);
+/* out[0] = weight * mean|a - b| (losses/losses.py L1Loss, reduction mean); part: 1024 floats scratch; fixed-order reduction */
+int smx_l1_loss_f32(const float* a, const float* b, int64_t n, float weight, float* part, float* out, void* stream);
+int smx_l1_loss_bwd_f32(const float* a, const float* b, const float* g_loss, int64_t n, float weight, float* da, int accumulate, void* stream);
+/* y = alpha * x (+ y) */
+int smx_scale_f32(const float* x, float* y, int64_t n, float alpha, int accumulate, void* stream);
+/* one torch.optim.Adam step (t = 1, 2, ...; no amsgrad) over n contiguous fp32 parameters; the gradient is multiplied by gscale first */
+int smx_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int t, float gscale, void* stream);
+/* ema = decay * ema + (1 - decay) * p (models/sr_model.py model_ema) */
+int smx_ema_f32(float* ema, const float* p, int64_t n, float decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,7 +135,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
             v = *reinterpret_cast<const float4*>(A + a_base[i] + k0 + c4 * 4);
           } else {
             int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
-            if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim) {
+            // up2 == 1: nearest x2 (Upsample folded into the gather); up2 == 2: ZERO-INSERT x2 -- the data gradient of a
+            // stride-2 convolution is a stride-1 convolution over the zero-stuffed output gradient: odd virtual positions are 0
+            if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim && !(p.up2 == 2 && ((iy | ix) & 1))) {
               if (p.up2) { iy >>= 1; ix >>= 1; }
               v = *reinterpret_cast<const float4*>(A + a_base[i] + ((long long)iy * p.Win + ix) * p.lda + l_c);
             }
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
             int tap = k / p.Cin, cc = k - tap * p.Cin;
             int ky = tap / p.kw, kx = tap - ky * p.kw;
             int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-            if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim) {
+            if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim && !(p.up2 == 2 && ((iy | ix) & 1))) {
               if (p.up2) { iy >>= 1; ix >>= 1; }
               x = A[a_base[i] + ((long long)iy * p.Win + ix) * p.lda + cc];
             }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 // scale/shift
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ ss, int HW, int C,
-                                                         int groups, int nch, int ppc, float eps) {
+                                                         int groups, int nch, int ppc, float eps, float* __restrict__ mr = nullptr) {
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
   const int cpg = C / groups, items = nch * cpg;
   double s = 0.0;
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const double var = q / n;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (mr && threadIdx.x == 0) { mr[(long long)blockIdx.x * 2] = (float)mean; mr[(long long)blockIdx.x * 2 + 1] = rstd; }   // training: saved for the backward
   for (int j = threadIdx.x; j < cpg; j += 64) {
     const int c = g * cpg + j;
     const float sc = rstd * gamma[c];
@@ -200,6 +201,196 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(TS* __restrict__ s, i
   sum = wave_sum(sum);
 #pragma unroll
   for (int e = 0; e < SPL; ++e) { int c = lane + 64 * e; if (c < S) St<TS>::st(row + c, v[e] / sum); }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Training: GroupNorm(+swish) backward.  z = act(y), y = xh * gamma + beta, xh = (x - mean_g) * rstd_g.
+//   dy = dz * act'(y);  dgamma_c = sum dy * xh;  dbeta_c = sum dy;
+//   dx = rstd_g * (gamma_c dy - mean_g(gamma dy) - xh * mean_g(gamma dy xh))       (means over the group's HW * C/G elements)
+// pass 1: per (b, chunk, c) {sum dy, sum dy*xh};  pass 2: per (b, group) the two means + per (b, c) totals;  pass 3: dx.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float swish_grad(float y) { const float s = 1.f / (1.f + expf(-y)); return s * (1.f + y * (1.f - s)); }
+
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int ldz,
+                                                             const float* __restrict__ ss, const float* __restrict__ mr,
+                                                             float* __restrict__ part, int HW, int C, int groups, int ppc, int nch, int swish) {
+  extern __shared__ float red[];                       // [rows][C][2]
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cq = C >> 2, cpg = C / groups;
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, rows = 256 / cq;
+  const int p0 = chunk * ppc, p1 = min(p0 + ppc, HW);
+  float sc[4], sh[4], mu[4], rs[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = tx * 4 + e, g = c / cpg;
+    sc[e] = ss[((long long)b * C + c) * 2]; sh[e] = ss[((long long)b * C + c) * 2 + 1];
+    mu[e] = mr[((long long)b * groups + g) * 2]; rs[e] = mr[((long long)b * groups + g) * 2 + 1];
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* xb = x + (long long)b * HW * ldx + tx * 4;
+  const float* zb = dz + (long long)b * HW * ldz + tx * 4;
+  for (int p = p0 + ty; p < p1; p += rows) {
+    const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
+    const float4 gv = *reinterpret_cast<const float4*>(zb + (long long)p * ldz);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dy = swish ? gs[e] * swish_grad(xs[e] * sc[e] + sh[e]) : gs[e];
+      s1[e] += dy; s2[e] += dy * ((xs[e] - mu[e]) * rs[e]);
+    }
+  }
+  float* r = red + ((ty * C) + tx * 4) * 2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[2 * e] = s1[e]; r[2 * e + 1] = s2[e]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int t = 0; t < rows; ++t) { a += red[(t * C + c) * 2]; q += red[(t * C + c) * 2 + 1]; }
+    float* o = part + (((long long)b * nch + chunk) * C + c) * 2;
+    o[0] = a; o[1] = q;
+  }
+}
+
+// one wave per (b, group): coef[b][g] = {mean_g(gamma dy), mean_g(gamma dy xh)}; bc[b][c] = {sum dy, sum dy xh}
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                             float* __restrict__ coef, float* __restrict__ bc, int HW, int C, int groups, int nch) {
+  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+  const int cpg = C / groups;
+  double A = 0.0, Q = 0.0;
+  for (int j = threadIdx.x; j < cpg; j += 64) {
+    const int c = g * cpg + j;
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < nch; ++k) { const float* pp = part + (((long long)b * nch + k) * C + c) * 2; a += pp[0]; q += pp[1]; }
+    bc[((long long)b * C + c) * 2] = (float)a; bc[((long long)b * C + c) * 2 + 1] = (float)q;
+    A += a * gamma[c]; Q += q * gamma[c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o, 64); Q += __shfl_xor(Q, o, 64); }
+  if (threadIdx.x == 0) {
+    const double n = (double)HW * cpg;
+    coef[(long long)blockIdx.x * 2] = (float)(A / n); coef[(long long)blockIdx.x * 2 + 1] = (float)(Q / n);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int ldz,
+                                                           float* __restrict__ dx, int ldo, const float* __restrict__ ss,
+                                                           const float* __restrict__ mr, const float* __restrict__ coef,
+                                                           const float* __restrict__ gamma, long long total4, int HW, int C, int groups, int swish) {
+  const int cq = C >> 2, cpg = C / groups;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % cq); const long long pix = i / cq; const int b = (int)(pix / HW);
+    const float4 xv = *reinterpret_cast<const float4*>(x + pix * ldx + c4 * 4);
+    const float4 gv = *reinterpret_cast<const float4*>(dz + pix * ldz + c4 * 4);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c4 * 4 + e, g = c / cpg;
+      const float sc = ss[((long long)b * C + c) * 2], sh = ss[((long long)b * C + c) * 2 + 1];
+      const float mu = mr[((long long)b * groups + g) * 2], rs = mr[((long long)b * groups + g) * 2 + 1];
+      const float dy = swish ? gs[e] * swish_grad(xs[e] * sc + sh) : gs[e];
+      const float xh = (xs[e] - mu) * rs;
+      o[e] = rs * (gamma[c] * dy - coef[((long long)b * groups + g) * 2] - xh * coef[((long long)b * groups + g) * 2 + 1]);
+    }
+    *reinterpret_cast<float4*>(dx + pix * ldo + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dgamma[c] += sum_b bc[b][c][1]; dbeta[c] += sum_b bc[b][c][0]
+__global__ __launch_bounds__(256) void gn_bwd_params_kernel(const float* __restrict__ bc, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, q = 0.f;
+  for (int b = 0; b < B; ++b) { a += bc[((long long)b * C + c) * 2]; q += bc[((long long)b * C + c) * 2 + 1]; }
+  dgamma[c] += q; dbeta[c] += a;
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm(+pos) backward: one wave per token; dy = g_y + g_ypos; dx as above with the token as the group;
+// per-block partial {dbeta, dgamma} rows for a deterministic second stage (smx_partial_reduce_f32)
+// ---------------------------------------------------------------------------------------
+template <int EPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ gy, const float* __restrict__ gyp,
+                                                            float* __restrict__ dx, float* __restrict__ part, int T, int E, float eps, int tpw) {
+  __shared__ float red[4][2][64 * EPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dgm[EPL], dbt[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { dgm[e] = 0.f; dbt[e] = 0.f; }
+  for (int k = 0; k < tpw; ++k) {
+    const int t = (blockIdx.x * 4 + wave) * tpw + k;
+    if (t >= T) break;
+    const float* xr = x + (long long)t * E;
+    float v[EPL], d[EPL]; float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { const int c = lane + 64 * e; v[e] = c < E ? xr[c] : 0.f; s += v[e]; }
+    const float mean = wave_sum(s) / E;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { const int c = lane + 64 * e; const float dd = c < E ? v[e] - mean : 0.f; q += dd * dd; }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / E + eps);
+    float a = 0.f, bq = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int c = lane + 64 * e;
+      float dy = 0.f;
+      if (c < E) { if (gy) dy += gy[(long long)t * E + c]; if (gyp) dy += gyp[(long long)t * E + c]; }
+      const float xh = c < E ? (v[e] - mean) * rstd : 0.f;
+      d[e] = dy; v[e] = xh;
+      const float gd = c < E ? gamma[c] * dy : 0.f;
+      a += gd; bq += gd * xh;
+      dgm[e] += dy * xh; dbt[e] += dy;
+    }
+    a = wave_sum(a) / E; bq = wave_sum(bq) / E;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int c = lane + 64 * e;
+      if (c < E) dx[(long long)t * E + c] = rstd * (gamma[c] * d[e] - a - v[e] * bq);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { red[wave][0][lane + 64 * e] = dbt[e]; red[wave][1][lane + 64 * e] = dgm[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * E; i += 256) {
+    const int which = i / E, c = i - which * E;
+    part[(long long)blockIdx.x * 2 * E + i] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
+// dpos[n][c] += sum_b g[b][n][c]   (the position embedding is added to every sample's tokens)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, long long per) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += g[(long long)b * per + i];
+    out[i] += s;
+  }
+}
+
+// softmax backward in place on dP: dS = scale * P * (dP - sum_j dP P); one wave per row (AttnBlock, scores materialised)
+template <int SPL>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long long R, int S, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long r = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* pr = P + r * S; float* dr = dP + r * S;
+  float pv[SPL], dv[SPL]; float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < SPL; ++e) { const int c = lane + 64 * e; pv[e] = c < S ? pr[c] : 0.f; dv[e] = c < S ? dr[c] : 0.f; s += pv[e] * dv[e]; }
+  s = wave_sum(s);
+#pragma unroll
+  for (int e = 0; e < SPL; ++e) { const int c = lane + 64 * e; if (c < S) dr[c] = scale * pv[e] * (dv[e] - s); }
+}
+
+
+// ws[blk][0:E] = dbeta partials, ws[blk][E:2E] = dgamma partials -> accumulate into dbeta / dgamma (fixed order over blocks)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ ws, int nblk, int E, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * E) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += ws[(long long)k * 2 * E + i];
+  if (i < E) dbeta[i] += s; else dgamma[i - E] += s;
 }
 
 }  // namespace
@@ -329,4 +520,79 @@ extern "C" int smx_softmax_rows_f32(float* s, int ld, int R, int S, float scale,
 extern "C" int smx_softmax_rows_bf16(void* s, int ld, int R, int S, float scale, const uint8_t* mask,
                                      int rows_per_mask, void* stream) {
   return softmax_launch<bf16_t>((bf16_t*)s, ld, R, S, scale, mask, rows_per_mask, stream);
+}
+
+
+/* ---- training entry points (GroupNorm / LayerNorm / softmax backward) ------------------------------------------------ */
+extern "C" int smx_groupnorm_stats_train_f32(const float* x, int ldx, const float* gamma, const float* beta, float* ss, float* mr,
+                                             int B, int HW, int C, int groups, float eps, float* ws, void* stream) {
+  if (!x || !ss || !mr || !gamma || !beta || !ws || B <= 0 || HW <= 0) return SMX_EINVAL;
+  if (C < 4 || C > 1024 || (C & (C - 1)) != 0 || C % groups != 0 || ldx % 4 != 0 || ldx < C) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
+  const int nch = (HW + ppc - 1) / ppc;
+  const int rows = 256 / (C / 4);
+  SMX_LAUNCH(gn_partial_kernel<float>, dim3(nch, B), dim3(256), (size_t)rows * C * 3 * sizeof(float), st, x, ldx, ws, HW, C, ppc, nch);
+  SMX_LAUNCH(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, ws, gamma, beta, ss, HW, C, groups, nch, ppc, eps, mr);
+  return smx_launch_status();
+}
+
+/* ws: smx_groupnorm_ws_floats(B, HW, C) + 2*B*groups floats.  dgamma / dbeta are ACCUMULATED into. */
+extern "C" int smx_groupnorm_bwd_f32(const float* x, int ldx, const float* dz, int ldz, const float* ss, const float* mr,
+                                     const float* gamma, float* dx, int ldo, float* dgamma, float* dbeta,
+                                     int B, int HW, int C, int groups, int swish, float* ws, void* stream) {
+  if (!x || !dz || !ss || !mr || !gamma || !dx || !dgamma || !dbeta || !ws || B <= 0 || HW <= 0) return SMX_EINVAL;
+  if (C < 4 || C > 1024 || (C & (C - 1)) != 0 || C % groups != 0 || ldx % 4 || ldz % 4 || ldo % 4 || ldx < C || ldz < C || ldo < C) return SMX_EINVAL;
+  if ((((uintptr_t)x) | ((uintptr_t)dz) | ((uintptr_t)dx)) & 15) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
+  const int nch = (HW + ppc - 1) / ppc;
+  const int rows = 256 / (C / 4);
+  float* part = ws; float* bc = ws + (int64_t)B * nch * C * 2; float* coef = bc + (int64_t)B * C * 2;
+  SMX_LAUNCH(gn_bwd_partial_kernel, dim3(nch, B), dim3(256), (size_t)rows * C * 2 * sizeof(float), st, x, ldx, dz, ldz, ss, mr, part, HW, C, groups, ppc, nch, swish);
+  SMX_LAUNCH(gn_bwd_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, gamma, coef, bc, HW, C, groups, nch);
+  const long long total4 = (long long)B * HW * (C / 4);
+  int blocks = smx_cdiv(total4, 256); if (blocks > 8192) blocks = 8192;
+  SMX_LAUNCH(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, dz, ldz, dx, ldo, ss, mr, coef, gamma, total4, HW, C, groups, swish);
+  SMX_LAUNCH(gn_bwd_params_kernel, dim3(smx_cdiv(C, 256)), dim3(256), 0, st, bc, dgamma, dbeta, B, C);
+  return smx_launch_status();
+}
+
+extern "C" int64_t smx_layernorm_bwd_ws_floats(int T, int E) { return (int64_t)smx_cdiv(T, 16) * 2 * E; }
+
+/* gy / gypos: gradients of LN(x) and of LN(x)+pos (either may be null); dgamma / dbeta / dpos are ACCUMULATED into (dpos may be null). */
+extern "C" int smx_layernorm_bwd_f32(const float* x, const float* gamma, const float* gy, const float* gypos, float* dx,
+                                     float* dgamma, float* dbeta, float* dpos, int T, int E, int npos, float eps, float* ws, void* stream) {
+  if (!x || !gamma || (!gy && !gypos) || !dx || !dgamma || !dbeta || !ws || T <= 0 || E <= 0 || E > 512) return SMX_EINVAL;
+  if (dpos && (!gypos || npos <= 0 || T % npos != 0)) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = smx_cdiv(T, 16);
+  if (E <= 64) SMX_LAUNCH(layernorm_bwd_kernel<1>, dim3(nblk), dim3(256), 0, st, x, gamma, gy, gypos, dx, ws, T, E, eps, 4);
+  else if (E <= 256) SMX_LAUNCH(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), 0, st, x, gamma, gy, gypos, dx, ws, T, E, eps, 4);
+  else SMX_LAUNCH(layernorm_bwd_kernel<8>, dim3(nblk), dim3(256), 0, st, x, gamma, gy, gypos, dx, ws, T, E, eps, 4);
+  // ws rows are [dbeta(E) | dgamma(E)]: two strided column reductions in a fixed order
+  SMX_LAUNCH(ln_param_reduce_kernel, dim3(smx_cdiv(2 * E, 256)), dim3(256), 0, st, ws, nblk, E, dbeta, dgamma);
+  if (dpos) {
+    const long long per = (long long)npos * E;
+    int blocks = smx_cdiv(per, 256); if (blocks > 4096) blocks = 4096;
+    SMX_LAUNCH(batch_sum_kernel, dim3(blocks), dim3(256), 0, st, gypos, dpos, T / npos, per);
+  }
+  return smx_launch_status();
+}
+
+extern "C" int smx_batch_sum_f32(const float* g, float* out, int B, int64_t per, void* stream) {
+  if (!g || !out || B <= 0 || per <= 0) return SMX_EINVAL;
+  int blocks = smx_cdiv(per, 256); if (blocks > 4096) blocks = 4096;
+  SMX_LAUNCH(batch_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, out, B, (long long)per);
+  return smx_launch_status();
+}
+
+extern "C" int smx_softmax_rows_bwd_f32(const float* P, float* dP, int64_t R, int S, float scale, void* stream) {
+  if (!P || !dP || R <= 0 || S <= 0 || S > 1024) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(smx_cdiv(R, 4)), block(256);
+  if (S <= 256) SMX_LAUNCH(softmax_bwd_kernel<4>, grid, block, 0, st, P, dP, (long long)R, S, scale);
+  else if (S <= 512) SMX_LAUNCH(softmax_bwd_kernel<8>, grid, block, 0, st, P, dP, (long long)R, S, scale);
+  else SMX_LAUNCH(softmax_bwd_kernel<16>, grid, block, 0, st, P, dP, (long long)R, S, scale);
+  return smx_launch_status();
 }

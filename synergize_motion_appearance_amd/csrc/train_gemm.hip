@@ -1,0 +1,411 @@
+// Training-step GEMM side (backward of the convolution / Linear / batched-GEMM family) for gfx950.
+//
+//   * wgrad_kernel: the WEIGHT gradient of a convolution as a "TN" GEMM on the fp32 MFMA,
+//         dW[co][(ky,kx,ci)] = sum_m dY[m][co] * X~[m][(ky,kx,ci)],
+//     m over the B*Ho*Wo output pixels (the REDUCTION runs over rows, unlike the forward's NT form), X~ the implicit
+//     im2col of the NHWC input (zero pad, stride, nearest-x2) gathered on the fly.  Both operands are staged as
+//     [32 pixels][64 columns] LDS tiles (coalesced 16-B global reads along the channel axis) and the MFMA fragments are
+//     read "down the columns": lane l supplies column (l & 31) of pixel p (lanes 0-31) and p+8 (lanes 32-63) -- with a
+//     row pitch of 68 floats the two half-waves hit disjoint bank halves, so every fragment is ONE conflict-free
+//     ds_read_b32.  The pixel axis is split over blockIdx.z (few output tiles, very long reduction): raw partials go
+//     to a workspace and wgrad_reduce_kernel adds them IN A FIXED ORDER (deterministic, no atomics) while scattering
+//     into the parameter's own layout (OIHW / [out][in] / transposed) and accumulating onto an existing .grad.
+//     The same kernel is the batched TN GEMM of the AttnBlock backward (dV = P^T dH, dK = dS^T Q).
+//   * colsum: per-column sums over rows (bias gradients, per-channel statistics), two deterministic stages.
+//   * pack kernels: parameter layout (OIHW) -> the forward's [Cout][kh][kw][Cin] and the data-gradient's
+//     [Cin][kh'][kw'][Cout] (taps flipped): the data gradient is then a FORWARD convolution through gemm_conv /
+//     winograd (smx_gemm_conv_f32 with up2 = 2 zero-insertion for stride-2 layers), no separate dgrad kernel.
+//   * batched transpose, activation backward.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "smx.h"
+#include "smx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+inline int grid_for(long long total) { int g = smx_cdiv(total, 256); return g > 16384 ? 16384 : (g < 1 ? 1 : g); }
+
+constexpr int WPITCH = 68;     // LDS row pitch (floats): 8 * 68 = 544 = 8 * 64 + 32 -> rows p and p+8 sit in opposite bank halves
+
+struct WG {
+  const float* dy; const float* x; float* ws;
+  long long dy_bs, x_bs;
+  int M, Cout, K, ldy, ldx;
+  int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
+  int is1x1, vec_x, vec_y;
+  int msplit, mper, tiles_k;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
+  __shared__ __attribute__((aligned(16))) float As[2][32 * WPITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[2][32 * WPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_k = blockIdx.x % p.tiles_k, tile_c = blockIdx.x / p.tiles_k;
+  const int co0 = tile_c * 64, k0 = tile_k * 64;
+  const int g = blockIdx.y, z = blockIdx.z;
+  const float* __restrict__ DY = p.dy + (long long)g * p.dy_bs;
+  const float* __restrict__ X = p.x + (long long)g * p.x_bs;
+  const int m_begin = z * p.mper, m_end = min(p.M, m_begin + p.mper);
+
+  // staging coordinates: float4 column c4 of rows r0 and r0 + 16
+  const int c4 = tid & 15, r0 = tid >> 4;
+  // this thread's B columns k0 + 4 c4 + e are fixed for the whole block: resolve (tap, channel) once
+  int b_ky[4], b_kx[4], b_cc[4]; bool b_in[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = k0 + c4 * 4 + e;
+    b_in[e] = k < p.K;
+    const int tap = b_in[e] ? k / p.Cin : 0;
+    b_cc[e] = b_in[e] ? k - tap * p.Cin : 0; b_ky[e] = tap / p.kw; b_kx[e] = tap - b_ky[e] * p.kw;
+  }
+  const int HoWo = p.Ho * p.Wo;
+  const int Hlim = p.up2 ? 2 * p.Hin : p.Hin, Wlim = p.up2 ? 2 * p.Win : p.Win;
+
+  float4 areg[2], breg[2];
+  auto load_slice = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + r0 + 16 * i;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (m < m_end) {
+        const int co = co0 + c4 * 4;
+        if (p.vec_y && co + 3 < p.Cout) {
+          a = *reinterpret_cast<const float4*>(DY + (long long)m * p.ldy + co);
+        } else {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (co + e < p.Cout) ? DY[(long long)m * p.ldy + co + e] : 0.f;
+          a = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (p.is1x1) {
+          const int k = k0 + c4 * 4;
+          if (p.vec_x && k + 3 < p.K) {
+            b = *reinterpret_cast<const float4*>(X + (long long)m * p.ldx + k);
+          } else {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (k + e < p.K) ? X[(long long)m * p.ldx + k + e] : 0.f;
+            b = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        } else {
+          const int img = m / HoWo, rem = m - img * HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          const long long base = (long long)img * p.Hin * p.Win * p.ldx;
+          const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+          if (p.vec_x && b_in[3] && b_cc[3] == b_cc[0] + 3) {          // the four columns share one tap: one 16-B load
+            int iy = iy0 + b_ky[0], ix = ix0 + b_kx[0];
+            if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim) {
+              if (p.up2) { iy >>= 1; ix >>= 1; }
+              b = *reinterpret_cast<const float4*>(X + base + ((long long)iy * p.Win + ix) * p.ldx + b_cc[0]);
+            }
+          } else {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = 0.f;
+              if (b_in[e]) {
+                int iy = iy0 + b_ky[e], ix = ix0 + b_kx[e];
+                if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim) {
+                  if (p.up2) { iy >>= 1; ix >>= 1; }
+                  t = X[base + ((long long)iy * p.Win + ix) * p.ldx + b_cc[e]];
+                }
+              }
+              v[e] = t;
+            }
+            b = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+      areg[i] = a; breg[i] = b;
+    }
+  };
+  auto store_slice = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&As[buf][(r0 + 16 * i) * WPITCH + c4 * 4]) = areg[i];
+      *reinterpret_cast<float4*>(&Bs[buf][(r0 + 16 * i) * WPITCH + c4 * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int wm = wave >> 1, wn = wave & 1;                 // wave tile: co rows 32 wm.., k columns 32 wn..
+  // fragment base: pixel (l >> 5) * 8 within a 16-pixel group, column (l & 31) of the wave's half
+  const int fa = (lane >> 5) * 8 * WPITCH + wm * 32 + (lane & 31);
+  const int fb = (lane >> 5) * 8 * WPITCH + wn * 32 + (lane & 31);
+
+  const int nslices = (m_end - m_begin + 31) / 32;
+  if (nslices > 0) {
+    load_slice(m_begin);
+    store_slice(0);
+    __syncthreads();
+    for (int s = 0; s < nslices; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nslices) load_slice(m_begin + (s + 1) * 32);      // in flight across this slice's MFMAs
+      const float* as = &As[buf][fa];
+      const float* bs = &Bs[buf][fb];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int prow = (j & 7) + 16 * (j >> 3);            // pixels prow (lanes 0-31) and prow + 8 (lanes 32-63)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[prow * WPITCH], bs[prow * WPITCH], acc, 0, 0, 0);
+      }
+      if (s + 1 < nslices) store_slice(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // raw partial tile -> ws[(g * msplit + z)][Cout][K]
+  float* W = p.ws + ((long long)g * p.msplit + z) * p.Cout * p.K;
+  const int kcol = k0 + wn * 32 + (lane & 31);
+  if (kcol < p.K) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (co < p.Cout) W[(long long)co * p.K + kcol] = acc[r];
+    }
+  }
+}
+
+// out (+)= sum_z ws[g][z][co][k], scattered into the destination's layout:
+//   layout 0: OIHW parameter  out[co][ci][ky][kx]           (k = (ky*kw + kx)*Cin + ci)
+//   layout 1: row-major       out[g][co * ldo + k]          (Linear [out][in]; patch-embedding Linear [out][(p1 p2 c)]; batched GEMM C)
+//   layout 2: transposed      out[g][k * ldo + co]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long out_bs,
+                                                           int nb, int msplit, int Cout, int K, int Cin, int khw, int layout, int ldo,
+                                                           int accumulate, float alpha) {
+  const long long per = (long long)Cout * K, total = per * nb;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int g = (int)(i / per); const long long j = i - (long long)g * per;
+    const int co = (int)(j / K), k = (int)(j - (long long)co * K);
+    const float* w = ws + (long long)g * msplit * per + j;
+    float s = 0.f;
+    for (int zz = 0; zz < msplit; ++zz) s += w[(long long)zz * per];
+    s *= alpha;
+    long long o;
+    if (layout == 0) { const int tap = k / Cin, ci = k - tap * Cin; o = ((long long)co * Cin + ci) * khw + tap; }
+    else if (layout == 1) o = (long long)co * ldo + k;
+    else o = (long long)k * ldo + co;
+    float* d = out + (long long)g * out_bs + o;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// ---- column sums: part[chunk][C] = sum over the chunk's rows; then out[c] (+)= sum_chunk part[chunk][c] (fixed order) ----
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, long long P, int C, int rows_per_chunk,
+                                                             float* __restrict__ part) {
+  __shared__ float red[256 * 4];
+  int cw = 1; while (cw < C && cw < 256) cw <<= 1;
+  const int tx = threadIdx.x % cw, ty = threadIdx.x / cw, rpar = 256 / cw;
+  const long long r_begin = (long long)blockIdx.x * rows_per_chunk, r_end = min(P, r_begin + rows_per_chunk);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long long r = r_begin + ty; r < r_end; r += rpar) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int c = tx + q * cw; if (c < C) s[q] += x[r * ld + c]; }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[threadIdx.x * 4 + q] = s[q];
+  __syncthreads();
+  if (ty == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = tx + q * cw;
+      if (c < C) {
+        float t = 0.f;
+        for (int y = 0; y < rpar; ++y) t += red[(y * cw + tx) * 4 + q];
+        part[(long long)blockIdx.x * C + c] = t;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int nchunk, int C, float* __restrict__ out,
+                                                             int accumulate, float alpha) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[(long long)k * C + c];
+  s *= alpha;
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---- parameter packing ---------------------------------------------------------------------------------------------
+// mode 0: OIHW -> [Cout][(ky,kx,ci)]            (the forward operand)
+// mode 1: OIHW -> [Cin][(kh-1-ky, kw-1-kx, co)] (the data-gradient operand: transposed channels, flipped taps)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int Cout, int Cin, int kh, int kw, int mode) {
+  const long long total = (long long)Cout * Cin * kh * kw;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    // i indexes the OUTPUT so that writes are coalesced
+    if (mode == 0) {
+      const int K = kh * kw * Cin; const int co = (int)(i / K), k = (int)(i - (long long)co * K);
+      const int tap = k / Cin, ci = k - tap * Cin;
+      o[i] = w[((long long)co * Cin + ci) * kh * kw + tap];
+    } else {
+      const int K = kh * kw * Cout; const int ci = (int)(i / K), k = (int)(i - (long long)ci * K);
+      const int tap = k / Cout, co = k - tap * Cout; const int ky = kh - 1 - tap / kw, kx = kw - 1 - tap % kw;
+      o[i] = w[((long long)co * Cin + ci) * kh * kw + ky * kw + kx];
+    }
+  }
+}
+
+// ---- batched transpose: y[g][c][r] = x[g][r][c] -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int ldx, long long x_bs, float* __restrict__ y, int ldy,
+                                                        long long y_bs, int R, int C) {
+  __shared__ float t[32][33];
+  const float* X = x + (long long)blockIdx.z * x_bs; float* Y = y + (long long)blockIdx.z * y_bs;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) if (r0 + j < R && c0 + tx < C) t[j][tx] = X[(long long)(r0 + j) * ldx + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) if (c0 + j < C && r0 + tx < R) Y[(long long)(c0 + j) * ldy + r0 + tx] = t[tx][j];
+}
+
+// ---- activation backward: gx = g * f'(.)  with the reference tensor the derivative is cheapest from -----------------
+//   RELU / LRELU02 / SIGMOID: ref = the activation's OUTPUT y;  SWISH / GELU: ref = its INPUT x
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ ref, int ldr,
+                                                      float* __restrict__ gx, int ldo, long long P, int C, int act) {
+  const long long total = P * C;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C; const int c = (int)(i - r * C);
+    const float gv = g[r * ldg + c], v = ref[r * ldr + c];
+    float d;
+    switch (act) {
+      case SMX_ACT_RELU: d = v > 0.f ? 1.f : 0.f; break;
+      case SMX_ACT_LRELU02: d = v > 0.f ? 1.f : 0.2f; break;
+      case SMX_ACT_SIGMOID: d = v * (1.f - v); break;
+      case SMX_ACT_SWISH: { const float s = 1.f / (1.f + expf(-v)); d = s * (1.f + v * (1.f - s)); break; }
+      case SMX_ACT_GELU: d = 0.5f * (1.f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v); break;
+      default: d = 1.f; break;
+    }
+    gx[r * ldo + c] = gv * d;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C, int act) {
+  const long long total = P * C;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C; const int c = (int)(i - r * C);
+    const float v = x[r * ldx + c];
+    float o;
+    switch (act) {
+      case SMX_ACT_RELU: o = v > 0.f ? v : 0.f; break;
+      case SMX_ACT_LRELU02: o = v > 0.f ? v : 0.2f * v; break;
+      case SMX_ACT_SWISH: o = v / (1.f + expf(-v)); break;
+      case SMX_ACT_GELU: o = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); break;
+      case SMX_ACT_SIGMOID: o = 1.f / (1.f + expf(-v)); break;
+      default: o = v; break;
+    }
+    y[r * ldy + c] = o;
+  }
+}
+
+// y[.., :C] (ld ldy) += alpha * x[.., :C] (ld ldx): gradient accumulation into channel slices of concat buffers
+__global__ __launch_bounds__(256) void axpy_slice_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C, float alpha) {
+  const long long total = P * C;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C; const int c = (int)(i - r * C);
+    y[r * ldy + c] += alpha * x[r * ldx + c];
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t smx_wgrad_ws_floats(int nb, int M, int Cout, int K, int* msplit_out) {
+  if (nb <= 0 || M <= 0 || Cout <= 0 || K <= 0) return 0;
+  const long long tiles = (long long)smx_cdiv(Cout, 64) * smx_cdiv(K, 64) * nb;
+  // aim at >= 1024 blocks (4 per CU), at least 256 pixels per block, partial workspace <= 64 MB
+  long long ms = (1024 + tiles - 1) / tiles;
+  const long long max_by_m = (M + 255) / 256;
+  if (ms > max_by_m) ms = max_by_m;
+  const long long cap = (64LL << 20) / 4 / ((long long)nb * Cout * K);
+  if (ms > cap) ms = cap;
+  if (ms < 1) ms = 1;
+  if (msplit_out) *msplit_out = (int)ms;
+  return (int64_t)nb * ms * Cout * K;
+}
+
+extern "C" int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
+                             int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
+                             float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
+                             void* stream) {
+  if (!dy || !x || !ws || !out || nb <= 0 || M <= 0 || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return SMX_EINVAL;
+  if (msplit < 1 || nb > 65535 || msplit > 65535 || layout < 0 || layout > 2 || ldy < Cout || ldx < Cin) return SMX_EINVAL;
+  if (Ho <= 0 || Wo <= 0 || M % (Ho * Wo) != 0 || (up2 != 0 && up2 != 1)) return SMX_EINVAL;
+  WG p;
+  p.dy = dy; p.x = x; p.ws = ws; p.dy_bs = dy_bs; p.x_bs = x_bs;
+  p.M = M; p.Cout = Cout; p.K = kh * kw * Cin; p.ldy = ldy; p.ldx = ldx;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.up2 = up2;
+  p.is1x1 = (kh == 1 && kw == 1 && stride == 1 && !up2 && pad_t == 0 && pad_l == 0 && Hin == Ho && Win == Wo) ? 1 : 0;
+  if (layout != 0 && ldo < (layout == 1 ? p.K : Cout)) return SMX_EINVAL;
+  p.vec_x = (Cin % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && x_bs % 4 == 0) ? 1 : 0;
+  p.vec_y = (ldy % 4 == 0 && (((uintptr_t)dy) & 15) == 0 && dy_bs % 4 == 0) ? 1 : 0;
+  p.msplit = msplit;
+  p.mper = ((M + msplit - 1) / msplit + 31) / 32 * 32;
+  p.tiles_k = smx_cdiv(p.K, 64);
+  hipStream_t st = (hipStream_t)stream;
+  const long long tiles = (long long)smx_cdiv(Cout, 64) * p.tiles_k;
+  if (tiles > 2147483647LL) return SMX_EINVAL;
+  SMX_LAUNCH(wgrad_kernel, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
+  SMX_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long long)nb * Cout * p.K)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
+             Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha);
+  return smx_launch_status();
+}
+
+static void colsum_chunks(long long P, long long* rows, long long* nchunk) {
+  *rows = 256; *nchunk = (P + *rows - 1) / *rows;
+  if (*nchunk > 2048) { *rows = (P + 2047) / 2048; *nchunk = (P + *rows - 1) / *rows; }
+}
+
+extern "C" int64_t smx_colsum_ws_floats(int64_t P, int C) {
+  if (P <= 0 || C <= 0) return 0;
+  long long rows, nchunk; colsum_chunks(P, &rows, &nchunk);
+  return nchunk * (C < 1024 ? C : 1024);
+}
+
+extern "C" int smx_colsum_f32(const float* x, int ld, int64_t P, int C, float* ws, float* out, int accumulate, float alpha, void* stream) {
+  if (!x || !ws || !out || P <= 0 || C <= 0 || ld < C) return SMX_EINVAL;
+  long long rows, nchunk; colsum_chunks(P, &rows, &nchunk);
+  hipStream_t st = (hipStream_t)stream;
+  for (int c0 = 0; c0 < C; c0 += 1024) {              // wide rows (the un-patchify bias: p*p*C columns) go in column blocks of 1024
+    const int cw = C - c0 < 1024 ? C - c0 : 1024;
+    SMX_LAUNCH(colsum_partial_kernel, dim3((unsigned)nchunk), dim3(256), 0, st, x + c0, ld, (long long)P, cw, (int)rows, ws);
+    SMX_LAUNCH(partial_reduce_kernel, dim3(smx_cdiv(cw, 256)), dim3(256), 0, st, ws, (int)nchunk, cw, out + c0, accumulate, alpha);
+  }
+  return smx_launch_status();
+}
+
+extern "C" int smx_partial_reduce_f32(const float* part, int nchunk, int C, float* out, int accumulate, float alpha, void* stream) {
+  if (!part || !out || nchunk <= 0 || C <= 0) return SMX_EINVAL;
+  SMX_LAUNCH(partial_reduce_kernel, dim3(smx_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part, nchunk, C, out, accumulate, alpha);
+  return smx_launch_status();
+}
+
+extern "C" int smx_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int kh, int kw, int mode, void* stream) {
+  if (!w_oihw || !packed || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || (mode != 0 && mode != 1)) return SMX_EINVAL;
+  SMX_LAUNCH(pack_weight_kernel, dim3(grid_for((long long)Cout * Cin * kh * kw)), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin, kh, kw, mode);
+  return smx_launch_status();
+}
+
+extern "C" int smx_transpose_f32(const float* x, int ldx, int64_t x_bs, float* y, int ldy, int64_t y_bs, int nb, int R, int C, void* stream) {
+  if (!x || !y || nb <= 0 || nb > 65535 || R <= 0 || C <= 0 || ldx < C || ldy < R) return SMX_EINVAL;
+  SMX_LAUNCH(transpose_kernel, dim3(smx_cdiv(C, 32), smx_cdiv(R, 32), nb), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)x_bs, y, ldy, (long long)y_bs, R, C);
+  return smx_launch_status();
+}
+
+extern "C" int smx_act_bwd_f32(const float* g, int ldg, const float* ref, int ldr, float* gx, int ldo, int64_t P, int C, int act, void* stream) {
+  if (!g || !ref || !gx || P <= 0 || C <= 0 || ldg < C || ldr < C || ldo < C) return SMX_EINVAL;
+  SMX_LAUNCH(act_bwd_kernel, dim3(grid_for((long long)P * C)), dim3(256), 0, (hipStream_t)stream, g, ldg, ref, ldr, gx, ldo, (long long)P, C, act);
+  return smx_launch_status();
+}
+
+extern "C" int smx_act_f32(const float* x, int ldx, float* y, int ldy, int64_t P, int C, int act, void* stream) {
+  if (!x || !y || P <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
+  SMX_LAUNCH(act_fwd_kernel, dim3(grid_for((long long)P * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (long long)P, C, act);
+  return smx_launch_status();
+}
+
+extern "C" int smx_axpy_slice_f32(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float alpha, void* stream) {
+  if (!x || !y || P <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
+  SMX_LAUNCH(axpy_slice_kernel, dim3(grid_for((long long)P * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (long long)P, C, alpha);
+  return smx_launch_status();
+}

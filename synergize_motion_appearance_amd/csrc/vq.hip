@@ -7,7 +7,7 @@
 // codebook axis finishes with wavefront shuffles, and nothing but z, the codebook, the
 // indices and z_q touches HBM.  z fragments stay in registers for the whole codebook sweep;
 // code tiles (32 x D) are double-buffered in LDS (row stride D+4 dwords: conflict-free ds_read_b128),
-// the next tile prefetched into registers across the current tile's MFMAs (one barrier per tile);
+// the next tile streamed through a few registers in chunks inside the current tile's MFMA loop (one barrier per tile);
 // sum (z_q - z)^2 leaves as per-block partials summed in a fixed order (bit-reproducible loss).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,9 +23,9 @@ template <int D>
 __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                  int64_t* __restrict__ idx_out, float* __restrict__ zq,
                                                  float* __restrict__ dmin_out, float* __restrict__ sq_part, int N, int Ks) {
-  // 32 codes per tile, two LDS buffers: the next tile's global loads are issued BEFORE the current tile's MFMAs and land in
-  // registers while the matrix pipe works; they go to the other buffer afterwards -> ONE barrier per tile and no exposed
-  // HBM/L2 round trip (the single-buffered form had a load -> barrier -> compute -> barrier sequence per 64 codes)
+  // 32 codes per tile, two LDS buffers: the next tile's global loads are issued DURING the current tile's MFMAs and land in
+  // registers while the matrix pipe works; they go to the other buffer a quarter tile later -> ONE barrier per tile and no
+  // exposed HBM/L2 round trip (the single-buffered form had a load -> barrier -> compute -> barrier sequence per 64 codes)
   constexpr int LD = D + 4, KS = D / 8, CT = 32;
   constexpr int PF = CT * (D / 4) / 256;               // float4 per thread per tile (D=256: 8, D=32: 1)
   static_assert(CT * (D / 4) % 256 == 0, "tile must split evenly over the block");
@@ -60,25 +60,29 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
     if (part == 0) ee[code] = s;
   }
-  float4 pf[PF];
-  auto fetch = [&](int t) {
+  // the next tile travels global -> registers -> LDS in NCH chunks INSIDE the current tile's MFMA loop (chunk q is requested at
+  // kk = q*KS/NCH and written to the other buffer KS/NCH steps later): only PF/NCH float4 are live at a time -- the whole-tile
+  // prefetch cost 32 VGPRs at D = 256 and dropped the kernel to one wave per SIMD
+  constexpr int NCH = PF >= 4 ? 4 : 1, PC = PF / NCH, KSTEP = KS / NCH;
+  float4 pf[PC];
+  auto fetch = [&](int t, int q0) {
 #pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int i = threadIdx.x + q * 256;
+    for (int q = 0; q < PC; ++q) {
+      const int i = threadIdx.x + (q0 + q) * 256;
       const int r = i / (D / 4), c4 = i % (D / 4); const int code = t * CT + r;
       pf[q] = code < Ks ? *reinterpret_cast<const float4*>(cb + (long long)code * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, int q0) {
 #pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int i = threadIdx.x + q * 256;
+    for (int q = 0; q < PC; ++q) {
+      const int i = threadIdx.x + (q0 + q) * 256;
       const int r = i / (D / 4), c4 = i % (D / 4);
       *reinterpret_cast<float4*>(cs + (buf * CT + r) * LD + c4 * 4) = pf[q];
     }
   };
-  fetch(0);
-  stash(0);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { fetch(0, c * PC); stash(0, c * PC); }
   __syncthreads();
   float zzr[16];
 #pragma unroll
@@ -90,19 +94,24 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
 
   const int ntiles = ks_pad / CT;
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) fetch(t + 1);                  // in flight during this tile's MFMAs
+    const bool more = t + 1 < ntiles;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* bp = cs + ((t & 1) * CT + (lane & 31)) * LD + (lane >> 5) * 4;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
+      if (kk % KSTEP == 0) {                           // compile-time positions (the loop is fully unrolled)
+        if (kk > 0 && more) stash((t + 1) & 1, (kk / KSTEP - 1) * PC);   // the buffer tile t-1 used: free since the barrier that ended t-1
+        if (more) fetch(t + 1, (kk / KSTEP) * PC);
+      }
       const float4 bf = *reinterpret_cast<const float4*>(bp + kk * 8);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf.w, acc, 0, 0, 0);
     }
+    if (more) stash((t + 1) & 1, (NCH - 1) * PC);
     const int code = t * CT + (lane & 31);
     if (code < Ks) {
       const float e2 = ee[code];
@@ -112,7 +121,6 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
         if (d < bestd[r]) { bestd[r] = d; besti[r] = code; }
       }
     }
-    if (t + 1 < ntiles) stash((t + 1) & 1);            // the buffer tile t-1 used: every wave passed the barrier that ended t-1
     __syncthreads();
   }
   // reduce over the 32 code lanes (same lane>>5 half): smaller d, ties -> smaller index

@@ -121,6 +121,35 @@ SIGNATURES = {
     "smx_nhwc_to_nchw_bf16": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "smx_vq_ws_floats": (_i64, [_i]),
     "smx_vq_nearest_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    # ---- training step ----
+    "smx_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, C.POINTER(_i)]),
+    "smx_wgrad_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p]),
+    "smx_colsum_ws_floats": (_i64, [_i64, _i]),
+    "smx_colsum_f32": (_i, [_p, _i, _i64, _i, _p, _p, _i, _f, _p]),
+    "smx_partial_reduce_f32": (_i, [_p, _i, _i, _p, _i, _f, _p]),
+    "smx_pack_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_transpose_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _p]),
+    "smx_act_f32": (_i, [_p, _i, _p, _i, _i64, _i, _i, _p]),
+    "smx_act_bwd_f32": (_i, [_p, _i, _p, _i, _p, _i, _i64, _i, _i, _p]),
+    "smx_axpy_slice_f32": (_i, [_p, _i, _p, _i, _i64, _i, _f, _p]),
+    "smx_groupnorm_stats_train_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
+    "smx_groupnorm_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "smx_layernorm_bwd_ws_floats": (_i64, [_i, _i]),
+    "smx_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p]),
+    "smx_batch_sum_f32": (_i, [_p, _p, _i, _i64, _p]),
+    "smx_softmax_rows_bwd_f32": (_i, [_p, _p, _i64, _i, _f, _p]),
+    "smx_attention_bwd_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "smx_warp_bwd_f32": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_resize_ac_bwd_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_space_to_depth_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_vq_bwd_f32": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i64, _i, _p]),
+    "smx_flow_occ_update_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "smx_sft_combine_bwd_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _f, _i64, _i, _p]),
+    "smx_l1_loss_f32": (_i, [_p, _p, _i64, _f, _p, _p, _p]),
+    "smx_l1_loss_bwd_f32": (_i, [_p, _p, _p, _i64, _f, _p, _i, _p]),
+    "smx_scale_f32": (_i, [_p, _p, _i64, _f, _i, _p]),
+    "smx_adam_step_f32": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
+    "smx_ema_f32": (_i, [_p, _p, _i64, _f, _p]),
 }
 
 _lib = None

@@ -253,10 +253,14 @@ def _wino_wide(B, H, W, cout):
 
 
 def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None,
-         d2s=None, tile=0, in_ss=None, in_swish=False, want_stats=False, mfma16=False, out_dtype=None):
+         d2s=None, tile=0, in_ss=None, in_swish=False, want_stats=False, mfma16=False, out_dtype=None, direct=False):
     """y = act(conv(x) + bias) [+ res].  x [B,H,W,Cin] (slice ok) -> out [B,Ho,Wo,Cout] (slice ok).
     pad: (top, left) (default (kh//2, kw//2)); out_hw for asymmetric pads / strides.
     d2s=(p, C): un-patchify store, out is [B,Ho*p,Wo*p,C].
+    up2: True = nearest x2 folded into the gather; 2 = ZERO-INSERT x2 (the data gradient of a stride-2 convolution as a
+    stride-1 launch; implicit-GEMM kernel only).
+    direct: always the implicit-GEMM kernel (training: weights change every step, so the Winograd-domain / fragment-ordered
+    packings of the inference engines are not built).
     want_stats: the output feeds a GroupNorm -- on the fused Winograd path the epilogue also emits the
     per-block {sum, sum^2} partials and tags the returned tensor with them (`_gn_part`), so that
     `groupnorm_stats(y, ...)` is a finalize over a few KB instead of a read of y."""
@@ -283,7 +287,7 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
     if getattr(out, "_gn_part", None) is not None:      # a caller-provided buffer tagged by an earlier producer
         out._gn_part = None
-    if (SMALLN and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s and not up2
+    if (SMALLN and not direct and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s and not up2
             and res is None and cv.cout <= 4 and Cin in (64, 128, 256) and (Ho, Wo) == (H, W) and W % 4 == 0 and lda % 4 == 0 and a_ptr % 16 == 0):
         # N <= 4: HBM-shaped, runs on the vector ALUs (the matrix cores would pad N to 32)
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 0.0, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin,
@@ -292,7 +296,7 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
                        None if cv.b is None else cv.b.data_ptr(), c_ptr, ldc, B, H, W, Cin, cv.cout, act,
                        None if in_ss is None else in_ss.data_ptr(), int(in_swish), _stream()), "smx_conv3x3_smalln_f32")
         return out
-    if (WINOGRAD and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s
+    if (WINOGRAD and not direct and up2 != 2 and tile == 0 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1) and not d2s
             and (Ho, Wo) == (He, We) and Cin % 32 == 0 and He % 8 == 0 and We % 16 == 0
             and lda % 4 == 0 and a_ptr % 16 == 0):
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * Ho * Wo * cv.cout * 4 * Cin,

@@ -1,0 +1,605 @@
+"""Differentiable wrappers of the hot-path kernels for the training step: each function launches the forward
+kernel(s) through `ops` and records on the `Tape` the closure that launches the backward kernels declared under "TRAINING STEP"
+in `include/smx.h`.  fp32 NHWC activations; parameters are referenced by state_dict name (optionally a row range of one:
+`("app_block.0.self_attn.in_proj_weight", slice(0, 256))`), their gradients accumulate into `tape.G[name]`.
+
+Reference semantics each op replaces (forward file:line in /root/reference/basicsr, the backward is what torch.autograd derives
+from it): conv / Linear `F.conv2d`, `nn.Linear`; `normalize`+`swish` archs/vqgan_arch.py:14-20; `nn.LayerNorm`;
+`nn.MultiheadAttention` archs/appmotioncodebook_arch.py:101-115; AttnBlock archs/vqgan_arch.py:229-253; `deform_input` /
+`occlude_input` archs/appmotioncodebook_arch.py:349-362; `VectorQuantizer.forward` archs/vqgan_arch.py:33-93;
+`Fuse_sft_block` archs/appmotioncodebook_arch.py:28-52; `L1Loss` losses/losses.py.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from . import ops
+from .lib import ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SWISH, ACT_GELU, ACT_SIGMOID  # noqa: F401
+from .ops import Conv
+from .tape import _stream, _pix, _dense, _axpy
+
+F32 = torch.float32
+
+
+def _empty(shape, like):
+    return torch.empty(shape, device=like.device, dtype=F32)
+
+
+def _zeros(shape, like):
+    return torch.zeros(shape, device=like.device, dtype=F32)
+
+
+# ---- parameters -----------------------------------------------------------------------------------------------------------
+def _param(tp, ref):
+    """(value view, grad view, cache key) of a parameter reference: a name, or (name, row slice)."""
+    if isinstance(ref, tuple):
+        name, sl = ref
+        return tp.P[name][sl], tp.G[name][sl], (name, sl.start, sl.stop)
+    return tp.P[ref], tp.G[ref], (ref, None, None)
+
+
+def leaf(tp, name):
+    """a parameter used as an ACTIVATION (the codebooks as attention context / quantiser table, position embeddings): returns
+    the value tensor; whatever gradient the tape collects for it is added to tape.G[name] after all its consumers ran."""
+    cache = tp.packed.setdefault("_leaves", {})
+    if name in cache:
+        return cache[name]
+    t = tp.P[name]
+    cache[name] = t
+
+    def bwd():
+        g = tp.take(t)
+        if g is not None:
+            _axpy(tp.lib, g, tp.G[name], 1.0)
+    tp.record(bwd)                       # recorded before any consumer -> runs after all of them
+    return t
+
+
+def _packed(tp, ref, mode, cout, cin, kh, kw):
+    """per-step cache of a packed weight: mode 0 forward [Cout][(ky,kx,ci)], mode 1 data gradient [Cin][(flipped taps, co)]."""
+    w, _, key = _param(tp, ref)
+    ck = (key, mode)
+    if ck not in tp.packed:
+        wc = w if w.is_contiguous() else w.contiguous()
+        out = torch.empty((cout, kh * kw * cin) if mode == 0 else (cin, kh * kw * cout), device=w.device, dtype=F32)
+        L.check(tp.lib.smx_pack_weight_f32(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, mode, _stream()), "pack_weight")
+        tp.packed[ck] = out
+    return tp.packed[ck]
+
+
+# ---- low-level launchers ----------------------------------------------------------------------------------------------------
+def _colsum(tp, x2d_ptr, ld, P, Cc, out, accumulate=True, alpha=1.0):
+    ws = torch.empty((int(tp.lib.smx_colsum_ws_floats(P, Cc)),), device=out.device, dtype=F32)
+    L.check(tp.lib.smx_colsum_f32(x2d_ptr, ld, P, Cc, ws.data_ptr(), out.data_ptr(), int(accumulate), float(alpha), _stream()), "colsum")
+
+
+def _wgrad(tp, dy, x, out, *, nb=1, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, up2=0, layout=0, ldo=0, accumulate=True,
+           alpha=1.0, dy_ld=None, x_ld=None, dy_bs=0, x_bs=0, out_bs=0):
+    ms = C.c_int(1)
+    n = int(tp.lib.smx_wgrad_ws_floats(nb, M, cout, kh * kw * cin, C.byref(ms)))
+    ws = torch.empty((n,), device=out.device, dtype=F32)
+    dyp, ldy = (dy.data_ptr(), dy_ld) if dy_ld is not None else _pix(dy)[:2]
+    xp, ldx = (x.data_ptr(), x_ld) if x_ld is not None else _pix(x)[:2]
+    L.check(tp.lib.smx_wgrad_f32(dyp, ldy, dy_bs, xp, ldx, x_bs, nb, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, int(up2),
+                                 ws.data_ptr(), ms.value, out.data_ptr(), out_bs, layout, ldo, int(accumulate), float(alpha), _stream()), "wgrad")
+
+
+def act_bwd(tp, g, ref, act):
+    out = _empty(g.shape, g)
+    gp, ldg, P, Cc = _pix(g)
+    rp, ldr, _, _ = _pix(ref)
+    L.check(tp.lib.smx_act_bwd_f32(gp, ldg, rp, ldr, out.data_ptr(), Cc, P, Cc, act, _stream()), "act_bwd")
+    return out
+
+
+def scaled(tp, x, alpha):
+    """alpha * x as a new dense tensor (no tape)."""
+    xd = x if x.is_contiguous() else _dense(tp.lib, x)
+    out = _empty(x.shape, x)
+    L.check(tp.lib.smx_scale_f32(xd.data_ptr(), out.data_ptr(), xd.numel(), float(alpha), 0, _stream()), "scale")
+    return out
+
+
+def transpose(tp, x, nb, R, Cc):
+    """[nb][R][C] -> [nb][C][R] (dense)."""
+    y = torch.empty((nb, Cc, R), device=x.device, dtype=F32)
+    L.check(tp.lib.smx_transpose_f32(x.data_ptr(), Cc, R * Cc, y.data_ptr(), R, R * Cc, nb, R, Cc, _stream()), "transpose")
+    return y
+
+
+# ---- convolution / Linear -------------------------------------------------------------------------------------------------
+def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None, kind="conv", patch=None):
+    """y = act(conv(x) + bias) (+ res).  kind:
+      "conv":    parameter [Cout,Cin,kh,kw] (or Linear [out,in] = 1x1); stride 1, or the stride-2 / pad (0,1,0,1) Downsample form;
+      "patch":   Linear [Cout, p*p*C] applied as a p x p / stride-p convolution (patchify + Linear, patch=(p, C));
+      "unpatch": Linear [p*p*C, Cin] as a 1x1 convolution with the un-patchify (depth-to-space) store (patch=(p, C))."""
+    wv, wg, _ = _param(tp, w)
+    bv, bg = (None, None) if b is None else _param(tp, b)[:2]
+    B, H, W, Cin = x.shape
+    if act not in (ACT_NONE, ACT_RELU, ACT_LRELU02):
+        raise L.SmxError("train conv: only ReLU / LeakyReLU epilogues are fused (their derivative needs the output only)")
+    if act != ACT_NONE and res is not None:
+        raise L.SmxError("train conv: activation + residual in one epilogue hides the activation's output (no call site of the path has both)")
+    if kind == "conv":
+        if wv.dim() == 4:
+            cout, cin, kh, kw = wv.shape
+        else:
+            (cout, cin), kh, kw = wv.shape, 1, 1
+        d2s = None
+    elif kind == "patch":
+        p_, Cc = patch
+        cout, cin, kh, kw, stride, pad, d2s = wv.shape[0], Cc, p_, p_, p_, (0, 0), None
+    elif kind == "unpatch":
+        p_, Cc = patch
+        cout, cin, kh, kw, d2s = wv.shape[0], wv.shape[1], 1, 1, (p_, Cc)
+    else:
+        raise ValueError(kind)
+    if cin != Cin:
+        raise L.SmxError(f"train conv {w}: input has {Cin} channels, weight expects {cin}")
+    if stride not in (1, 2) and kind == "conv":
+        raise L.SmxError("train conv: stride 1 or 2")
+    wp = wv.contiguous() if kind == "patch" else _packed(tp, w, 0, cout, cin, kh, kw)      # the patch Linear is already [Cout][(p1 p2 c)]
+    cv = Conv(wp.view(cout, kh * kw * cin), None if bv is None else bv.contiguous(), kh, kw, cin, cout)
+    pt, pl = (kh // 2, kw // 2) if pad is None else pad
+    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=True)
+    He, We = (2 * H, 2 * W) if up2 else (H, W)
+    Ho, Wo = (y.shape[1], y.shape[2]) if d2s is None else (H, W)
+
+    def bwd():
+        g = tp.take(y)
+        if g is None:
+            return
+        if act != ACT_NONE:
+            g = act_bwd(tp, g, y, act)
+        if res is not None:
+            tp.acc(res, g, owned=False)
+        lib = tp.lib
+        if kind == "unpatch":
+            gs = torch.empty((B, H, W, cout), device=g.device, dtype=F32)        # tokens x (p1 p2 c): the store's inverse
+            gp_, ldg_, _, _ = _pix(g)
+            L.check(lib.smx_space_to_depth_f32(gp_, ldg_, gs.data_ptr(), B, H, W, d2s[1], d2s[0], _stream()), "space_to_depth")
+            g2 = gs
+        else:
+            g2 = g if g.is_contiguous() else _dense(lib, g)
+        M = B * Ho * Wo
+        if bg is not None:
+            _colsum(tp, g2.data_ptr(), cout, M, cout, bg)
+        # weight gradient
+        if kind == "patch":
+            _wgrad(tp, g2, x, wg, M=M, cout=cout, Hin=H, Win=W, cin=cin, Ho=Ho, Wo=Wo, kh=kh, kw=kw, stride=stride, pt=0, pl=0,
+                   layout=1, ldo=kh * kw * cin, dy_ld=cout)
+        else:
+            _wgrad(tp, g2, x, wg, M=M, cout=cout, Hin=H, Win=W, cin=cin, Ho=Ho, Wo=Wo, kh=kh, kw=kw, stride=stride, pt=pt, pl=pl,
+                   up2=1 if up2 else 0, layout=0, dy_ld=cout)
+        # data gradient: a forward convolution of g with the transposed, tap-flipped weights
+        if not tp.needs(x):
+            return
+        # (the patch Linear is stored [Cout][(p1 p2 c)], not OIHW: its data-gradient operand is the plain transpose)
+        wt = _packed(tp, w, 1, cout, kh * kw * cin, 1, 1) if kind == "patch" else _packed(tp, w, 1, cout, cin, kh, kw)
+        if kind == "patch":
+            dx = ops.conv(g2, Conv(wt.view(kh * kw * cin, cout), None, 1, 1, cout, kh * kw * cin), d2s=(kh, cin), direct=True)
+        elif kind == "unpatch":
+            dx = ops.conv(g2, Conv(wt.view(cin, cout), None, 1, 1, cout, cin), direct=True)
+        elif stride == 1:
+            dcv = Conv(wt.view(cin, kh * kw * cout), None, kh, kw, cout, cin)
+            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=True)
+            if up2:             # adjoint of nearest x2: sum of each 2x2 block
+                dx = scaled(tp, ops.avgpool2(dx), 4.0)
+        else:                   # stride 2: zero-insert gather (smx_gemm_conv_f32 up2 = 2)
+            dcv = Conv(wt.view(cin, kh * kw * cout), None, kh, kw, cout, cin)
+            dx = ops.conv(g2, dcv, up2=2, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(H, W), direct=True)
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y
+
+
+def act(tp, x, kind):
+    """y = act(x) as its own pass (GELU / swish / sigmoid: the derivative needs the pre-activation, which stays alive here)."""
+    y = _empty(x.shape, x)
+    xp, ldx, P, Cc = _pix(x)
+    L.check(tp.lib.smx_act_f32(xp, ldx, y.data_ptr(), Cc, P, Cc, kind, _stream()), "act")
+
+    def bwd():
+        g = tp.take(y)
+        if g is not None and tp.needs(x):
+            tp.acc(x, act_bwd(tp, g, y if kind in (ACT_RELU, ACT_LRELU02, ACT_SIGMOID) else x, kind))
+    tp.record(bwd)
+    return y
+
+
+# ---- normalisation ---------------------------------------------------------------------------------------------------------
+def groupnorm(tp, x, gamma, beta, swish=True, groups=32, eps=1e-6):
+    gv, gg, _ = _param(tp, gamma)
+    bv, bg, _ = _param(tp, beta)
+    B, H, W, Cc = x.shape
+    lib = tp.lib
+    xp, ldx = ops._pix(x, "groupnorm input")
+    ss = torch.empty((B, Cc, 2), device=x.device, dtype=F32)
+    mr = torch.empty((B, groups, 2), device=x.device, dtype=F32)
+    ws = torch.empty((int(lib.smx_groupnorm_ws_floats(B, H * W, Cc)) + 2 * B * groups,), device=x.device, dtype=F32)
+    L.check(lib.smx_groupnorm_stats_train_f32(xp, ldx, gv.data_ptr(), bv.data_ptr(), ss.data_ptr(), mr.data_ptr(), B, H * W, Cc, groups, eps,
+                                              ws.data_ptr(), _stream()), "groupnorm_stats_train")
+    y = ops.groupnorm_apply(x, ss, swish)
+
+    def bwd():
+        g = tp.take(y)
+        if g is None:
+            return
+        g = g if g.is_contiguous() else _dense(lib, g)
+        dx = _empty((B, H, W, Cc), x)
+        L.check(lib.smx_groupnorm_bwd_f32(xp, ldx, g.data_ptr(), Cc, ss.data_ptr(), mr.data_ptr(), gv.data_ptr(), dx.data_ptr(), Cc,
+                                          gg.data_ptr(), bg.data_ptr(), B, H * W, Cc, groups, int(swish), ws.data_ptr(), _stream()), "groupnorm_bwd")
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y
+
+
+def layernorm(tp, x, gamma, beta, pos=None, eps=1e-5):
+    """-> (LN(x), LN(x) + pos or None); pos: a `leaf` tensor [npos, E] (its gradient is the batch sum of d(LN(x)+pos))."""
+    gv, gg, _ = _param(tp, gamma)
+    bv, bg, _ = _param(tp, beta)
+    xc = x if x.is_contiguous() else _dense(tp.lib, x)
+    y, yp = ops.layernorm(xc, gv, bv, pos=pos, eps=eps)
+    E = x.shape[-1]
+    T = x.numel() // E
+
+    def bwd():
+        gy, gyp = tp.take(y), (tp.take(yp) if yp is not None else None)
+        if gy is None and gyp is None:
+            return
+        lib = tp.lib
+        gy = gy if gy is None or gy.is_contiguous() else _dense(lib, gy)
+        gyp = gyp if gyp is None or gyp.is_contiguous() else _dense(lib, gyp)
+        dx = _empty(x.shape, x)
+        ws = torch.empty((int(lib.smx_layernorm_bwd_ws_floats(T, E)),), device=x.device, dtype=F32)
+        dpos = None
+        if gyp is not None and pos is not None and tp.needs(pos):
+            dpos = _zeros(pos.shape, pos)
+        L.check(lib.smx_layernorm_bwd_f32(xc.data_ptr(), gv.data_ptr(), None if gy is None else gy.data_ptr(),
+                                          None if gyp is None else gyp.data_ptr(), dx.data_ptr(), gg.data_ptr(), bg.data_ptr(),
+                                          None if dpos is None else dpos.data_ptr(), T, E, 0 if pos is None else pos.shape[0], eps,
+                                          ws.data_ptr(), _stream()), "layernorm_bwd")
+        if dpos is not None:
+            tp.acc(pos, dpos)
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y, yp
+
+
+# ---- attention ---------------------------------------------------------------------------------------------------------------
+def attention(tp, q, k, v, nhead, dh, S, *, mask=None, ctx=None):
+    """o = softmax(q k^T / sqrt(dh) [+ key mask]) v per head.  Self attention: q, k, v dense [B,L,E].  Cross attention against a
+    projected codebook: ctx = the [K, 2E] = [K | V] tensor (k, v ignored), first S rows used, shared by the batch."""
+    B = q.shape[0]
+    E = nhead * dh
+    Lq = q.numel() // B // E
+    if ctx is not None:
+        k, v = ctx[:, :E], ctx[:, E:]
+    o = ops.attention(q, k, v, nhead, dh, S, k_shared=ctx is not None, mask=mask)
+
+    def bwd():
+        g = tp.take(o)
+        if g is None:
+            return
+        lib = tp.lib
+        g = g if g.is_contiguous() else _dense(lib, g)
+        shared = ctx is not None
+        dq = _empty((B, Lq, E), q)
+        dk = _empty((1 if shared else B, S, E), q)
+        dv = _empty((1 if shared else B, S, E), q)
+        stats = _empty((B * nhead * Lq * 3,), q)
+        qp, ldq = ops._pix(q, "attention q")
+        kp, ldk = ops._pix(k, "attention k")
+        vp, ldv = ops._pix(v, "attention v")
+        kbs = 0 if shared else S * ldk
+        vbs = 0 if shared else S * ldv
+        L.check(lib.smx_attention_bwd_f32(qp, ldq, Lq * ldq, kp, ldk, kbs, vp, ldv, vbs, o.data_ptr(), g.data_ptr(),
+                                          None if mask is None else mask.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                          stats.data_ptr(), B, nhead, Lq, S, dh, dh ** -0.5, _stream()), "attention_bwd")
+        tp.acc(q, dq.view(q.shape))
+        if shared:
+            dctx = _zeros(ctx.shape, ctx)
+            _axpy(lib, dk.view(S, E), dctx[:S, :E], 1.0)
+            _axpy(lib, dv.view(S, E), dctx[:S, E:], 1.0)
+            tp.acc(ctx, dctx)
+        else:
+            tp.acc(k, dk.view(k.shape))
+            tp.acc(v, dv.view(v.shape))
+    tp.record(bwd)
+    return o
+
+
+def attn_core(tp, q, k, v, scale):
+    """AttnBlock core (archs/vqgan_arch.py:236-249): h = softmax(scale q k^T) v, one head of width C; q, k, v dense [B,H,W,C].
+    The [B,N,N] probabilities are kept for the backward (N = 1024: 4 MB per sample)."""
+    B, H, W, Cc = q.shape
+    N = H * W
+    s = torch.empty((B, N, N), device=q.device, dtype=F32)
+    ops.gemm_nt(q, k, s, M=N, N=N, K=Cc, lda=Cc, ldb=Cc, ldc=N, nb0=B, a_bs=(N * Cc, 0), bt_bs=(N * Cc, 0), c_bs=(N * N, 0))
+    ops.softmax_rows(s, N, float(scale))
+    vt = transpose(tp, v, B, N, Cc)
+    h = torch.empty((B, H, W, Cc), device=q.device, dtype=F32)
+    ops.gemm_nt(s, vt, h, M=N, N=Cc, K=N, lda=N, ldb=N, ldc=Cc, nb0=B, a_bs=(N * N, 0), bt_bs=(Cc * N, 0), c_bs=(N * Cc, 0))
+
+    def bwd():
+        g = tp.take(h)
+        if g is None:
+            return
+        lib = tp.lib
+        g = g if g.is_contiguous() else _dense(lib, g)
+        dP = torch.empty((B, N, N), device=q.device, dtype=F32)
+        ops.gemm_nt(g, v, dP, M=N, N=N, K=Cc, lda=Cc, ldb=Cc, ldc=N, nb0=B, a_bs=(N * Cc, 0), bt_bs=(N * Cc, 0), c_bs=(N * N, 0))
+        dv = _empty((B, H, W, Cc), q)        # dV[j][c] = sum_i P[i][j] dH[i][c]
+        _wgrad(tp, s, g, dv, nb=B, M=N, cout=N, Hin=N, Win=1, cin=Cc, Ho=N, Wo=1, kh=1, kw=1, stride=1, pt=0, pl=0, layout=1, ldo=Cc,
+               accumulate=False, dy_ld=N, x_ld=Cc, dy_bs=N * N, x_bs=N * Cc, out_bs=N * Cc)
+        L.check(lib.smx_softmax_rows_bwd_f32(s.data_ptr(), dP.data_ptr(), B * N, N, float(scale), _stream()), "softmax_bwd")
+        kt = transpose(tp, k, B, N, Cc)
+        dq = _empty((B, H, W, Cc), q)        # dQ = dS K
+        ops.gemm_nt(dP, kt, dq, M=N, N=Cc, K=N, lda=N, ldb=N, ldc=Cc, nb0=B, a_bs=(N * N, 0), bt_bs=(Cc * N, 0), c_bs=(N * Cc, 0))
+        dk = _empty((B, H, W, Cc), q)        # dK[j][c] = sum_i dS[i][j] Q[i][c]
+        _wgrad(tp, dP, q, dk, nb=B, M=N, cout=N, Hin=N, Win=1, cin=Cc, Ho=N, Wo=1, kh=1, kw=1, stride=1, pt=0, pl=0, layout=1, ldo=Cc,
+               accumulate=False, dy_ld=N, x_ld=Cc, dy_bs=N * N, x_bs=N * Cc, out_bs=N * Cc)
+        tp.acc(q, dq)
+        tp.acc(k, dk)
+        tp.acc(v, dv)
+    tp.record(bwd)
+    return h
+
+
+# ---- warp / resize -----------------------------------------------------------------------------------------------------------
+def warp(tp, feat, flow, occ=None):
+    out = ops.warp(feat, flow, occ)
+    B, Hf, Wf, _ = flow.shape
+    _, H, W, Cc = feat.shape
+
+    def bwd():
+        g = tp.take(out)
+        if g is None:
+            return
+        lib = tp.lib
+        g = g if g.is_contiguous() else _dense(lib, g)
+        need_f = tp.needs(feat)
+        need_m = tp.needs(flow) or (occ is not None and tp.needs(occ))
+        dfeat = _zeros(feat.shape, feat) if need_f else None
+        gsm = _empty((B, H, W, 3), feat) if need_m else None
+        L.check(lib.smx_warp_bwd_f32(feat.data_ptr(), feat.shape[0], flow.data_ptr(), None if occ is None else occ.data_ptr(), g.data_ptr(),
+                                     None if dfeat is None else dfeat.data_ptr(), None if gsm is None else gsm.data_ptr(),
+                                     B, H, W, Cc, Hf, Wf, _stream()), "warp_bwd")
+        if need_f:
+            tp.acc(feat, dfeat)
+        if need_m:
+            if (Hf, Wf) != (H, W):
+                coarse = _zeros((B, Hf, Wf, 3), feat)
+                L.check(lib.smx_resize_ac_bwd_f32(gsm.data_ptr(), 3, coarse.data_ptr(), 3, B, Hf, Wf, H, W, 3, _stream()), "resize_ac_bwd")
+            else:
+                coarse = gsm
+            tp.acc(flow, _dense(lib, coarse[..., :2]))
+            if occ is not None:
+                tp.acc(occ, _dense(lib, coarse[..., 2:3]).view(occ.shape))
+    tp.record(bwd)
+    return out
+
+
+def resize(tp, x, Ho, Wo):
+    y = ops.resize(x, Ho, Wo)
+    B, H, W, Cc = x.shape
+
+    def bwd():
+        g = tp.take(y)
+        if g is None or not tp.needs(x):
+            return
+        dx = _zeros(x.shape, x)
+        gp, ldg, _, _ = _pix(g)
+        L.check(tp.lib.smx_resize_ac_bwd_f32(gp, ldg, dx.data_ptr(), Cc, B, H, W, Ho, Wo, Cc, _stream()), "resize_ac_bwd")
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y
+
+
+# ---- vector quantiser -----------------------------------------------------------------------------------------------------------
+def quantize(tp, z, cb_name, Ks, beta):
+    """VectorQuantizer.forward on NHWC tokens -> (z_q NHWC, loss [1] device scalar, stats).  Straight-through: d z_q flows to z;
+    the codebook loss moves z (beta term) and the selected codebook rows."""
+    B, H, W, D = z.shape
+    zc = z if z.is_contiguous() else _dense(tp.lib, z)
+    cb = tp.P[cb_name]
+    idx, zq, dmin, sq = ops.vq_nearest(zc.view(-1, D), cb, Ks)
+    loss = scaled(tp, sq, (1.0 + beta) / float(zc.numel()))
+    zq = zq.view(B, H, W, D)
+
+    def bwd():
+        gz, gl = tp.take(zq), tp.take(loss)
+        if gz is None and gl is None:
+            return
+        lib = tp.lib
+        gz = gz if gz is None or gz.is_contiguous() else _dense(lib, gz)
+        dz = _empty(zc.shape, zc)
+        L.check(lib.smx_vq_bwd_f32(zc.data_ptr(), cb.data_ptr(), idx.data_ptr(), None if gz is None else gz.data_ptr(),
+                                   None if gl is None else gl.data_ptr(), float(beta), dz.data_ptr(), tp.G[cb_name].data_ptr(),
+                                   zc.numel() // D, D, _stream()), "vq_bwd")
+        tp.acc(z, dz.view(z.shape))
+    tp.record(bwd)
+    return zq, loss, {"min_encoding_indices": idx.view(-1, 1), "min_distance": dmin}
+
+
+# ---- flow / occlusion / SFT / plumbing --------------------------------------------------------------------------------------------
+def flow_to_residual(tp, flow):
+    res = ops.flow_to_residual(flow)
+    hs = (flow.shape[1] - 1) / 2.0
+
+    def bwd():
+        g = tp.take(res)
+        if g is not None and tp.needs(flow):
+            tp.acc(flow, scaled(tp, g, hs))
+    tp.record(bwd)
+    return res
+
+
+def flow_occ_update(tp, flow, r, occ_prev):
+    m_com, res_norm, occ = ops.flow_occ_update(flow, r, occ_prev)
+    B, H, W, _ = flow.shape
+
+    def bwd():
+        gm, go = tp.take(m_com), tp.take(occ)
+        tp.take(res_norm)
+        if gm is None and go is None:
+            return
+        lib = tp.lib
+        gm = gm if gm is None or gm.is_contiguous() else _dense(lib, gm)
+        go = go if go is None or go.is_contiguous() else _dense(lib, go)
+        d_flow, d_r, d_occ = _empty(flow.shape, flow), _empty(r.shape, r), _empty(occ_prev.shape, occ_prev)
+        L.check(lib.smx_flow_occ_update_bwd_f32(None if gm is None else gm.data_ptr(), None if go is None else go.data_ptr(), occ.data_ptr(),
+                                                d_flow.data_ptr(), d_r.data_ptr(), d_occ.data_ptr(), B, H, W, _stream()), "flow_occ_update_bwd")
+        tp.acc(flow, d_flow)
+        tp.acc(r, d_r)
+        tp.acc(occ_prev, d_occ)
+    tp.record(bwd)
+    return m_com, res_norm, occ
+
+
+def sft_combine(tp, dec, scale, shift, w):
+    out = ops.sft_combine(dec, scale, shift, w)
+    Cc = dec.shape[-1]
+
+    def bwd():
+        g = tp.take(out)
+        if g is None:
+            return
+        lib = tp.lib
+        g = g if g.is_contiguous() else _dense(lib, g)
+        dp, ldd = ops._pix(dec, "dec")
+        d_dec, d_sc, d_sh = _empty(g.shape, g), _empty(g.shape, g), _empty(g.shape, g)
+        L.check(lib.smx_sft_combine_bwd_f32(g.data_ptr(), dp, ldd, scale.data_ptr(), d_dec.data_ptr(), d_sc.data_ptr(), d_sh.data_ptr(),
+                                            float(w), g.numel() // Cc, Cc, _stream()), "sft_combine_bwd")
+        tp.acc(dec, d_dec)
+        tp.acc(scale, d_sc)
+        tp.acc(shift, d_sh)
+    tp.record(bwd)
+    return out
+
+
+def scale(tp, x, alpha):
+    y = scaled(tp, x, alpha)
+
+    def bwd():
+        g = tp.take(y)
+        if g is not None and tp.needs(x):
+            tp.acc(x, scaled(tp, g, alpha))
+    tp.record(bwd)
+    return y
+
+
+def cat(tp, parts):
+    """channel concatenation into a fresh buffer (copy kernels); gradient = dense copies of the slices."""
+    Cs = [p.shape[-1] for p in parts]
+    out = _empty(parts[0].shape[:-1] + (sum(Cs),), parts[0])
+    o = 0
+    for p, c in zip(parts, Cs):
+        ops.copy_slice(p, out[..., o:o + c])
+        o += c
+
+    def bwd():
+        g = tp.take(out)
+        if g is None:
+            return
+        o2 = 0
+        for p, c in zip(parts, Cs):
+            if tp.needs(p):
+                tp.acc(p, _dense(tp.lib, g[..., o2:o2 + c]))
+            o2 += c
+    tp.record(bwd)
+    return out
+
+
+def slice_ch(tp, x, a, b):
+    """x[..., a:b] as a view usable by every launcher; its gradient lands in a zero-initialised full-width buffer."""
+    y = x[..., a:b]
+
+    def bwd():
+        g = tp.take(y)
+        if g is None or not tp.needs(x):
+            return
+        full = _zeros(x.shape, x)
+        _axpy(tp.lib, g, full[..., a:b], 1.0)
+        tp.acc(x, full)
+    tp.record(bwd)
+    return y
+
+
+def detach(tp, x):
+    """x.detach(): the same memory under a new tensor object that takes no gradient."""
+    return tp.stop(x.view(x.shape))
+
+
+def view(tp, x, shape):
+    """a reshaping view (dense tensors) -- tokens [B,1024,E] <-> maps [B,32,32,E]."""
+    y = x.view(shape)
+
+    def bwd():
+        g = tp.take(y)
+        if g is not None and tp.needs(x):
+            tp.acc(x, (g if g.is_contiguous() else _dense(tp.lib, g)).view(x.shape), owned=False)
+    tp.record(bwd)
+    return y
+
+
+def nchw_to_nhwc(tp, x):
+    y = ops.nchw_to_nhwc(x)
+
+    def bwd():
+        g = tp.take(y)
+        if g is not None and tp.needs(x):
+            tp.acc(x, ops.nhwc_to_nchw(g))
+    tp.record(bwd)
+    return y
+
+
+def nhwc_to_nchw(tp, x):
+    y = ops.nhwc_to_nchw(x)
+
+    def bwd():
+        g = tp.take(y)
+        if g is not None and tp.needs(x):
+            tp.acc(x, ops.nchw_to_nhwc(g.contiguous()))
+    tp.record(bwd)
+    return y
+
+
+# ---- losses ---------------------------------------------------------------------------------------------------------------------
+def l1_loss(tp, a, target, weight=1.0):
+    """weight * mean |a - target| -> [1] device scalar; target takes no gradient (losses/losses.py L1Loss, reduction='mean')."""
+    ac = a if a.is_contiguous() else _dense(tp.lib, a)
+    tc = target if target.is_contiguous() else _dense(tp.lib, target)
+    if ac.numel() != tc.numel():
+        raise L.SmxError("l1_loss: operand sizes differ")
+    out = _empty((1,), a)
+    part = _empty((1024,), a)
+    L.check(tp.lib.smx_l1_loss_f32(ac.data_ptr(), tc.data_ptr(), ac.numel(), float(weight), part.data_ptr(), out.data_ptr(), _stream()), "l1_loss")
+
+    def bwd():
+        g = tp.take(out)
+        if g is None or not tp.needs(a):
+            return
+        da = _empty(ac.shape, ac)
+        L.check(tp.lib.smx_l1_loss_bwd_f32(ac.data_ptr(), tc.data_ptr(), g.data_ptr(), ac.numel(), float(weight), da.data_ptr(), 0, _stream()), "l1_loss_bwd")
+        tp.acc(a, da.view(a.shape))
+    tp.record(bwd)
+    return out
+
+
+def weighted_sum(tp, terms):
+    """sum_i w_i * t_i over [1] device scalars -> [1]."""
+    out = _zeros((1,), terms[0][0])
+    for t, w in terms:
+        L.check(tp.lib.smx_scale_f32(t.data_ptr(), out.data_ptr(), 1, float(w), 1, _stream()), "scale")
+
+    def bwd():
+        g = tp.take(out)
+        if g is None:
+            return
+        for t, w in terms:
+            if tp.needs(t):
+                tp.acc(t, scaled(tp, g, w))
+    tp.record(bwd)
+    return out

@@ -1,0 +1,171 @@
+"""The generator-side training step on the HIP path (BASELINE configs[4]; reference
+`models/appmotioncomp_model.py:294-434` `optimize_parameters`): forward of the training branch with a gradient tape
+(`engine_train.NetGTrainEngine`), the losses that need no downloaded network, `Tape.backward()`, gradient all-reduce over
+`torch.distributed` (RCCL on the GPU box: the DDP of `models/base_model.py:71-74` as bucketed all-reduces of ONE flat buffer),
+a fused Adam step and the EMA copy -- all of it C-ABI kernels (`include/smx.h`, "TRAINING STEP").
+
+`FlatParams` puts every parameter of a network into one fp32 device buffer (256-B aligned slots); the module's `nn.Parameter`s
+are re-pointed at views of it, so `state_dict()` / checkpoints / `load_state_dict` keep the reference's names and shapes while
+the optimiser, the EMA and the collectives see three flat arrays (values, gradients, moments): one Adam launch and a few large
+all-reduces per step instead of 472 small ones (xGMI rings are per-link bound: big buckets)."""
+import torch
+
+from . import lib as L
+from . import ops
+from . import train_ops as T
+from .engine_train import NetGTrainEngine
+from .tape import Tape, _stream
+
+
+class FlatParams:
+    ALIGN = 64      # floats (256 B): every slot is float4-aligned for the vector kernels
+
+    def __init__(self, module):
+        named = [(n, p) for n, p in module.named_parameters()]
+        if not named:
+            raise ValueError("FlatParams: the module has no parameters")
+        dev = named[0][1].device
+        if dev.type != "cuda":
+            raise L.SmxError("FlatParams: parameters must be on the MI355X (call .cuda()); there is no CPU training path")
+        offs, off = [], 0
+        for _, p in named:
+            offs.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = off
+        self.value = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.P, self.G, self.slots = {}, {}, {}
+        for (n, p), o in zip(named, offs):
+            view = self.value[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view                                    # the module's parameter now IS the slot
+            gview = self.grad[o:o + p.numel()].view(p.shape)
+            p.grad = gview
+            self.P[n], self.G[n], self.slots[n] = view, gview, (o, p.numel())
+        self.t = 0
+        self.lib = L.load()
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def all_reduce(self, dist, group=None, bucket_mb=64):
+        """sum the flat gradient over the ranks in a few large buckets (async, then one wait); the 1/world factor is applied
+        inside the Adam kernel (gscale)."""
+        n = max(1, int(bucket_mb * (1 << 20) // 4))
+        cpu = dist.get_backend(group) == "gloo"
+        works = []
+        for a in range(0, self.numel, n):
+            chunk = self.grad[a:a + n]
+            if cpu:                                         # gloo (tests on one device): host-staged
+                h = chunk.cpu()
+                dist.all_reduce(h, group=group)
+                chunk.copy_(h)
+            else:
+                works.append(dist.all_reduce(chunk, group=group, async_op=True))
+        for w in works:
+            w.wait()
+
+    def adam_step(self, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, gscale=1.0):
+        self.t += 1
+        L.check(self.lib.smx_adam_step_f32(self.value.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.numel,
+                                           float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.t, float(gscale),
+                                           _stream()), "adam_step")
+
+    def ema_into(self, other, decay):
+        """other.value = decay * other.value + (1 - decay) * self.value (models/sr_model.py model_ema); same slot layout required."""
+        if other.numel != self.numel:
+            raise ValueError("EMA copy has a different parameter layout")
+        L.check(self.lib.smx_ema_f32(other.value.data_ptr(), self.value.data_ptr(), self.numel, float(decay), _stream()), "ema")
+
+
+class NetGTrainStep:
+    """One generator step: losses of `optimize_parameters` (:308-386) that need no downloaded network.
+    train_opt: the yml's `train` dict; used keys: pixel_opt, motion_codebook_code_opt, motion_codebook_recon_opt,
+    lr_pixel_perceptual_opt, app_codebook_code_opt, optim_g, ema_decay."""
+
+    def __init__(self, net_g, train_opt):
+        self.net_g = net_g
+        self.opt = dict(train_opt)
+        self.flat = FlatParams(net_g)
+        net_g.refresh()                                      # the inference engine's packed copies are stale from now on
+        self.engine = NetGTrainEngine(net_g.cfg)
+        og = dict(self.opt.get("optim_g", {}))
+        og.pop("type", None)
+        self.lr, self.betas = float(og.get("lr", 8e-5)), tuple(og.get("betas", (0.9, 0.99)))
+        self.wd, self.eps = float(og.get("weight_decay", 0)), float(og.get("eps", 1e-8))
+
+    @staticmethod
+    def _w(opt, key, default=0.0):
+        o = opt.get(key)
+        if not o:
+            return default
+        lw = o.get("loss_weight", 1.0)
+        return lw
+
+    def forward_backward(self, source, driving, dense_motion, w=1.0, backward=True):
+        """source / driving [B,3,256,256] in [-1,1]; dense_motion: deformation [B,64,64,2], occlusion_map [B,1,64,64],
+        driving_kp_heatmap [B,15,64,64] (device tensors).  -> (loss_dict of device scalars incl. 'l_g_total', out_dict with NCHW
+        'out', gradients w.r.t. the three dense-motion inputs in their own layouts).  Parameter gradients accumulate into
+        `self.flat.grad` (call `flat.zero_grad()` first)."""
+        flat = self.flat
+        tp = Tape(flat.P, flat.G)
+        B = driving.shape[0]
+        defo = dense_motion["deformation"].float().contiguous()
+        occ = dense_motion["occlusion_map"].float().reshape(B, 64, 64).contiguous()
+        heat = ops.nchw_to_nhwc(dense_motion["driving_kp_heatmap"].float())
+        st = self.engine.forward(tp, source.float(), defo, occ, heat, float(w), gt_nchw=driving.float())
+        gt = tp.stop(ops.nchw_to_nhwc(driving.float()))
+        o = self.opt
+        terms, losses = [], {}
+
+        def add(name, t, weight=1.0):
+            losses[name] = t
+            terms.append((t, weight))
+        if o.get("pixel_opt"):
+            add("l_g_pix", T.l1_loss(tp, st["out"], gt, self._w(o, "pixel_opt", 1.0)))
+        wc = self._w(o, "motion_codebook_code_opt", 1.0)
+        if wc:
+            add("l_g_motion_codebook_code", T.weighted_sum(tp, [(l, wc) for l in st["train"]["loss_motion"]]))
+        if o.get("motion_codebook_recon_opt"):
+            wr = self._w(o, "motion_codebook_recon_opt", 1.0)
+            recs = []
+            for i, rec in enumerate(st["train"]["motion_recon"]):      # L1(m_recon / 31.5, (deformation_list[i] - grid).detach()) (:342-352)
+                tgt = tp.stop(T.scaled(tp, ops.flow_to_residual(st["flows"][i]), 1.0 / 31.5))
+                recs.append((T.l1_loss(tp, T.scale(tp, rec, 1.0 / 31.5), tgt, wr), 1.0))
+            add("l_g_motion_codebook_recon", T.weighted_sum(tp, recs))
+        lrw = (o.get("lr_pixel_perceptual_opt") or {}).get("loss_weight", [])
+        if len(lrw) > 0 and o.get("pixel_opt"):
+            add("l_g_pix_lr_0", T.l1_loss(tp, st["out_lr"], gt, self._w(o, "pixel_opt", 1.0) * float(lrw[0])))
+        wa = self._w(o, "app_codebook_code_opt", 1.0)
+        if wa > 0:
+            add("l_g_app_codebook_code", T.weighted_sum(tp, [(l, wa) for l in st["app"][1]]))
+        total = T.weighted_sum(tp, terms)
+        losses["l_g_total"] = total
+        grads_in = None
+        if backward:
+            tp.acc(total, torch.ones(1, device=total.device))
+            tp.backward()
+            gd, go, gh = tp.take(defo), tp.take(occ), tp.take(heat)
+            grads_in = {"deformation": gd, "occlusion_map": None if go is None else go.view(B, 1, 64, 64),
+                        "driving_kp_heatmap": None if gh is None else ops.nhwc_to_nchw(gh)}
+        out = {"out": ops.nhwc_to_nchw(st["out"]), "out_lr": [ops.nhwc_to_nchw(st["out_lr"])], "deformation_list": st["flows"],
+               "out_occ": [t.view(B, 1, 64, 64) for t in st["occ"][1:]],
+               "codebook_loss_motion_list": st["train"]["loss_motion"], "codebook_loss_app_list": st["app"][1],
+               "_vq_stats_motion": st["train"]["stats_motion"], "_vq_stats_app": st["app"][2]}
+        return losses, out, grads_in
+
+    def step(self, source, driving, dense_motion, w=1.0, ema=None, ema_decay=0.0):
+        """zero_grad -> forward/backward -> (all-reduce) -> Adam -> (EMA).  -> (loss_dict, out_dict, input gradients)"""
+        import torch.distributed as dist
+        self.flat.zero_grad()
+        losses, out, grads_in = self.forward_backward(source, driving, dense_motion, w)
+        world = 1
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            world = dist.get_world_size()
+            self.flat.all_reduce(dist)
+        self.flat.adam_step(self.lr, self.betas, self.eps, self.wd, gscale=1.0 / world)
+        if ema is not None and ema_decay > 0:
+            self.flat.ema_into(ema, ema_decay)
+        return losses, out, grads_in
