@@ -440,6 +440,35 @@ int smx_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, f
 /* ema = decay * ema + (1 - decay) * p (models/sr_model.py model_ema) */
 int smx_ema_f32(float* ema, const float* p, int64_t n, float decay, void* stream);
 
+/* ---- motion estimator in training mode (csrc/train_motion.hip) ---- */
+/* y = relu?(BatchNorm(x)) with BATCH statistics over the P rows (F.batch_norm(training=True), sync_batchnorm/batchnorm.py:48-53);
+ * mr [C][2] = {mean, rstd} kept for the backward; running_mean / running_var (may be null) updated with `momentum`, unbiased variance.
+ * ws: smx_batchnorm_ws_floats(P, C) floats */
+int64_t smx_batchnorm_ws_floats(int64_t P, int C);
+int smx_batchnorm_train_f32(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, float* mr, float* running_mean,
+                            float* running_var, int64_t P, int C, float eps, float momentum, int relu, float* ws, void* stream);
+/* backward of y = relu(BN_train(x)): dx; dgamma / dbeta ACCUMULATED */
+int smx_batchnorm_train_bwd_f32(const float* x, int ldx, const float* g, int ldg, const float* y, int ldy, const float* mr, const float* gamma,
+                                float* dx, int ldo, float* dgamma, float* dbeta, int64_t P, int C, float* ws, void* stream);
+int smx_avgpool2_bwd_f32(const float* g, int ldg, float* dx, int ldx, int B, int H, int W, int C, void* stream);
+/* A3 backward (archs/keypoint_detector_arch.py:48-86): dvalue [B][K][2], djac [B][K][4] (either may be null)
+ * -> dlogits [B][H][W][lddl] (channels 0..K-1), djmaps [B][H][W][lddj] (channel 4k+j) */
+int smx_kp_head_bwd_f32(const float* logits, int ldl, const float* jmaps, int ldj, const float* dvalue, const float* djac, float* dlogits, int lddl,
+                        float* djmaps, int lddj, int B, int H, int W, int K, float temperature, void* stream);
+/* A4-A6 backward (archs/dense_motion_arch.py:65-116): gradients of the hourglass input (g_hg NHWC, ld ldh), the sparse motions (g_sparse
+ * [B][K+1][H][W][2], may be null) and the driving heatmaps (g_dheat [B][H][W][K], may be null) -> keypoint gradients (written) */
+int smx_sparse_motion_bwd_f32(const float* src, const float* kpd_value, const float* kpd_jac, const float* kps_value, const float* kps_jac,
+                              const float* g_hg, int ldh, const float* g_sparse, const float* g_dheat, float* d_kpd_value, float* d_kpd_jac,
+                              float* d_kps_value, float* d_kps_jac, int B, int H, int W, int K, float kp_variance, void* stream);
+/* A6b backward (archs/dense_motion_arch.py:140-158): g_def [B][H][W][2], g_occ [B][H][W] (either may be null) -> d_logits [B][H][W][lddm]
+ * (K1 mask logits + the occlusion logit at channel K1), d_sparse [B][K1][H][W][2] */
+int smx_mask_deformation_bwd_f32(const float* mask_logits, int ldm, const float* sparse, const float* g_def, const float* g_occ, float* d_logits,
+                                 int lddm, float* d_sparse, int B, int H, int W, int K1, void* stream);
+/* Transform.transform_frame (models/appmotioncomp_model.py:50-72): random affine + thin-plate warp of a frame, sampled with reflection
+ * padding; x, y NCHW; theta [B][2][3]; control_points [ncp][2], control_params [B][ncp] (both null = affine only) */
+int smx_tps_transform_frame_f32(const float* x, float* y, const float* theta, const float* control_points, const float* control_params,
+                                int ncp, int B, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

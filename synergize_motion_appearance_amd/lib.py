@@ -150,6 +150,14 @@ SIGNATURES = {
     "smx_scale_f32": (_i, [_p, _p, _i64, _f, _i, _p]),
     "smx_adam_step_f32": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
     "smx_ema_f32": (_i, [_p, _p, _i64, _f, _p]),
+    "smx_batchnorm_ws_floats": (_i64, [_i64, _i]),
+    "smx_batchnorm_train_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _i, _p, _p]),
+    "smx_batchnorm_train_bwd_f32": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i64, _i, _p, _p]),
+    "smx_avgpool2_bwd_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_kp_head_bwd_f32": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "smx_sparse_motion_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "smx_tps_transform_frame_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_mask_deformation_bwd_f32": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
 }
 
 _lib = None

@@ -603,3 +603,131 @@ def weighted_sum(tp, terms):
                 tp.acc(t, scaled(tp, g, w))
     tp.record(bwd)
     return out
+
+
+# ---- motion estimator (training mode) ---------------------------------------------------------------------------------------------
+def bn_relu(tp, x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, relu=True):
+    """relu(BatchNorm2d(x)) with BATCH statistics (utils/motion_estimator_util.py:214-231, 363-380 under .train()); the running
+    buffers (tensors, updated in place like F.batch_norm(training=True)) are optional."""
+    if not relu:
+        raise L.SmxError("bn_relu: the backward kernel gates on y > 0 (every BatchNorm of the hourglass is followed by a ReLU)")
+    gv, gg, _ = _param(tp, gamma)
+    bv, bg, _ = _param(tp, beta)
+    lib = tp.lib
+    xp, ldx, P, Cc = _pix(x)
+    y = _empty(x.shape, x)
+    mr = _empty((Cc, 2), x)
+    ws = _empty((int(lib.smx_batchnorm_ws_floats(P, Cc)),), x)
+    L.check(lib.smx_batchnorm_train_f32(xp, ldx, y.data_ptr(), Cc, gv.data_ptr(), bv.data_ptr(), mr.data_ptr(),
+                                        None if running_mean is None else running_mean.data_ptr(),
+                                        None if running_var is None else running_var.data_ptr(), P, Cc, eps, momentum, int(relu), ws.data_ptr(),
+                                        _stream()), "batchnorm_train")
+
+    def bwd():
+        g = tp.take(y)
+        if g is None:
+            return
+        g = g if g.is_contiguous() else _dense(lib, g)
+        dx = _empty(x.shape, x)
+        L.check(lib.smx_batchnorm_train_bwd_f32(xp, ldx, g.data_ptr(), Cc, y.data_ptr(), Cc, mr.data_ptr(), gv.data_ptr(), dx.data_ptr(), Cc,
+                                                gg.data_ptr(), bg.data_ptr(), P, Cc, ws.data_ptr(), _stream()), "batchnorm_train_bwd")
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y
+
+
+def avgpool2(tp, x):
+    y = ops.avgpool2(x)
+    B, H, W, Cc = x.shape
+
+    def bwd():
+        g = tp.take(y)
+        if g is None or not tp.needs(x):
+            return
+        dx = _empty(x.shape, x)
+        gp, ldg, _, _ = _pix(g)
+        L.check(tp.lib.smx_avgpool2_bwd_f32(gp, ldg, dx.data_ptr(), Cc, B, H, W, Cc, _stream()), "avgpool2_bwd")
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y
+
+
+def kp_head(tp, logits, jmaps, K, temperature):
+    """gaussian2kp + heatmap-weighted jacobians (archs/keypoint_detector_arch.py:48-86): logits [B,58,58,K], jmaps [B,58,58,4K]
+    -> (value [B,K,2], jacobian [B,K,2,2])."""
+    value, jac = ops.kp_head(logits, jmaps, K, temperature)
+    B, H, W, _ = logits.shape
+
+    def bwd():
+        gv, gj = tp.take(value), tp.take(jac)
+        if gv is None and gj is None:
+            return
+        lib = tp.lib
+        gv = gv if gv is None or gv.is_contiguous() else gv.contiguous()
+        gj = gj if gj is None or gj.is_contiguous() else gj.contiguous()
+        dl, dj = _empty((B, H, W, K), logits), _empty((B, H, W, 4 * K), logits)
+        lp, ldl = ops._pix(logits, "kp logits")
+        jp, ldj = ops._pix(jmaps, "kp jacobian maps")
+        L.check(lib.smx_kp_head_bwd_f32(lp, ldl, jp, ldj, None if gv is None else gv.data_ptr(), None if gj is None else gj.data_ptr(),
+                                        dl.data_ptr(), K, dj.data_ptr(), 4 * K, B, H, W, K, float(temperature), _stream()), "kp_head_bwd")
+        tp.acc(logits, dl)
+        tp.acc(jmaps, dj)
+    tp.record(bwd)
+    return value, jac
+
+
+def sparse_motion(tp, src64, kpd_value, kpd_jac, kps_value, kps_jac, K=15, var=0.01):
+    """heatmaps + sparse motions + 16 sparse warps (archs/dense_motion_arch.py:65-116) -> (hg_in [B,64,64,4(K+1)], sparse
+    [B,K+1,64,64,2], drv_heat [B,64,64,K]); gradients reach the four keypoint tensors."""
+    B = kpd_value.shape[0]
+    hg_in = _empty((B, 64, 64, 4 * (K + 1)), src64)
+    dj, sj = kpd_jac.reshape(B, K, 4), kps_jac.reshape(B, K, 4)
+    sparse, heat = ops.sparse_motion(src64, kpd_value, dj, kps_value, sj, hg_in, B, K, var)
+
+    def bwd():
+        gh, gs, gd = tp.take(hg_in), tp.take(sparse), tp.take(heat)
+        if gh is None and gs is None and gd is None:
+            return
+        lib = tp.lib
+        if gh is None:
+            gh = _zeros(hg_in.shape, hg_in)
+        gh = gh if gh.is_contiguous() else _dense(lib, gh)
+        gs = gs if gs is None or gs.is_contiguous() else gs.contiguous()
+        gd = gd if gd is None or gd.is_contiguous() else _dense(lib, gd)
+        d = [_empty((B, K, 2), src64), _empty((B, K, 4), src64), _empty((B, K, 2), src64), _empty((B, K, 4), src64)]
+        L.check(lib.smx_sparse_motion_bwd_f32(src64.data_ptr(), kpd_value.contiguous().data_ptr(), dj.contiguous().data_ptr(),
+                                              kps_value.contiguous().data_ptr(), sj.contiguous().data_ptr(), gh.data_ptr(), 4 * (K + 1),
+                                              None if gs is None else gs.data_ptr(), None if gd is None else gd.data_ptr(),
+                                              d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), B, 64, 64, K, float(var), _stream()),
+                "sparse_motion_bwd")
+        tp.acc(kpd_value, d[0])
+        tp.acc(kpd_jac, d[1].view(kpd_jac.shape))
+        tp.acc(kps_value, d[2])
+        tp.acc(kps_jac, d[3].view(kps_jac.shape))
+    tp.record(bwd)
+    return hg_in, sparse, heat
+
+
+def mask_deformation(tp, mlog, sparse, K1):
+    """mask softmax + flow blend + occlusion sigmoid (archs/dense_motion_arch.py:140-158): mlog [B,64,64,K1+1] -> (deformation
+    [B,64,64,2], occlusion [B,64,64])."""
+    deform, _, occ = ops.mask_deformation(mlog, sparse, want_mask=False, K1=K1, fused_occ=True)
+    B, H, W, Cl = mlog.shape
+
+    def bwd():
+        gd, go = tp.take(deform), tp.take(occ)
+        if gd is None and go is None:
+            return
+        lib = tp.lib
+        gd = gd if gd is None or gd.is_contiguous() else _dense(lib, gd)
+        go = go if go is None or go.is_contiguous() else go.contiguous()
+        dl = _zeros(mlog.shape, mlog)
+        ds = _empty(sparse.shape, sparse)
+        mp, ldm = ops._pix(mlog, "mask logits")
+        L.check(lib.smx_mask_deformation_bwd_f32(mp, ldm, sparse.data_ptr(), None if gd is None else gd.data_ptr(),
+                                                 None if go is None else go.data_ptr(), dl.data_ptr(), Cl, ds.data_ptr(), B, H, W, K1, _stream()),
+                "mask_deformation_bwd")
+        tp.acc(mlog, dl)
+        tp.acc(sparse, ds)
+    tp.record(bwd)
+    return deform, occ

@@ -169,3 +169,178 @@ class NetGTrainStep:
         if ema is not None and ema_decay > 0:
             self.flat.ema_into(ema, ema_decay)
         return losses, out, grads_in
+
+
+class EquivarianceTransform:
+    """The random affine + thin-plate warp of the equivariance constraint (reference `Transform`,
+    models/appmotioncomp_model.py:50-104): theta = I + N(0, sigma_affine) [B,2,3], a points x points control grid on [-1,1]^2 with weights
+    N(0, sigma_tps) [B,1,points^2].  The FRAME is warped by a HIP kernel (`smx_tps_transform_frame_f32`); the 15 keypoints per sample go
+    through the same map with a handful of torch ops (30 numbers per sample: host-side bookkeeping like the hull scale, not a hot path)."""
+
+    def __init__(self, bs, sigma_affine=0.05, sigma_tps=None, points_tps=None, theta=None, control_params=None, device="cuda", generator=None):
+        dev = torch.device(device)
+        if theta is None:
+            theta = torch.normal(mean=0, std=sigma_affine * torch.ones([bs, 2, 3]), generator=generator) + torch.eye(2, 3).view(1, 2, 3)
+        self.theta = theta.to(dev).float().contiguous()
+        self.bs = bs
+        self.tps = (sigma_tps is not None and points_tps is not None) or control_params is not None
+        if self.tps:
+            n = int(points_tps) if points_tps is not None else int(round(control_params.shape[-1] ** 0.5))
+            lin = 2.0 * (torch.arange(n, dtype=torch.float32) / (n - 1)) - 1.0
+            yy, xx = lin.view(-1, 1).repeat(1, n), lin.view(1, -1).repeat(n, 1)
+            self.control_points = torch.stack([xx, yy], -1).view(1, n * n, 2).to(dev)          # make_coordinate_grid order: (x, y), x fastest
+            if control_params is None:
+                control_params = torch.normal(mean=0, std=sigma_tps * torch.ones([bs, 1, n * n]), generator=generator)
+            self.control_params = control_params.to(dev).float().contiguous()
+
+    def transform_frame(self, frame_nchw):
+        x = frame_nchw.float().contiguous()
+        y = torch.empty_like(x)
+        B, C_, H, W = x.shape
+        lib = L.load()
+        L.check(lib.smx_tps_transform_frame_f32(x.data_ptr(), y.data_ptr(), self.theta.data_ptr(),
+                                                self.control_points.data_ptr() if self.tps else None,
+                                                self.control_params.data_ptr() if self.tps else None,
+                                                self.control_points.shape[1] if self.tps else 0, B, C_, H, W, _stream()), "tps_transform_frame")
+        return y
+
+    def warp_coordinates(self, coordinates):
+        """coordinates [B,N,2] -> [B,N,2] (the keypoint-sized torch path)."""
+        theta = self.theta.unsqueeze(1)
+        out = torch.matmul(theta[:, :, :, :2], coordinates.unsqueeze(-1)).squeeze(-1) + theta[:, :, :, 2]
+        if self.tps:
+            d = (coordinates.view(coordinates.shape[0], -1, 1, 2) - self.control_points.view(1, 1, -1, 2)).abs().sum(-1)
+            r = (d ** 2 * torch.log(d + 1e-6) * self.control_params).sum(dim=2).view(self.bs, coordinates.shape[1], 1)
+            out = out + r
+        return out
+
+    def jacobian(self, coordinates):
+        new = self.warp_coordinates(coordinates)
+        gx = torch.autograd.grad(new[..., 0].sum(), coordinates, create_graph=True)[0]
+        gy = torch.autograd.grad(new[..., 1].sum(), coordinates, create_graph=True)[0]
+        return torch.cat([gx.unsqueeze(-2), gy.unsqueeze(-2)], dim=-2)
+
+
+def equivariance_losses(kp_driving, kp_transformed, transform, w_value=1.0, w_jacobian=1.0):
+    """EquivarianceLoss.forward (losses/losses.py:540-560) on keypoint-sized torch tensors (requires_grad leaves)."""
+    lv = (kp_driving["value"] - transform.warp_coordinates(kp_transformed["value"])).abs().mean() * w_value
+    jt = torch.matmul(transform.jacobian(kp_transformed["value"]), kp_transformed["jacobian"])
+    val = torch.matmul(torch.inverse(kp_driving["jacobian"]), jt)
+    eye = torch.eye(2, device=val.device).view(1, 1, 2, 2)
+    lj = (eye - val).abs().mean() * w_jacobian
+    return lv, lj
+
+
+def kp_distance_value(kp_driving_value, kp_source_value, weight=1.0):
+    """KPDistanceLoss (losses/losses.py:609-616): a torch.sign of distances -- a logged VALUE with zero gradient."""
+    def one(v):
+        d = v.unsqueeze(2) - v.unsqueeze(1)
+        K = v.shape[1]
+        return (-torch.sign((torch.sqrt((d * d).sum(-1) + 1e-8) + torch.eye(K, device=v.device) * 0.2) - 0.2) + 1).mean()
+    return (one(kp_source_value) + one(kp_driving_value)) * weight
+
+
+class TrainStep:
+    """The generator + motion-estimator half of `optimize_parameters` (models/appmotioncomp_model.py:294-420) on the HIP path:
+    motion_estimator(gt, source) in training mode -> net_g(source, dense_motion, w=1, gt=gt) -> losses -> ONE backward through both
+    networks -> Adam on each (optim_g / optim_motion) -> EMA of net_g.  One tape spans both networks (their parameter names are disjoint)."""
+
+    def __init__(self, net_g, motion_estimator, train_opt):
+        from .engine_motion_train import MotionTrainEngine
+        self.g = NetGTrainStep(net_g, train_opt)
+        self.me = motion_estimator
+        self.flat_m = FlatParams(motion_estimator)
+        motion_estimator.refresh()
+        common, dense, kp = motion_estimator._cfg
+        self.bufs = dict(motion_estimator.named_buffers())
+        self.me_engine = MotionTrainEngine(common, dense, kp, self.bufs)
+        self.opt = dict(train_opt)
+        om = dict(self.opt.get("optim_motion") or {})
+        om.pop("type", None)
+        self.lr_m, self.betas_m = float(om.get("lr", 8e-5)), tuple(om.get("betas", (0.9, 0.99)))
+        self.wd_m = float(om.get("weight_decay", 0))
+        self.P = {**self.g.flat.P, **self.flat_m.P}
+        self.G = {**self.g.flat.G, **self.flat_m.G}
+
+    def forward_backward(self, source, driving, w=1.0, transform=None):
+        g = self.g
+        tp = Tape(self.P, self.G)
+        src, drv = source.float().contiguous(), driving.float().contiguous()
+        B = drv.shape[0]
+        eng = self.me_engine
+        kp_d = eng.kp_detector(tp, drv)
+        kp_s = eng.kp_detector(tp, src)
+        deform, occ, heat, aux = eng.dense_motion(tp, src, kp_d, kp_s)
+        st = g.engine.forward(tp, src, deform, occ, heat, float(w), gt_nchw=drv)
+        gt = tp.stop(ops.nchw_to_nhwc(drv))
+        o = self.opt
+        terms, losses = [], {}
+
+        def add(name, t, weight=1.0):
+            losses[name] = t
+            terms.append((t, weight))
+        if o.get("pixel_opt"):
+            add("l_g_pix", T.l1_loss(tp, st["out"], gt, g._w(o, "pixel_opt", 1.0)))
+        wc = g._w(o, "motion_codebook_code_opt", 1.0)
+        if wc:
+            add("l_g_motion_codebook_code", T.weighted_sum(tp, [(l, wc) for l in st["train"]["loss_motion"]]))
+        if o.get("motion_codebook_recon_opt"):
+            wr = g._w(o, "motion_codebook_recon_opt", 1.0)
+            recs = []
+            for i, rec in enumerate(st["train"]["motion_recon"]):
+                tgt = tp.stop(T.scaled(tp, ops.flow_to_residual(st["flows"][i]), 1.0 / 31.5))
+                recs.append((T.l1_loss(tp, T.scale(tp, rec, 1.0 / 31.5), tgt, wr), 1.0))
+            add("l_g_motion_codebook_recon", T.weighted_sum(tp, recs))
+        lrw = (o.get("lr_pixel_perceptual_opt") or {}).get("loss_weight", [])
+        if len(lrw) > 0 and o.get("pixel_opt"):
+            add("l_g_pix_lr_0", T.l1_loss(tp, st["out_lr"], gt, g._w(o, "pixel_opt", 1.0) * float(lrw[0])))
+        wa = g._w(o, "app_codebook_code_opt", 1.0)
+        if wa > 0:
+            add("l_g_app_codebook_code", T.weighted_sum(tp, [(l, wa) for l in st["app"][1]]))
+        total = T.weighted_sum(tp, terms)
+        # equivariance (:388-399): third keypoint pass on the TPS-warped driving frames; the keypoint-sized loss algebra runs on torch
+        # leaves whose gradients are handed to the tape
+        eq = o.get("equivariance_opt")
+        total_val = total
+        if eq:
+            if transform is None:
+                tparams = dict(eq.get("transform_params", {}))
+                transform = EquivarianceTransform(B, **tparams, device=drv.device)
+            kp_t = eng.kp_detector(tp, transform.transform_frame(drv))
+            leaves = {k: v.detach().clone().requires_grad_() for k, v in (("dv", kp_d[0]), ("dj", kp_d[1]), ("tv", kp_t[0]), ("tj", kp_t[1]))}
+            with torch.enable_grad():
+                lv, lj = equivariance_losses({"value": leaves["dv"], "jacobian": leaves["dj"]}, {"value": leaves["tv"], "jacobian": leaves["tj"]},
+                                             transform, eq.get("loss_weight_value", 1.0), eq.get("loss_weight_jacobian", 1.0))
+                (lv + lj).backward()
+            losses["l_equivariance_value"], losses["l_equivariance_jacobian"] = lv.detach().view(1), lj.detach().view(1)
+            for t, k in ((kp_d[0], "dv"), (kp_d[1], "dj"), (kp_t[0], "tv"), (kp_t[1], "tj")):
+                tp.acc(t, leaves[k].grad.contiguous())
+            total_val = total + lv.detach() + lj.detach()
+        if o.get("kp_distance_opt"):
+            losses["l_kpd"] = kp_distance_value(kp_d[0], kp_s[0], o["kp_distance_opt"].get("loss_weight", 1.0)).view(1)
+            total_val = total_val + losses["l_kpd"]
+        losses["l_g_total"] = total_val
+        tp.acc(total, torch.ones(1, device=total.device))
+        tp.backward()
+        out = {"out": ops.nhwc_to_nchw(st["out"]), "out_lr": [ops.nhwc_to_nchw(st["out_lr"])], "deformation_list": st["flows"],
+               "kp_driving": {"value": kp_d[0], "jacobian": kp_d[1]}, "kp_source": {"value": kp_s[0], "jacobian": kp_s[1]},
+               "deformation": deform, "occlusion_map": occ.view(B, 1, 64, 64), "driving_kp_heatmap_nhwc": heat}
+        if eq:
+            out["kp_transformed"] = {"value": kp_t[0], "jacobian": kp_t[1]}
+        return losses, out
+
+    def step(self, source, driving, w=1.0, transform=None, ema=None, ema_decay=0.0):
+        import torch.distributed as dist
+        self.g.flat.zero_grad()
+        self.flat_m.zero_grad()
+        losses, out = self.forward_backward(source, driving, w, transform)
+        world = 1
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            world = dist.get_world_size()
+            self.g.flat.all_reduce(dist)
+            self.flat_m.all_reduce(dist)
+        self.g.flat.adam_step(self.g.lr, self.g.betas, self.g.eps, self.g.wd, gscale=1.0 / world)
+        self.flat_m.adam_step(self.lr_m, self.betas_m, 1e-8, self.wd_m, gscale=1.0 / world)
+        if ema is not None and ema_decay > 0:
+            self.g.flat.ema_into(ema, ema_decay)
+        return losses, out

@@ -1,0 +1,104 @@
+"""SURVEY row N2 / BASELINE configs[4]: the generator + motion-estimator half of `AppMotionCompModel.optimize_parameters` on the HIP path
+against the reference's own step (fixture `tests/golden/train_step_full.npz`, `make_golden_r3.py train_step_full`): both networks in
+.train() -- BatchNorm on batch statistics, three keypoint-detector passes (driving, source, TPS-warped driving) -- L1 pixel + codebook +
+motion reconstruction + low-resolution pixel + equivariance (value + jacobian) losses, ONE backward through both networks.
+The random TPS transform's parameters come from the fixture (the reference drew them with torch.normal)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from tests.util import golden, weights, HERE
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def run():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_clip
+    from synergize_motion_appearance_amd.trainer import TrainStep, EquivarianceTransform
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+    net_g.load_state_dict(weights("network_g"), strict=True)
+    me.load_state_dict(weights("network_motion_estimator"), strict=True)
+    net_g, me = net_g.cuda(), me.cuda()
+    g = golden("train_step_full.npz")
+    _, clip = synth_clip(8, seed=int(g["clip_seed"]))
+    src, drv = clip[g["src_frames"].tolist()].contiguous().cuda(), clip[g["drv_frames"].tolist()].contiguous().cuda()
+    train_opt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt", "kp_distance_opt")}
+    step = TrainStep(net_g, me, train_opt)
+    tf = EquivarianceTransform(2, theta=torch.from_numpy(g["theta"]), control_params=torch.from_numpy(g["control_params"]))
+    step.g.flat.zero_grad()
+    step.flat_m.zero_grad()
+    losses, out = step.forward_backward(src, drv, transform=tf)
+    torch.cuda.synchronize()
+    return g, step, losses, out, tf, drv
+
+
+def _close(a, b, tol, what):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float()
+    err = float((a - b).abs().max())
+    assert err < tol * max(1.0, float(b.abs().max())), (what, err)
+
+
+def test_training_mode_forward_of_the_motion_estimator(run):
+    g, step, losses, out, tf, drv = run
+    _close(tf.control_points.view(-1, 2), g["control_points"].reshape(-1, 2), 1e-6, "control grid")
+    _close(tf.transform_frame(drv)[:, :, ::4, ::4], g["transformed_frame"], 2e-4, "TPS-warped frame (reflection padding)")
+    _close(out["kp_driving"]["value"], g["kp_driving_value"], 1e-4, "kp_driving.value")
+    _close(out["kp_driving"]["jacobian"], g["kp_driving_jacobian"], 2e-4, "kp_driving.jacobian")
+    _close(out["kp_source"]["value"], g["kp_source_value"], 1e-4, "kp_source.value")
+    _close(out["kp_transformed"]["value"], g["kp_transformed_value"], 1e-4, "kp_transformed.value")
+    _close(out["kp_transformed"]["jacobian"], g["kp_transformed_jacobian"], 2e-4, "kp_transformed.jacobian")
+    _close(out["deformation"], g["deformation"], 1e-4, "deformation")
+    _close(out["occlusion_map"], g["occlusion_map"], 1e-4, "occlusion map")
+    _close(out["driving_kp_heatmap_nhwc"].permute(0, 3, 1, 2)[:, :, ::2, ::2], g["driving_kp_heatmap"], 1e-4, "driving heatmap")
+    _close(out["out"][:, :, ::4, ::4], g["out"], 1e-3, "out")
+    # BatchNorm running statistics moved like F.batch_norm(training=True) (momentum 0.1, unbiased variance); the kp detector saw 3 batches
+    sd = step.me.state_dict()
+    for n in [k[8:] for k in g.files if k.startswith("bn_mean:")]:
+        _close(sd[n + ".running_mean"], g["bn_mean:" + n], 1e-4, n + ".running_mean")
+        _close(sd[n + ".running_var"], g["bn_var:" + n], 1e-4, n + ".running_var")
+        assert int(sd[n + ".num_batches_tracked"]) == int(g["bn_count:" + n]), n
+
+
+def test_full_step_losses_and_gradients_vs_reference(run):
+    from tests.golden.make_golden_r3 import ME_SAMPLES
+    g, step, losses, out, tf, drv = run
+    for k in ("l_g_pix", "l_g_motion_codebook_code", "l_g_motion_codebook_recon", "l_g_pix_lr_0", "l_g_app_codebook_code",
+              "l_equivariance_value", "l_equivariance_jacobian"):
+        ref = float(g["loss_" + k])
+        assert abs(float(losses[k]) - ref) < 3e-4 * abs(ref), (k, float(losses[k]), ref)
+    assert abs(float(losses["l_g_total"]) - float(g["l_g_total"])) < 3e-4 * float(g["l_g_total"])
+    for tag, G in (("me", step.flat_m.G), ("g", step.g.flat.G)):
+        names = [str(n) for n in g[f"{tag}_param_names"]]
+        ref = g[f"{tag}_grad_norms"]
+        assert names == list(G)
+        mine = np.array([float(G[n].double().norm()) for n in names])
+        floor = 1e-6 * ref.max()
+        bad = [(n, a, b) for n, a, b in zip(names, mine, ref) if abs(a - b) > 2e-3 * b + floor]
+        assert not bad, (tag, bad[:10])
+    floor = 1e-6 * float(g["me_grad_norms"].max())        # kp.bias: a shift of softmax logits, analytically zero gradient (noise ~2e-7 on both sides)
+    for n, s0, s1 in ME_SAMPLES:
+        ref = torch.from_numpy(g["grad:" + n])
+        t = step.flat_m.G[n]
+        got = (t[::s0] if t.dim() == 1 else t.reshape(t.shape[0], -1)[::s0, ::s1]).cpu()
+        mx = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < 2e-3 * mx + floor, (n, float((got - ref).abs().max()), mx)
+
+
+def test_full_step_runs_and_updates_both_networks(run):
+    g, step, losses, out, tf, drv = run
+    _, clip = __import__("synergize_motion_appearance_amd.synth", fromlist=["synth_clip"]).synth_clip(8, seed=int(g["clip_seed"]))
+    src = clip[g["src_frames"].tolist()].contiguous().cuda()
+    pg, pm = step.g.flat.value.clone(), step.flat_m.value.clone()
+    l2, _ = step.step(src, drv, transform=tf)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in l2.values())
+    assert float((step.g.flat.value - pg).abs().max()) > 1e-5 and float((step.flat_m.value - pm).abs().max()) > 1e-5
+    assert float((step.g.flat.value - pg).abs().max()) < 1e-3            # one Adam step moves a weight by about lr = 8e-5
