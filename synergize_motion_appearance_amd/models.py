@@ -7,8 +7,14 @@ drive them (reference `basicsr/models/__init__.py:19-30`, `sr_model.py:17-31`,
 Same names, argument meaning and return types (BGR uint8 HWC arrays, the same files at the same
 relative paths); the per-frame loop inside is the batched HIP path of `driver.animate_batched`:
 one keypoint / dense-motion / generator launch sequence per `val.batch` frames, the source
-encoded once per video.  Training members (`optimize_parameters`, losses, EMA, schedulers) are
-row N2 and raise."""
+encoded once per video.
+
+Training members (row N2, BASELINE configs[4]; `appmotioncomp_model.py:116-434, 598-605`): `init_training_settings`,
+`optimize_parameters`, `model_ema`, `update_learning_rate`, `save` drive `trainer.TrainStep` -- the generator + motion-estimator
+half of the reference step as HIP kernels with a gradient tape, Adam per network on flat parameter buffers, gradients summed over
+`torch.distributed` (RCCL) when it is initialised.  Terms that need networks the reference downloads are NOT silently dropped:
+`perceptual_opt` (VGG19) raises unless `train.allow_missing_losses` is true, and the discriminator branch (active from
+`net_d_start_iter`, 5001 in the shipped yml) raises when reached."""
 from collections import OrderedDict
 from copy import deepcopy
 from os import path as osp
@@ -75,7 +81,8 @@ _ARRAY_METRICS = {"calculate_psnr": calculate_psnr, "calculate_l1": calculate_l1
 
 @MODEL_REGISTRY.register()
 class AppMotionCompModel:
-    """Inference half of the reference model class (`appmotioncomp_model.py:108`)."""
+    """The reference model class (`appmotioncomp_model.py:108`): inference surface, and -- with opt['is_train'] -- the generator /
+    motion-estimator training step (see the module docstring for what is deliberately absent)."""
 
     def __init__(self, opt):
         self.opt = opt
@@ -83,8 +90,6 @@ class AppMotionCompModel:
             raise RuntimeError("the MI355X-native path has no CPU mode (num_gpu: 0)")
         self.device = torch.device("cuda")
         self.is_train = opt.get("is_train", False)
-        if self.is_train:
-            raise NotImplementedError("training (optimize_parameters, losses, EMA) is SURVEY row N2, not built")
         self.net_g = build_network(opt["network_g"]).to(self.device).eval()
         path = opt.get("path", {})
         if path.get("pretrain_network_g") is not None:
@@ -92,6 +97,108 @@ class AppMotionCompModel:
                               path.get("param_key_g", "params"))
         self.motion_estimator = None
         self.metric_results = {}
+        if self.is_train:
+            self.init_training_settings()
+
+    # -- appmotioncomp_model.py:116-221 (what of it the HIP step consumes) ------------------------------------------------------
+    def init_training_settings(self):
+        from .trainer import TrainStep, FlatParams
+        train_opt = self.opt["train"]
+        missing = [k for k in ("perceptual_opt",) if train_opt.get(k)]
+        if missing and not train_opt.get("allow_missing_losses", False):
+            raise NotImplementedError(f"train.{missing[0]} (MultiScalePyramidPerceptualLoss) needs the torchvision VGG19 weights the reference "
+                                      "downloads (archs/vgg_arch.py:173); set train.allow_missing_losses: true to train without that term")
+        self.skipped_losses = missing
+        self.ema_decay = float(train_opt.get("ema_decay", 0) or 0)
+        me = self._ensure_motion_estimator()
+        self.net_g.train()
+        me.train()
+        self.train_step = TrainStep(self.net_g, me, {k: v for k, v in train_opt.items() if k not in ("perceptual_opt", "gan_opt")})
+        self.net_g_ema, self._ema_flat = None, None
+        if self.ema_decay > 0:
+            self.net_g_ema = build_network(self.opt["network_g"]).to(self.device).eval()
+            self._ema_flat = FlatParams(self.net_g_ema)
+            path = self.opt.get("path", {})
+            if path.get("pretrain_network_g") is not None:
+                self.load_network(self.net_g_ema, path["pretrain_network_g"], path.get("strict_load_g", True), "params_ema")
+            else:
+                self.model_ema(0)
+        self.net_g_start_iter = train_opt.get("net_g_start_iter", 0)
+        self.net_d_iters = train_opt.get("net_d_iters", 1)
+        self.net_d_start_iter = train_opt.get("net_d_start_iter", 0)
+        sch = dict(train_opt.get("scheduler") or {})
+        self._milestones, self._gamma = list(sch.get("milestones", [])), float(sch.get("gamma", 1.0))
+        self._base_lr = (self.train_step.g.lr, self.train_step.lr_m)
+        self.log_dict = OrderedDict()
+
+    def model_ema(self, decay=0.999):
+        """models/sr_model.py model_ema: net_g_ema = decay * net_g_ema + (1 - decay) * net_g (one kernel over the flat buffers)."""
+        self.train_step.g.flat.ema_into(self._ema_flat, decay)
+        self.net_g_ema.refresh()
+
+    def update_learning_rate(self, current_iter, warmup_iter=-1):
+        """base_model.py:144-165 for the shipped MultiStepLR: lr = base * gamma^(milestones passed), linear warm-up when configured."""
+        k = sum(1 for m in self._milestones if current_iter > m)
+        f = self._gamma ** k
+        if 0 < current_iter < warmup_iter:
+            f *= current_iter / warmup_iter
+        self.train_step.g.lr, self.train_step.lr_m = self._base_lr[0] * f, self._base_lr[1] * f
+
+    def get_current_learning_rate(self):
+        return [self.train_step.g.lr]
+
+    def get_current_log(self):
+        return self.log_dict
+
+    def optimize_parameters(self, current_iter):
+        """appmotioncomp_model.py:294-434: motion_estimator(gt, source) -> net_g(source, dense_motion, w=1, gt=gt) -> l_g_total.backward()
+        -> optimizer_g.step(), optimizer_m.step() -> EMA; then `reduce_loss_dict`."""
+        if not self.is_train:
+            raise RuntimeError("optimize_parameters needs opt['is_train'] = True")
+        if current_iter > self.net_d_start_iter:
+            raise NotImplementedError("the discriminator branch (hinge GAN + adaptive weight, appmotioncomp_model.py:322-340, 408-432) starts at "
+                                      f"net_d_start_iter = {self.net_d_start_iter}: VQGANDiscriminator has no backward on the HIP path")
+        loss_dict = OrderedDict()
+        if current_iter % self.net_d_iters == 0 and current_iter > self.net_g_start_iter:
+            losses, self.out_dict = self.train_step.step(self.source, self.gt, w=1.0)
+            self.dense_motion = {k: self.out_dict[k] for k in ("deformation", "occlusion_map", "kp_driving", "kp_source")}
+            for k, v in losses.items():
+                if k != "l_g_total":
+                    loss_dict[k] = v.detach().reshape(())
+        if self.ema_decay > 0:
+            self.model_ema(decay=self.ema_decay)
+        self.log_dict = self.reduce_loss_dict(loss_dict)
+
+    def reduce_loss_dict(self, loss_dict):
+        """base_model.py:298-323: average over ranks (to rank 0), then python floats."""
+        import torch.distributed as dist
+        with torch.no_grad():
+            if loss_dict and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                keys = list(loss_dict)
+                t = torch.stack([loss_dict[k] for k in keys], 0)
+                if dist.get_backend() == "gloo":
+                    h = t.cpu()
+                    dist.reduce(h, dst=0)
+                    t = h
+                else:
+                    dist.reduce(t, dst=0)
+                if dist.get_rank() == 0:
+                    t = t / dist.get_world_size()
+                loss_dict = OrderedDict(zip(keys, t))
+            return OrderedDict((k, float(v)) for k, v in loss_dict.items())
+
+    def save_network(self, net, net_label, current_iter, param_key="params"):
+        """base_model.py:171-200: `{net_label}_{iter}.pth` holding {'params': state_dict} (and 'params_ema')."""
+        import os
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return
+        nets = net if isinstance(net, list) else [net]
+        keys = param_key if isinstance(param_key, list) else [param_key]
+        name = f"{net_label}_{'latest' if current_iter == -1 else current_iter}.pth"
+        os.makedirs(self.opt["path"]["models"], exist_ok=True)
+        torch.save({k: OrderedDict((n, v.detach().cpu().clone()) for n, v in n_.state_dict().items()) for n_, k in zip(nets, keys)},
+                   os.path.join(self.opt["path"]["models"], name))
 
     # -- base_model.py:236-262 ------------------------------------------------------------------------
     def load_network(self, net, load_path, strict=True, param_key="params"):
@@ -125,6 +232,9 @@ class AppMotionCompModel:
     @torch.no_grad()
     def test(self):
         me = self._ensure_motion_estimator()
+        if self.is_train:                     # parameters moved since the inference engines packed them
+            self.net_g.refresh()
+            me.refresh()
         self.dense_motion = me(self.gt, self.source)
         self.out_dict = self.net_g(self.source, self.dense_motion, w=self.opt.get("val", {}).get("w", 1), inference=True)
         self.driving_feat = self.net_g.encode_driving(self.gt)
@@ -224,8 +334,10 @@ class AppMotionCompModel:
     def validation(self, dataloader, current_iter, tb_logger, save_img=False, **kwargs):
         raise NotImplementedError("frame-pair validation (test.py) is outside the animation path; use generate_video_image")
 
-    def optimize_parameters(self, current_iter):
-        raise NotImplementedError("training is SURVEY row N2, not built")
-
     def save(self, epoch, current_iter):
-        raise NotImplementedError("training is SURVEY row N2, not built")
+        """appmotioncomp_model.py:598-605 (net_d and the optimizer state file are the discriminator / harness side: not written)."""
+        if self.ema_decay > 0:
+            self.save_network([self.net_g, self.net_g_ema], "net_g", current_iter, param_key=["params", "params_ema"])
+        else:
+            self.save_network(self.net_g, "net_g", current_iter)
+        self.save_network(self.motion_estimator, "net_motion_estimator", current_iter)

@@ -20,12 +20,14 @@ from .tape import Tape, _stream
 class FlatParams:
     ALIGN = 64      # floats (256 B): every slot is float4-aligned for the vector kernels
 
-    def __init__(self, module):
+    def __init__(self, module, allow_cpu=False):
+        """allow_cpu: host tensors are accepted for the bookkeeping / collective logic only (the CPU `gloo` tests); `adam_step` and
+        `ema_into` are HIP kernels and raise without a device."""
         named = [(n, p) for n, p in module.named_parameters()]
         if not named:
             raise ValueError("FlatParams: the module has no parameters")
         dev = named[0][1].device
-        if dev.type != "cuda":
+        if dev.type != "cuda" and not allow_cpu:
             raise L.SmxError("FlatParams: parameters must be on the MI355X (call .cuda()); there is no CPU training path")
         offs, off = [], 0
         for _, p in named:
@@ -45,7 +47,7 @@ class FlatParams:
             p.grad = gview
             self.P[n], self.G[n], self.slots[n] = view, gview, (o, p.numel())
         self.t = 0
-        self.lib = L.load()
+        self.lib = L.load() if dev.type == "cuda" else None
 
     def zero_grad(self):
         self.grad.zero_()
@@ -54,11 +56,11 @@ class FlatParams:
         """sum the flat gradient over the ranks in a few large buckets (async, then one wait); the 1/world factor is applied
         inside the Adam kernel (gscale)."""
         n = max(1, int(bucket_mb * (1 << 20) // 4))
-        cpu = dist.get_backend(group) == "gloo"
+        cpu = dist.get_backend(group) == "gloo" and self.grad.is_cuda
         works = []
         for a in range(0, self.numel, n):
             chunk = self.grad[a:a + n]
-            if cpu:                                         # gloo (tests on one device): host-staged
+            if cpu:                                         # gloo with device tensors (tests on one device): host-staged
                 h = chunk.cpu()
                 dist.all_reduce(h, group=group)
                 chunk.copy_(h)
@@ -68,6 +70,8 @@ class FlatParams:
             w.wait()
 
     def adam_step(self, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, gscale=1.0):
+        if self.lib is None:
+            raise L.SmxError("FlatParams.adam_step is a HIP kernel: the parameters must be on the MI355X")
         self.t += 1
         L.check(self.lib.smx_adam_step_f32(self.value.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.numel,
                                            float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.t, float(gscale),

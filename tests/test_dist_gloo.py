@@ -163,3 +163,40 @@ def test_animate_sharded_with_an_empty_shard_does_not_hang():
     res = _run_subgroup(2, [0, 1], 1)
     assert res[0][1] == _expected(1) and res[1][1] is None
     assert res[0][2] == (0, 1) and res[1][2] == (1, 1) and res[1][3] == (0, 8, 8, 3)
+
+
+# ---- the training step's gradient collective (DDP as bucketed all-reduces of one flat buffer), host tensors -------------
+def _flat_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synergize_motion_appearance_amd.trainer import FlatParams
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 101), torch.nn.Linear(101, 5))
+    flat = FlatParams(net, allow_cpu=True)
+    # parameters alias the flat buffer (checkpoint names / shapes intact), slots are 256-B aligned
+    assert all(p.data_ptr() == flat.P[n].data_ptr() for n, p in net.named_parameters())
+    assert all(o % FlatParams.ALIGN == 0 for o, _ in flat.slots.values())
+    for n, g in flat.G.items():
+        g.fill_(float(rank + 1))                                  # rank r contributes r+1 everywhere
+    flat.all_reduce(dist, bucket_mb=0.001)                        # 262-float buckets: many collectives, same result
+    ok = all(bool((g == 3.0).all()) for g in flat.G.values())     # 1 + 2
+    pad_untouched = float(flat.grad.sum()) == 3.0 * sum(n for _, n in flat.slots.values())
+    q.put((rank, ok, pad_untouched, [tuple(p.grad.shape) for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_flat_gradient_all_reduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, ok, pad, shapes in res:
+        assert ok and pad, rank
+        assert shapes == [(101, 37), (101,), (5, 101), (5,)]

@@ -123,3 +123,72 @@ def test_bench_refuses_a_silent_backend_fallback():
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import yaml
+        from basicsr.archs import build_network
+        from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
+        from synergize_motion_appearance_amd.trainer import TrainStep, EquivarianceTransform
+        cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+        net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+        net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
+        me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
+        net_g, me = net_g.cuda(), me.cuda()
+        topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt", "kp_distance_opt")}
+        step = TrainStep(net_g, me, topt)
+        _, clip = synth_clip(8, seed=321)
+        # each rank owns ONE different (source, driving) pair (a DistributedSampler shard)
+        src, drv = clip[[0, 5][rank]][None].cuda(), clip[[3, 7][rank]][None].cuda()
+        tf = EquivarianceTransform(1, sigma_affine=0.05, sigma_tps=0.005, points_tps=5, generator=torch.Generator().manual_seed(100 + rank))
+        # local gradients first (no collective), then the real step
+        step.g.flat.zero_grad(), step.flat_m.zero_grad()
+        step.forward_backward(src, drv, transform=tf)
+        local = [float(step.g.flat.grad.double().sum()), float(step.flat_m.grad.double().sum())]
+        local_probe = step.g.flat.G["generator.blocks.18.weight"].clone()
+        # BatchNorm running statistics moved in that probe pass: reset them so both passes start alike is NOT needed for this check
+        step.g.flat.zero_grad(), step.flat_m.zero_grad()
+        step.forward_backward(src, drv, transform=tf)
+        step.g.flat.all_reduce(dist), step.flat_m.all_reduce(dist)
+        summed = [float(step.g.flat.grad.double().sum()), float(step.flat_m.grad.double().sum())]
+        summed_probe = step.g.flat.G["generator.blocks.18.weight"].clone()
+        step.g.flat.adam_step(8e-5, gscale=1.0 / world)
+        step.flat_m.adam_step(8e-5, gscale=1.0 / world)
+        torch.cuda.synchronize()
+        # numpy, not tensors: a tensor in a Queue travels as a shared-memory handle that dies with this process
+        q.put({"rank": rank, "local": local, "summed": summed, "local_probe": local_probe.cpu().numpy(), "summed_probe": summed_probe.cpu().numpy(),
+               "w": step.g.flat.P["generator.blocks.18.weight"].cpu().numpy(), "wm": step.flat_m.P["kp_detector.kp.weight"].cpu().numpy(),
+               "chk": [float(step.g.flat.value.double().sum()), float(step.flat_m.value.double().sum())]})
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_training_step_sums_gradients_and_keeps_replicas_identical():
+    """SURVEY row N2 (DDP of models/base_model.py:71-74 as bucketed all-reduces of the flat gradient buffer): two ranks on the one
+    device of this box (gloo, host-staged), each with its own (source, driving) pair: after the all-reduce both hold the SUM of the two
+    local gradients, Adam applies it with gscale = 1/world (the average), and the replicas stay bit-identical."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda r: r["rank"])
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    r0, r1 = res
+    import numpy as np
+    assert not np.array_equal(r0["local_probe"], r1["local_probe"])                    # different data, different local gradients
+    assert np.array_equal(r0["summed_probe"], r1["summed_probe"])                      # one reduced gradient on both ranks
+    ref = r0["local_probe"] + r1["local_probe"]
+    assert float(np.abs(r0["summed_probe"] - ref).max()) < 1e-5 * float(np.abs(ref).max()) + 1e-9
+    for i in range(2):
+        assert abs(r0["summed"][i] - (r0["local"][i] + r1["local"][i])) < 1e-4 * (abs(r0["summed"][i]) + 1e-3)
+    assert np.array_equal(r0["w"], r1["w"]) and np.array_equal(r0["wm"], r1["wm"]) and r0["chk"] == r1["chk"]   # replicas identical after Adam

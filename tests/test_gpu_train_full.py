@@ -102,3 +102,47 @@ def test_full_step_runs_and_updates_both_networks(run):
     assert all(torch.isfinite(v).all() for v in l2.values())
     assert float((step.g.flat.value - pg).abs().max()) > 1e-5 and float((step.flat_m.value - pm).abs().max()) > 1e-5
     assert float((step.g.flat.value - pg).abs().max()) < 1e-3            # one Adam step moves a weight by about lr = 8e-5
+
+
+def test_model_level_optimize_parameters(tmp_path):
+    """`build_model(opt)` with is_train: feed_data -> optimize_parameters(current_iter) -> log dict / EMA / checkpoint files, the way
+    train.py:178-215 drives the reference model; perceptual_opt raises unless allow_missing_losses, the GAN branch raises when reached."""
+    from synergize_motion_appearance_amd.models import build_model
+    from synergize_motion_appearance_amd.synth import synth_clip
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    cfg.update(is_train=True, dist=False, rank=0, world_size=1, num_gpu=1)
+    cfg["path"] = dict(cfg["path"], models=str(tmp_path / "models"))
+    with pytest.raises(NotImplementedError, match="allow_missing_losses"):
+        build_model(cfg)
+    cfg["train"]["allow_missing_losses"] = True
+    model = build_model(cfg)
+    model.net_g.load_state_dict(weights("network_g"), strict=True)
+    model.motion_estimator.load_state_dict(weights("network_motion_estimator"), strict=True)
+    model.model_ema(0)
+    _, clip = synth_clip(8, seed=321)
+    model.feed_data({"source": clip[[0, 5]], "driving": clip[[3, 7]]})
+    w0 = model.net_g.state_dict()["generator.blocks.18.weight"].clone()
+    e0 = model.net_g_ema.state_dict()["generator.blocks.18.weight"].clone()
+    assert torch.equal(w0, e0)
+    model.update_learning_rate(1)
+    model.optimize_parameters(1)
+    log = model.get_current_log()
+    for k in ("l_g_pix", "l_g_motion_codebook_code", "l_g_motion_codebook_recon", "l_g_pix_lr_0", "l_g_app_codebook_code",
+              "l_equivariance_value", "l_equivariance_jacobian", "l_kpd"):
+        assert k in log and np.isfinite(log[k]), k
+    g = golden("train_step_full.npz")
+    assert abs(log["l_g_pix"] - float(g["loss_l_g_pix"])) < 3e-4 * float(g["loss_l_g_pix"])          # same pairs as the fixture
+    w1 = model.net_g.state_dict()["generator.blocks.18.weight"]
+    e1 = model.net_g_ema.state_dict()["generator.blocks.18.weight"]
+    assert 1e-5 < float((w1 - w0).abs().max()) < 1e-3
+    assert torch.allclose(e1, 0.995 * e0 + 0.005 * w1, atol=1e-7)                                    # ema_decay 0.995
+    model.update_learning_rate(200001)
+    assert abs(model.get_current_learning_rate()[0] - 4e-5) < 1e-12                                  # MultiStepLR milestone, gamma 0.5
+    model.save(0, 1)
+    ck = torch.load(str(tmp_path / "models" / "net_g_1.pth"))
+    assert set(ck) == {"params", "params_ema"} and torch.equal(ck["params"]["generator.blocks.18.weight"], w1.cpu())
+    assert os.path.exists(str(tmp_path / "models" / "net_motion_estimator_1.pth"))
+    model.test()                                                                                     # validation forward on the updated weights
+    assert torch.isfinite(model.out_dict["out"]).all()
+    with pytest.raises(NotImplementedError, match="discriminator"):
+        model.optimize_parameters(5002)
