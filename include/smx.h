@@ -366,11 +366,14 @@ int smx_nhwc_to_nchw_bf16(const void* x, int ldx, float* y, int B, int C, int H,
  * WEIGHT gradient: dW[co][(ky,kx,ci)] = sum_m dY[m][co] X~[m][(ky,kx,ci)], m over the nb x (B*Ho*Wo) output pixels, X~ the implicit
  * im2col of x (zero pad, stride, up2 = nearest x2).  ws: smx_wgrad_ws_floats(...) floats (also returns the pixel split to pass).
  * out layout 0: OIHW parameter; 1: row-major out[co*ldo + k] (Linear / batched C); 2: transposed out[k*ldo + co].
- * accumulate: out += alpha * dW (a .grad that already holds another call site's contribution), else out = alpha * dW. */
+ * accumulate: out += alpha * dW (a .grad that already holds another call site's contribution), else out = alpha * dW.
+ * bias_out (nullable): the BIAS gradient sum_m dY[m][co] comes out of the same pass (the dY tiles stream through the k-tile-0 blocks anyway;
+ * their column sums are finished in a fixed order) -- same accumulate / alpha. */
 int64_t smx_wgrad_ws_floats(int nb, int M, int Cout, int K, int* msplit_out);
 int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
                   int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
-                  float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha, void* stream);
+                  float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
+                  float* bias_out, void* stream);
 /* out[c] (+)= alpha * sum_p x[p*ld + c]  (bias gradients); ws: smx_colsum_ws_floats(P, C) floats; two fixed-order stages */
 int64_t smx_colsum_ws_floats(int64_t P, int C);
 int smx_colsum_f32(const float* x, int ld, int64_t P, int C, float* ws, float* out, int accumulate, float alpha, void* stream);
@@ -378,6 +381,11 @@ int smx_partial_reduce_f32(const float* part, int nchunk, int C, float* out, int
 /* parameter (OIHW, or Linear [out][in] with kh = kw = 1) -> mode 0: [Cout][(ky,kx,ci)] (forward operand);
  * mode 1: [Cin][(kh-1-ky, kw-1-kx, co)] (data-gradient operand) */
 int smx_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int kh, int kw, int mode, void* stream);
+/* OIHW 3x3 parameter -> the fragment-ordered Winograd-domain weights smx_winograd_conv3x3_f32 reads (u: smx_winograd_u_floats(N, C)
+ * floats incl. the prefetch pad): mode 0 forward (N = Cout, C = Cin), mode 1 data gradient (N = Cin, C = Cout, taps flipped) --
+ * the training step's 3x3 forward and data-gradient convolutions run on the fused Winograd kernel with the current weights */
+int64_t smx_winograd_u_floats(int N, int C);
+int smx_pack_winograd_u_f32(const float* w_oihw, float* u, int Cout, int Cin, int mode, void* stream);
 /* batched y[g][c][r] = x[g][r][c] */
 int smx_transpose_f32(const float* x, int ldx, int64_t x_bs, float* y, int ldy, int64_t y_bs, int nb, int R, int C, void* stream);
 /* y = act(x) as its own pass (training keeps the pre-activation of GELU / swish / sigmoid for the backward) */
@@ -405,8 +413,9 @@ int smx_batch_sum_f32(const float* g, float* out, int B, int64_t per, void* stre
 int smx_softmax_rows_bwd_f32(const float* P, float* dP, int64_t R, int S, float scale, void* stream);
 
 /* ---- multi-head attention core backward (csrc/train_attn.hip), flash style: P recomputed from q, k and row statistics ----
- * layouts as smx_attention_f32; o / d_o [B][L][H*dh] dense; k_bs = v_bs = 0: context shared by the batch (dk / dv batch-summed,
- * fixed order); dq [B][L][H*dh]; dk, dv [B or 1][S][H*dh]; stats: B*H*L*3 floats scratch; dh in {4, 32} */
+ * layouts as smx_attention_f32; o / d_o [B][L][H*dh] dense; k_bs = v_bs = 0: context shared by the batch; dq [B][L][H*dh];
+ * dk, dv [B][S][H*dh] per sample (shared context: sum them over the batch with smx_batch_sum_f32); stats: B*H*L*3 floats scratch;
+ * dh in {4, 32} */
 int smx_attention_bwd_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs, const float* v, int ldv, int64_t v_bs,
                           const float* o, const float* d_o, const uint8_t* key_mask, float* dq, float* dk, float* dv, float* stats,
                           int B, int H, int L, int S, int dh, float scale, void* stream);

@@ -9,8 +9,8 @@
 //
 // Two kernels: (1) one thread per QUERY: pass 1 over the keys -> row max / sum (and D_i), pass 2 -> dQ; the statistics
 // {m, 1/l, D} are written for kernel (2), one thread per KEY: loops the queries (Q / dO / statistics tiles broadcast from LDS)
-// -> dK, dV.  With a codebook context shared by the batch (cross attention: K/V batch stride 0) the key thread also loops
-// the batch, so dK / dV are the batch sums in a fixed order -- no atomics, bit-reproducible.
+// -> dK, dV per sample.  With a codebook context shared by the batch (cross attention: K/V batch stride 0) the caller sums the
+// per-sample dK / dV over the batch in a fixed order (smx_batch_sum_f32) -- no atomics, bit-reproducible.
 // d_head is 4 (motion transformer) or 32 (appearance transformer): q / k / v / dO rows live in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -90,11 +90,13 @@ __global__ __launch_bounds__(128) void attn_bwd_q_kernel(ABP p) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(128) void attn_bwd_kv_kernel(ABP p, int shared) {
+__global__ __launch_bounds__(128) void attn_bwd_kv_kernel(ABP p) {
   constexpr int TQ = 64;
   __shared__ float Qs[TQ * DH], Gs[TQ * DH], St[TQ * 3];
-  // grid.y = (shared ? 1 : B) * H
-  const int bb = shared ? 0 : blockIdx.y / p.H, h = blockIdx.y - (shared ? 0 : bb * p.H);
+  // grid.y = B * H: one (sample, head) per block row also when the context is shared by the batch (k_bs = v_bs = 0) -- the per-sample
+  // dK / dV are then summed over the batch by the caller's fixed-order batch sum; looping the batch inside a (head, key-tile) block
+  // left 8 x H blocks for 256 CUs
+  const int bb = blockIdx.y / p.H, h = blockIdx.y - bb * p.H;
   const int j = blockIdx.x * 128 + threadIdx.x;
   const bool ok = j < p.S;
   const int E = p.H * DH;
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(ABP p, int shared) {
     vv[d] = ok ? p.v[(long long)bb * p.v_bs + (long long)j * p.ldv + h * DH + d] : 0.f;
     dk[d] = 0.f; dv[d] = 0.f;
   }
-  const int b0 = shared ? 0 : bb, b1 = shared ? p.B : bb + 1;
-  for (int b = b0; b < b1; ++b) {
+  {
+    const int b = bb;
     const bool masked = p.mask && ok && p.mask[(long long)b * p.S + j];
     for (int i0 = 0; i0 < p.L; i0 += TQ) {
       __syncthreads();
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(ABP p, int shared) {
 template <int DH>
 int launch(ABP& p, int shared, hipStream_t st) {
   SMX_LAUNCH(attn_bwd_q_kernel<DH>, dim3(smx_cdiv(p.L, 128), p.B * p.H), dim3(128), 0, st, p);
-  SMX_LAUNCH(attn_bwd_kv_kernel<DH>, dim3(smx_cdiv(p.S, 128), (shared ? 1 : p.B) * p.H), dim3(128), 0, st, p, shared);
+  (void)shared;
+  SMX_LAUNCH(attn_bwd_kv_kernel<DH>, dim3(smx_cdiv(p.S, 128), p.B * p.H), dim3(128), 0, st, p);
   return smx_launch_status();
 }
 
@@ -154,7 +157,8 @@ int launch(ABP& p, int shared, hipStream_t st) {
 
 /* q [B][L][ldq] (head h at column h*dh; sample stride q_bs), k / v rows [S] (ld, sample stride k_bs / v_bs; 0 = a context
  * shared by the batch), o / d_o [B][L][H*dh] dense (the forward output and its gradient), key_mask [B][S] bytes or null.
- * -> dq [B][L][H*dh]; dk, dv [B or 1][S][H*dh] (batch-summed when the context is shared); stats: B*H*L*3 floats scratch. */
+ * -> dq [B][L][H*dh]; dk, dv [B][S][H*dh] PER SAMPLE (a shared context's gradient is their batch sum: smx_batch_sum_f32);
+ * stats: B*H*L*3 floats scratch. */
 extern "C" int smx_attention_bwd_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
                                      const float* v, int ldv, int64_t v_bs, const float* o, const float* d_o,
                                      const uint8_t* key_mask, float* dq, float* dk, float* dv, float* stats,

@@ -31,7 +31,7 @@ inline int grid_for(long long total) { int g = smx_cdiv(total, 256); return g > 
 constexpr int WPITCH = 68;     // LDS row pitch (floats): 8 * 68 = 544 = 8 * 64 + 32 -> rows p and p+8 sit in opposite bank halves
 
 struct WG {
-  const float* dy; const float* x; float* ws;
+  const float* dy; const float* x; float* ws; float* bias_ws;      // bias_ws [nb][msplit][Cout] (nullable): column sums of dy per pixel split
   long long dy_bs, x_bs;
   int M, Cout, K, ldy, ldx;
   int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
@@ -65,6 +65,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
   const int Hlim = p.up2 ? 2 * p.Hin : p.Hin, Wlim = p.up2 ? 2 * p.Win : p.Win;
 
   float4 areg[2], breg[2];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);            // bias gradient: this thread's 4 dy columns summed over its rows (tile_k == 0 blocks)
+  const bool do_bias = p.bias_ws != nullptr && tile_k == 0;
   auto load_slice = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
         }
       }
       areg[i] = a; breg[i] = b;
+      if (do_bias) { bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w; }
     }
   };
   auto store_slice = [&](int buf) {
@@ -156,6 +159,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
       __syncthreads();
     }
   }
+  if (do_bias) {
+    // the dy tile streamed through this block anyway: its column sums are the bias gradient of this pixel split.  16 row-lanes
+    // (tid >> 4) hold partial sums of the same 4 columns: fixed-order LDS finish (the staging buffers are free now)
+    float* red = &As[0][0];
+    __syncthreads();
+    *reinterpret_cast<float4*>(red + (r0 * 16 + c4) * 4) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      const int col = tid;                                     // column co0 + col: float4 c4 = col >> 2, element col & 3
+      float t = 0.f;
+      for (int r = 0; r < 16; ++r) t += red[(r * 16 + (col >> 2)) * 4 + (col & 3)];
+      if (co0 + col < p.Cout) p.bias_ws[((long long)g * p.msplit + z) * p.Cout + co0 + col] = t;
+    }
+  }
   // raw partial tile -> ws[(g * msplit + z)][Cout][K]
   float* W = p.ws + ((long long)g * p.msplit + z) * p.Cout * p.K;
   const int kcol = k0 + wn * 32 + (lane & 31);
@@ -190,6 +207,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     float* d = out + (long long)g * out_bs + o;
     *d = accumulate ? *d + s : s;
   }
+}
+
+// bias[co] (+)= alpha * sum_{g,z} bias_ws[g][z][co]  (fixed order)
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bws, int n, int Cout, float* __restrict__ out, int accumulate, float alpha) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cout) return;
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += bws[(long long)k * Cout + c];
+  s *= alpha;
+  out[c] = accumulate ? out[c] + s : s;
 }
 
 // ---- column sums: part[chunk][C] = sum over the chunk's rows; then out[c] (+)= sum_chunk part[chunk][c] (fixed order) ----
@@ -246,6 +273,36 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
       const int tap = k / Cout, co = k - tap * Cout; const int ky = kh - 1 - tap / kw, kx = kw - 1 - tap % kw;
       o[i] = w[((long long)co * Cin + ci) * kh * kw + ky * kw + kx];
     }
+  }
+}
+
+// Winograd-domain weights U = G g G^T of F(2x2,3x3) in the fragment order winograd.hip reads ([16 f][N/32][C/8][2][32][4]:
+// lane l = 32 hh + r <-> output channel 32 nt + r, input channels 8 s + 4 hh + e), straight from the OIHW parameter:
+//   mode 0 (forward):       N = Cout, C = Cin,  g[n][a][b][c] = w[n][c][a][b]
+//   mode 1 (data gradient): N = Cin,  C = Cout, g[n][a][b][c] = w[c][n][2-a][2-b]
+// so the training step's 3x3 convolutions (forward AND data gradient) run on the fused Winograd kernel with this step's weights
+__global__ __launch_bounds__(256) void pack_winograd_u_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int mode, long long total) {
+  const int N = mode ? Cin : Cout, Cc = mode ? Cout : Cin;
+  const int n32 = (N + 31) / 32, c8 = Cc / 8;
+  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long t = i;
+    const int e = (int)(t & 3); t >>= 2; const int r = (int)(t & 31); t >>= 5; const int hh = (int)(t & 1); t >>= 1;
+    const int s = (int)(t % c8); t /= c8; const int nt = (int)(t % n32); const int f = (int)(t / n32);
+    float out = 0.f;
+    if (f < 16) {
+      const int n = nt * 32 + r, c = 8 * s + 4 * hh + e, fi = f >> 2, fj = f & 3;
+      if (n < N) {
+        double acc = 0.0;
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) {
+            const float g = mode ? w[((long long)c * Cin + n) * 9 + (2 - a) * 3 + (2 - b)] : w[((long long)n * Cin + c) * 9 + a * 3 + b];
+            acc += G[fi][a] * (double)g * G[fj][b];
+          }
+        out = (float)acc;
+      }
+    }
+    u[i] = out;                                             // f >= 16: the prefetch pad behind the last fragment (zeros)
   }
 }
 
@@ -321,18 +378,20 @@ extern "C" int64_t smx_wgrad_ws_floats(int nb, int M, int Cout, int K, int* mspl
   if (ms > cap) ms = cap;
   if (ms < 1) ms = 1;
   if (msplit_out) *msplit_out = (int)ms;
-  return (int64_t)nb * ms * Cout * K;
+  return (int64_t)nb * ms * Cout * K + (int64_t)nb * ms * Cout;      // weight partials + the bias-gradient partials
 }
 
 extern "C" int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
                              int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
                              float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
-                             void* stream) {
+                             float* bias_out, void* stream) {
   if (!dy || !x || !ws || !out || nb <= 0 || M <= 0 || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return SMX_EINVAL;
   if (msplit < 1 || nb > 65535 || msplit > 65535 || layout < 0 || layout > 2 || ldy < Cout || ldx < Cin) return SMX_EINVAL;
   if (Ho <= 0 || Wo <= 0 || M % (Ho * Wo) != 0 || (up2 != 0 && up2 != 1)) return SMX_EINVAL;
   WG p;
   p.dy = dy; p.x = x; p.ws = ws; p.dy_bs = dy_bs; p.x_bs = x_bs;
+  // the bias gradient (column sums of dy) rides along: partials live behind the weight partials in ws
+  p.bias_ws = bias_out ? ws + (long long)nb * msplit * Cout * (kh * kw * Cin) : nullptr;
   p.M = M; p.Cout = Cout; p.K = kh * kw * Cin; p.ldy = ldy; p.ldx = ldx;
   p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.up2 = up2;
   p.is1x1 = (kh == 1 && kw == 1 && stride == 1 && !up2 && pad_t == 0 && pad_l == 0 && Hin == Ho && Win == Wo) ? 1 : 0;
@@ -348,6 +407,7 @@ extern "C" int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const floa
   SMX_LAUNCH(wgrad_kernel, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
   SMX_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long long)nb * Cout * p.K)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
              Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha);
+  if (bias_out) SMX_LAUNCH(wgrad_bias_reduce_kernel, dim3(smx_cdiv(Cout, 256)), dim3(256), 0, st, p.bias_ws, nb * msplit, Cout, bias_out, accumulate, alpha);
   return smx_launch_status();
 }
 
@@ -383,6 +443,17 @@ extern "C" int smx_partial_reduce_f32(const float* part, int nchunk, int C, floa
 extern "C" int smx_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int kh, int kw, int mode, void* stream) {
   if (!w_oihw || !packed || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || (mode != 0 && mode != 1)) return SMX_EINVAL;
   SMX_LAUNCH(pack_weight_kernel, dim3(grid_for((long long)Cout * Cin * kh * kw)), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin, kh, kw, mode);
+  return smx_launch_status();
+}
+
+extern "C" int64_t smx_winograd_u_floats(int N, int C) { return (N > 0 && C > 0) ? 16LL * ((N + 31) / 32) * 32 * C + 1024 : 0; }
+
+extern "C" int smx_pack_winograd_u_f32(const float* w_oihw, float* u, int Cout, int Cin, int mode, void* stream) {
+  if (!w_oihw || !u || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return SMX_EINVAL;
+  const int N = mode ? Cin : Cout, Cc = mode ? Cout : Cin;
+  if (Cc % 8 != 0) return SMX_EINVAL;
+  const long long total = smx_winograd_u_floats(N, Cc);
+  SMX_LAUNCH(pack_winograd_u_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, mode, total);
   return smx_launch_status();
 }
 

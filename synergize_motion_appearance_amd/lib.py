@@ -123,11 +123,13 @@ SIGNATURES = {
     "smx_vq_nearest_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     # ---- training step ----
     "smx_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, C.POINTER(_i)]),
-    "smx_wgrad_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p]),
+    "smx_wgrad_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p, _p]),
     "smx_colsum_ws_floats": (_i64, [_i64, _i]),
     "smx_colsum_f32": (_i, [_p, _i, _i64, _i, _p, _p, _i, _f, _p]),
     "smx_partial_reduce_f32": (_i, [_p, _i, _i, _p, _i, _f, _p]),
     "smx_pack_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_winograd_u_floats": (_i64, [_i, _i]),
+    "smx_pack_winograd_u_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "smx_transpose_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _p]),
     "smx_act_f32": (_i, [_p, _i, _p, _i, _i64, _i, _i, _p]),
     "smx_act_bwd_f32": (_i, [_p, _i, _p, _i, _p, _i, _i64, _i, _i, _p]),

@@ -68,6 +68,22 @@ def _packed(tp, ref, mode, cout, cin, kh, kw):
     return tp.packed[ck]
 
 
+def _packed_u(tp, ref, mode, cout, cin):
+    """per-step cache of the Winograd-domain weights of a 3x3 parameter (mode 0 forward, 1 data gradient)."""
+    w, _, key = _param(tp, ref)
+    ck = (key, "u", mode)
+    if ck not in tp.packed:
+        wc = w if w.is_contiguous() else w.contiguous()
+        n, c = (cin, cout) if mode else (cout, cin)
+        out = torch.empty((int(tp.lib.smx_winograd_u_floats(n, c)),), device=w.device, dtype=F32)
+        L.check(tp.lib.smx_pack_winograd_u_f32(wc.data_ptr(), out.data_ptr(), cout, cin, mode, _stream()), "pack_winograd_u")
+        tp.packed[ck] = out
+    return tp.packed[ck]
+
+
+WINOGRAD_TRAIN = True       # 3x3 / stride-1 forward and data-gradient convolutions on the fused Winograd kernel (False: implicit GEMM)
+
+
 # ---- low-level launchers ----------------------------------------------------------------------------------------------------
 def _colsum(tp, x2d_ptr, ld, P, Cc, out, accumulate=True, alpha=1.0):
     ws = torch.empty((int(tp.lib.smx_colsum_ws_floats(P, Cc)),), device=out.device, dtype=F32)
@@ -75,14 +91,15 @@ def _colsum(tp, x2d_ptr, ld, P, Cc, out, accumulate=True, alpha=1.0):
 
 
 def _wgrad(tp, dy, x, out, *, nb=1, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, up2=0, layout=0, ldo=0, accumulate=True,
-           alpha=1.0, dy_ld=None, x_ld=None, dy_bs=0, x_bs=0, out_bs=0):
+           alpha=1.0, dy_ld=None, x_ld=None, dy_bs=0, x_bs=0, out_bs=0, bias_out=None):
     ms = C.c_int(1)
     n = int(tp.lib.smx_wgrad_ws_floats(nb, M, cout, kh * kw * cin, C.byref(ms)))
     ws = torch.empty((n,), device=out.device, dtype=F32)
     dyp, ldy = (dy.data_ptr(), dy_ld) if dy_ld is not None else _pix(dy)[:2]
     xp, ldx = (x.data_ptr(), x_ld) if x_ld is not None else _pix(x)[:2]
     L.check(tp.lib.smx_wgrad_f32(dyp, ldy, dy_bs, xp, ldx, x_bs, nb, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, int(up2),
-                                 ws.data_ptr(), ms.value, out.data_ptr(), out_bs, layout, ldo, int(accumulate), float(alpha), _stream()), "wgrad")
+                                 ws.data_ptr(), ms.value, out.data_ptr(), out_bs, layout, ldo, int(accumulate), float(alpha),
+                                 None if bias_out is None else bias_out.data_ptr(), _stream()), "wgrad")
 
 
 def act_bwd(tp, g, ref, act):
@@ -142,8 +159,12 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
     wp = wv.contiguous() if kind == "patch" else _packed(tp, w, 0, cout, cin, kh, kw)      # the patch Linear is already [Cout][(p1 p2 c)]
     cv = Conv(wp.view(cout, kh * kw * cin), None if bv is None else bv.contiguous(), kh, kw, cin, cout)
     pt, pl = (kh // 2, kw // 2) if pad is None else pad
-    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=True)
     He, We = (2 * H, 2 * W) if up2 else (H, W)
+    # the fused Winograd F(2x2,3x3) kernel takes this step's weights in its own packing (smx_pack_winograd_u_f32)
+    wino3 = WINOGRAD_TRAIN and kind == "conv" and (kh, kw, stride, pt, pl) == (3, 3, 1, 1, 1) and He % 8 == 0 and We % 16 == 0
+    if wino3 and cin % 32 == 0:
+        cv._u = _packed_u(tp, w, 0, cout, cin)
+    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=cv._u is None)
     Ho, Wo = (y.shape[1], y.shape[2]) if d2s is None else (H, W)
 
     def bwd():
@@ -163,15 +184,13 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
         else:
             g2 = g if g.is_contiguous() else _dense(lib, g)
         M = B * Ho * Wo
-        if bg is not None:
-            _colsum(tp, g2.data_ptr(), cout, M, cout, bg)
-        # weight gradient
+        # weight gradient (+ the bias gradient out of the same pass over g)
         if kind == "patch":
             _wgrad(tp, g2, x, wg, M=M, cout=cout, Hin=H, Win=W, cin=cin, Ho=Ho, Wo=Wo, kh=kh, kw=kw, stride=stride, pt=0, pl=0,
-                   layout=1, ldo=kh * kw * cin, dy_ld=cout)
+                   layout=1, ldo=kh * kw * cin, dy_ld=cout, bias_out=bg)
         else:
             _wgrad(tp, g2, x, wg, M=M, cout=cout, Hin=H, Win=W, cin=cin, Ho=Ho, Wo=Wo, kh=kh, kw=kw, stride=stride, pt=pt, pl=pl,
-                   up2=1 if up2 else 0, layout=0, dy_ld=cout)
+                   up2=1 if up2 else 0, layout=0, dy_ld=cout, bias_out=bg)
         # data gradient: a forward convolution of g with the transposed, tap-flipped weights
         if not tp.needs(x):
             return
@@ -183,7 +202,9 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
             dx = ops.conv(g2, Conv(wt.view(cin, cout), None, 1, 1, cout, cin), direct=True)
         elif stride == 1:
             dcv = Conv(wt.view(cin, kh * kw * cout), None, kh, kw, cout, cin)
-            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=True)
+            if wino3 and cout % 32 == 0:
+                dcv._u = _packed_u(tp, w, 1, cout, cin)
+            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=dcv._u is None)
             if up2:             # adjoint of nearest x2: sum of each 2x2 block
                 dx = scaled(tp, ops.avgpool2(dx), 4.0)
         else:                   # stride 2: zero-insert gather (smx_gemm_conv_f32 up2 = 2)
@@ -286,8 +307,8 @@ def attention(tp, q, k, v, nhead, dh, S, *, mask=None, ctx=None):
         g = g if g.is_contiguous() else _dense(lib, g)
         shared = ctx is not None
         dq = _empty((B, Lq, E), q)
-        dk = _empty((1 if shared else B, S, E), q)
-        dv = _empty((1 if shared else B, S, E), q)
+        dk = _empty((B, S, E), q)
+        dv = _empty((B, S, E), q)
         stats = _empty((B * nhead * Lq * 3,), q)
         qp, ldq = ops._pix(q, "attention q")
         kp, ldk = ops._pix(k, "attention k")
@@ -298,10 +319,13 @@ def attention(tp, q, k, v, nhead, dh, S, *, mask=None, ctx=None):
                                           None if mask is None else mask.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                           stats.data_ptr(), B, nhead, Lq, S, dh, dh ** -0.5, _stream()), "attention_bwd")
         tp.acc(q, dq.view(q.shape))
-        if shared:
+        if shared:                       # per-sample dK / dV -> their batch sums (fixed order) -> rows :S of d ctx = [dK | dV]
+            sk, sv = _zeros((S, E), q), _zeros((S, E), q)
+            L.check(lib.smx_batch_sum_f32(dk.data_ptr(), sk.data_ptr(), B, S * E, _stream()), "batch_sum")
+            L.check(lib.smx_batch_sum_f32(dv.data_ptr(), sv.data_ptr(), B, S * E, _stream()), "batch_sum")
             dctx = _zeros(ctx.shape, ctx)
-            _axpy(lib, dk.view(S, E), dctx[:S, :E], 1.0)
-            _axpy(lib, dv.view(S, E), dctx[:S, E:], 1.0)
+            _axpy(lib, sk, dctx[:S, :E], 1.0)
+            _axpy(lib, sv, dctx[:S, E:], 1.0)
             tp.acc(ctx, dctx)
         else:
             tp.acc(k, dk.view(k.shape))

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Time the generator + motion-estimator training step (BASELINE configs[4]: train.yml, B pairs per GPU, fp32) on one MI355X.
+usage: python tools/train_bench.py [--batch 4] [--steps 5] [--warmup 2]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
+    from synergize_motion_appearance_amd.trainer import TrainStep
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+    net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
+    me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
+    net_g, me = net_g.cuda(), me.cuda()
+    topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt")}
+    step = TrainStep(net_g, me, topt)
+    _, clip = synth_clip(2 * a.batch, seed=321)
+    src, drv = clip[:a.batch].contiguous().cuda(), clip[a.batch:].contiguous().cuda()
+    for _ in range(a.warmup):
+        step.step(src, drv)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses, _ = step.step(src, drv)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"what": "train.yml generator + motion-estimator step (no VGG / GAN), fp32, 1 GPU", "batch": a.batch, "ms_per_step": round(1e3 * dt, 2),
+                      "pairs_per_s": round(a.batch / dt, 2), "l_g_total": float(losses["l_g_total"]),
+                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+
+
+if __name__ == "__main__":
+    main()
