@@ -1,5 +1,5 @@
 """yaml -> OrderedDict loader used by demo.py (`basicsr.utils.options.ordered_yaml`,
-reference `basicsr/utils/options.py:7-29`)."""
+reference `basicsr/utils/options.py:7-29`) and the option parser of animate.py / train.py (`parse`, :32-88)."""
 from collections import OrderedDict
 
 import yaml
@@ -30,29 +30,37 @@ def _expand_user_paths(section, wanted):
 
 
 def parse(opt_path, root_path, is_train=True):
-    """Test yml -> option dict with the derived entries `animate.py` / the model expect (reference
-    `basicsr/utils/options.py:32-88`): `is_train`, a time-stamped `name`, per-dataset `phase` (+ `scale`), `~`
-    expanded in dataset / checkpoint paths, and `path.{results_root, log, visualization}` under
-    `<path.save_path or root_path>/results/<name>`.  A yml without `datasets:` / `path:` (the shipped test.yml)
-    gets empty sections instead of a KeyError.  Training ymls are SURVEY row N2 and are rejected."""
+    """yml -> option dict with the derived entries `animate.py` / `train.py` / the model expect (reference
+    `basicsr/utils/options.py:32-88`): `is_train`, a time-stamped `name` (or the experiment folder of `path.resume_state`),
+    per-dataset `phase` (+ `scale`), `~` expanded in dataset / checkpoint paths, and under `<path.save_path or root_path>`
+    either `results/<name>` with `path.{results_root, log, visualization}` (test) or `experiments/<name>` with
+    `path.{experiments_root, models, training_states, log, visualization}` (train).  A yml without `datasets:` / `path:`
+    (the shipped test.yml) gets empty sections instead of a KeyError."""
     import time
     from os.path import join
-    if is_train:
-        raise NotImplementedError("training options are SURVEY row N2; the MI355X-native build parses test ymls")
     with open(opt_path, "r") as f:
         opt = yaml.load(f, Loader=ordered_yaml()[0])
-    opt["is_train"] = False
-    opt["name"] = time.strftime("%Y%m%d_%H%M%S", time.localtime()) + "_" + opt["name"]
+    opt["is_train"] = bool(is_train)
+    paths = opt.setdefault("path", OrderedDict())
+    if paths.get("resume_state"):
+        opt["name"] = paths["resume_state"].split("/")[-3]
+    else:
+        opt["name"] = time.strftime("%Y%m%d_%H%M%S", time.localtime()) + "_" + opt["name"]
     datasets = opt.setdefault("datasets", OrderedDict())
     for key in datasets:
         datasets[key]["phase"] = key.split("_")[0]
         if "scale" in opt:
             datasets[key]["scale"] = opt["scale"]
         _expand_user_paths(datasets[key], lambda k: k == "dataroot_gt")
-    paths = opt.setdefault("path", OrderedDict())
     _expand_user_paths(paths, lambda k: any(tag in k for tag in _CHECKPOINT_KEYS))
-    root = join(paths.get("save_path", root_path), "results", opt["name"])
-    paths.update(results_root=root, log=root, visualization=join(root, "visualization"))
+    save = paths.get("save_path") or root_path
+    if is_train:
+        root = join(save, "experiments", opt["name"])
+        paths.update(experiments_root=root, models=join(root, "models"), training_states=join(root, "training_states"), log=root,
+                     visualization=join(root, "visualization"))
+    else:
+        root = join(save, "results", opt["name"])
+        paths.update(results_root=root, log=root, visualization=join(root, "visualization"))
     return opt
 
 

@@ -157,14 +157,16 @@ def test_parse_and_model_registry(tmp_path):
     assert opt["path"]["visualization"] == os.path.join(opt["path"]["results_root"], "visualization")
     assert opt["path"]["results_root"].startswith(os.path.join(opt["path"]["save_path"], "results"))
     assert "network_g:[" in dict2str(opt) and opt["model_type"] in MODEL_REGISTRY
-    with pytest.raises(NotImplementedError):
-        parse(os.path.join(REPO, "options/test.yml"), str(tmp_path), is_train=True)
+    # training ymls (row N2): experiments/<name>/{models, training_states, visualization}
+    topt = parse(os.path.join(REPO, "options/train.yml"), str(tmp_path), is_train=True)
+    assert topt["is_train"] is True and topt["path"]["models"] == os.path.join(topt["path"]["experiments_root"], "models")
+    assert topt["path"]["experiments_root"] == os.path.join("./train_log", "experiments", topt["name"])
+    assert topt["path"]["training_states"].endswith("training_states") and topt["train"]["optim_g"]["lr"] == 8e-5
+    assert topt["datasets"]["train"]["phase"] == "train" and topt["train"]["net_d_start_iter"] == 5001
     with pytest.raises(KeyError):
         build_model({"model_type": "NoSuchModel"})
     with pytest.raises(RuntimeError):                        # no CPU mode, and it says so
         build_model(dict(opt, num_gpu=0))
-    with pytest.raises(NotImplementedError):                 # training is row N2
-        build_model(dict(opt, is_train=True))
 
 
 # ---------------------------------------------------------------- GPU: parity with the reference's class
