@@ -39,11 +39,31 @@ def _gen(name: str) -> torch.Generator:
     return g
 
 
-def synth_tensor(name: str, shape, dtype=torch.float32) -> torch.Tensor:
-    """Value of state_dict entry `name` with `shape` -- a pure function of (name, shape)."""
+_BIG_MEAN_BIAS = (".conv1.bias", ".conv2.bias", ".conv_out.bias", ".conv.bias")
+_BIG_MEAN_SCOPE = ("encoder.blocks.", "generator.blocks.", "fuse_convs_dict.", "to_motion.1.", "motion_emb.2.")
+
+
+def synth_tensor(name: str, shape, dtype=torch.float32, style: str = "default") -> torch.Tensor:
+    """Value of state_dict entry `name` with `shape` -- a pure function of (name, shape, style).
+
+    style "checkpoint": the statistics a TRAINED checkpoint has and the default synthesis avoids on purpose -- convolutions in front
+    of a GroupNorm carry a large common bias (4 + 0.3 N: |group mean| >> std at the normalisation, where E[x^2] - mean^2 cancels in
+    fp32), BatchNorm running statistics far from (0, 1) (mean ~ N, var in [e^-1, e^1]), and the codebooks keep the reference's
+    own init U(-1/K, 1/K) (archs/vqgan_arch.py:31: top-2 distance gaps down to fp32 noise, i.e. near-ties)."""
     shape = tuple(shape)
     g = _gen(name)
     leaf = name.rsplit(".", 1)[-1]
+    if style == "checkpoint":
+        if leaf == "running_var":
+            return torch.exp(2.0 * torch.rand(shape, generator=g) - 1.0).to(dtype)
+        if leaf == "running_mean":
+            return (1.0 * torch.randn(shape, generator=g)).to(dtype)
+        if name.endswith("embedding.weight"):
+            return ((2.0 * torch.rand(shape, generator=g) - 1.0) / shape[0]).to(dtype)
+        if name.startswith(_BIG_MEAN_SCOPE) and name.endswith(_BIG_MEAN_BIAS):
+            return (4.0 + 0.3 * torch.randn(shape, generator=g)).to(dtype)
+    elif style != "default":
+        raise ValueError(f"unknown synthesis style {style!r}")
     if leaf == "num_batches_tracked":
         return torch.zeros(shape, dtype=torch.long)
     if name.endswith("down.weight"):
@@ -83,14 +103,14 @@ def synth_input(name: str, shape) -> torch.Tensor:
     return torch.randn(tuple(shape), generator=_gen("input:" + name))
 
 
-def synth_state_dict(manifest):
+def synth_state_dict(manifest, style: str = "default"):
     """manifest: iterable of (name, shape) or a state_dict -> OrderedDict name -> tensor."""
     from collections import OrderedDict
     items = manifest.items() if hasattr(manifest, "items") else manifest
     out = OrderedDict()
     for name, v in items:
         shape = tuple(v.shape) if hasattr(v, "shape") else tuple(v)
-        out[name] = synth_tensor(name, shape)
+        out[name] = synth_tensor(name, shape, style=style)
     return out
 
 

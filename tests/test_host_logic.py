@@ -4,6 +4,7 @@ sharding, and that libsmx.so loads and exports every symbol include/smx.h declar
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -265,3 +266,63 @@ def test_demo_entry_command_line_readers_and_refusals(tmp_path):
         demo.main(["--config", os.path.join(os.path.dirname(HERE), "options", "test.yml"), "--cpu"])
     with pytest.raises(SystemExit, match="face_alignment"):
         demo.main(["--config", os.path.join(os.path.dirname(HERE), "options", "test.yml"), "--find_best_frame"])
+
+
+# ---- basicsr/demo.py: the container (imageio) branch, pinned with a stub module (VERDICT r2 "missing" #4) ---------------------------
+class _StubReader:
+    """what demo.py needs of `imageio.get_reader(path)` (reference demo.py:166-174): iteration over frames, `get_meta_data()['fps']`,
+    `close()`; a truncated stream raises RuntimeError from the iterator, which the reference (and this entry) swallow."""
+
+    def __init__(self, frames, fps, truncated_after=None):
+        self.frames, self.fps, self.cut, self.closed = frames, fps, truncated_after, False
+
+    def get_meta_data(self):
+        return {"fps": self.fps}
+
+    def __iter__(self):
+        for i, f in enumerate(self.frames):
+            if self.cut is not None and i == self.cut:
+                raise RuntimeError("truncated stream")
+            yield f
+
+    def close(self):
+        self.closed = True
+
+
+def test_demo_container_branch_with_a_stub_imageio(tmp_path, monkeypatch):
+    import importlib.util
+    import types
+    rng = np.random.default_rng(0)
+    clip = rng.integers(0, 256, size=(5, 24, 32, 4), dtype=np.uint8)                    # RGBA frames: demo keeps [..., :3]
+    written = {}
+    stub = types.ModuleType("imageio")
+    readers = []
+
+    def get_reader(path):
+        r = _StubReader(list(clip), 30.0, truncated_after=4 if "cut" in path else None)
+        readers.append(r)
+        return r
+    stub.get_reader = get_reader
+    stub.imread = lambda path: clip[0]
+    stub.mimwrite = lambda path, frames, **kw: written.update(path=path, n=len(frames), kw=kw, first=np.asarray(frames[0]).copy())
+    monkeypatch.setitem(sys.modules, "imageio", stub)
+    spec = importlib.util.spec_from_file_location("smx_demo_stub", os.path.join(REPO, "basicsr", "demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    frames, fps = demo.read_clip(str(tmp_path / "driving.mp4"))
+    assert frames.shape == (5, 24, 32, 3) and frames.dtype == np.uint8 and fps == 30.0 and readers[-1].closed
+    assert np.array_equal(frames, clip[..., :3])
+    cut, _ = demo.read_clip(str(tmp_path / "cut.mp4"))                                  # the RuntimeError of a truncated stream ends the clip
+    assert cut.shape[0] == 4 and readers[-1].closed
+    assert np.array_equal(demo.read_rgb(str(tmp_path / "source.jpg")), clip[0][..., :3])  # non-PNG images go through imageio.imread
+    # result side: mimsave == imageio.mimwrite(path, frames, fps=...) when imageio is importable (demo.py:222)
+    from basicsr.utils import mimsave
+    out = mimsave([f for f in frames], str(tmp_path / "out" / "result.mp4"), fps=fps)
+    assert out is None and written["path"].endswith("result.mp4") and written["n"] == 5 and written["kw"] == {"fps": 30.0}
+    assert np.array_equal(written["first"], frames[0]) and os.path.isdir(tmp_path / "out")
+    # without imageio the same call falls back to a PNG folder and says where
+    monkeypatch.setitem(sys.modules, "imageio", None)
+    d = mimsave([f for f in frames[:2]], str(tmp_path / "out2" / "r.mp4"), fps=fps)
+    assert d.endswith("r.mp4.frames") and sorted(os.listdir(d)) == ["000000.png", "000001.png"]
+    with pytest.raises(RuntimeError, match="imageio"):
+        demo.read_clip(str(tmp_path / "driving.mp4"))
