@@ -112,3 +112,44 @@ class FramesMotionTransferTestDataset_CrossID_videopair_anchor(Dataset):
         else:                                                     # no anchor column: the first driving frame
             item["anchor"], item["anchor_idx"] = item["driving_video"][0].clone(), 0
         return item
+
+
+def _frame_name(path_source, path_driving):
+    """`<src folder -4>_<src file -4>_<drv folder -4>_<drv file -4>` (`frames_dataset.py:367`)."""
+    parts = (os.path.basename(os.path.dirname(path_source)), os.path.basename(path_source),
+             os.path.basename(os.path.dirname(path_driving)), os.path.basename(path_driving))
+    return "_".join(p[:-4] for p in parts)
+
+
+@DATASET_REGISTRY.register()
+class FramesMotionTransferTestDataset_PairsList(Dataset):
+    """frame-PAIR evaluation set of `test.py` (reference `data/frames_dataset.py:309-399`): pairs csv with columns source, driving
+    and optionally anchor (frame paths; no anchor column: the driving frame).  Every frame is resized on its OWN size test
+    (`:372-384`, unlike the video dataset) and normalised; -> {'source', 'driving', 'anchor' [3,S,S], 'frame_name'}."""
+
+    def __init__(self, opt):
+        super().__init__()
+        import pandas as pd
+        self.opt = opt
+        self.root_dir = opt.get("root_dir")
+        self.gt_size = opt.get("gt_size", 512)
+        self.mean = opt.get("mean", [0.5, 0.5, 0.5])
+        self.std = opt.get("std", [0.5, 0.5, 0.5])
+        if opt.get("pairs_list") is None:
+            raise NotImplementedError("Shoule provide pairs_list for dataset.")
+        table = pd.read_csv(opt["pairs_list"])
+        self.source, self.driving = table["source"].tolist(), table["driving"].tolist()
+        self.anchors = table["anchor"].tolist() if "anchor" in table else self.driving
+
+    def __len__(self):
+        return len(self.source)
+
+    def __getitem__(self, idx):
+        out = {}
+        for key, path in (("source", self.source[idx]), ("driving", self.driving[idx]), ("anchor", self.anchors[idx])):
+            prep = _FramePrep(self.gt_size, self.mean, self.std)
+            img = prep.decode(path)
+            prep.resize = img.shape[-2] != self.gt_size
+            out[key] = prep.finish(img)
+        out["frame_name"] = _frame_name(self.source[idx], self.driving[idx])
+        return out

@@ -246,6 +246,8 @@ class AppMotionCompModel:
         out = OrderedDict()
         out["gt"], out["source"] = self.gt.detach().cpu(), self.source.detach().cpu()
         out["result"] = self.out_dict["out"].detach().cpu()
+        if hasattr(self, "lq_recon"):                        # generator(lq_feat): the un-fused decode (appmotioncomp_model.py:590-592)
+            out["recon"] = self.lq_recon.detach().cpu()
         return out
 
     # -- appmotioncomp_model.py:607-639 -----------------------------------------------------------------
@@ -332,7 +334,56 @@ class AppMotionCompModel:
         return self.metric_results
 
     def validation(self, dataloader, current_iter, tb_logger, save_img=False, **kwargs):
-        raise NotImplementedError("frame-pair validation (test.py) is outside the animation path; use generate_video_image")
+        """base_model.py:39-52: distributed validation runs on rank 0 only (`dist_validation`, appmotioncomp_model.py:458-460)."""
+        if self.opt.get("dist") and self.opt.get("rank", 0) != 0:
+            return None
+        return self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
+    @torch.no_grad()
+    def nondist_validation(self, dataloader, current_iter, tb_logger, save_img):
+        """appmotioncomp_model.py:463-566 -- the frame-pair evaluation `test.py` drives: per item feed_data -> test() -> the four PNGs
+        (`visual/_v`, `result/_r`, `source/_s`, `driving/_d` under path.visualization/<dataset>) and the array metrics psnr / ssim / l1
+        (averaged over the items; metrics that need downloaded networks are NaN, as in generate_video_image)."""
+        dataset_name = dataloader.dataset.opt["name"]
+        metrics = self.opt.get("val", {}).get("metrics")
+        self.metric_results = {m: 0 for m in metrics.keys()} if metrics is not None else {}
+        self._ensure_motion_estimator()
+        vis_root = osp.join(self.opt["path"]["visualization"], dataset_name)
+        n = 0
+        for val_data in dataloader:
+            img_name = val_data["frame_name"][0]
+            self.feed_data(val_data)
+            self.test()
+            visuals = self.get_current_visuals()
+            result_img = tensor2img([visuals["result"]], rgb2bgr=True, min_max=(-1, 1))
+            gt_img = tensor2img([visuals["gt"]], rgb2bgr=True, min_max=(-1, 1))
+            source = tensor2img([visuals["source"]], rgb2bgr=True, min_max=(-1, 1))
+            visual = tensor2img([torch.cat((visuals["source"], visuals["gt"], visuals["result"]), 3)], rgb2bgr=True, min_max=(-1, 1))
+            if "recon" in visuals:
+                visual = np.concatenate((visual, tensor2img(visuals["recon"], rgb2bgr=True, min_max=(-1, 1))), axis=1)
+            if save_img:
+                if self.opt.get("is_train"):
+                    imwrite(visual, osp.join(self.opt["path"]["visualization"], img_name, f"{img_name}_{current_iter}.png"))
+                else:
+                    imwrite(visual, osp.join(vis_root, "visual", f"{img_name}_v.png"))
+                    imwrite(result_img, osp.join(vis_root, "result", f"{img_name}_r.png"))
+                    imwrite(source, osp.join(vis_root, "source", f"{img_name}_s.png"))
+                    imwrite(gt_img, osp.join(vis_root, "driving", f"{img_name}_d.png"))
+            if metrics is not None:
+                for name, opt_ in metrics.items():
+                    if name in ("psnr", "ssim", "l1"):
+                        o = dict(opt_)
+                        self.metric_results[name] += _ARRAY_METRICS[o.pop("type")](result_img, gt_img, **o)
+            n += 1
+        if metrics is not None:
+            for metric in list(metrics.keys()):
+                if metric in ("psnr", "ssim", "l1"):
+                    self.metric_results[metric] /= max(n, 1)
+                    if metric == "l1":
+                        self.metric_results["l1_255"] = self.metric_results["l1"] / 255.0
+                else:
+                    self.metric_results[metric] = float("nan")
+        return self.metric_results
 
     def save(self, epoch, current_iter):
         """appmotioncomp_model.py:598-605 (net_d and the optimizer state file are the discriminator / harness side: not written)."""

@@ -169,6 +169,40 @@ def test_parse_and_model_registry(tmp_path):
         build_model(dict(opt, num_gpu=0))
 
 
+def _write_pairs(root, n=3, seed=11):
+    """frame-pair csv for FramesMotionTransferTestDataset_PairsList on top of the clip files of `_write_clip`."""
+    _, src, drv = _write_clip(root, n=n, seed=seed)
+    sdir, ddir = os.path.join(root, "id01.mp4"), os.path.join(root, "id02.mp4")
+    csv = os.path.join(root, "frame_pairs.csv")
+    with open(csv, "w") as f:
+        f.write("source,driving\n")
+        for i in range(1, n):
+            f.write(f"{os.path.join(sdir, '0000.png')},{os.path.join(ddir, f'{i:04d}.png')}\n")
+    return csv, src, drv
+
+
+def test_pairs_list_dataset(tmp_path):
+    """`test.py`'s frame-pair dataset (reference data/frames_dataset.py:309-399): dict keys, the 4-component frame_name, anchor falling
+    back to the driving frame, per-frame resize to gt_size."""
+    from basicsr.data import build_dataset, build_dataloader
+    csv, src, drv = _write_pairs(str(tmp_path), n=3)
+    opt = {"name": "pairs", "type": "FramesMotionTransferTestDataset_PairsList", "phase": "test", "root_dir": str(tmp_path),
+           "pairs_list": csv, "gt_size": 256, "io_backend": {"type": "disk"}}
+    ds = build_dataset(opt)
+    assert len(ds) == 2
+    it = ds[1]
+    assert set(it) == {"source", "driving", "anchor", "frame_name"} and it["frame_name"] == "id01_0000_id02_0002"
+    assert it["source"].shape == (3, 256, 256) and torch.equal(it["anchor"], it["driving"])
+    q = lambda t: ((t.clamp(-1, 1) + 1) * 127.5).round() / 127.5 - 1                    # noqa: E731  (the PNGs hold uint8-quantised frames)
+    assert float((it["driving"] - q(drv[2])).abs().max()) < 1e-6 and float((it["source"] - q(src)).abs().max()) < 1e-6
+    small = build_dataset(dict(opt, gt_size=128))[0]
+    assert small["source"].shape == (3, 128, 128) and small["driving"].shape == (3, 128, 128)
+    batch = next(iter(build_dataloader(ds, opt)))
+    assert batch["source"].shape == (1, 3, 256, 256) and batch["frame_name"] == ["id01_0000_id02_0001"]
+    with pytest.raises(NotImplementedError):
+        build_dataset({k: v for k, v in opt.items() if k != "pairs_list"})
+
+
 # ---------------------------------------------------------------- GPU: parity with the reference's class
 class FakeLoader:
     def __init__(self, items):
@@ -235,7 +269,7 @@ def test_model_test_entry_and_metrics(tmp_path):
     model.feed_data({"driving": drv[:2], "source": src[None].repeat(2, 1, 1, 1)})
     model.test()
     assert model.out_dict["out"].shape == (2, 3, 256, 256) and model.lq_recon.shape == (2, 3, 256, 256)
-    assert set(model.driving_feat) == set(model.source_feat) and set(model.get_current_visuals()) == {"gt", "source", "result"}
+    assert set(model.driving_feat) == set(model.source_feat) and set(model.get_current_visuals()) == {"gt", "source", "result", "recon"}     # recon = generator(lq_feat) (appmotioncomp_model.py:590-592)
     item = {"source": src[None], "driving_video": [f[None] for f in drv], "anchor_idx": torch.tensor([0]),
             "video_name": ["c"], "driving_name_list": [[f"{i}"] for i in range(3)]}
     res = model.generate_video_image(FakeLoader([item]), "m", None)
@@ -247,9 +281,8 @@ def test_model_test_entry_and_metrics(tmp_path):
     assert abs(res["l1_255"] - res["l1"] / 255.0) < 1e-12 and np.isnan(res["fid"])
     with pytest.raises(TypeError):
         model.generate_video_image(FakeLoader([dict(item, anchor_idx=None)]), "m", None)
-    for fn in (lambda: model.optimize_parameters(0), lambda: model.save(0, 0)):
-        with pytest.raises(NotImplementedError):
-            fn()
+    with pytest.raises(RuntimeError, match="is_train"):               # a test-mode model has no optimiser state (training: test_gpu_train_full)
+        model.optimize_parameters(0)
 
 
 @pytest.mark.gpu
@@ -288,3 +321,45 @@ def test_animate_pipeline_from_yml_dataset_and_checkpoints(tmp_path):
                                   adapt_movement_scale=True, batch=4, anchor_idx=1).cpu().numpy()
     got = np.stack([U.imfrombytes(open(os.path.join(vis, "result", n), "rb").read())[:, :, ::-1] for n in names])
     assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_test_py_frame_pair_validation(tmp_path):
+    """`basicsr/test.py` end to end (reference test.py:52-80 -> AppMotionCompModel.nondist_validation :463-566): frame-pair csv ->
+    FramesMotionTransferTestDataset_PairsList -> model.validation -> result / source / driving / visual PNGs + psnr / l1; the result
+    PNG equals the direct module call on the decoded pair (<= 1 LSB) and the visual strip is [source | driving | result | recon]."""
+    import importlib.util
+    from basicsr.archs import build_network
+    from basicsr.data import build_dataset
+    csv, _, _ = _write_pairs(str(tmp_path / "data"), n=3, seed=23)
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/test.yml")))
+    ck_g, ck_m = str(tmp_path / "g.pth"), str(tmp_path / "m.pth")
+    torch.save({"params": dict(weights("network_g"))}, ck_g)
+    torch.save({"params": dict(weights("network_motion_estimator"))}, ck_m)
+    cfg["path"] = {"pretrain_network_g": ck_g, "param_key_g": "params", "strict_load_g": True, "pretrain_network_motion_estimator": ck_m,
+                   "strict_load_motion_estimator": True, "save_path": str(tmp_path / "log")}
+    cfg["val"] = {"save_img": True, "metrics": {"psnr": {"type": "calculate_psnr", "crop_border": 0}, "l1": {"type": "calculate_l1"},
+                                                "lpips": {"type": "calculate_lpips"}}}
+    cfg["datasets"] = {"test_1": {"name": "pairs", "type": "FramesMotionTransferTestDataset_PairsList", "root_dir": str(tmp_path / "data"),
+                                  "pairs_list": csv, "gt_size": 256, "io_backend": {"type": "disk"}}}
+    yml = str(tmp_path / "test.yml")
+    yaml.safe_dump(cfg, open(yml, "w"))
+    spec = importlib.util.spec_from_file_location("smx_test_entry", os.path.join(REPO, "basicsr", "test.py"))
+    T = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(T)
+    opt, results = T.test_pipeline(str(tmp_path), argv=["-opt", yml])
+    vis = os.path.join(opt["path"]["visualization"], "pairs")
+    for sub, sfx in (("result", "r"), ("source", "s"), ("driving", "d"), ("visual", "v")):
+        assert sorted(os.listdir(os.path.join(vis, sub))) == [f"id01_0000_id02_{i:04d}_{sfx}.png" for i in (1, 2)], sub
+    m = results["pairs"]
+    assert np.isfinite(m["psnr"]) and np.isfinite(m["l1"]) and abs(m["l1_255"] - m["l1"] / 255.0) < 1e-12 and np.isnan(m["lpips"])
+    it = build_dataset(dict(cfg["datasets"]["test_1"], phase="test"))[0]
+    net_g, me = build_network(cfg["network_g"]).cuda().eval(), build_network(cfg["network_motion_estimator"]).cuda().eval()
+    net_g.load_state_dict(weights("network_g"))
+    me.load_state_dict(weights("network_motion_estimator"))
+    dm = me(it["driving"][None].cuda(), it["source"][None].cuda())
+    want = U.tensor2img([net_g(it["source"][None].cuda(), dm, w=1, inference=True)["out"].cpu()], rgb2bgr=True, min_max=(-1, 1))
+    got = U.imfrombytes(open(os.path.join(vis, "result", "id01_0000_id02_0001_r.png"), "rb").read())
+    assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1
+    strip = U.imfrombytes(open(os.path.join(vis, "visual", "id01_0000_id02_0001_v.png"), "rb").read())
+    assert strip.shape == (256, 4 * 256, 3) and np.array_equal(strip[:, 512:768], got)
