@@ -296,6 +296,14 @@ int smx_frames_u8_to_nchw_f32(const uint8_t* x, float* y, int B, int Hin, int Wi
 /* tensor2img (utils/img_util.py:70,93): clamp[lo,hi] -> (x-lo)/(hi-lo)*255 -> round-half-even -> uint8, HWC */
 int smx_to_uint8_f32(const float* x, uint8_t* y, int64_t n, float lo, float hi, void* stream);
 
+/* F(4x4,3x3) form of smx_winograd_conv3x3_f32 for the big launches (csrc/winograd43.hip): 36 multiplies per 4x4 output tile and channel
+ * (2.25 per output; F(2x2,3x3): 4, direct: 9).  H % 16 == 0, W % 32 == 0, Cin % 16 == 0, Cout % 32 == 0, rows 16-B aligned.
+ * u43 = G g G^T (6x6 frequencies) packed [36 f][Cout/32][Cin/8][64 lanes][4] (lane l <-> output channel 32 nt + (l & 31), input channels
+ * 8 s + 4 (l >> 5) + 0..3), + 1024 floats of prefetch pad.  in_ss / in_swish: the producing GroupNorm(+swish) folded into the staging pass.
+ * stats_part (optional): [B][(H/16)*(W/32)][Cout][2] = {mean, M2} of each stored 16x32-pixel block (smx_groupnorm_finalize_f32, nch = that). */
+int smx_winograd43_conv3x3_f32(const float* x, int lda, const float* u43, const float* bias, const float* res, int ldres, float* y, int ldc,
+                               int B, int H, int W, int Cin, int Cout, int act, const float* in_ss, int in_swish, float* stats_part, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * A12: VectorQuantizer.forward (archs/vqgan_arch.py:33-93), fused: d = |z|^2 + |e|^2 - 2 z.e
  * over the first Ks rows, first-minimum argmin, gather, z_q = z + (e - z).

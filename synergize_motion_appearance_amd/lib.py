@@ -69,6 +69,7 @@ SIGNATURES = {
     "smx_gemm_conv_f32": (_i, [C.POINTER(GemmDesc), _p]),
     "smx_gemm_conv_bf16": (_i, [C.POINTER(Gemm16Desc), _p]),
     "smx_winograd_conv3x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "smx_winograd43_conv3x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "smx_winograd_conv3x3_sft_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "smx_groupnorm_stats_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
     "smx_conv3x3_smalln_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),

@@ -113,12 +113,13 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
         self._u = None
         self._w16 = None
+        self._u43 = None
 
     @property
     def w16(self):
@@ -140,6 +141,21 @@ class Conv:
             Up = Up.view(16, n32, 32, self.cin // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
             self._u = torch.cat([Up.view(-1), torch.zeros(1024, device=g.device, dtype=torch.float32)])   # prefetch pad (up to 3 units of 256 floats past the end)
         return self._u
+
+    def winograd43_u(self):
+        """U = G g G^T for F(4x4,3x3) (G 6x3: Lavin & Gray), fragment-ordered [36][Cout/32][Cin/8][64 lanes][4] like `winograd_u`;
+        built once per layer (fp64 products, rounded once)."""
+        if self._u43 is None:
+            g = self.w.view(self.cout, 3, 3, self.cin).double()
+            G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                              [0, 0, 1]], dtype=torch.float64, device=g.device)
+            U = torch.einsum("ia,nabc,jb->ijnc", G, g, G).float()                     # [6,6,Cout,Cin]
+            n32 = (self.cout + 31) // 32
+            Up = torch.zeros((36, n32 * 32, self.cin), device=g.device, dtype=torch.float32)
+            Up[:, :self.cout] = U.reshape(36, self.cout, self.cin)
+            Up = Up.view(36, n32, 32, self.cin // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
+            self._u43 = torch.cat([Up.view(-1), torch.zeros(1024, device=g.device, dtype=torch.float32)])
+        return self._u43
 
     @staticmethod
     def from_torch(weight, bias):
@@ -246,6 +262,19 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
     return out
 
 
+# F(4x4,3x3) (csrc/winograd43.hip): parity-tested, selectable, OFF by default -- measured 0.81-0.93x the speed of the F(2x2,3x3) wide
+# kernel on the B=60 shapes (executed-MFMA fraction 0.23-0.29 vs 0.45-0.61; profiles/r03_wino43_*.txt, DESIGN section 4 "Round 3")
+WINO43 = int(_os.environ.get("SMX_WINO43", "0"))
+WINO43_MIN_BLOCKS = 512                                 # tests force the kernel on small inputs by lowering this
+
+
+def _wino43_ok(B, H, W, cin, cout, up2, lda, ldc, ldres):
+    """launches that go to the F(4x4,3x3) kernel: whole 16x32-pixel blocks, 32-channel N blocks, and enough of them to fill the chip
+    (one 768-thread block per CU): the B=60 launches of the big layers."""
+    return (WINO43 and not up2 and H % 16 == 0 and W % 32 == 0 and cin % 16 == 0 and cout % 32 == 0 and lda % 4 == 0 and ldc % 4 == 0
+            and ldres % 4 == 0 and B * (H // 16) * (W // 32) * (cout // 32) >= WINO43_MIN_BLOCKS)
+
+
 def _wino_wide(B, H, W, cout):
     """mirror of winograd_launch's block-shape rule (csrc/winograd.hip): 64-channel 'wide' blocks once >= 1024 of them exist --
     in this pipeline exactly the B=60 launches of the big layers; used to label profile rows only."""
@@ -302,6 +331,18 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * Ho * Wo * cv.cout * 4 * Cin,
                 "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1,
                 "wide": _wino_wide(B, He, We, cv.cout)} if _PROFILE is not None else None
+        if (_wino43_ok(B, He, We, Cin, cv.cout, up2, lda, ldc, ldr) and c_ptr % 16 == 0 and (r_ptr or 0) % 16 == 0
+                and (cv.b is None or cv.b.data_ptr() % 16 == 0) and (in_ss is None or in_ss.data_ptr() % 16 == 0)):
+            if meta is not None:
+                meta.update(mfma_flops=2.0 * B * Ho * Wo * cv.cout * 2.25 * Cin, wide=0, w43=1)
+            part = torch.empty((B, (He // 16) * (We // 32), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
+            L.check(_timed("gemm_conv", meta, L.load().smx_winograd43_conv3x3_f32, a_ptr, lda, cv.winograd43_u().data_ptr(),
+                           None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout, act,
+                           None if in_ss is None else in_ss.data_ptr(), int(in_swish), None if part is None else part.data_ptr(), _stream()),
+                    "smx_winograd43_conv3x3_f32")
+            if part is not None:
+                out._gn_part = part
+            return out
         part = torch.empty((B, (He // 8) * (We // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
         L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                        None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,

@@ -781,3 +781,65 @@ def test_fingerprint_sees_single_bit_changes(ops):
     y2 = x.clone()
     y2.view(-1)[[5, 6]] = y2.view(-1)[[6, 5]]            # a permutation of two unequal elements changes it too
     assert ops.fingerprint(y2) != k0
+
+
+W43_CASES = [(2, 64, 64, 32, 64, 0, True), (1, 128, 128, 64, 64, 3, False), (2, 256, 128, 16, 32, 1, True), (1, 32, 96, 32, 32, 0, False),
+             (3, 32, 32, 16, 32, 2, True), (1, 64, 64, 256, 256, 0, True)]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,act,with_res", W43_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_act{c[5]}_res{int(c[6])}" for c in W43_CASES])
+def test_winograd43_conv3x3(ops, B, Cin, Cout, H, W, act, with_res, monkeypatch):
+    """round 3: fused Winograd F(4x4,3x3) (csrc/winograd43.hip) == F.conv2d (3x3, s1, p1) at 1e-4 (transform coefficients up to 8: the
+    error budget the DESIGN quotes), through channel-slice operands, with bias / activation / residual, border blocks, one block per
+    image and many; forced on small inputs (the launcher only picks it for >= 512 blocks)."""
+    monkeypatch.setattr(ops, "WINO43_MIN_BLOCKS", 1)
+    monkeypatch.setattr(ops, "WINO43", 1)
+    tag = f"{B}{Cin}{Cout}{H}{W}"
+    x = rnd(f"w43x{tag}", (B, Cin, H, W))
+    w = rnd(f"w43w{tag}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd(f"w43b{tag}", (Cout,), 0.1)
+    ref = F.conv2d(x, w, b, padding=1)
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: O.swish}[act](ref)
+    r = rnd(f"w43r{tag}", tuple(ref.shape)) if with_res else None
+    if with_res:
+        ref = ref + r
+    xin = torch.zeros((B, H, W, Cin + 32), device="cuda")
+    xin[..., 32:] = nhwc(x)
+    out = torch.full((B, H, W, Cout + 8), 5.0, device="cuda")
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    with ops.profile() as rec:
+        ops.conv(xin[..., 32:], cv, out=out[..., 4:4 + Cout], act=act, res=None if r is None else nhwc(r))
+    assert rec.rows[0][1].get("w43") == 1                              # the F(4x4,3x3) kernel ran, not a fallback
+    assert maxabs(nchw(out[..., 4:4 + Cout]), ref) < 1e-4
+    assert float(out[..., :4].min()) == 5.0 and float(out[..., 4 + Cout:].max()) == 5.0
+    monkeypatch.setattr(ops, "WINO43", 0)
+    old = ops.conv(xin[..., 32:], cv, act=act, res=None if r is None else nhwc(r))
+    assert maxabs(nchw(old), ref) < 5e-5
+
+
+def test_winograd43_fused_groupnorm_loader_and_stats(ops, monkeypatch):
+    """the F(4x4,3x3) kernel with the producing GroupNorm(+swish) folded into its staging pass and the Welford partials of its own
+    output for the next GroupNorm (the ResBlock form of the big launches) == group_norm -> swish -> conv2d -> group_norm statistics."""
+    monkeypatch.setattr(ops, "WINO43_MIN_BLOCKS", 1)
+    monkeypatch.setattr(ops, "WINO43", 1)
+    for (B, C, Co, H, W, sw) in ((2, 64, 64, 32, 64, True), (1, 128, 64, 64, 64, True), (2, 256, 128, 16, 32, False)):
+        x = rnd(f"g43x{C}{H}", (B, C, H, W)) * 1.5 + 0.2
+        g, bt = 1 + 0.1 * rnd(f"g43g{C}", (C,)), 0.1 * rnd(f"g43b{C}", (C,))
+        w = rnd(f"g43w{C}{Co}", (Co, C, 3, 3), 1.0 / math.sqrt(9 * C))
+        b = rnd(f"g43bb{Co}", (Co,), 0.1) + 2.0                        # a large common mean: the partials must not cancel
+        hn = F.group_norm(x, 32, g, bt, 1e-6)
+        ref = F.conv2d(O.swish(hn) if sw else hn, w, b, padding=1)
+        xin = nhwc(x)
+        ss = ops.groupnorm_stats(xin, g.cuda(), bt.cuda())
+        with ops.profile() as rec:
+            y = ops.conv(xin, ops.Conv.from_torch(w.cuda(), b.cuda()), in_ss=ss, in_swish=sw, want_stats=True)
+        assert [r for r in rec.rows if r[0] == "gemm_conv"][0][1].get("w43") == 1
+        err = maxabs(nchw(y), ref)
+        assert err < 1e-4, (C, Co, H, W, err)
+        assert y._gn_part is not None and tuple(y._gn_part.shape) == (B, (H // 16) * (W // 32), Co, 2)
+        g2, b2 = 1 + 0.1 * rnd(f"g43g2{Co}", (Co,)), 0.1 * rnd(f"g43b2{Co}", (Co,))
+        ss_fused = ops.groupnorm_stats(y, g2.cuda(), b2.cuda())          # finalize over the epilogue's partials
+        y_plain = y.clone()                                               # no partials attached: the statistics pass reads the tensor
+        ss_plain = ops.groupnorm_stats(y_plain, g2.cuda(), b2.cuda())
+        d = maxabs(ss_fused.cpu(), ss_plain.cpu())
+        assert d < 2e-5 * float(ss_plain.abs().max()), (C, Co, H, W, d)
