@@ -47,10 +47,10 @@ CLIP = 300                       # frames of the driving clip (BASELINE.json con
 PROFILE_TAG = "r03"              # profiles/<tag>_{traffic,mfma}_pmc[_bf16].json: the committed counter summaries this run quotes
 
 
-def build_nets(device):
+def build_nets(device, img_size=256):
     from basicsr.archs import build_network
     from synergize_motion_appearance_amd.synth import synth_state_dict
-    cfg = yaml.safe_load(open(os.path.join(REPO, "options/test.yml")))
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/test.yml" if img_size == 256 else f"options/test_{img_size}.yml")))
     net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
     Pg = synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()])
     Pm = synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()])
@@ -232,7 +232,7 @@ def render_leg(args, dtype, world, rank, dev, dist, collective, net_g, me, drv, 
         dist.all_gather(allt, mine)
         rank_times = [float(x.item()) for x in allt]
     n_mine = sum(fr.shape[0] for _, fr in work[W + K - 1])
-    assert out.shape == (n_mine, 256, 256, 3) and out.dtype == torch.uint8
+    assert out.shape == (n_mine, args.img_size, args.img_size, 3) and out.dtype == torch.uint8
     frames_total = (K * B) if strong else (world * K * B)
     fps = frames_total / dt
 
@@ -356,7 +356,7 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
         kern["warp"]["note"] = ("algorithmic = SURVEY 8(d) bytes (every frame charged a source read + output write + flow + occlusion); pmc = "
                                 "what reaches HBM (the broadcast source stays in L2/MALL, the output stream is compulsory)")
     # warp by scale (A7) and the VQ kernel (A12)
-    for s in (32, 64, 128, 256):
+    for s in (32, 64, 128, 256, 512):
         rows = [(m, ms) for n, m, ms in rec.rows if n == "warp" and m["s"] == s]
         if rows:
             by, ms = sum(m["bytes"] for m, _ in rows), sum(x for _, x in rows)
@@ -407,8 +407,14 @@ def main():
     ap.add_argument("--no-consistency", action="store_true", help="skip the B=1 re-render check (profiling runs: keeps B=1 launches out of the counters)")
     ap.add_argument("--profile-only", action="store_true", help="the command the rocprofv3 passes wrap: timed steps only (no B=1 re-renders, "
                                                                  "no roofline / PCIe / CPU / bf16 legs)")
+    ap.add_argument("--img-size", type=int, default=256, choices=[256, 512], help="512: BASELINE configs[3] (options/test_512.yml, DESIGN N4: every grid x2; "
+                                                                                    "default --batch 15; no bf16 / CPU legs); never the headline")
     ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")
     args = ap.parse_args()
+    if args.img_size != 256:
+        args.no_cpu_baseline = args.no_bf16_leg = True
+        if "--batch" not in sys.argv:
+            args.batch = 15
     if args.profile_only:
         args.no_cpu_baseline = args.no_roofline = args.no_d2h = args.no_bf16_leg = args.no_consistency = True
 
@@ -428,24 +434,25 @@ def main():
     from synergize_motion_appearance_amd import ops, driver
     from synergize_motion_appearance_amd.synth import synth_clip
 
-    net_g, me, Pg, Pm = build_nets(dev)
+    net_g, me, Pg, Pm = build_nets(dev, args.img_size)
     B, K, W = args.batch, args.steps, args.warmup
     # N sources (seeds 123, 124, ...), one driving clip shared by all of them (device resident before timing); --strong: ONE source
-    src_cpu, drv_cpu = synth_clip(CLIP, seed=123)
+    src_cpu, drv_cpu = synth_clip(CLIP, seed=123, size=args.img_size)
     drv = drv_cpu.to(dev)
     n_src = 1 if args.strong else world
-    my_sources = {j: (src_cpu if j == 0 else synth_clip(1, seed=123 + j)[0]).unsqueeze(0).to(dev) for j in range(n_src) if j % world == rank}
+    my_sources = {j: (src_cpu if j == 0 else synth_clip(1, seed=123 + j, size=args.img_size)[0]).unsqueeze(0).to(dev) for j in range(n_src) if j % world == rank}
 
     leg = render_leg(args, args.dtype, world, rank, dev, dist, collective, net_g, me, drv, my_sources, n_src)
     dt, fps = leg["dt"], leg["fps"]
     dname = args.dtype
-    cfg_ix = 1 if (world == 1 and args.dtype == "f32") else 2
+    cfg_ix = 3 if args.img_size == 512 else 1 if (world == 1 and args.dtype == "f32") else 2
+    px = args.img_size
     rt = leg["rank_times"]
     result = {
-        "metric": "reenactment frames/sec at 256x256", "value": round(fps, 3), "unit": "frames/s",
+        "metric": f"reenactment frames/sec at {px}x{px}", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 3),
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
-        "config": {"workload": (f"BASELINE.json configs[{cfg_ix}]: 256x256, {n_src} source(s) x 300-frame driving clip, {dname}, options/test.yml, "
+        "config": {"workload": (f"BASELINE.json configs[{cfg_ix}]: {px}x{px}, {n_src} source(s) x 300-frame driving clip, {dname}, options/test{'' if px == 256 else '_512'}.yml, "
                                 "name-keyed random-init weights"), "frames_per_step": B, "frames_total": leg["frames_total"],
                    "sources": n_src,
                    "parallelism": ((f"strong scaling: ONE source x {CLIP} frames; each step's {B} frames sharded x{world} (driver.shard_frames, "
@@ -453,7 +460,7 @@ def main():
                                     f"{n_src} sources x {CLIP} frames = {leg['total_units']} (source, frame) units; each step's window of {world * B} "
                                     f"units sharded x{world} (driver.shard_frames)") +
                                    f"; one {collective} broadcast per source of its packed frame-invariant state "
-                                   f"({4 * driver.cache_numel(net_g.engine().adt) / 1e6:.1f} MB) from the owner rank, inside the timed region: every rank "
+                                   f"({4 * driver.cache_numel(net_g.engine().adt, px) / 1e6:.1f} MB) from the owner rank, inside the timed region: every rank "
                                    "encodes the sources it owns first, then all broadcasts are issued async and waited together")
                    if world > 1 else "1 GPU",
                    "relative": True, "adapt_movement_scale": True, "output": "uint8 HWC frames in HBM"},
@@ -473,8 +480,8 @@ def main():
         u8 = ops.to_uint8(drv.permute(0, 2, 3, 1).contiguous(), -1.0, 1.0).cpu()            # the clip as a decoder would deliver it
         reps = (K * B + CLIP - 1) // CLIP
         host_in = (u8 if reps == 1 else u8.repeat(reps, 1, 1, 1))[:K * B].contiguous().pin_memory()
-        host_out = torch.empty((K * B, 256, 256, 3), dtype=torch.uint8).pin_memory()
-        pipe = driver.FramePipeline(net_g, me, batch=B)
+        host_out = torch.empty((K * B, px, px, 3), dtype=torch.uint8).pin_memory()
+        pipe = driver.FramePipeline(net_g, me, batch=B, frame_hw=(px, px))
         pipe.run(leg["states"][j0], host_in[:B], host_out[:B])                             # warm the staging path
         torch.cuda.synchronize()
         t1 = time.perf_counter()

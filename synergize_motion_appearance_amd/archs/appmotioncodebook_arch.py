@@ -33,13 +33,14 @@ class AppMotionCompFormer(HipArch):
                  multiscale_sft=True, app_codebook_split=True, wo_motion_cdbk_share=False, wo_app_cdbk_share=False,
                  connect_list=['64', '128', '256'], connect_app_list=['32', '64', '128', '256'],
                  fix_modules=[], ae_path=None):
-        supported = (img_size == 256 and quantizer_type == "nearest" and split == 1 and with_position_emb
+        supported = (img_size in (256, 512) and quantizer_type == "nearest" and split == 1 and with_position_emb
                      and warp_s_d_kp_query and MRFA_motion_enc and motion_codebook_split and multiscale_feature_fusion
                      and multiscale_sft and app_codebook_split and not wo_motion_cdbk_share and not wo_app_cdbk_share
                      and list(connect_list) == ['64', '128', '256'] and list(connect_app_list) == ['32', '64', '128', '256']
-                     and embed_dim_motion == dim_embd_motion and embed_dim_app == dim_embd_app and list(attn_resolutions) == [32])
+                     and embed_dim_motion == dim_embd_motion and embed_dim_app == dim_embd_app and list(attn_resolutions) == [img_size // 8])
         if not supported:
-            raise NotImplementedError("only the options/test.yml flag set has a HIP plan (SURVEY.md section 8b)")
+            raise NotImplementedError("only the options/test.yml flag set has a HIP plan (SURVEY.md section 8b); img_size 512 (DESIGN N4) "
+                                      "is that flag set with attn_resolutions [64]")
         self.cfg = dict(beta=beta, img_size=img_size, nf=nf, ch_mult=list(ch_mult), res_blocks=res_blocks,
                         attn_resolutions=list(attn_resolutions), n_head=n_head, dim_embd_motion=dim_embd_motion,
                         n_layers_motion=n_layers_motion, dim_embd_app=dim_embd_app, n_layers_app=n_layers_app,
@@ -104,9 +105,10 @@ class AppMotionCompFormer(HipArch):
         occ = dense_motion["occlusion_map"]
         if isinstance(occ, list):
             raise NotImplementedError("multi_mask occlusion lists are not part of options/test.yml")
-        st = eng.forward(cache, flow.float(), occ.float().reshape(B, 64, 64), heat, float(w), train=train)
+        Fg = flow.shape[1]                                             # flow grid: 64 (128 at img_size 512)
+        st = eng.forward(cache, flow.float(), occ.float().reshape(B, Fg, Fg), heat, float(w), train=train)
         out = {"_out_nhwc": st["out"], "out": ops.nhwc_to_nchw(st["out"]), "lq_feat": ops.nhwc_to_nchw(st["lq"]),
-               "out_occ": [o.view(B, 1, 64, 64) for o in st["occ"][1:]],
+               "out_occ": [o.view(B, 1, Fg, Fg) for o in st["occ"][1:]],
                "deformation_list": st["flows"], "res_deform_list": st["res"]}
         if self.full_outputs:
             out["app_before_comp_list"] = [ops.nhwc_to_nchw(t) for t in st["before"]]
@@ -117,7 +119,7 @@ class AppMotionCompFormer(HipArch):
             # VectorQuantizer calls run on the fused HIP kernel.  No autograd graph is built (backward kernels: N2 slice 2).
             tr = st["train"]
             out["out_lr"] = [ops.nhwc_to_nchw(st["out_lr"])]
-            out["motion_recon_list"] = [m / 31.5 for m in tr["motion_recon"]]          # pixels@64x64 -> normalised ((64-1)/2)
+            out["motion_recon_list"] = [m / ((Fg - 1) / 2.0) for m in tr["motion_recon"]]   # pixels@64x64 -> normalised ((64-1)/2)
             out["codebook_loss_motion_list"] = tr["loss_motion"]
             out["_vq_stats_motion"] = tr["stats_motion"]
             if gt is not None:

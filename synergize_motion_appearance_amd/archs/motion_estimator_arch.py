@@ -12,12 +12,13 @@ from ._base import HipArch
 
 def _dense_outputs(r, src64, B, kp_driving, aux):
     """engine result -> the reference's out_dict (archs/dense_motion_arch.py:118-161), NCHW where it is NCHW there."""
-    out = {"deformation": r["deformation"], "occlusion_map": r["occlusion_nhwc"].view(B, 1, 64, 64),
+    Fg = r["deformation"].shape[1]
+    out = {"deformation": r["deformation"], "occlusion_map": r["occlusion_nhwc"].view(B, 1, Fg, Fg),
            "sparse_motion": r["sparse_motion"], "_heat_nhwc": r["heat_nhwc"]}
     out["driving_kp_heatmap"] = ops.nhwc_to_nchw(r["heat_nhwc"])
     if aux:
         out["mask"] = ops.nhwc_to_nchw(r["mask_nhwc"])
-        hg = ops.nhwc_to_nchw(r["hg_in_nhwc"]).view(B, -1, 4, 64, 64)
+        hg = ops.nhwc_to_nchw(r["hg_in_nhwc"]).view(B, -1, 4, Fg, Fg)
         out["kp_heatmap"] = hg[:, :, 0]
         out["sparse_deformed"] = hg[:, :, 1:4]
         s = ops.nhwc_to_nchw(src64)

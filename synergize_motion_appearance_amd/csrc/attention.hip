@@ -18,6 +18,7 @@
 //   (attn_mfma4_kernel below); the VALU kernel (one query per lane, keys/values broadcast from LDS) stays selectable.
 // Fully masked rows give NaN exactly like the reference (0/0).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <math.h>
 #include "smx.h"
@@ -448,8 +449,16 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
   AP<T> p{q, k, v, o, key_mask, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo, H, L, S, scale};
   hipStream_t st = (hipStream_t)stream;
   if (dh == 4) {
-    if (L % 64 || S % 32 || S > 2048) return SMX_EINVAL;
+    if (L % 64 || S % 32 || S > 4096) return SMX_EINVAL;       // all keys of a head live in LDS: 4096 (the 512 variant's 64x64 tokens) = 141 KB
     const size_t lds = (size_t)S * 33 + 4 * 64 * 6 * sizeof(float);
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+      const void* fns[] = {(const void*)(attn_mfma4_kernel<T, true>), (const void*)(attn_mfma4_kernel<T, false>), (const void*)(attn_valu4_kernel<T>)};
+      for (const void* f : fns)
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 36 + 4 * 64 * 6 * (int)sizeof(float));
+    });
+    if (attr_err != hipSuccess) return SMX_ELAUNCH;
     if (smx_tune(SMX_TUNE_ATTN4_MFMA) && S % 64 == 0) {
       if (key_mask) SMX_LAUNCH((attn_mfma4_kernel<T, true>), dim3(L / 64, B * H), dim3(256), (size_t)S * 36 + 4 * 64 * 6 * sizeof(float), st, p);
       else SMX_LAUNCH((attn_mfma4_kernel<T, false>), dim3(L / 64, B * H), dim3(256), (size_t)S * 32 + 4 * 64 * 6 * sizeof(float), st, p);

@@ -457,12 +457,14 @@ int layernorm_launch(const T* x, const float* gamma, const float* beta, const fl
 
 template <typename T>
 int softmax_launch(T* s, int ld, int R, int S, float scale, const uint8_t* mask, int rows_per_mask, void* stream) {
-  if (!s || R <= 0 || S <= 0 || S > 1024 || ld < S || (mask && rows_per_mask <= 0)) return SMX_EINVAL;
+  if (!s || R <= 0 || S <= 0 || S > 4096 || ld < S || (mask && rows_per_mask <= 0)) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(smx_cdiv(R, 4)), block(256);
   if (S <= 256) SMX_LAUNCH((softmax_rows_kernel<T, 4>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
   else if (S <= 512) SMX_LAUNCH((softmax_rows_kernel<T, 8>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
-  else SMX_LAUNCH((softmax_rows_kernel<T, 16>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else if (S <= 1024) SMX_LAUNCH((softmax_rows_kernel<T, 16>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else if (S <= 2048) SMX_LAUNCH((softmax_rows_kernel<T, 32>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);
+  else SMX_LAUNCH((softmax_rows_kernel<T, 64>), grid, block, 0, st, s, ld, (long long)R, S, scale, mask, rows_per_mask);   // 64x64 tokens: the 512 variant's AttnBlock
   return smx_launch_status();
 }
 }  // namespace

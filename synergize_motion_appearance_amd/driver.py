@@ -74,11 +74,24 @@ def _numel(shape):
     return n
 
 
-def cache_numel(dtype=torch.float32) -> int:
+def _img_size(net_g) -> int:
+    """frame size of the generator network (options yml `network_g.img_size`): 256, or 512 for the N4 variant."""
+    return int(getattr(net_g, "cfg", {}).get("img_size", 256))
+
+
+def cache_shapes(img_size=256):
+    """encoder-tap shapes keyed by the scale's name (its size in the 256 layout); every grid scales with img_size / 256 (N4)."""
+    k = img_size // 256
+    return {s: (1, sh[1] * k, sh[2] * k, sh[3]) for s, sh in CACHE_SHAPES.items()}
+
+
+def cache_numel(dtype=torch.float32, img_size=256) -> int:
     """floats in the packed state: 7,077,888 encoder elements (28.3 MB fp32; bf16 taps travel as raw bits, two per
-    float: 14.2 MB) + 12,288 (down-sampled source) + 2 x 90 keypoint floats + 1."""
-    n = sum(_numel(CACHE_SHAPES[s]) for s in CACHE_ORDER)
-    return (n // 2 if dtype == torch.bfloat16 else n) + _TAIL
+    float: 14.2 MB) + 12,288 (down-sampled source) + 2 x 90 keypoint floats + 1 at img_size 256; the encoder and
+    down-sampled-source parts x4 at 512."""
+    k = img_size // 256
+    n = sum(_numel(CACHE_SHAPES[s]) for s in CACHE_ORDER) * k * k
+    return (n // 2 if dtype == torch.bfloat16 else n) + _SRC64 * k * k + _TAIL - _SRC64
 
 
 class SourceState:
@@ -101,20 +114,23 @@ def pack_source_state(cache, src64, kp_source, kp_initial, scale) -> torch.Tenso
                       torch.full((1,), float("nan") if scale is None else float(scale), device=dev, dtype=torch.float32)])
 
 
-def unpack_source_state(flat: torch.Tensor, dtype=torch.float32) -> SourceState:
+def unpack_source_state(flat: torch.Tensor, dtype=torch.float32, img_size=256) -> SourceState:
     """dtype: storage type of the encoder taps inside `flat` (the receiving engine's activation type)."""
     from .engine_netg import SourceCache
     feats, off = {}, 0
+    shapes, k = cache_shapes(img_size), img_size // 256
+    if flat.numel() != cache_numel(dtype, img_size):
+        raise ValueError(f"unpack_source_state: {flat.numel()} floats, a packed img_size-{img_size} state has {cache_numel(dtype, img_size)}")
     for s in CACHE_ORDER:
-        n = _numel(CACHE_SHAPES[s])
+        n = _numel(shapes[s])
         if dtype == torch.bfloat16:
-            feats[s] = flat[off:off + n // 2].view(torch.bfloat16).view(CACHE_SHAPES[s])
+            feats[s] = flat[off:off + n // 2].view(torch.bfloat16).view(shapes[s])
             off += n // 2
         else:
-            feats[s] = flat[off:off + n].view(CACHE_SHAPES[s])
+            feats[s] = flat[off:off + n].view(shapes[s])
             off += n
-    src64 = flat[off:off + _SRC64].view(1, 64, 64, 3)
-    off += _SRC64
+    src64 = flat[off:off + _SRC64 * k * k].view(1, 64 * k, 64 * k, 3)
+    off += _SRC64 * k * k
     kps = []
     for _ in range(2):
         kps.append({"value": flat[off:off + _KP_VALUE].view(1, 15, 2),
@@ -125,12 +141,12 @@ def unpack_source_state(flat: torch.Tensor, dtype=torch.float32) -> SourceState:
     return SourceState(SourceCache(feats, 1), src64, kps[0], kps[1], flat[off:off + 1], flat)
 
 
-def broadcast_flat(flat_or_none, device, src=0, group=None, dtype=torch.float32, async_op=False):
+def broadcast_flat(flat_or_none, device, src=0, group=None, dtype=torch.float32, async_op=False, img_size=256):
     """rank `src` (a GLOBAL rank, as torch.distributed.broadcast reads it) passes the packed state, the others None;
     everyone returns the broadcast buffer -- or (buffer, work handle) with async_op=True.
     torch.distributed broadcast == RCCL over xGMI on the GPU box (gloo in the CPU tests)."""
     import torch.distributed as dist
-    buf = flat_or_none if dist.get_rank() == src else torch.empty(cache_numel(dtype), device=device, dtype=torch.float32)
+    buf = flat_or_none if dist.get_rank() == src else torch.empty(cache_numel(dtype, img_size), device=device, dtype=torch.float32)
     if dist.get_rank() == src and buf is None:
         raise ValueError(f"broadcast_flat: rank {src} is the source of this broadcast and must pass the packed state")
     work = dist.broadcast(buf, src=src, group=group, async_op=async_op)
@@ -153,11 +169,12 @@ def broadcast_source_states(net_g, motion_estimator, owned, owners, adapt_moveme
             device = flats[j].device
     if device is None:
         device = next(net_g.parameters()).device
-    pending = [(j,) + broadcast_flat(flats.get(j), device, owner, group, adt, async_op=True) for j, owner in sorted(owners.items())]
+    img = _img_size(net_g)
+    pending = [(j,) + broadcast_flat(flats.get(j), device, owner, group, adt, async_op=True, img_size=img) for j, owner in sorted(owners.items())]
     out = {}
     for j, buf, work in pending:
         work.wait()
-        out[j] = unpack_source_state(buf, adt)
+        out[j] = unpack_source_state(buf, adt, img)
     return out
 
 
@@ -186,7 +203,8 @@ def broadcast_source_state(net_g, motion_estimator, source=None, initial_frame=N
     if device is None:
         device = next(net_g.parameters()).device
     adt = net_g.engine().adt
-    return unpack_source_state(broadcast_flat(flat, device, src, group, adt), adt)
+    img = _img_size(net_g)
+    return unpack_source_state(broadcast_flat(flat, device, src, group, adt, img_size=img), adt, img)
 
 
 def render_frames(state: SourceState, frames, net_g, motion_estimator, relative=True, adapt_movement_scale=True,
@@ -204,7 +222,7 @@ def render_frames(state: SourceState, frames, net_g, motion_estimator, relative=
         kp_d = eng_m.estimate_kp(frames[i:i + batch].float())
         kp_n = normalize_kp(state.kp_source, kp_d, state.kp_initial, adapt_movement_scale, relative, relative, state.scale)
         dm = eng_m.dense_motion(state.src64, kp_n, state.kp_source)
-        st = eng_g.forward(state.cache, dm["deformation"], dm["occlusion_nhwc"].view(-1, 64, 64), dm["heat_nhwc"], float(w))
+        st = eng_g.forward(state.cache, dm["deformation"], dm["occlusion_nhwc"], dm["heat_nhwc"], float(w))
         if want in ("uint8", "both"):
             u8.append(ops.to_uint8(st["out"], -1.0, 1.0))
         if want in ("float", "both"):
@@ -299,9 +317,10 @@ class FramePipeline:
             raise ops.L.SmxError("FramePipeline: the networks must be on an MI355X (call .cuda())")
         self.dev = dev
         H, W = self.hw
+        self.img = _img_size(net_g)                  # the network's frame size: 256 (512: DESIGN N4)
         self.pin_in = [torch.empty((self.B, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.dev_in = [torch.empty((self.B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.pin_out = [torch.empty((self.B, 256, 256, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.pin_out = [torch.empty((self.B, self.img, self.img, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.s_h2d, self.s_d2h = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 
     @torch.no_grad()
@@ -330,7 +349,7 @@ class FramePipeline:
                 h2d = torch.cuda.Event()
                 h2d.record()
             cur.wait_event(h2d)
-            x = ops.frames_u8_to_nchw(self.dev_in[k][:n], (256, 256), self.swap_rb)
+            x = ops.frames_u8_to_nchw(self.dev_in[k][:n], (self.img, self.img), self.swap_rb)
             in_free[k] = torch.cuda.Event()
             in_free[k].record(cur)
             out = render_frames(state, x, self.net_g, self.me, self.relative, self.adapt, batch=B)
@@ -356,7 +375,7 @@ class FramePipeline:
         """all frames -> one uint8 host tensor [N,256,256,3] (`out` may be a preallocated, e.g. pinned, destination)."""
         frames = torch.as_tensor(frames)
         if out is None:
-            out = torch.empty((frames.shape[0], 256, 256, 3), dtype=torch.uint8)
+            out = torch.empty((frames.shape[0], self.img, self.img, 3), dtype=torch.uint8)
         for a, chunk in self.stream(state, frames):
             out[a:a + chunk.shape[0]].copy_(chunk)
         return out

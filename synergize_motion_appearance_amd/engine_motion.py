@@ -102,9 +102,10 @@ class KPEngine:
 
     def estimate_kp(self, image_nchw):
         B = image_nchw.shape[0]
-        buf, inp = self.hg.alloc_input(B, 64, image_nchw.device)
+        r = image_nchw.shape[-1] // 4                         # scale_factor 0.25: 64 at img_size 256, 128 at 512 (N4)
+        buf, inp = self.hg.alloc_input(B, r, image_nchw.device)
         ops.antialias_down(image_nchw, self.down, out=inp)
-        fm = self.hg.run(buf, B, 64)                          # [B,64,64,35 (+1 zero pad)]
+        fm = self.hg.run(buf, B, r)                           # [B,64,64,35 (+1 zero pad)]
         heads = ops.conv(fm, self.head_conv, pad=(0, 0))      # 7x7 valid -> [B,58,58,76] = [jac 60 | kp 15 | 0]
         value, jac = ops.kp_head(heads[..., self.n_jac:self.n_jac + self.num_kp], heads[..., :self.n_jac],
                                  self.num_kp, self.temperature)
@@ -130,11 +131,12 @@ class DenseEngine:
 
     def dense_motion(self, src64, kp_driving, kp_source, want_aux=False):
         B = kp_driving["value"].shape[0]
-        buf, inp = self.hg.alloc_input(B, 64, src64.device)
+        r = src64.shape[1]                                    # 64 (128 at img_size 512)
+        buf, inp = self.hg.alloc_input(B, r, src64.device)
         sparse, heat = ops.sparse_motion(src64, kp_driving["value"], kp_driving["jacobian"].reshape(B, -1, 4),
                                          kp_source["value"], kp_source["jacobian"].reshape(kp_source["value"].shape[0], -1, 4),
                                          inp, B, self.num_kp, self.kp_variance)
-        pred = self.hg.run(buf, B, 64)                        # [B,64,64,128]
+        pred = self.hg.run(buf, B, r)                         # [B,64,64,128]
         mlog = ops.conv(pred, self.mo_conv)                   # 7x7 pad 3 -> [B,64,64,17] = [mask 16 | occlusion logit]
         deformation, mask, occ = ops.mask_deformation(mlog, sparse, want_mask=want_aux, K1=self.num_kp + 1, fused_occ=True)
         out = {"deformation": deformation, "occlusion_nhwc": occ, "heat_nhwc": heat, "sparse_motion": sparse}

@@ -105,20 +105,20 @@ class _Transformer:
         self.f2 = Conv.from_torch(P[pre + ".conv2.weight"], P[pre + ".conv2.bias"])
 
     def __call__(self, tgt, S, pos, mask=None):
-        """tgt [B,32,32,E] (== tokens [B,1024,E]); S = codebook prefix rows."""
-        B = tgt.shape[0]
-        E, H, dh, N = self.E, self.H, self.dh, 1024
+        """tgt [B,g,g,E] (== tokens [B,g*g,E]; g = 32, 64 at img_size 512); S = codebook prefix rows."""
+        B, g = tgt.shape[0], tgt.shape[1]
+        E, H, dh, N = self.E, self.H, self.dh, g * g
         # self attention: q = k = LN(x)+pos, v = LN(x)
         t2, qk_in = ops.layernorm(tgt, *self.n1, pos=pos)
         qk = ops.conv(qk_in, self.s_qk)                                       # [B,32,32,2E] = [q | k]
         v = ops.conv(t2, self.s_v)                                            # [B,32,32,E]
         o = ops.attention(qk[..., :E], qk[..., E:], v, H, dh, N, mask=mask)
-        tgt = ops.conv(o.view(B, 32, 32, E), self.s_out, res=tgt)
+        tgt = ops.conv(o.view(B, g, g, E), self.s_out, res=tgt)
         # cross attention against the codebook prefix
         t2, q_in = ops.layernorm(tgt, *self.n2, pos=pos)
         q = ops.conv(q_in, self.c_q)
         o = ops.attention(q, self.ckv[:, :E], self.ckv[:, E:], H, dh, S, k_shared=True)
-        tgt = ops.conv(o.view(B, 32, 32, E), self.c_out, res=tgt)
+        tgt = ops.conv(o.view(B, g, g, E), self.c_out, res=tgt)
         # conv FFN
         t2, _ = ops.layernorm(tgt, *self.n3)
         h = ops.conv(t2, self.f1, act=ACT_GELU)
@@ -163,6 +163,10 @@ class NetGEngine:
         self.motion_emb2 = _Res(P, "motion_emb.2")
         self.mq1, self.mq2 = cv("motion_query_enc_1"), cv("motion_query_enc_2")
         self.kp_enc = cv("driving_kp_enc")
+        # N4: every grid scales with k = img_size / 256 (token grid g = 32 k, flow grid 2 g, features at s k); the per-scale modules
+        # keep the names of the 256 layout (s = 32 / 64 / 128 / 256: the state_dict is the 256 one but for the g*g position rows)
+        self.k = cfg["img_size"] // 256
+        self.g = 32 * self.k
         self.sizes = [32] + [int(s) for s in cfg["connect_list"]]
         self.wsrc = {s: cv(f"warped_source_enc_{s}") for s in self.sizes}
         self.to_ctx = {s: cv(f"to_context.{int(math.log2(s)) - 5}") for s in self.sizes}
@@ -270,7 +274,7 @@ class NetGEngine:
             if i > 0:
                 x = self._run(kind, blk, x)
             if i in (2, 5, 8, 11):
-                out[str(x.shape[1])] = x
+                out[str(x.shape[1] // self.k)] = x                            # keyed by the scale's size in the 256 layout
             if i == 11:
                 break
         return out
@@ -322,8 +326,9 @@ class NetGEngine:
         B = flow_res.shape[0]
         Em = self.Em
         m1 = ops.conv(flow_res, self.motion_emb0, mfma16=self.is16)           # [B,64,64,32]  (fp32 flow in)
-        m2 = ops.conv(m1, self.motion_emb1, stride=2, pad=(0, 0), out_hw=(32, 32))
-        qin = torch.empty((B, 32, 32, 2 * Em), device=flow_res.device, dtype=self.adt)
+        g, Fg = self.g, flow_res.shape[1]
+        m2 = ops.conv(m1, self.motion_emb1, stride=2, pad=(0, 0), out_hw=(g, g))
+        qin = torch.empty((B, g, g, 2 * Em), device=flow_res.device, dtype=self.adt)
         self.motion_emb2(m2, out=qin[..., :Em])
         if train is not None:
             # training branch (:379-386, :426): quantise m_feat against the scale's motion-codebook prefix, reconstruct the flow
@@ -336,24 +341,24 @@ class NetGEngine:
         S = self.cb_motion.shape[0] // 4 * _SCALE_K[s]
         for blk in self.motion_blocks:
             q = blk(q, S, self.pos_motion)
-        motion_f = ops.resize(q, 64, 64)
-        cf = torch.empty((B, 64, 64, 160), device=q.device, dtype=self.adt)
+        motion_f = ops.resize(q, Fg, Fg)
+        cf = torch.empty((B, Fg, Fg, 160), device=q.device, dtype=self.adt)
         cor = ops.conv(motion_f, self.bme["convc1"], act=ACT_RELU)
         ops.conv(cor, self.bme["convc2"], out=cf[..., :96], act=ACT_RELU)
         flo = ops.conv(flow_res, self.bme["convf1"], act=ACT_RELU, mfma16=self.is16)   # 7x7 pad 3 (fp32 flow in)
         ops.conv(flo, self.bme["convf2"], out=cf[..., 96:], act=ACT_RELU)
-        inp = torch.empty((B, 64, 64, 256), device=q.device, dtype=self.adt)
+        inp = torch.empty((B, Fg, Fg, 256), device=q.device, dtype=self.adt)
         ops.conv(cf, self.bme["conv"], out=inp[..., :126], act=ACT_RELU)
         ops.copy_slice(flow_res, inp[..., 126:128])
         if s > 128:
             # relu(to_context(.)) is per pixel and only its 4 bilinear taps per 64x64 output pixel survive the
             # resize: evaluate it on the gathered taps (1/4 of the 256x256 pixels), then blend (same values up to 1 ulp)
-            taps = ops.resize_taps_gather(warp0, 64, 64)                      # [B,64,256,C]
-            wf = ops.resize_taps_combine(ops.conv(taps, self.to_ctx[s], act=ACT_RELU), s, s)
+            taps = ops.resize_taps_gather(warp0, Fg, Fg)                      # [B,64,256,C]
+            wf = ops.resize_taps_combine(ops.conv(taps, self.to_ctx[s], act=ACT_RELU), s * self.k, s * self.k)
         else:
             wf = ops.conv(warp0, self.to_ctx[s], act=ACT_RELU)                # [B,s,s,192]
             if s != 64:
-                wf = ops.resize(wf, 64, 64)
+                wf = ops.resize(wf, Fg, Fg)
         ops.conv(wf, self.ref_c1, out=inp[..., 128:], act=ACT_RELU)
         h = ops.conv(inp, self.ref_h, act=ACT_RELU)                           # [B,64,64,256] = [conv1 | convo1]
         return ops.conv(h, self.ref_out, out_dtype=torch.float32)             # [B,64,64,3] = [dflow(2) | docc(1)], always fp32
@@ -361,7 +366,7 @@ class NetGEngine:
     # ---- A10 ------------------------------------------------------------------------------
     def _app_comp(self, feat, m_com, s, out=None):
         C = feat.shape[-1]
-        ign = ops.motion_ignore(m_com)
+        ign = ops.motion_ignore(m_com, self.g, self.g)
         if s == 32:
             q = ops.conv(feat, self.app_in[32])
         else:
@@ -377,9 +382,9 @@ class NetGEngine:
     def _one_scale(self, st, feat, s, first, out=None):
         flow = st["flows"][-1]
         warp0 = ops.warp(feat, flow)
-        wsrc = warp0 if s == 32 else ops.resize(warp0, 32, 32)
+        wsrc = warp0 if s == 32 else ops.resize(warp0, self.g, self.g)
         B = flow.shape[0]
-        mqin = torch.empty((B, 32, 32, 2 * self.Em), device=flow.device, dtype=self.adt)
+        mqin = torch.empty((B, self.g, self.g, 2 * self.Em), device=flow.device, dtype=self.adt)
         ops.conv(wsrc, self.wsrc[s], out=mqin[..., :self.Em], act=ACT_RELU)
         ops.copy_slice(st["kp_feat"], mqin[..., self.Em:])
         mq = ops.conv(mqin, self.mq1)
@@ -417,7 +422,7 @@ class NetGEngine:
             if self.is16:
                 raise NotImplementedError("the training branch is fp32 (configs[1] arithmetic)")
             st["train"] = {"motion_recon": [], "loss_motion": [], "stats_motion": []}
-        st["kp_feat"] = ops.conv(ops.resize(heat_nhwc, 32, 32), self.kp_enc, act=ACT_RELU, mfma16=self.is16)   # fp32 heatmaps in
+        st["kp_feat"] = ops.conv(ops.resize(heat_nhwc, self.g, self.g), self.kp_enc, act=ACT_RELU, mfma16=self.is16)   # fp32 heatmaps in
         x = self._one_scale(st, cache.feats[32], 32, True)
         st["lq"] = x
         cats = {}

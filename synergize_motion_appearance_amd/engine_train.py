@@ -27,6 +27,8 @@ _SCALE_K = {32: 1, 64: 2, 128: 3, 256: 4}
 class NetGTrainEngine:
     def __init__(self, cfg):
         self.cfg = cfg
+        if cfg["img_size"] != 256:
+            raise NotImplementedError("the training step is planned for img_size 256 (BASELINE configs[4]); the 512 variant (N4) is inference")
         nf, ch_mult, rb = cfg["nf"], tuple(cfg["ch_mult"]), cfg["res_blocks"]
         attn = tuple(cfg["attn_resolutions"])
         eplan, _ = encoder_plan(nf, ch_mult, rb, cfg["img_size"], attn)

@@ -106,7 +106,8 @@ def netg_manifest(img_size=256, nf=64, ch_mult=(1, 2, 2, 4), res_blocks=2, attn_
                   connect_list=("64", "128", "256"), connect_app_list=("32", "64", "128", "256"), emb_dim=256):
     """[(name, shape)] of AppMotionCompFormer for the options/test.yml flag set
     (with_position_emb, warp_s_d_kp_query, MRFA_motion_enc, multiscale_sft/feature_fusion)."""
-    out = [("position_emb_app", (32 * 32, dim_embd_app)), ("position_emb_motion", (32 * 32, dim_embd_motion))]
+    g = img_size // 8            # token grid: 32 in the reference (appmotioncodebook_arch.py:266-267); 64 for the 512 variant (DESIGN "N4")
+    out = [("position_emb_app", (g * g, dim_embd_app)), ("position_emb_motion", (g * g, dim_embd_motion))]
     enc, _ = encoder_plan(nf, ch_mult, res_blocks, img_size, attn_resolutions)
     enc = enc + [("conv", enc[-1][1], emb_dim)]
     _blocks(out, "encoder.blocks", enc)

@@ -326,3 +326,32 @@ def test_demo_container_branch_with_a_stub_imageio(tmp_path, monkeypatch):
     assert d.endswith("r.mp4.frames") and sorted(os.listdir(d)) == ["000000.png", "000001.png"]
     with pytest.raises(RuntimeError, match="imageio"):
         demo.read_clip(str(tmp_path / "driving.mp4"))
+
+
+def test_n4_512_layout_host_side():
+    """N4 (DESIGN "N4", BASELINE configs[3]): the 512 variant is the test.yml network with every grid doubled -- the checkpoint layout is
+    the 256 one but for 64*64-row position embeddings, the packed frame-invariant state is 4x the taps + a 128x128 source, and the
+    unsupported combinations (512 with the 256 AttnBlock resolution, other sizes) still raise like every non-test.yml flag set."""
+    import pytest
+    from synergize_motion_appearance_amd import driver
+    from synergize_motion_appearance_amd.manifest import netg_manifest
+    from synergize_motion_appearance_amd.engine_netg import SourceCache
+    a, b = dict(netg_manifest(256)), dict(netg_manifest(512, attn_resolutions=(64,)))
+    assert list(a) == list(b)
+    assert {k for k in a if a[k] != b[k]} == {"position_emb_app", "position_emb_motion"} and b["position_emb_motion"] == (4096, 32)
+    assert "encoder.blocks.11.q.weight" not in dict(netg_manifest(512))          # attn_resolutions [32] at 512: no AttnBlock in the ladder
+    shapes = driver.cache_shapes(512)
+    assert shapes == {32: (1, 64, 64, 256), 64: (1, 128, 128, 128), 128: (1, 256, 256, 128), 256: (1, 512, 512, 64)}
+    assert driver.cache_numel(torch.float32, 512) == 4 * (7077888 + 12288) + 181
+    assert driver.cache_numel(torch.bfloat16, 512) == 4 * (7077888 // 2 + 12288) + 181
+    feats = {s: torch.full(sh, float(s)) for s, sh in shapes.items()}
+    kp = {"value": synth_input("cv", (1, 15, 2)), "jacobian": synth_input("cj", (1, 15, 2, 2))}
+    flat = driver.pack_source_state(SourceCache(feats, 1), torch.ones(1, 128, 128, 3), kp, None, None)
+    st = driver.unpack_source_state(flat, torch.float32, 512)
+    assert all(torch.equal(st.cache.feats[s], feats[s]) for s in feats) and tuple(st.src64.shape) == (1, 128, 128, 3)
+    with pytest.raises(ValueError):
+        driver.unpack_source_state(flat)
+    from basicsr.archs import build_network
+    for bad in (dict(img_size=512), dict(img_size=1024, attn_resolutions=[128]), dict(img_size=256, attn_resolutions=[64])):
+        with pytest.raises(NotImplementedError):
+            build_network(dict(type="AppMotionCompFormer", **bad))
