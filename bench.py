@@ -147,6 +147,47 @@ def init_distributed(rank, world, dev):
     return dist, "gloo (explicitly requested via SMX_BENCH_BACKEND)"
 
 
+def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32"):
+    """BASELINE configs[4] on ONE GPU: the train.yml generator + motion-estimator step (forward of both networks in training mode,
+    L1 / codebook / equivariance losses, one backward through both on the HIP backward kernels, Adam per network on flat buffers, EMA)
+    on `batch` (source, driving) pairs.  No VGG / discriminator (SURVEY 8d config 5 allows that).  An extra key, never `value`."""
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
+    from synergize_motion_appearance_amd.trainer import TrainStep
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+    net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
+    me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
+    net_g, me = net_g.to(dev), me.to(dev)
+    topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt")}
+    topt["compute_dtype"] = compute_dtype
+    step = TrainStep(net_g, me, topt)
+    _, clip = synth_clip(2 * batch, seed=321)
+    src, drv = clip[:batch].contiguous().to(dev), clip[batch:].contiguous().to(dev)
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(warmup):
+        step.step(src, drv)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses, _ = step.step(src, drv)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    total = float(losses["l_g_total"])
+    if not (total == total and abs(total) < 1e6):
+        raise SystemExit(f"[bench] training leg: non-finite / exploding loss {total}")
+    return {"workload": f"BASELINE.json configs[4] on ONE GPU: options/train.yml generator + motion-estimator step, {batch} (source, driving) pairs at "
+                        "256x256, " +
+                        ("fp32" if compute_dtype == "f32" else "bf16 compute (every convolution / Linear contraction, forward + data + weight gradient, on "
+                         "v_mfma_f32_32x32x16_bf16 with operands rounded like torch.autocast(bfloat16); fp32 storage, normalisation, attention, optimiser)") +
+                        ", Adam per network + EMA inside the step; perceptual (VGG) and GAN terms not built (SURVEY 8d config 5)",
+            "value": round(batch / dt, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * dt, 2), "batch": batch, "steps": steps, "warmup": warmup,
+            "dtype": compute_dtype, "l_g_total_last": round(total, 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "parity": ("tests/test_gpu_train_full.py: every parameter-gradient norm and sampled gradients / Adam updates vs the reference's own backward"
+                       if compute_dtype == "f32" else "tests/test_gpu_train_full.py::test_bf16_compute_step...: gradient-norm deviation from the fp32 "
+                       "fixture within 1.25x of the reference's own torch.autocast(bfloat16) step (tests/golden/train_step_autocast.npz)")}
+
+
 def load_profile_json(name):
     p = os.path.join(REPO, "profiles", name)
     return json.load(open(p)) if os.path.exists(p) else None
@@ -404,6 +445,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-d2h", action="store_true")
     ap.add_argument("--no-bf16-leg", action="store_true", help="N=1 fp32 runs append a configs[2] (bf16) sub-record by default; skip it")
+    ap.add_argument("--no-train-leg", action="store_true", help="N=1 fp32 runs append a configs[4] (training step) sub-record by default; skip it")
     ap.add_argument("--no-consistency", action="store_true", help="skip the B=1 re-render check (profiling runs: keeps B=1 launches out of the counters)")
     ap.add_argument("--profile-only", action="store_true", help="the command the rocprofv3 passes wrap: timed steps only (no B=1 re-renders, "
                                                                  "no roofline / PCIe / CPU / bf16 legs)")
@@ -412,11 +454,11 @@ def main():
     ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")
     args = ap.parse_args()
     if args.img_size != 256:
-        args.no_cpu_baseline = args.no_bf16_leg = True
+        args.no_cpu_baseline = args.no_bf16_leg = args.no_train_leg = True
         if "--batch" not in sys.argv:
             args.batch = 15
     if args.profile_only:
-        args.no_cpu_baseline = args.no_roofline = args.no_d2h = args.no_bf16_leg = args.no_consistency = True
+        args.no_cpu_baseline = args.no_roofline = args.no_d2h = args.no_bf16_leg = args.no_consistency = args.no_train_leg = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -519,6 +561,14 @@ def main():
         leg16 = None
         net_g.set_compute_dtype("f32")
         me.set_compute_dtype("f32")
+
+    if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_train_leg:
+        leg = None
+        torch.cuda.empty_cache()
+        result["configs4_train"] = train_leg(dev)
+        torch.cuda.empty_cache()
+        result["configs4_train"]["bf16_compute"] = train_leg(dev, compute_dtype="bf16")
+        torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(Pg, Pm, src_cpu, drv_cpu)

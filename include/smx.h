@@ -382,6 +382,13 @@ int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int l
                   int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
                   float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
                   float* bias_out, void* stream);
+/* the same contraction on v_mfma_f32_32x32x16_bf16: both operands rounded to bfloat16 (RNE) on the way to the matrix cores, fp32
+ * accumulate, fp32 result -- torch.autocast(bfloat16)'s arithmetic for the weight gradient of F.conv2d / F.linear (the bf16-compute
+ * training mode; the bias gradient still sums the unrounded dY). */
+int smx_wgrad_mfma16_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
+                         int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
+                         float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
+                         float* bias_out, void* stream);
 /* out[c] (+)= alpha * sum_p x[p*ld + c]  (bias gradients); ws: smx_colsum_ws_floats(P, C) floats; two fixed-order stages */
 int64_t smx_colsum_ws_floats(int64_t P, int C);
 int smx_colsum_f32(const float* x, int ld, int64_t P, int C, float* ws, float* out, int accumulate, float alpha, void* stream);

@@ -21,6 +21,7 @@
 #include <math.h>
 #include "smx.h"
 #include "smx_common.h"
+#include "bf16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -39,6 +40,10 @@ struct WG {
   int msplit, mper, tiles_k;
 };
 
+// BF16: the same tiles, staged in fp32 as they are read, but contracted on v_mfma_f32_32x32x16_bf16 -- each lane rounds its 8 pixels of a
+// column to bf16 (RNE) on the way from LDS to the MFMA, fp32 accumulate: what torch.autocast(bfloat16) does to this GEMM (the bias
+// gradient keeps summing the unrounded dy).  2 MFMAs per 32-pixel slice instead of 16: the kernel turns LDS / load bound.
+template <bool BF16>
 __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
   __shared__ __attribute__((aligned(16))) float As[2][32 * WPITCH];
   __shared__ __attribute__((aligned(16))) float Bs[2][32 * WPITCH];
@@ -150,10 +155,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
       if (s + 1 < nslices) load_slice(m_begin + (s + 1) * 32);      // in flight across this slice's MFMAs
       const float* as = &As[buf][fa];
       const float* bs = &Bs[buf][fb];
+      if constexpr (BF16) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int prow = (j & 7) + 16 * (j >> 3);            // pixels prow (lanes 0-31) and prow + 8 (lanes 32-63)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[prow * WPITCH], bs[prow * WPITCH], acc, 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {                          // pixels 16 h + 0..7 (lanes 0-31) and 16 h + 8..15 (lanes 32-63)
+          float av[8], bv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { av[j] = as[(16 * h + j) * WPITCH]; bv[j] = bs[(16 * h + j) * WPITCH]; }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pack8(av)), __builtin_bit_cast(bf16x8, pack8(bv)), acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int prow = (j & 7) + 16 * (j >> 3);            // pixels prow (lanes 0-31) and prow + 8 (lanes 32-63)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[prow * WPITCH], bs[prow * WPITCH], acc, 0, 0, 0);
+        }
       }
       if (s + 1 < nslices) store_slice(buf ^ 1);
       __syncthreads();
@@ -381,10 +396,10 @@ extern "C" int64_t smx_wgrad_ws_floats(int nb, int M, int Cout, int K, int* mspl
   return (int64_t)nb * ms * Cout * K + (int64_t)nb * ms * Cout;      // weight partials + the bias-gradient partials
 }
 
-extern "C" int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
-                             int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
-                             float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
-                             float* bias_out, void* stream) {
+static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
+                        int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
+                        float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
+                        float* bias_out, void* stream) {
   if (!dy || !x || !ws || !out || nb <= 0 || M <= 0 || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return SMX_EINVAL;
   if (msplit < 1 || nb > 65535 || msplit > 65535 || layout < 0 || layout > 2 || ldy < Cout || ldx < Cin) return SMX_EINVAL;
   if (Ho <= 0 || Wo <= 0 || M % (Ho * Wo) != 0 || (up2 != 0 && up2 != 1)) return SMX_EINVAL;
@@ -404,11 +419,30 @@ extern "C" int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const floa
   hipStream_t st = (hipStream_t)stream;
   const long long tiles = (long long)smx_cdiv(Cout, 64) * p.tiles_k;
   if (tiles > 2147483647LL) return SMX_EINVAL;
-  SMX_LAUNCH(wgrad_kernel, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
+  if (bf16) SMX_LAUNCH(wgrad_kernel<true>, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
+  else SMX_LAUNCH(wgrad_kernel<false>, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
   SMX_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long long)nb * Cout * p.K)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
              Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha);
   if (bias_out) SMX_LAUNCH(wgrad_bias_reduce_kernel, dim3(smx_cdiv(Cout, 256)), dim3(256), 0, st, p.bias_ws, nb * msplit, Cout, bias_out, accumulate, alpha);
   return smx_launch_status();
+}
+
+extern "C" int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
+                             int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
+                             float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
+                             float* bias_out, void* stream) {
+  return wgrad_launch(false, dy, ldy, dy_bs, x, ldx, x_bs, nb, M, Cout, Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2, ws, msplit, out, out_bs,
+                      layout, ldo, accumulate, alpha, bias_out, stream);
+}
+
+/* the same contraction on the bf16 MFMA (operands rounded to bf16 on the way to the matrix cores, fp32 accumulate and fp32 result):
+ * the weight gradient of the bf16-compute training mode (torch.autocast(bfloat16) semantics for F.conv2d / F.linear backward). */
+extern "C" int smx_wgrad_mfma16_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
+                                    int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
+                                    float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
+                                    float* bias_out, void* stream) {
+  return wgrad_launch(true, dy, ldy, dy_bs, x, ldx, x_bs, nb, M, Cout, Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2, ws, msplit, out, out_bs,
+                      layout, ldo, accumulate, alpha, bias_out, stream);
 }
 
 static void colsum_chunks(long long P, long long* rows, long long* nchunk) {

@@ -125,6 +125,7 @@ SIGNATURES = {
     # ---- training step ----
     "smx_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, C.POINTER(_i)]),
     "smx_wgrad_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p, _p]),
+    "smx_wgrad_mfma16_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p, _p]),
     "smx_colsum_ws_floats": (_i64, [_i64, _i]),
     "smx_colsum_f32": (_i, [_p, _i, _i64, _i, _p, _p, _i, _f, _p]),
     "smx_partial_reduce_f32": (_i, [_p, _i, _i, _p, _i, _f, _p]),

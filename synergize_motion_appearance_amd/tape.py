@@ -23,10 +23,15 @@ from . import lib as L
 
 
 class Tape:
-    def __init__(self, params, grads):
+    def __init__(self, params, grads, mfma16=False):
         """params / grads: {name: device tensor}; grads[name] has the parameter's shape (usually a view of one flat buffer) and is
-        ACCUMULATED into by the weight-gradient kernels (zero it before the step)."""
+        ACCUMULATED into by the weight-gradient kernels (zero it before the step).
+        mfma16: the bf16-compute training mode (BASELINE configs[4] "bf16"): every convolution / Linear contraction -- forward, data
+        gradient and weight gradient -- runs on the bf16 MFMA with operands rounded to bfloat16 on the way in and fp32 accumulation
+        (torch.autocast(bfloat16)'s arithmetic for those ops); activations, gradients, parameters, normalisation, softmax / attention,
+        warps and the optimiser stay fp32 (autocast additionally rounds the STORED conv outputs to bf16; this mode does not)."""
         self.P, self.G = params, grads
+        self.mfma16 = bool(mfma16)
         self.nodes = []
         self._g = {}            # id(tensor) -> [grad tensor, owned by the tape?]
         self._keep = {}         # id(tensor) -> tensor (keeps ids stable while a gradient is pending)

@@ -91,13 +91,14 @@ def _colsum(tp, x2d_ptr, ld, P, Cc, out, accumulate=True, alpha=1.0):
 
 
 def _wgrad(tp, dy, x, out, *, nb=1, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, up2=0, layout=0, ldo=0, accumulate=True,
-           alpha=1.0, dy_ld=None, x_ld=None, dy_bs=0, x_bs=0, out_bs=0, bias_out=None):
+           alpha=1.0, dy_ld=None, x_ld=None, dy_bs=0, x_bs=0, out_bs=0, bias_out=None, mfma16_ok=False):
     ms = C.c_int(1)
     n = int(tp.lib.smx_wgrad_ws_floats(nb, M, cout, kh * kw * cin, C.byref(ms)))
     ws = torch.empty((n,), device=out.device, dtype=F32)
     dyp, ldy = (dy.data_ptr(), dy_ld) if dy_ld is not None else _pix(dy)[:2]
     xp, ldx = (x.data_ptr(), x_ld) if x_ld is not None else _pix(x)[:2]
-    L.check(tp.lib.smx_wgrad_f32(dyp, ldy, dy_bs, xp, ldx, x_bs, nb, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, int(up2),
+    fn = tp.lib.smx_wgrad_mfma16_f32 if (tp.mfma16 and mfma16_ok) else tp.lib.smx_wgrad_f32
+    L.check(fn(dyp, ldy, dy_bs, xp, ldx, x_bs, nb, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, int(up2),
                                  ws.data_ptr(), ms.value, out.data_ptr(), out_bs, layout, ldo, int(accumulate), float(alpha),
                                  None if bias_out is None else bias_out.data_ptr(), _stream()), "wgrad")
 
@@ -160,11 +161,14 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
     cv = Conv(wp.view(cout, kh * kw * cin), None if bv is None else bv.contiguous(), kh, kw, cin, cout)
     pt, pl = (kh // 2, kw // 2) if pad is None else pad
     He, We = (2 * H, 2 * W) if up2 else (H, W)
+    # bf16-compute mode: forward and data gradient through the bf16 implicit GEMM (fp32 tensors converted while staging, fp32 out)
+    m16 = tp.mfma16
+    f16 = dict(mfma16=True, out_dtype=F32) if m16 else {}
     # the fused Winograd F(2x2,3x3) kernel takes this step's weights in its own packing (smx_pack_winograd_u_f32)
-    wino3 = WINOGRAD_TRAIN and kind == "conv" and (kh, kw, stride, pt, pl) == (3, 3, 1, 1, 1) and He % 8 == 0 and We % 16 == 0
+    wino3 = (not m16) and WINOGRAD_TRAIN and kind == "conv" and (kh, kw, stride, pt, pl) == (3, 3, 1, 1, 1) and He % 8 == 0 and We % 16 == 0
     if wino3 and cin % 32 == 0:
         cv._u = _packed_u(tp, w, 0, cout, cin)
-    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=cv._u is None)
+    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=cv._u is None, **f16)
     Ho, Wo = (y.shape[1], y.shape[2]) if d2s is None else (H, W)
 
     def bwd():
@@ -187,24 +191,24 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
         # weight gradient (+ the bias gradient out of the same pass over g)
         if kind == "patch":
             _wgrad(tp, g2, x, wg, M=M, cout=cout, Hin=H, Win=W, cin=cin, Ho=Ho, Wo=Wo, kh=kh, kw=kw, stride=stride, pt=0, pl=0,
-                   layout=1, ldo=kh * kw * cin, dy_ld=cout, bias_out=bg)
+                   layout=1, ldo=kh * kw * cin, dy_ld=cout, bias_out=bg, mfma16_ok=True)
         else:
             _wgrad(tp, g2, x, wg, M=M, cout=cout, Hin=H, Win=W, cin=cin, Ho=Ho, Wo=Wo, kh=kh, kw=kw, stride=stride, pt=pt, pl=pl,
-                   up2=1 if up2 else 0, layout=0, dy_ld=cout, bias_out=bg)
+                   up2=1 if up2 else 0, layout=0, dy_ld=cout, bias_out=bg, mfma16_ok=True)
         # data gradient: a forward convolution of g with the transposed, tap-flipped weights
         if not tp.needs(x):
             return
         # (the patch Linear is stored [Cout][(p1 p2 c)], not OIHW: its data-gradient operand is the plain transpose)
         wt = _packed(tp, w, 1, cout, kh * kw * cin, 1, 1) if kind == "patch" else _packed(tp, w, 1, cout, cin, kh, kw)
         if kind == "patch":
-            dx = ops.conv(g2, Conv(wt.view(kh * kw * cin, cout), None, 1, 1, cout, kh * kw * cin), d2s=(kh, cin), direct=True)
+            dx = ops.conv(g2, Conv(wt.view(kh * kw * cin, cout), None, 1, 1, cout, kh * kw * cin), d2s=(kh, cin), direct=True, **f16)
         elif kind == "unpatch":
-            dx = ops.conv(g2, Conv(wt.view(cin, cout), None, 1, 1, cout, cin), direct=True)
+            dx = ops.conv(g2, Conv(wt.view(cin, cout), None, 1, 1, cout, cin), direct=True, **f16)
         elif stride == 1:
             dcv = Conv(wt.view(cin, kh * kw * cout), None, kh, kw, cout, cin)
             if wino3 and cout % 32 == 0:
                 dcv._u = _packed_u(tp, w, 1, cout, cin)
-            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=dcv._u is None)
+            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=dcv._u is None, **f16)
             if up2:             # adjoint of nearest x2: sum of each 2x2 block
                 dx = scaled(tp, ops.avgpool2(dx), 4.0)
         else:                   # stride 2: zero-insert gather (smx_gemm_conv_f32 up2 = 2)

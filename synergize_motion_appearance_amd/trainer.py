@@ -89,9 +89,14 @@ class NetGTrainStep:
     train_opt: the yml's `train` dict; used keys: pixel_opt, motion_codebook_code_opt, motion_codebook_recon_opt,
     lr_pixel_perceptual_opt, app_codebook_code_opt, optim_g, ema_decay."""
 
-    def __init__(self, net_g, train_opt):
+    def __init__(self, net_g, train_opt, compute_dtype="f32"):
+        """compute_dtype "bf16": every convolution / Linear contraction of the step (forward, data and weight gradient) on the bf16
+        MFMA, everything else fp32 (Tape(mfma16=True)); yml: `train.compute_dtype: bf16`."""
         self.net_g = net_g
         self.opt = dict(train_opt)
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError(f"compute_dtype {compute_dtype!r}: f32 or bf16")
+        self.mfma16 = compute_dtype == "bf16"
         self.flat = FlatParams(net_g)
         net_g.refresh()                                      # the inference engine's packed copies are stale from now on
         self.engine = NetGTrainEngine(net_g.cfg)
@@ -114,7 +119,7 @@ class NetGTrainStep:
         'out', gradients w.r.t. the three dense-motion inputs in their own layouts).  Parameter gradients accumulate into
         `self.flat.grad` (call `flat.zero_grad()` first)."""
         flat = self.flat
-        tp = Tape(flat.P, flat.G)
+        tp = Tape(flat.P, flat.G, mfma16=self.mfma16)
         B = driving.shape[0]
         defo = dense_motion["deformation"].float().contiguous()
         occ = dense_motion["occlusion_map"].float().reshape(B, 64, 64).contiguous()
@@ -249,9 +254,10 @@ class TrainStep:
     motion_estimator(gt, source) in training mode -> net_g(source, dense_motion, w=1, gt=gt) -> losses -> ONE backward through both
     networks -> Adam on each (optim_g / optim_motion) -> EMA of net_g.  One tape spans both networks (their parameter names are disjoint)."""
 
-    def __init__(self, net_g, motion_estimator, train_opt):
+    def __init__(self, net_g, motion_estimator, train_opt, compute_dtype=None):
         from .engine_motion_train import MotionTrainEngine
-        self.g = NetGTrainStep(net_g, train_opt)
+        compute_dtype = compute_dtype or str(dict(train_opt).get("compute_dtype", "f32"))
+        self.g = NetGTrainStep(net_g, train_opt, compute_dtype)
         self.me = motion_estimator
         self.flat_m = FlatParams(motion_estimator)
         motion_estimator.refresh()
@@ -268,7 +274,7 @@ class TrainStep:
 
     def forward_backward(self, source, driving, w=1.0, transform=None):
         g = self.g
-        tp = Tape(self.P, self.G)
+        tp = Tape(self.P, self.G, mfma16=self.g.mfma16)
         src, drv = source.float().contiguous(), driving.float().contiguous()
         B = drv.shape[0]
         eng = self.me_engine

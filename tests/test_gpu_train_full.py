@@ -146,3 +146,57 @@ def test_model_level_optimize_parameters(tmp_path):
     assert torch.isfinite(model.out_dict["out"]).all()
     with pytest.raises(NotImplementedError, match="discriminator"):
         model.optimize_parameters(5002)
+
+
+def test_bf16_compute_step_within_the_references_own_autocast_distance():
+    """BASELINE configs[4] names bf16: the bf16-compute mode (`train.compute_dtype: bf16`: every convolution / Linear contraction --
+    forward, data gradient, weight gradient -- on the bf16 MFMA, fp32 elsewhere) on the inputs of train_step_full.npz.  There is no
+    bit-level target for bf16 training; the bar is the reference's OWN distance from its fp32 step when it runs under
+    torch.autocast(bfloat16) (tests/golden/train_step_autocast.npz, make_golden_r3.py train_step_autocast): over the parameters whose
+    fp32 gradient is not analytically zero, the relative gradient-norm deviation of this mode must stay within 1.25x of autocast's
+    (median and 90th percentile, per network), and the total loss within 1.25x of autocast's shift."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_clip
+    from synergize_motion_appearance_amd.trainer import TrainStep, EquivarianceTransform
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+    net_g.load_state_dict(weights("network_g"), strict=True)
+    me.load_state_dict(weights("network_motion_estimator"), strict=True)
+    net_g, me = net_g.cuda(), me.cuda()
+    g, ga = golden("train_step_full.npz"), golden("train_step_autocast.npz")
+    _, clip = synth_clip(8, seed=int(g["clip_seed"]))
+    src, drv = clip[g["src_frames"].tolist()].contiguous().cuda(), clip[g["drv_frames"].tolist()].contiguous().cuda()
+    train_opt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt", "kp_distance_opt")}
+    train_opt["compute_dtype"] = "bf16"
+    step = TrainStep(net_g, me, train_opt)
+    assert step.g.mfma16
+    tf = EquivarianceTransform(2, theta=torch.from_numpy(g["theta"]), control_params=torch.from_numpy(g["control_params"]))
+    step.g.flat.zero_grad()
+    step.flat_m.zero_grad()
+    from synergize_motion_appearance_amd import ops
+    with ops.profile() as rec:
+        losses, out = step.forward_backward(src, drv, transform=tf)
+    torch.cuda.synchronize()
+    kinds = {r[0] for r in rec.rows}
+    assert "gemm_bf16" in kinds, kinds                                     # the contractions really ran on the bf16 MFMA
+    ref_total, auto_total, mine_total = float(g["l_g_total"]), float(ga["l_g_total"]), float(losses["l_g_total"])
+    assert abs(mine_total - ref_total) <= 1.25 * abs(auto_total - ref_total) + 1e-3 * ref_total, (mine_total, ref_total, auto_total)
+    report = {}
+    for tag, G in (("me", step.flat_m.G), ("g", step.g.flat.G)):
+        names = [str(n) for n in g[f"{tag}_param_names"]]
+        assert names == [str(n) for n in ga[f"{tag}_param_names"]]
+        ref, auto = g[f"{tag}_grad_norms"], ga[f"{tag}_grad_norms"]
+        mine = np.array([float(G[n].double().norm()) for n in names])
+        live = ref > 1e-3 * np.median(ref)                                  # drop the analytically-zero gradients (bias in front of BN / softmax-invariant k bias)
+        dev_auto = np.abs(auto[live] - ref[live]) / ref[live]
+        dev_mine = np.abs(mine[live] - ref[live]) / ref[live]
+        assert np.isfinite(mine).all()
+        report[tag] = (float(np.median(dev_mine)), float(np.median(dev_auto)), float(np.percentile(dev_mine, 90)), float(np.percentile(dev_auto, 90)))
+        assert np.median(dev_mine) <= 1.25 * np.median(dev_auto), (tag, report[tag])
+        assert np.percentile(dev_mine, 90) <= 1.25 * np.percentile(dev_auto, 90), (tag, report[tag])
+    print("bf16-compute step: (median mine, median autocast, p90 mine, p90 autocast)", report)
+    # and the optimiser step on top of it stays finite
+    step.step(src, drv)
+    torch.cuda.synchronize()
+    assert torch.isfinite(step.g.flat.value).all() and torch.isfinite(step.flat_m.value).all()

@@ -426,3 +426,60 @@ def test_gelu_and_adam_and_ema(T):
     ref = ema.cpu() * 0.995 + pd.cpu() * 0.005
     L.check(lib.smx_ema_f32(ema.data_ptr(), pd.data_ptr(), 4097, 0.995, _stream()), "ema")
     assert float((ema.cpu() - ref).abs().max()) < 1e-6
+
+
+BF16_CONV = [c for c in CONV_BWD if c[-1] in ("3x3", "3x3 relu", "1x1", "7x7 pad 3 relu", "7x7 valid (kp head)", "3x3 160->126 lrelu (odd Cout)",
+                                              "Downsample pad(0,1,0,1) stride 2", "Upsample nearest x2 + conv", "3x3 128->3 (image head)")]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k,stride,pad,up2,act,res,tag", BF16_CONV, ids=[c[-1] for c in BF16_CONV])
+def test_conv_backward_bf16_compute_mode(T, B, Cin, Cout, H, k, stride, pad, up2, act, res, tag):
+    """Tape(mfma16=True): forward, data gradient and weight gradient (smx_wgrad_mfma16_f32) on the bf16 MFMA == the fp32 op evaluated on
+    bf16-ROUNDED operands (x, w for the forward; g, w for the data gradient; g, x for the weight gradient) with fp32 accumulation --
+    i.e. exactly the rounding torch.autocast(bfloat16) applies to F.conv2d and its backward, to fp32 summation-order tolerance (2e-4).
+    The stride-2 data gradient stays on the fp32 zero-insert gather (no bf16 form): compared against the unrounded operands there."""
+    from synergize_motion_appearance_amd.tape import Tape
+    r16 = lambda t: t.to(torch.bfloat16).float()           # noqa: E731
+    x = rnd(f"cbx{tag}", (B, Cin, H, H))
+    w = rnd(f"cbw{tag}", (Cout, Cin, k, k), 1.0 / (Cin * k * k) ** 0.5)
+    b = rnd(f"cbb{tag}", (Cout,), 0.1)
+
+    def ref_conv(xi, wi):
+        xin = F.interpolate(xi, scale_factor=2, mode="nearest") if up2 else xi
+        y = F.conv2d(F.pad(xin, (0, 1, 0, 1)), wi, b, stride=2) if stride == 2 else F.conv2d(xin, wi, b, padding=pad)
+        return F.relu(y) if act == 1 else F.leaky_relu(y, 0.2) if act == 2 else y
+    y_ref = ref_conv(r16(x), r16(w))
+    g = rnd(f"cbg{tag}", tuple(y_ref.shape))
+    # the activation derivative is taken at the (bf16-product) output; the gradient that enters the contractions is g * act'(y)
+    gm = g * ((y_ref > 0).float() if act == 1 else torch.where(y_ref > 0, torch.ones(()), torch.full((), 0.2)) if act == 2 else 1.0)
+
+    def lin(xi, wi):                                       # the linear part only (no bias / activation): its autograd gives both adjoints
+        xin = F.interpolate(xi, scale_factor=2, mode="nearest") if up2 else xi
+        return F.conv2d(F.pad(xin, (0, 1, 0, 1)), wi, None, stride=2) if stride == 2 else F.conv2d(xin, wi, None, padding=pad)
+    xa = r16(x).requires_grad_()                           # dW = adjoint wrt w at (round(x), round(gm))
+    wa = w.clone().requires_grad_()
+    lin(xa, wa).backward(r16(gm))
+    dW = wa.grad.clone()
+    xb, wb = x.clone().requires_grad_(), r16(w).requires_grad_()   # dX = adjoint wrt x at (round(w), round(gm)); stride 2: unrounded
+    if stride == 2:
+        wb = w.clone().requires_grad_()
+        lin(xb, wb).backward(gm)
+    else:
+        lin(xb, wb).backward(r16(gm))
+    dX = xb.grad
+
+    P = {"w": w.cuda().contiguous(), "b": b.cuda().contiguous()}
+    tp = Tape(P, {n: torch.zeros_like(v) for n, v in P.items()}, mfma16=True)
+    xd = nhwc(x).cuda()
+    kw = dict(stride=2, pad=(0, 0), out_hw=(H // 2, H // 2)) if stride == 2 else dict(pad=(pad, pad)) if pad != k // 2 else {}
+    yd = T.conv(tp, xd, "w", "b", up2=up2, act=act, **kw)
+    assert yd.dtype == torch.float32 and rel(nchw(yd), y_ref) < 2e-4, tag
+    tp.acc(yd, nhwc(g).cuda())
+    tp.backward()
+    assert rel(tp.G["w"], dW) < 2e-4, tag
+    assert rel(nchw(tp.grad(xd)), dX) < 2e-4, tag
+    assert rel(tp.G["b"], gm.sum((0, 2, 3))) < 2e-4, tag
+    # and it is NOT the fp32 result: the rounding is really there (guards against a silent fp32 fallback)
+    wf = w.clone().requires_grad_()
+    lin(x, wf).backward(gm)
+    assert rel(tp.G["w"], wf.grad) > 1e-4, tag
