@@ -147,7 +147,7 @@ def init_distributed(rank, world, dev):
     return dist, "gloo (explicitly requested via SMX_BENCH_BACKEND)"
 
 
-def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32"):
+def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=True):
     """BASELINE configs[4] on ONE GPU: the train.yml generator + motion-estimator step (forward of both networks in training mode,
     L1 / codebook / equivariance losses, one backward through both on the HIP backward kernels, Adam per network on flat buffers, EMA)
     on `batch` (source, driving) pairs.  No VGG / discriminator (SURVEY 8d config 5 allows that).  An extra key, never `value`."""
@@ -161,7 +161,8 @@ def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32"):
     net_g, me = net_g.to(dev), me.to(dev)
     topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt")}
     topt["compute_dtype"] = compute_dtype
-    step = TrainStep(net_g, me, topt)
+    step = TrainStep(net_g, me, topt, use_graph=use_graph)
+    warmup += (step.GRAPH_WARMUP + 1) if use_graph else 0          # eager steps, then the capture
     _, clip = synth_clip(2 * batch, seed=321)
     src, drv = clip[:batch].contiguous().to(dev), clip[batch:].contiguous().to(dev)
     torch.cuda.reset_peak_memory_stats()
@@ -182,7 +183,8 @@ def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32"):
                          "v_mfma_f32_32x32x16_bf16 with operands rounded like torch.autocast(bfloat16); fp32 storage, normalisation, attention, optimiser)") +
                         ", Adam per network + EMA inside the step; perceptual (VGG) and GAN terms not built (SURVEY 8d config 5)",
             "value": round(batch / dt, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * dt, 2), "batch": batch, "steps": steps, "warmup": warmup,
-            "dtype": compute_dtype, "l_g_total_last": round(total, 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "dtype": compute_dtype, "launch": "hipGraph replay of zero_grad + forward + losses + backward (train.use_hip_graph); all-reduce / Adam / EMA outside"
+            if use_graph else "eager launches", "l_g_total_last": round(total, 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             "parity": ("tests/test_gpu_train_full.py: every parameter-gradient norm and sampled gradients / Adam updates vs the reference's own backward"
                        if compute_dtype == "f32" else "tests/test_gpu_train_full.py::test_bf16_compute_step...: gradient-norm deviation from the fp32 "
                        "fixture within 1.25x of the reference's own torch.autocast(bfloat16) step (tests/golden/train_step_autocast.npz)")}
@@ -566,6 +568,8 @@ def main():
         leg = None
         torch.cuda.empty_cache()
         result["configs4_train"] = train_leg(dev)
+        torch.cuda.empty_cache()
+        result["configs4_train"]["eager_ms_per_step"] = train_leg(dev, use_graph=False)["ms_per_step"]
         torch.cuda.empty_cache()
         result["configs4_train"]["bf16_compute"] = train_leg(dev, compute_dtype="bf16")
         torch.cuda.empty_cache()

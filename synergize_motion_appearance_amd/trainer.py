@@ -234,7 +234,12 @@ def equivariance_losses(kp_driving, kp_transformed, transform, w_value=1.0, w_ja
     """EquivarianceLoss.forward (losses/losses.py:540-560) on keypoint-sized torch tensors (requires_grad leaves)."""
     lv = (kp_driving["value"] - transform.warp_coordinates(kp_transformed["value"])).abs().mean() * w_value
     jt = torch.matmul(transform.jacobian(kp_transformed["value"]), kp_transformed["jacobian"])
-    val = torch.matmul(torch.inverse(kp_driving["jacobian"]), jt)
+    # 2x2 inverse in closed form (adjugate / determinant): torch.inverse checks its `info` on the host, which a hipGraph capture of the
+    # step cannot contain; same value to fp32 rounding
+    J = kp_driving["jacobian"]
+    a, b, c, d = J[..., 0, 0], J[..., 0, 1], J[..., 1, 0], J[..., 1, 1]
+    inv = torch.stack([torch.stack([d, -b], -1), torch.stack([-c, a], -1)], -2) / (a * d - b * c).unsqueeze(-1).unsqueeze(-1)
+    val = torch.matmul(inv, jt)
     eye = torch.eye(2, device=val.device).view(1, 1, 2, 2)
     lj = (eye - val).abs().mean() * w_jacobian
     return lv, lj
@@ -254,9 +259,15 @@ class TrainStep:
     motion_estimator(gt, source) in training mode -> net_g(source, dense_motion, w=1, gt=gt) -> losses -> ONE backward through both
     networks -> Adam on each (optim_g / optim_motion) -> EMA of net_g.  One tape spans both networks (their parameter names are disjoint)."""
 
-    def __init__(self, net_g, motion_estimator, train_opt, compute_dtype=None):
+    def __init__(self, net_g, motion_estimator, train_opt, compute_dtype=None, use_graph=None):
+        """use_graph (yml `train.use_hip_graph`): capture zero_grad + forward + losses + tape backward of one step in a hipGraph after
+        `GRAPH_WARMUP` eager steps and replay it from then on (inputs and the equivariance transform's random parameters are copied
+        into static buffers; all-reduce, Adam and EMA stay outside: they carry the step counter).  The step is launch-bound at the
+        reference's batch sizes (~2,400 launches behind Python + ctypes); the replay removes the host from the critical path."""
         from .engine_motion_train import MotionTrainEngine
         compute_dtype = compute_dtype or str(dict(train_opt).get("compute_dtype", "f32"))
+        self.use_graph = bool(dict(train_opt).get("use_hip_graph", False)) if use_graph is None else bool(use_graph)
+        self._graph, self._static, self._eager_steps = None, None, 0
         self.g = NetGTrainStep(net_g, train_opt, compute_dtype)
         self.me = motion_estimator
         self.flat_m = FlatParams(motion_estimator)
@@ -339,11 +350,48 @@ class TrainStep:
             out["kp_transformed"] = {"value": kp_t[0], "jacobian": kp_t[1]}
         return losses, out
 
+    GRAPH_WARMUP = 2
+
+    def _draw_transform(self, B, dev):
+        eq = self.opt.get("equivariance_opt")
+        return EquivarianceTransform(B, **dict(eq.get("transform_params", {})), device=dev) if eq else None
+
+    def _graph_step(self, source, driving, w, transform):
+        """replay (capturing first) the hipGraph of zero_grad + forward_backward for this input shape."""
+        st = self._static
+        key = (tuple(source.shape), tuple(driving.shape), float(w))
+        if st is not None and st["key"] != key:
+            raise L.SmxError(f"TrainStep(use_graph): the captured step is for {st['key']}, got {key}; build another TrainStep for another shape")
+        tf_new = transform if transform is not None else self._draw_transform(driving.shape[0], driving.device)
+        if st is None:
+            st = {"key": key, "src": source.float().contiguous().clone(), "drv": driving.float().contiguous().clone(), "tf": tf_new}
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.g.flat.zero_grad()
+                self.flat_m.zero_grad()
+                st["losses"], st["out"] = self.forward_backward(st["src"], st["drv"], w, st["tf"])
+            self._graph, self._static = g, st
+        else:
+            st["src"].copy_(source)
+            st["drv"].copy_(driving)
+            if tf_new is not None:
+                st["tf"].theta.copy_(tf_new.theta)
+                if st["tf"].tps:
+                    st["tf"].control_params.copy_(tf_new.control_params)
+        self._graph.replay()
+        return st["losses"], st["out"]
+
     def step(self, source, driving, w=1.0, transform=None, ema=None, ema_decay=0.0):
+        """zero_grad -> forward/backward -> (all-reduce) -> Adam x2 -> (EMA).  With use_graph the returned loss / output tensors are the
+        graph's static buffers: they are overwritten by the next step."""
         import torch.distributed as dist
-        self.g.flat.zero_grad()
-        self.flat_m.zero_grad()
-        losses, out = self.forward_backward(source, driving, w, transform)
+        if self.use_graph and self._eager_steps >= self.GRAPH_WARMUP:
+            losses, out = self._graph_step(source, driving, w, transform)
+        else:
+            self._eager_steps += 1
+            self.g.flat.zero_grad()
+            self.flat_m.zero_grad()
+            losses, out = self.forward_backward(source, driving, w, transform)
         world = 1
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             world = dist.get_world_size()

@@ -200,3 +200,61 @@ def test_bf16_compute_step_within_the_references_own_autocast_distance():
     step.step(src, drv)
     torch.cuda.synchronize()
     assert torch.isfinite(step.g.flat.value).all() and torch.isfinite(step.flat_m.value).all()
+
+
+def test_hip_graph_replay_of_the_step_equals_eager_launches():
+    """`train.use_hip_graph`: zero_grad + forward + losses + tape backward captured once and replayed.  The replay must be the same
+    computation: at IDENTICAL parameters, losses and the two flat gradient buffers equal those of eager launches on the same inputs and
+    transform (to the run-to-run noise of the warp-backward atomics) -- for the batch it was captured on and for a second batch copied
+    into the static buffers -- and full steps through the graph keep training."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_clip
+    from synergize_motion_appearance_amd.trainer import TrainStep, EquivarianceTransform
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    train_opt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt", "kp_distance_opt")}
+    _, clip = synth_clip(8, seed=99)
+    batches = [(clip[[0, 1]].contiguous().cuda(), clip[[2, 3]].contiguous().cuda()), (clip[[4, 5]].contiguous().cuda(), clip[[6, 7]].contiguous().cuda()),
+               (clip[[1, 6]].contiguous().cuda(), clip[[3, 0]].contiguous().cuda())]
+    gen = torch.Generator().manual_seed(3)
+    tfs = [EquivarianceTransform(2, sigma_affine=0.05, sigma_tps=0.005, points_tps=5, generator=gen) for _ in batches]
+    net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+    net_g.load_state_dict(weights("network_g"), strict=True)
+    me.load_state_dict(weights("network_motion_estimator"), strict=True)
+    step = TrainStep(net_g.cuda(), me.cuda(), train_opt, use_graph=True)
+    for _ in range(step.GRAPH_WARMUP):                                      # eager steps (they also move the parameters off the init)
+        step.step(*batches[2], transform=tfs[2])
+    assert step._graph is None
+    bn = {k: v.clone() for k, v in step.bufs.items()}                       # BatchNorm running statistics move in the forward: rewind between runs
+
+    def rewind():
+        for k, v in step.bufs.items():
+            v.copy_(bn[k])
+
+    def eager(i):
+        rewind()
+        step.g.flat.zero_grad()
+        step.flat_m.zero_grad()
+        losses, _ = step.forward_backward(*batches[i], transform=tfs[i])
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in losses.items()}, step.g.flat.grad.clone(), step.flat_m.grad.clone()
+
+    def replay(i):
+        rewind()
+        losses, _ = step._graph_step(*batches[i], 1.0, tfs[i])
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in losses.items()}, step.g.flat.grad.clone(), step.flat_m.grad.clone()
+    for i in (0, 1, 0):                                                     # capture on batch 0, replay on batch 1 (new inputs + transform), and back
+        le, ge, me_ = eager(i)
+        lg, gg, mg = replay(i)
+        assert step._graph is not None
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 2e-6 * max(1.0, abs(le[k])), (i, k, le[k], lg[k])
+        for a, b, what in ((ge, gg, "net_g"), (me_, mg, "motion estimator")):
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (i, what, float((a - b).abs().max()), float(a.abs().max()))
+    before = step.g.flat.value.clone()
+    losses, _ = step.step(*batches[1], transform=tfs[1])                    # a full step through the replay: Adam moves the parameters
+    torch.cuda.synchronize()
+    assert torch.isfinite(step.g.flat.value).all() and float((step.g.flat.value - before).abs().max()) > 1e-5
+    with pytest.raises(Exception):
+        step.step(batches[0][0][:1], batches[0][1][:1])                     # another shape needs another TrainStep

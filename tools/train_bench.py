@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--graph", action="store_true", help="train.use_hip_graph: replay the captured step")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: convolution / Linear contractions on the bf16 MFMA (train.compute_dtype)")
     a = ap.parse_args()
     from basicsr.archs import build_network
@@ -30,10 +31,10 @@ def main():
     net_g, me = net_g.cuda(), me.cuda()
     topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt")}
     topt["compute_dtype"] = a.dtype
-    step = TrainStep(net_g, me, topt)
+    step = TrainStep(net_g, me, topt, use_graph=a.graph)
     _, clip = synth_clip(2 * a.batch, seed=321)
     src, drv = clip[:a.batch].contiguous().cuda(), clip[a.batch:].contiguous().cuda()
-    for _ in range(a.warmup):
+    for _ in range(a.warmup + (3 if a.graph else 0)):
         step.step(src, drv)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -41,7 +42,7 @@ def main():
         losses, _ = step.step(src, drv)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"what": f"train.yml generator + motion-estimator step (no VGG / GAN), compute {a.dtype}, 1 GPU", "batch": a.batch, "ms_per_step": round(1e3 * dt, 2),
+    print(json.dumps({"what": f"train.yml generator + motion-estimator step (no VGG / GAN), compute {a.dtype}{', hipGraph replay' if a.graph else ''}, 1 GPU", "batch": a.batch, "ms_per_step": round(1e3 * dt, 2),
                       "pairs_per_s": round(a.batch / dt, 2), "l_g_total": float(losses["l_g_total"]),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
 
