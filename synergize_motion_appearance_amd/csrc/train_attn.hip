@@ -145,8 +145,223 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(ABP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// d_head = 32 on the fp32 MFMA (v_mfma_f32_32x32x2_f32), same "swapped product" layout as the forward kernel (attention.hip): one
+// wave owns 32 queries (kernel Q) or 32 keys (kernel KV), whose q / dO (k / v) rows live in registers as MFMA B operands; the other
+// side streams through LDS in 32-row tiles (pitch 36: conflict-free ds_read_b128 A fragments, and the [row][d] tile read "down the
+// d axis" one dword per lane is the TRANSPOSED A operand of the second product -- no transpose pass).
+//   kernel Q :  S^T = K Q^T and dP^T = V dO^T are [keys x queries] accumulators (lane = one query, 16 keys): softmax statistics, P and
+//               dS are lane-local; dQ^T[d x queries] += K^T dS^T takes dS straight from those accumulator registers (the contraction
+//               runs over the keys in the order the C layout holds them).  Two sweeps over the keys: statistics, then gradients.
+//   kernel KV:  S = Q K^T and dP = dO V^T are [queries x keys] (lane = one key, 16 queries; the per-query {m, 1/l, D} come from the
+//               statistics kernel Q wrote);  dV^T[d x keys] += dO^T P,  dK^T[d x keys] += Q^T dS.
+// Scores are kept in log2 units (q pre-scaled by scale * log2 e, v_exp_f32): dS is the gradient w.r.t. the NATURAL score, so
+// dQ = scale * sum dS K and dK = ln2 * sum dS (q scale log2 e).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+
+__global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(ABP p) {
+  constexpr int DH = 32, TK = 32, KLD = DH + 4, KS = DH / 8;
+  __shared__ __attribute__((aligned(16))) float Ks[2][TK * KLD];
+  __shared__ __attribute__((aligned(16))) float Vs[2][TK * KLD];
+  __shared__ uint8_t Ms[2][TK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int E = p.H * DH;
+  const float* Q = p.q + (long long)b * p.q_bs + (long long)qrow * p.ldq + h * DH;
+  const float* G = p.d_o + ((long long)b * p.L + qrow) * E + h * DH;
+  const float* O = p.o + ((long long)b * p.L + qrow) * E + h * DH;
+  const float* K = p.k + (long long)b * p.k_bs + h * DH;
+  const float* V = p.v + (long long)b * p.v_bs + h * DH;
+  const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
+  float4 qf[KS], gf[KS];
+  float Di = 0.f;
+  const float sc = p.scale * LOG2E;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const float4 t = *reinterpret_cast<const float4*>(Q + kk * 8 + hh * 4);
+    qf[kk] = make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc);
+    gf[kk] = *reinterpret_cast<const float4*>(G + kk * 8 + hh * 4);
+    const float4 ov = *reinterpret_cast<const float4*>(O + kk * 8 + hh * 4);
+    Di += gf[kk].x * ov.x + gf[kk].y * ov.y + gf[kk].z * ov.z + gf[kk].w * ov.w;
+  }
+  Di += __shfl_xor(Di, 32, 64);
+
+  float4 kreg, vreg; uint8_t mreg = 0;
+  const int sr = threadIdx.x >> 3, sc4 = threadIdx.x & 7;           // staging: row, float4 column (32 rows x 8 float4 = 256 threads)
+  auto load_tile = [&](int key0, bool with_v) {
+    kreg = *reinterpret_cast<const float4*>(K + (long long)(key0 + sr) * p.ldk + sc4 * 4);
+    if (with_v) vreg = *reinterpret_cast<const float4*>(V + (long long)(key0 + sr) * p.ldv + sc4 * 4);
+    if (M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
+  };
+  auto store_tile = [&](int buf, bool with_v) {
+    *reinterpret_cast<float4*>(&Ks[buf][sr * KLD + sc4 * 4]) = kreg;
+    if (with_v) *reinterpret_cast<float4*>(&Vs[buf][sr * KLD + sc4 * 4]) = vreg;
+    if (threadIdx.x < TK) Ms[buf][threadIdx.x] = M ? mreg : 0;
+  };
+  auto scores = [&](const float* tile, const float4 (&bf)[KS]) {
+    f32x16 a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+    const float* kp = tile + (lane & 31) * KLD + hh * 4;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const float4 kf = *reinterpret_cast<const float4*>(kp + kk * 8);
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, bf[kk].x, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, bf[kk].y, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, bf[kk].z, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, bf[kk].w, a, 0, 0, 0);
+    }
+    return a;
+  };
+  const int ntiles = p.S / TK;
+  float m = -INFINITY, l = 0.f;
+  f32x16 dq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float il = pass ? 1.f / l : 0.f;
+    __syncthreads();                                      // the previous sweep's last tile is still being read
+    load_tile(0, pass); store_tile(0, pass);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < ntiles) load_tile((t + 1) * TK, pass);
+      f32x16 s = scores(Ks[buf], qf);
+      if (!pass) {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (Ms[buf][(r & 3) + 8 * (r >> 2) + 4 * hh]) s[r] = -INFINITY;
+          tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const bool dead = (m_new == -INFINITY);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psum += dead ? 0.f : __builtin_amdgcn_exp2f(s[r] - m_new);
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * (dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new)) + psum; m = m_new;
+      } else {
+        const f32x16 dp = scores(Vs[buf], gf);
+        const float* kt = &Ks[buf][lane & 31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const float pij = Ms[buf][key] ? 0.f : __builtin_amdgcn_exp2f(s[r] - m) * il;
+          const float ds = pij * (dp[r] - Di);
+          dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[key * KLD], ds, dq, 0, 0, 0);
+        }
+      }
+      if (t + 1 < ntiles) store_tile(buf ^ 1, pass);
+      __syncthreads();
+    }
+  }
+  float* DQ = p.dq + ((long long)b * p.L + qrow) * E + h * DH;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(DQ + 8 * g + 4 * hh) = make_float4(dq[4 * g] * p.scale, dq[4 * g + 1] * p.scale, dq[4 * g + 2] * p.scale, dq[4 * g + 3] * p.scale);
+  if (hh == 0) {
+    float* st = p.stats + (((long long)b * p.H + h) * p.L + qrow) * 3;
+    st[0] = m; st[1] = 1.f / l; st[2] = Di;               // m in log2 units (kernel KV uses the same scaling)
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(ABP p) {
+  constexpr int DH = 32, TQ = 32, KLD = DH + 4, KS = DH / 8;
+  __shared__ __attribute__((aligned(16))) float Qs[2][TQ * KLD];
+  __shared__ __attribute__((aligned(16))) float Gs[2][TQ * KLD];
+  __shared__ float St[2][TQ * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int krow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int E = p.H * DH;
+  const float* K = p.k + (long long)b * p.k_bs + (long long)krow * p.ldk + h * DH;
+  const float* V = p.v + (long long)b * p.v_bs + (long long)krow * p.ldv + h * DH;
+  const bool masked = p.mask && p.mask[(long long)b * p.S + krow];
+  float4 kf[KS], vf[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    kf[kk] = *reinterpret_cast<const float4*>(K + kk * 8 + hh * 4);
+    vf[kk] = *reinterpret_cast<const float4*>(V + kk * 8 + hh * 4);
+  }
+  const float* Qb = p.q + (long long)b * p.q_bs + h * DH;
+  const float* Gb = p.d_o + (long long)b * p.L * E + h * DH;
+  const float* Sb = p.stats + ((long long)b * p.H + h) * p.L * 3;
+  const float sc = p.scale * LOG2E;
+  float4 qreg, greg; float sreg = 0.f;
+  const int sr = threadIdx.x >> 3, sc4 = threadIdx.x & 7;
+  auto load_tile = [&](int q0) {
+    const float4 t = *reinterpret_cast<const float4*>(Qb + (long long)(q0 + sr) * p.ldq + sc4 * 4);
+    qreg = make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc);
+    greg = *reinterpret_cast<const float4*>(Gb + (long long)(q0 + sr) * E + sc4 * 4);
+    if (threadIdx.x < TQ * 3) sreg = Sb[(long long)q0 * 3 + threadIdx.x];
+  };
+  auto store_tile = [&](int buf) {
+    *reinterpret_cast<float4*>(&Qs[buf][sr * KLD + sc4 * 4]) = qreg;
+    *reinterpret_cast<float4*>(&Gs[buf][sr * KLD + sc4 * 4]) = greg;
+    if (threadIdx.x < TQ * 3) St[buf][threadIdx.x] = sreg;
+  };
+  auto scores = [&](const float* tile, const float4 (&bf)[KS]) {
+    f32x16 a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+    const float* ap = tile + (lane & 31) * KLD + hh * 4;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const float4 af = *reinterpret_cast<const float4*>(ap + kk * 8);
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[kk].x, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[kk].y, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[kk].z, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[kk].w, a, 0, 0, 0);
+    }
+    return a;
+  };
+  f32x16 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+  const int ntiles = p.L / TQ;
+  load_tile(0); store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile((t + 1) * TQ);
+    const f32x16 s = scores(Qs[buf], kf);                  // [queries x keys]: lane = key (lane & 31), row r = query (r&3) + 8 (r>>2) + 4 hh
+    const f32x16 dp = scores(Gs[buf], vf);
+    const float* qt = &Qs[buf][lane & 31];
+    const float* gt = &Gs[buf][lane & 31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float pij = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] - St[buf][qi * 3]) * St[buf][qi * 3 + 1];
+      const float ds = pij * (dp[r] - St[buf][qi * 3 + 2]);
+      dv = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[qi * KLD], pij, dv, 0, 0, 0);
+      dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qt[qi * KLD], ds, dk, 0, 0, 0);
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  float* DK = p.dk + ((long long)b * p.S + krow) * E + h * DH;
+  float* DV = p.dv + ((long long)b * p.S + krow) * E + h * DH;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    *reinterpret_cast<float4*>(DK + 8 * g + 4 * hh) = make_float4(dk[4 * g] * LN2, dk[4 * g + 1] * LN2, dk[4 * g + 2] * LN2, dk[4 * g + 3] * LN2);
+    *reinterpret_cast<float4*>(DV + 8 * g + 4 * hh) = make_float4(dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]);
+  }
+}
+
 template <int DH>
 int launch(ABP& p, int shared, hipStream_t st) {
+  if (DH == 32 && p.L % 128 == 0 && p.S % 128 == 0 && p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.q_bs % 4 == 0 && p.k_bs % 4 == 0 &&
+      p.v_bs % 4 == 0 && ((((uintptr_t)p.q) | ((uintptr_t)p.k) | ((uintptr_t)p.v) | ((uintptr_t)p.o) | ((uintptr_t)p.d_o) | ((uintptr_t)p.dq) |
+                            ((uintptr_t)p.dk) | ((uintptr_t)p.dv)) & 15) == 0 && smx_tune(SMX_TUNE_ATTN_BWD_MFMA)) {
+    SMX_LAUNCH(attn_bwd_q_mfma_kernel, dim3(p.L / 128, p.B * p.H), dim3(256), 0, st, p);
+    SMX_LAUNCH(attn_bwd_kv_mfma_kernel, dim3(p.S / 128, p.B * p.H), dim3(256), 0, st, p);
+    return smx_launch_status();
+  }
   SMX_LAUNCH(attn_bwd_q_kernel<DH>, dim3(smx_cdiv(p.L, 128), p.B * p.H), dim3(128), 0, st, p);
   (void)shared;
   SMX_LAUNCH(attn_bwd_kv_kernel<DH>, dim3(smx_cdiv(p.S, 128), p.B * p.H), dim3(128), 0, st, p);

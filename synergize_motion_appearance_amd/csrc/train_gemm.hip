@@ -206,8 +206,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
 //   layout 2: transposed      out[g][k * ldo + co]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long out_bs,
                                                            int nb, int msplit, int Cout, int K, int Cin, int khw, int layout, int ldo,
-                                                           int accumulate, float alpha) {
+                                                           int accumulate, float alpha, const float* __restrict__ bias_ws, float* __restrict__ bias_out) {
   const long long per = (long long)Cout * K, total = per * nb;
+  // the bias gradient rides in the same launch (it was a third launch of ~10 us per layer, 450 per step): the LAST block also sums
+  // the nb * msplit column-sum partials per channel, in a fixed order
+  if (bias_out && blockIdx.x == gridDim.x - 1) {
+    for (int c = threadIdx.x; c < Cout; c += 256) {
+      float t = 0.f;
+      for (int k = 0; k < nb * msplit; ++k) t += bias_ws[(long long)k * Cout + c];
+      t *= alpha;
+      bias_out[c] = accumulate ? bias_out[c] + t : t;
+    }
+  }
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int g = (int)(i / per); const long long j = i - (long long)g * per;
     const int co = (int)(j / K), k = (int)(j - (long long)co * K);
@@ -222,16 +232,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     float* d = out + (long long)g * out_bs + o;
     *d = accumulate ? *d + s : s;
   }
-}
-
-// bias[co] (+)= alpha * sum_{g,z} bias_ws[g][z][co]  (fixed order)
-__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bws, int n, int Cout, float* __restrict__ out, int accumulate, float alpha) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= Cout) return;
-  float s = 0.f;
-  for (int k = 0; k < n; ++k) s += bws[(long long)k * Cout + c];
-  s *= alpha;
-  out[c] = accumulate ? out[c] + s : s;
 }
 
 // ---- column sums: part[chunk][C] = sum over the chunk's rows; then out[c] (+)= sum_chunk part[chunk][c] (fixed order) ----
@@ -422,8 +422,7 @@ static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, cons
   if (bf16) SMX_LAUNCH(wgrad_kernel<true>, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
   else SMX_LAUNCH(wgrad_kernel<false>, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
   SMX_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long long)nb * Cout * p.K)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
-             Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha);
-  if (bias_out) SMX_LAUNCH(wgrad_bias_reduce_kernel, dim3(smx_cdiv(Cout, 256)), dim3(256), 0, st, p.bias_ws, nb * msplit, Cout, bias_out, accumulate, alpha);
+             Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha, p.bias_ws, bias_out);
   return smx_launch_status();
 }
 

@@ -203,8 +203,19 @@ def _mha_ref(q, k, v, H, dh, mask=None):
     return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, E)
 
 
-@pytest.mark.parametrize("dh,masked", [(32, False), (32, True), (4, False)])
-def test_self_attention_backward(T, dh, masked):
+@pytest.mark.parametrize("dh,masked,mfma", [(32, False, 1), (32, True, 1), (32, True, 0), (4, False, 1)])
+def test_self_attention_backward(T, dh, masked, mfma):
+    """d_head 32: the fp32-MFMA backward kernels (attn_bwd_q_mfma / attn_bwd_kv_mfma) and, with the knob off, the per-thread VALU
+    kernels they replaced (still the path for shapes off the 128-row grid); d_head 4: VALU."""
+    from synergize_motion_appearance_amd import lib as Lm
+    Lm.load().smx_set_tuning(b"attn_bwd_mfma", mfma)
+    try:
+        _self_attention_backward(T, dh, masked)
+    finally:
+        Lm.load().smx_set_tuning(b"attn_bwd_mfma", 1)
+
+
+def _self_attention_backward(T, dh, masked):
     B, H, Lq = 2, 8, 1024
     E = H * dh
     q, k, v = (rnd(f"sa{n}{dh}", (B, Lq, E)) for n in "qkv")
