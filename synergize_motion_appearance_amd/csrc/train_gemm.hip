@@ -29,8 +29,6 @@ namespace {
 
 inline int grid_for(long long total) { int g = smx_cdiv(total, 256); return g > 16384 ? 16384 : (g < 1 ? 1 : g); }
 
-constexpr int WPITCH = 68;     // LDS row pitch (floats): 8 * 68 = 544 = 8 * 64 + 32 -> rows p and p+8 sit in opposite bank halves
-
 struct WG {
   const float* dy; const float* x; float* ws; float* bias_ws;      // bias_ws [nb][msplit][Cout] (nullable): column sums of dy per pixel split
   long long dy_bs, x_bs;
@@ -38,30 +36,43 @@ struct WG {
   int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
   int is1x1, vec_x, vec_y;
   int msplit, mper, tiles_k;
+  int adv_y, adv_x;                                              // 32 pixels further along the row-major (oy, ox) walk: 32 / Wo rows and 32 % Wo columns
 };
 
+// Block tile TC (output channels) x TKT (k columns), 4 waves as 2 x 2, each wave (TC/2) x (TKT/2) = (TC/64) x (TKT/64) accumulators of 32 x 32.
+// Instantiated at 64 x 64 (124 / 128 VGPRs, 34 KB of LDS: four blocks per CU).  128 x 128 tiles (twice the flops per staged byte, half the
+// fragment reads per MFMA) were built and measured SLOWER on every layer of the step (two blocks per CU at 256 VGPRs: 38-54 TF against
+// 52-69): the kernel is bound by how many independent waves hide the gather latency, not by the L2 -> LDS stream.
+// LDS row pitch TC + 4 (TKT + 4): 8 * pitch = 32 mod 64, so rows p and p + 8 (the two half-waves of a fragment read) sit in opposite bank
+// halves and every fragment is one conflict-free ds_read_b32.
 // BF16: the same tiles, staged in fp32 as they are read, but contracted on v_mfma_f32_32x32x16_bf16 -- each lane rounds its 8 pixels of a
 // column to bf16 (RNE) on the way from LDS to the MFMA, fp32 accumulate: what torch.autocast(bfloat16) does to this GEMM (the bias
-// gradient keeps summing the unrounded dy).  2 MFMAs per 32-pixel slice instead of 16: the kernel turns LDS / load bound.
-template <bool BF16>
-__global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
-  __shared__ __attribute__((aligned(16))) float As[2][32 * WPITCH];
-  __shared__ __attribute__((aligned(16))) float Bs[2][32 * WPITCH];
+// gradient keeps summing the unrounded dy).  2 MFMAs per 32-pixel slice and accumulator instead of 16.
+template <bool BF16, int TC, int TKT>
+__global__ __launch_bounds__(256, 4) void wgrad_kernel(WG p) {
+  constexpr int PA = TC + 4, PB = TKT + 4;                 // LDS pitches
+  constexpr int CA4 = TC / 4, CB4 = TKT / 4;               // float4 columns per staged row
+  constexpr int RA = 256 / CA4, RB = 256 / CB4;            // rows covered per staging pass
+  constexpr int NA = 32 / RA, NB = 32 / RB;                // staging passes per 32-pixel slice
+  constexpr int AI = TC / 64, BJ = TKT / 64;               // accumulators per wave: AI x BJ
+  __shared__ __attribute__((aligned(16))) float As[2][32 * PA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][32 * PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile_k = blockIdx.x % p.tiles_k, tile_c = blockIdx.x / p.tiles_k;
-  const int co0 = tile_c * 64, k0 = tile_k * 64;
+  const int co0 = tile_c * TC, k0 = tile_k * TKT;
   const int g = blockIdx.y, z = blockIdx.z;
   const float* __restrict__ DY = p.dy + (long long)g * p.dy_bs;
   const float* __restrict__ X = p.x + (long long)g * p.x_bs;
   const int m_begin = z * p.mper, m_end = min(p.M, m_begin + p.mper);
 
-  // staging coordinates: float4 column c4 of rows r0 and r0 + 16
-  const int c4 = tid & 15, r0 = tid >> 4;
-  // this thread's B columns k0 + 4 c4 + e are fixed for the whole block: resolve (tap, channel) once
+  // staging coordinates: this thread's float4 column is fixed per operand; it covers rows ra0 + RA * i (A) and rb0 + RB * i (B)
+  const int ca4 = tid % CA4, ra0 = tid / CA4;
+  const int cb4 = tid % CB4, rb0 = tid / CB4;
+  // the B columns k0 + 4 cb4 + e are fixed for the whole block: resolve (tap, channel) once
   int b_ky[4], b_kx[4], b_cc[4]; bool b_in[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int k = k0 + c4 * 4 + e;
+    const int k = k0 + cb4 * 4 + e;
     b_in[e] = k < p.K;
     const int tap = b_in[e] ? k / p.Cin : 0;
     b_cc[e] = b_in[e] ? k - tap * p.Cin : 0; b_ky[e] = tap / p.kw; b_kx[e] = tap - b_ky[e] * p.kw;
@@ -69,16 +80,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
   const int HoWo = p.Ho * p.Wo;
   const int Hlim = p.up2 ? 2 * p.Hin : p.Hin, Wlim = p.up2 ? 2 * p.Win : p.Win;
 
-  float4 areg[2], breg[2];
+  // running output coordinates of this thread's NB staged rows (no integer division per slice: the address arithmetic of the gather was
+  // as expensive as the slice's MFMAs): one division when the block starts, then +32 pixels per slice along the (image, oy, ox) walk
+  int cy[NB], cx[NB]; long long cbase[NB];
+  const long long img_stride = (long long)p.Hin * p.Win * p.ldx;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int m = m_begin + rb0 + RB * i;
+    const int img = m / HoWo, rem = m - img * HoWo;
+    cy[i] = rem / p.Wo; cx[i] = rem - cy[i] * p.Wo; cbase[i] = (long long)img * img_stride;
+  }
+  // TWO register sets: the loads of slice s + 2 are issued while slice s is being multiplied (one slice of MFMAs, ~0.4 us, does not
+  // cover the latency of a gathered L2 / HBM load; with a single set every slice sat out the rest of it at the store)
+  float4 areg0[NA], breg0[NB], areg1[NA], breg1[NB];
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);            // bias gradient: this thread's 4 dy columns summed over its rows (tile_k == 0 blocks)
   const bool do_bias = p.bias_ws != nullptr && tile_k == 0;
-  auto load_slice = [&](int m0) {
+  auto load_slice = [&](int m0, float4 (&areg)[NA], float4 (&breg)[NB]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + r0 + 16 * i;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    for (int i = 0; i < NA; ++i) {
+      const int m = m0 + ra0 + RA * i;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < m_end) {
-        const int co = co0 + c4 * 4;
+        const int co = co0 + ca4 * 4;
         if (p.vec_y && co + 3 < p.Cout) {
           a = *reinterpret_cast<const float4*>(DY + (long long)m * p.ldy + co);
         } else {
@@ -87,8 +110,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
           for (int e = 0; e < 4; ++e) v[e] = (co + e < p.Cout) ? DY[(long long)m * p.ldy + co + e] : 0.f;
           a = make_float4(v[0], v[1], v[2], v[3]);
         }
+      }
+      areg[i] = a;
+      if (do_bias) { bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w; }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int m = m0 + rb0 + RB * i;
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < m_end) {
         if (p.is1x1) {
-          const int k = k0 + c4 * 4;
+          const int k = k0 + cb4 * 4;
           if (p.vec_x && k + 3 < p.K) {
             b = *reinterpret_cast<const float4*>(X + (long long)m * p.ldx + k);
           } else {
@@ -98,9 +130,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
             b = make_float4(v[0], v[1], v[2], v[3]);
           }
         } else {
-          const int img = m / HoWo, rem = m - img * HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-          const long long base = (long long)img * p.Hin * p.Win * p.ldx;
-          const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+          const long long base = cbase[i];
+          const int iy0 = cy[i] * p.stride - p.pad_t, ix0 = cx[i] * p.stride - p.pad_l;
           if (p.vec_x && b_in[3] && b_cc[3] == b_cc[0] + 3) {          // the four columns share one tap: one 16-B load
             int iy = iy0 + b_ky[0], ix = ix0 + b_kx[0];
             if (iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim) {
@@ -125,77 +156,120 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WG p) {
           }
         }
       }
-      areg[i] = a; breg[i] = b;
-      if (do_bias) { bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w; }
+      breg[i] = b;
+      if (!p.is1x1) {                                            // the walk to the same row of the next slice
+        cx[i] += p.adv_x; cy[i] += p.adv_y;
+        if (cx[i] >= p.Wo) { cx[i] -= p.Wo; ++cy[i]; }
+        while (cy[i] >= p.Ho) { cy[i] -= p.Ho; cbase[i] += img_stride; }
+      }
     }
   };
-  auto store_slice = [&](int buf) {
+  auto store_slice = [&](int buf, const float4 (&areg)[NA], const float4 (&breg)[NB]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4*>(&As[buf][(r0 + 16 * i) * WPITCH + c4 * 4]) = areg[i];
-      *reinterpret_cast<float4*>(&Bs[buf][(r0 + 16 * i) * WPITCH + c4 * 4]) = breg[i];
-    }
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(&As[buf][(ra0 + RA * i) * PA + ca4 * 4]) = areg[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[buf][(rb0 + RB * i) * PB + cb4 * 4]) = breg[i];
   };
 
-  f32x16 acc;
+  f32x16 acc[AI][BJ];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int wm = wave >> 1, wn = wave & 1;                 // wave tile: co rows 32 wm.., k columns 32 wn..
-  // fragment base: pixel (l >> 5) * 8 within a 16-pixel group, column (l & 31) of the wave's half
-  const int fa = (lane >> 5) * 8 * WPITCH + wm * 32 + (lane & 31);
-  const int fb = (lane >> 5) * 8 * WPITCH + wn * 32 + (lane & 31);
+  for (int i = 0; i < AI; ++i)
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int wm = wave >> 1, wn = wave & 1;                 // wave tile: co rows (TC/2) wm.., k columns (TKT/2) wn..
+  // fragment base: pixel (l >> 5) * 8 within a 16-pixel group, column (l & 31) of the wave's part
+  const int fa = (lane >> 5) * 8 * PA + wm * (TC / 2) + (lane & 31);
+  const int fb = (lane >> 5) * 8 * PB + wn * (TKT / 2) + (lane & 31);
 
   const int nslices = (m_end - m_begin + 31) / 32;
-  if (nslices > 0) {
-    load_slice(m_begin);
-    store_slice(0);
-    __syncthreads();
-    for (int s = 0; s < nslices; ++s) {
-      const int buf = s & 1;
-      if (s + 1 < nslices) load_slice(m_begin + (s + 1) * 32);      // in flight across this slice's MFMAs
-      const float* as = &As[buf][fa];
-      const float* bs = &Bs[buf][fb];
-      if constexpr (BF16) {
+  auto multiply = [&](int buf) {
+    const float* as = &As[buf][fa];
+    const float* bs = &Bs[buf][fb];
+    if constexpr (BF16) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                          // pixels 16 h + 0..7 (lanes 0-31) and 16 h + 8..15 (lanes 32-63)
-          float av[8], bv[8];
+      for (int h = 0; h < 2; ++h) {                          // pixels 16 h + 0..7 (lanes 0-31) and 16 h + 8..15 (lanes 32-63)
+        bf16x8 af[AI], bfr[BJ];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { av[j] = as[(16 * h + j) * WPITCH]; bv[j] = bs[(16 * h + j) * WPITCH]; }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pack8(av)), __builtin_bit_cast(bf16x8, pack8(bv)), acc, 0, 0, 0);
+        for (int i = 0; i < AI; ++i) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = as[(16 * h + j) * PA + 32 * i];
+          af[i] = __builtin_bit_cast(bf16x8, pack8(v));
         }
-      } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int prow = (j & 7) + 16 * (j >> 3);            // pixels prow (lanes 0-31) and prow + 8 (lanes 32-63)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[prow * WPITCH], bs[prow * WPITCH], acc, 0, 0, 0);
+        for (int jj = 0; jj < BJ; ++jj) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = bs[(16 * h + j) * PB + 32 * jj];
+          bfr[jj] = __builtin_bit_cast(bf16x8, pack8(v));
         }
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int jj = 0; jj < BJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jj], acc[i][jj], 0, 0, 0);
       }
-      if (s + 1 < nslices) store_slice(buf ^ 1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int prow = (j & 7) + 16 * (j >> 3);            // pixels prow (lanes 0-31) and prow + 8 (lanes 32-63)
+        float af[AI], bfr[BJ];
+#pragma unroll
+        for (int i = 0; i < AI; ++i) af[i] = as[prow * PA + 32 * i];
+#pragma unroll
+        for (int jj = 0; jj < BJ; ++jj) bfr[jj] = bs[prow * PB + 32 * jj];
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int jj = 0; jj < BJ; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[jj], acc[i][jj], 0, 0, 0);
+      }
+    }
+  };
+  if (nslices > 0) {
+    load_slice(m_begin, areg0, breg0);
+    store_slice(0, areg0, breg0);
+    if (nslices > 1) load_slice(m_begin + 32, areg0, breg0);        // slice 1 -> set 0, slice 2 -> set 1, slice 3 -> set 0, ...
+    __syncthreads();
+    for (int s = 0; s < nslices; s += 2) {
+      if (s + 2 < nslices) load_slice(m_begin + (s + 2) * 32, areg1, breg1);
+      multiply(0);
+      if (s + 1 < nslices) store_slice(1, areg0, breg0);
+      __syncthreads();
+      if (s + 1 >= nslices) break;
+      if (s + 3 < nslices) load_slice(m_begin + (s + 3) * 32, areg0, breg0);
+      multiply(1);
+      if (s + 2 < nslices) store_slice(0, areg1, breg1);
       __syncthreads();
     }
   }
   if (do_bias) {
-    // the dy tile streamed through this block anyway: its column sums are the bias gradient of this pixel split.  16 row-lanes
-    // (tid >> 4) hold partial sums of the same 4 columns: fixed-order LDS finish (the staging buffers are free now)
+    // the dy tile streamed through this block anyway: its column sums are the bias gradient of this pixel split.  RA row-lanes
+    // (tid / CA4) hold partial sums of the same 4 columns: fixed-order LDS finish (the staging buffers are free now)
     float* red = &As[0][0];
     __syncthreads();
-    *reinterpret_cast<float4*>(red + (r0 * 16 + c4) * 4) = bsum;
+    *reinterpret_cast<float4*>(red + (ra0 * CA4 + ca4) * 4) = bsum;
     __syncthreads();
-    if (tid < 64) {
-      const int col = tid;                                     // column co0 + col: float4 c4 = col >> 2, element col & 3
+    if (tid < TC) {
+      const int col = tid;                                     // column co0 + col: float4 ca4 = col >> 2, element col & 3
       float t = 0.f;
-      for (int r = 0; r < 16; ++r) t += red[(r * 16 + (col >> 2)) * 4 + (col & 3)];
+      for (int r = 0; r < RA; ++r) t += red[(r * CA4 + (col >> 2)) * 4 + (col & 3)];
       if (co0 + col < p.Cout) p.bias_ws[((long long)g * p.msplit + z) * p.Cout + co0 + col] = t;
     }
   }
   // raw partial tile -> ws[(g * msplit + z)][Cout][K]
   float* W = p.ws + ((long long)g * p.msplit + z) * p.Cout * p.K;
-  const int kcol = k0 + wn * 32 + (lane & 31);
-  if (kcol < p.K) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (co < p.Cout) W[(long long)co * p.K + kcol] = acc[r];
+  for (int jj = 0; jj < BJ; ++jj) {
+    const int kcol = k0 + wn * (TKT / 2) + 32 * jj + (lane & 31);
+    if (kcol < p.K) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + wm * (TC / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (co < p.Cout) W[(long long)co * p.K + kcol] = acc[i][jj][r];
+        }
     }
   }
 }
@@ -384,9 +458,12 @@ __global__ __launch_bounds__(256) void axpy_slice_kernel(const float* __restrict
 
 extern "C" int64_t smx_wgrad_ws_floats(int nb, int M, int Cout, int K, int* msplit_out) {
   if (nb <= 0 || M <= 0 || Cout <= 0 || K <= 0) return 0;
+  // 64 x 64 blocks, 4 resident per CU; at least 256 pixels per block, partial workspace <= 64 MB
   const long long tiles = (long long)smx_cdiv(Cout, 64) * smx_cdiv(K, 64) * nb;
-  // aim at >= 1024 blocks (4 per CU), at least 256 pixels per block, partial workspace <= 64 MB
-  long long ms = (1024 + tiles - 1) / tiles;
+  // ONE resident round: floor, not ceil -- 1026 blocks on 1024 slots run as two rounds, the second one with two blocks (measured: the
+  // 64 -> 64 @ 256^2 layer took 402 us with 114 splits of 9 tiles)
+  const long long slots = 1024;
+  long long ms = tiles >= slots ? 1 : slots / tiles;
   const long long max_by_m = (M + 255) / 256;
   if (ms > max_by_m) ms = max_by_m;
   const long long cap = (64LL << 20) / 4 / ((long long)nb * Cout * K);
@@ -415,12 +492,14 @@ static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, cons
   p.vec_y = (ldy % 4 == 0 && (((uintptr_t)dy) & 15) == 0 && dy_bs % 4 == 0) ? 1 : 0;
   p.msplit = msplit;
   p.mper = ((M + msplit - 1) / msplit + 31) / 32 * 32;
-  p.tiles_k = smx_cdiv(p.K, 64);
+  p.adv_y = 32 / Wo; p.adv_x = 32 % Wo;
   hipStream_t st = (hipStream_t)stream;
+  p.tiles_k = smx_cdiv(p.K, 64);
   const long long tiles = (long long)smx_cdiv(Cout, 64) * p.tiles_k;
   if (tiles > 2147483647LL) return SMX_EINVAL;
-  if (bf16) SMX_LAUNCH(wgrad_kernel<true>, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
-  else SMX_LAUNCH(wgrad_kernel<false>, dim3((unsigned)tiles, nb, msplit), dim3(256), 0, st, p);
+  const dim3 grid((unsigned)tiles, nb, msplit);
+  if (bf16) SMX_LAUNCH((wgrad_kernel<true, 64, 64>), grid, dim3(256), 0, st, p);
+  else SMX_LAUNCH((wgrad_kernel<false, 64, 64>), grid, dim3(256), 0, st, p);
   SMX_LAUNCH(wgrad_reduce_kernel, dim3(grid_for((long long)nb * Cout * p.K)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
              Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha, p.bias_ws, bias_out);
   return smx_launch_status();
