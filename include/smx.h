@@ -396,6 +396,8 @@ int smx_partial_reduce_f32(const float* part, int nchunk, int C, float* out, int
 /* parameter (OIHW, or Linear [out][in] with kh = kw = 1) -> mode 0: [Cout][(ky,kx,ci)] (forward operand);
  * mode 1: [Cin][(kh-1-ky, kw-1-kx, co)] (data-gradient operand) */
 int smx_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int kh, int kw, int mode, void* stream);
+/* the same packing, rounded to bfloat16 on the way out (the weight operand of the bf16-compute training mode) */
+int smx_pack_weight_bf16(const float* w_oihw, void* packed, int Cout, int Cin, int kh, int kw, int mode, void* stream);
 /* OIHW 3x3 parameter -> the fragment-ordered Winograd-domain weights smx_winograd_conv3x3_f32 reads (u: smx_winograd_u_floats(N, C)
  * floats incl. the prefetch pad): mode 0 forward (N = Cout, C = Cin), mode 1 data gradient (N = Cin, C = Cout, taps flipped) --
  * the training step's 3x3 forward and data-gradient convolutions run on the fused Winograd kernel with the current weights */

@@ -48,6 +48,51 @@ __global__ __launch_bounds__(256) void chan_pair_partial_kernel(const float* __r
   }
 }
 
+// float4 form of the pair sums: 16 lanes x 4 channels = a 64-channel column block (blockIdx.y), 16 rows in flight per block, rows split into
+// chunks along blockIdx.x -- the scalar kernel above ran P / 256 blocks of 4-byte loads (64 blocks for a 64 x 64 x B=4 hourglass level: 140 us
+// for 16 MB).  Same partial layout [chunk][C][2]: the finish kernels do not change.
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_pair_partial_v4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g, int ldg,
+                                                                   const float* __restrict__ y, int ldy, const float* __restrict__ mr,
+                                                                   long long P, int C, int rows_per_chunk, float* __restrict__ part) {
+  __shared__ float4 red[2][16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = (blockIdx.y * 16 + tx) * 4;
+  const long long r_begin = (long long)blockIdx.x * rows_per_chunk, r_end = min(P, r_begin + rows_per_chunk);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (c < C) {
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mu[e] = mr[2 * (c + e)]; rs[e] = mr[2 * (c + e) + 1]; }
+    }
+    for (long long r = r_begin + ty; r < r_end; r += 16) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+      if (MODE == 0) {
+        a.x += xv.x; a.y += xv.y; a.z += xv.z; a.w += xv.w;
+        b.x += xv.x * xv.x; b.y += xv.y * xv.y; b.z += xv.z * xv.z; b.w += xv.w * xv.w;
+      } else {
+        const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+        const float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + c);
+        const float d0 = yv.x > 0.f ? gv.x : 0.f, d1 = yv.y > 0.f ? gv.y : 0.f, d2 = yv.z > 0.f ? gv.z : 0.f, d3 = yv.w > 0.f ? gv.w : 0.f;
+        a.x += d0; a.y += d1; a.z += d2; a.w += d3;
+        b.x += d0 * (xv.x - mu[0]) * rs[0]; b.y += d1 * (xv.y - mu[1]) * rs[1]; b.z += d2 * (xv.z - mu[2]) * rs[2]; b.w += d3 * (xv.w - mu[3]) * rs[3];
+      }
+    }
+  }
+  red[0][ty][tx] = a; red[1][ty][tx] = b;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    for (int k = 0; k < 16; ++k) {                          // fixed order
+      const float4 u = red[0][k][tx], v = red[1][k][tx];
+      sa.x += u.x; sa.y += u.y; sa.z += u.z; sa.w += u.w; sb.x += v.x; sb.y += v.y; sb.z += v.z; sb.w += v.w;
+    }
+    float* o = part + ((long long)blockIdx.x * C + c) * 2;
+    o[0] = sa.x; o[1] = sb.x; o[2] = sa.y; o[3] = sb.y; o[4] = sa.z; o[5] = sb.z; o[6] = sa.w; o[7] = sb.w;
+  }
+}
+
 // BatchNorm statistics finish: mean, biased variance -> mr[c] = {mean, rstd}; running stats with momentum (unbiased variance), like
 // F.batch_norm(training=True)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nchunk, int C, long long n, float eps, float momentum,
@@ -324,16 +369,26 @@ __global__ __launch_bounds__(256) void tps_frame_kernel(const float* __restrict_
   }
 }
 
-static void chunks(long long P, long long* rows, long long* nchunk) {
-  *rows = 256; *nchunk = (P + *rows - 1) / *rows;
+// rows per chunk: enough (chunk, 64-channel column) blocks to fill the chip (~1024), 16..256 rows each, at most 1024 chunks (the finish
+// kernels walk them per channel)
+static void chunks(long long P, int C, long long* rows, long long* nchunk) {
+  const long long cols = (C + 63) / 64;
+  long long r = P * cols / 1024;
+  if (r < 16) r = 16;
+  if (r > 256) r = 256;
+  *rows = r; *nchunk = (P + r - 1) / r;
   if (*nchunk > 1024) { *rows = (P + 1023) / 1024; *nchunk = (P + *rows - 1) / *rows; }
+}
+
+static bool pair_v4(const float* x, int ldx, const float* g, int ldg, const float* y, int ldy, int C) {
+  return C % 4 == 0 && ldx % 4 == 0 && (!g || ldg % 4 == 0) && (!y || ldy % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)g) | ((uintptr_t)y)) & 15) == 0;
 }
 
 }  // namespace
 
 extern "C" int64_t smx_batchnorm_ws_floats(int64_t P, int C) {
   if (P <= 0 || C <= 0) return 0;
-  long long rows, nchunk; chunks(P, &rows, &nchunk);
+  long long rows, nchunk; chunks(P, C, &rows, &nchunk);
   return nchunk * C * 2 + 2 * (int64_t)C;
 }
 
@@ -343,10 +398,14 @@ extern "C" int smx_batchnorm_train_f32(const float* x, int ldx, float* y, int ld
                                        float* running_mean, float* running_var, int64_t P, int C, float eps, float momentum, int relu,
                                        float* ws, void* stream) {
   if (!x || !y || !gamma || !beta || !mr || !ws || P <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
-  long long rows, nchunk; chunks(P, &rows, &nchunk);
+  long long rows, nchunk; chunks(P, C, &rows, &nchunk);
   hipStream_t st = (hipStream_t)stream;
-  SMX_LAUNCH(chan_pair_partial_kernel<0>, dim3((unsigned)nchunk), dim3(256), 0, st, x, ldx, (const float*)nullptr, 0, (const float*)nullptr, 0,
-             (const float*)nullptr, (long long)P, C, (int)rows, ws);
+  if (pair_v4(x, ldx, nullptr, 0, nullptr, 0, C))
+    SMX_LAUNCH(chan_pair_partial_v4_kernel<0>, dim3((unsigned)nchunk, (C + 63) / 64), dim3(256), 0, st, x, ldx, (const float*)nullptr, 0, (const float*)nullptr, 0,
+               (const float*)nullptr, (long long)P, C, (int)rows, ws);
+  else
+    SMX_LAUNCH(chan_pair_partial_kernel<0>, dim3((unsigned)nchunk), dim3(256), 0, st, x, ldx, (const float*)nullptr, 0, (const float*)nullptr, 0,
+               (const float*)nullptr, (long long)P, C, (int)rows, ws);
   SMX_LAUNCH(bn_finalize_kernel, dim3(smx_cdiv(C, 256)), dim3(256), 0, st, ws, (int)nchunk, C, (long long)P, eps, momentum, mr, running_mean, running_var);
   SMX_LAUNCH(bn_relu_apply_kernel, dim3(grid_for((long long)P * C)), dim3(256), 0, st, x, ldx, y, ldy, mr, gamma, beta, (long long)P, C, relu);
   return smx_launch_status();
@@ -357,10 +416,13 @@ extern "C" int smx_batchnorm_train_bwd_f32(const float* x, int ldx, const float*
                                            const float* gamma, float* dx, int ldo, float* dgamma, float* dbeta, int64_t P, int C, float* ws,
                                            void* stream) {
   if (!x || !g || !y || !mr || !gamma || !dx || !dgamma || !dbeta || !ws || P <= 0 || C <= 0 || ldx < C || ldg < C || ldy < C || ldo < C) return SMX_EINVAL;
-  long long rows, nchunk; chunks(P, &rows, &nchunk);
+  long long rows, nchunk; chunks(P, C, &rows, &nchunk);
   hipStream_t st = (hipStream_t)stream;
   float* sums = ws + nchunk * C * 2;
-  SMX_LAUNCH(chan_pair_partial_kernel<1>, dim3((unsigned)nchunk), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, mr, (long long)P, C, (int)rows, ws);
+  if (pair_v4(x, ldx, g, ldg, y, ldy, C))
+    SMX_LAUNCH(chan_pair_partial_v4_kernel<1>, dim3((unsigned)nchunk, (C + 63) / 64), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, mr, (long long)P, C, (int)rows, ws);
+  else
+    SMX_LAUNCH(chan_pair_partial_kernel<1>, dim3((unsigned)nchunk), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, mr, (long long)P, C, (int)rows, ws);
   SMX_LAUNCH(bn_bwd_finalize_kernel, dim3(smx_cdiv(C, 256)), dim3(256), 0, st, ws, (int)nchunk, C, sums, dgamma, dbeta);
   SMX_LAUNCH(bn_relu_bwd_apply_kernel, dim3(grid_for((long long)P * C)), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, mr, sums, gamma, dx, ldo, (long long)P, C);
   return smx_launch_status();

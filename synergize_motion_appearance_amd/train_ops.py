@@ -68,6 +68,25 @@ def _packed(tp, ref, mode, cout, cin, kh, kw):
     return tp.packed[ck]
 
 
+def _packed16(tp, ref, mode, cout, cin, kh, kw):
+    """per-step cache of a packed weight rounded to bfloat16 (bf16-compute mode: pack and convert in one launch)."""
+    w, _, key = _param(tp, ref)
+    ck = (key, "bf16", mode)
+    if ck not in tp.packed:
+        wc = w if w.is_contiguous() else w.contiguous()
+        out = torch.empty((cout, kh * kw * cin) if mode == 0 else (cin, kh * kw * cout), device=w.device, dtype=torch.bfloat16)
+        L.check(tp.lib.smx_pack_weight_bf16(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, mode, _stream()), "pack_weight_bf16")
+        tp.packed[ck] = out
+    return tp.packed[ck]
+
+
+def _conv16(w16, bias, kh, kw, cin, cout):
+    """an ops.Conv that only carries the bf16 weight operand (what the mfma16 launch reads)."""
+    cv = Conv(None, bias, kh, kw, cin, cout)
+    cv._w16 = w16
+    return cv
+
+
 def _packed_u(tp, ref, mode, cout, cin):
     """per-step cache of the Winograd-domain weights of a 3x3 parameter (mode 0 forward, 1 data gradient)."""
     w, _, key = _param(tp, ref)
@@ -157,12 +176,16 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
         raise L.SmxError(f"train conv {w}: input has {Cin} channels, weight expects {cin}")
     if stride not in (1, 2) and kind == "conv":
         raise L.SmxError("train conv: stride 1 or 2")
-    wp = wv.contiguous() if kind == "patch" else _packed(tp, w, 0, cout, cin, kh, kw)      # the patch Linear is already [Cout][(p1 p2 c)]
-    cv = Conv(wp.view(cout, kh * kw * cin), None if bv is None else bv.contiguous(), kh, kw, cin, cout)
+    m16 = tp.mfma16
+    bc = None if bv is None else bv.contiguous()
+    if m16 and kind != "patch":
+        cv = _conv16(_packed16(tp, w, 0, cout, cin, kh, kw), bc, kh, kw, cin, cout)
+    else:
+        wp = wv.contiguous() if kind == "patch" else _packed(tp, w, 0, cout, cin, kh, kw)      # the patch Linear is already [Cout][(p1 p2 c)]
+        cv = Conv(wp.view(cout, kh * kw * cin), bc, kh, kw, cin, cout)
     pt, pl = (kh // 2, kw // 2) if pad is None else pad
     He, We = (2 * H, 2 * W) if up2 else (H, W)
     # bf16-compute mode: forward and data gradient through the bf16 implicit GEMM (fp32 tensors converted while staging, fp32 out)
-    m16 = tp.mfma16
     f16 = dict(mfma16=True, out_dtype=F32) if m16 else {}
     # the fused Winograd F(2x2,3x3) kernel takes this step's weights in its own packing (smx_pack_winograd_u_f32)
     wino3 = (not m16) and WINOGRAD_TRAIN and kind == "conv" and (kh, kw, stride, pt, pl) == (3, 3, 1, 1, 1) and He % 8 == 0 and We % 16 == 0
@@ -199,13 +222,15 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
         if not tp.needs(x):
             return
         # (the patch Linear is stored [Cout][(p1 p2 c)], not OIHW: its data-gradient operand is the plain transpose)
-        wt = _packed(tp, w, 1, cout, kh * kw * cin, 1, 1) if kind == "patch" else _packed(tp, w, 1, cout, cin, kh, kw)
+        pk = _packed16 if (m16 and stride == 1) else _packed        # (the stride-2 zero-insert gather has no bf16 form: fp32 operand)
+        mk = (lambda t, *dims: _conv16(t, None, *dims)) if (m16 and stride == 1) else (lambda t, *dims: Conv(t, None, *dims))
+        wt = pk(tp, w, 1, cout, kh * kw * cin, 1, 1) if kind == "patch" else pk(tp, w, 1, cout, cin, kh, kw)
         if kind == "patch":
-            dx = ops.conv(g2, Conv(wt.view(kh * kw * cin, cout), None, 1, 1, cout, kh * kw * cin), d2s=(kh, cin), direct=True, **f16)
+            dx = ops.conv(g2, mk(wt.view(kh * kw * cin, cout), 1, 1, cout, kh * kw * cin), d2s=(kh, cin), direct=True, **f16)
         elif kind == "unpatch":
-            dx = ops.conv(g2, Conv(wt.view(cin, cout), None, 1, 1, cout, cin), direct=True, **f16)
+            dx = ops.conv(g2, mk(wt.view(cin, cout), 1, 1, cout, cin), direct=True, **f16)
         elif stride == 1:
-            dcv = Conv(wt.view(cin, kh * kw * cout), None, kh, kw, cout, cin)
+            dcv = mk(wt.view(cin, kh * kw * cout), kh, kw, cout, cin)
             if wino3 and cout % 32 == 0:
                 dcv._u = _packed_u(tp, w, 1, cout, cin)
             dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=dcv._u is None, **f16)
