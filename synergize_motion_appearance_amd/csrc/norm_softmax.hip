@@ -256,14 +256,18 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
 __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                              float* __restrict__ coef, float* __restrict__ bc, int HW, int C, int groups, int nch) {
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
-  const int cpg = C / groups;
+  const int cpg = C / groups;                        // a power of two <= 32 (C a power of two <= 1024, 32 groups)
+  // lane = (channel j of the group, chunk slice kq): the 64 lanes walk the chunk partials interleaved and finish with a fixed butterfly --
+  // with one lane per channel a C = 64 layer kept 2 lanes busy for 256 sequential chunks (23 us per launch)
+  const int lane = threadIdx.x, j = lane & (cpg - 1), kq = lane / cpg, KQ = 64 / cpg;
+  const int c = g * cpg + j;
+  double a = 0.0, q = 0.0;
+  for (int k = kq; k < nch; k += KQ) { const float* pp = part + (((long long)b * nch + k) * C + c) * 2; a += pp[0]; q += pp[1]; }
+  for (int o = cpg; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
   double A = 0.0, Q = 0.0;
-  for (int j = threadIdx.x; j < cpg; j += 64) {
-    const int c = g * cpg + j;
-    double a = 0.0, q = 0.0;
-    for (int k = 0; k < nch; ++k) { const float* pp = part + (((long long)b * nch + k) * C + c) * 2; a += pp[0]; q += pp[1]; }
+  if (kq == 0) {
     bc[((long long)b * C + c) * 2] = (float)a; bc[((long long)b * C + c) * 2 + 1] = (float)q;
-    A += a * gamma[c]; Q += q * gamma[c];
+    A = a * gamma[c]; Q = q * gamma[c];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o, 64); Q += __shfl_xor(Q, o, 64); }
@@ -385,12 +389,21 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 
 
 // ws[blk][0:E] = dbeta partials, ws[blk][E:2E] = dgamma partials -> accumulate into dbeta / dgamma (fixed order over blocks)
+// 32 columns per block, 8 lanes per column walking the row blocks interleaved, fixed-order finish through LDS (one thread per column
+// walked all T / 16 row blocks alone: 60 us for 512 columns)
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ ws, int nblk, int E, float* __restrict__ dbeta, float* __restrict__ dgamma) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 2 * E) return;
+  __shared__ float red[8][32];
+  const int l = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + l;
   float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += ws[(long long)k * 2 * E + i];
-  if (i < E) dbeta[i] += s; else dgamma[i - E] += s;
+  if (i < 2 * E)
+    for (int k = q; k < nblk; k += 8) s += ws[(long long)k * 2 * E + i];
+  red[q][l] = s;
+  __syncthreads();
+  if (q == 0 && i < 2 * E) {
+    s = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + ((red[4][l] + red[5][l]) + (red[6][l] + red[7][l]));
+    if (i < E) dbeta[i] += s; else dgamma[i - E] += s;
+  }
 }
 
 }  // namespace
@@ -546,6 +559,7 @@ extern "C" int smx_groupnorm_bwd_f32(const float* x, int ldx, const float* dz, i
   if (!x || !dz || !ss || !mr || !gamma || !dx || !dgamma || !dbeta || !ws || B <= 0 || HW <= 0) return SMX_EINVAL;
   if (C < 4 || C > 1024 || (C & (C - 1)) != 0 || C % groups != 0 || ldx % 4 || ldz % 4 || ldo % 4 || ldx < C || ldz < C || ldo < C) return SMX_EINVAL;
   if ((((uintptr_t)x) | ((uintptr_t)dz) | ((uintptr_t)dx)) & 15) return SMX_EINVAL;
+  { const int cpg = C / groups; if (cpg > 64 || (cpg & (cpg - 1)) != 0) return SMX_EINVAL; }     // the finalize kernel's (channel, chunk slice) lane map
   hipStream_t st = (hipStream_t)stream;
   int ppc = HW / 64; if (ppc < 32) ppc = 32; if (ppc > 256) ppc = 256;
   const int nch = (HW + ppc - 1) / ppc;
@@ -573,7 +587,7 @@ extern "C" int smx_layernorm_bwd_f32(const float* x, const float* gamma, const f
   else if (E <= 256) SMX_LAUNCH(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), 0, st, x, gamma, gy, gypos, dx, ws, T, E, eps, 4);
   else SMX_LAUNCH(layernorm_bwd_kernel<8>, dim3(nblk), dim3(256), 0, st, x, gamma, gy, gypos, dx, ws, T, E, eps, 4);
   // ws rows are [dbeta(E) | dgamma(E)]: two strided column reductions in a fixed order
-  SMX_LAUNCH(ln_param_reduce_kernel, dim3(smx_cdiv(2 * E, 256)), dim3(256), 0, st, ws, nblk, E, dbeta, dgamma);
+  SMX_LAUNCH(ln_param_reduce_kernel, dim3(smx_cdiv(2 * E, 32)), dim3(256), 0, st, ws, nblk, E, dbeta, dgamma);
   if (dpos) {
     const long long per = (long long)npos * E;
     int blocks = smx_cdiv(per, 256); if (blocks > 4096) blocks = 4096;
