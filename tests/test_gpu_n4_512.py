@@ -98,3 +98,31 @@ def test_512_pipeline_batching_and_packed_state(nets512):
     x = ops.frames_u8_to_nchw(u8.cuda(), (512, 512))
     dev = driver.render_frames(st2, x, net_g, me, batch=2, want="uint8")
     assert tuple(host.shape) == (3, 512, 512, 3) and int((host.int() - dev.cpu().int()).abs().max()) <= 1
+
+
+def test_512_bf16_storage_within_the_oracles_own_autocast_error(nets512):
+    """configs[3] in bf16 (bf16 NHWC storage + bf16 MFMA, as configs[2] at 256): no 1e-3 claim is possible in bf16; the bar is the
+    error the 512 DEFINITION itself (the oracle) makes under CPU autocast(bfloat16) on the same inputs, x1.25 -- the rule the 256 path
+    is held to with the reference's autocast fixture (tests/test_gpu_bf16.py)."""
+    net_g, me, Pg, Pm = nets512
+    src, drv = synth_clip(3, seed=77, size=512)
+    s, d = src[None], drv[1:2]
+    with torch.no_grad():
+        kp_s_o, kp_d_o = O.kp_detector(Pm, s), O.kp_detector(Pm, d)
+        dm_o = O.dense_motion(Pm, s, kp_d_o, kp_s_o)
+        ref = O.netg_forward(Pg, s, dm_o)["out"]
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            auto = O.netg_forward(Pg, s, dm_o)["out"].float()
+    rmax, rmean = float((auto - ref).abs().max()), float((auto - ref).abs().mean())
+    net_g.set_compute_dtype("bf16")
+    me.set_compute_dtype("bf16")
+    try:
+        kp_s, kp_d = me.estimate_kp(s.cuda()), me.estimate_kp(d.cuda())
+        dm = me.estimate_motion_w_kp(kp_source=kp_s, kp_driving=kp_d, source_image=s.cuda())
+        out = net_g(s.cuda(), dm, w=1, inference=True)["out"].float().cpu()
+    finally:
+        net_g.set_compute_dtype("f32")
+        me.set_compute_dtype("f32")
+    emax, emean = float((out - ref).abs().max()), float((out - ref).abs().mean())
+    print(f"512 bf16: max {emax:.4f} mean {emean:.5f}   oracle under autocast: max {rmax:.4f} mean {rmean:.5f}")
+    assert emax <= 1.25 * rmax and emean <= 1.25 * rmean, (emax, emean, rmax, rmean)
