@@ -149,8 +149,9 @@ def init_distributed(rank, world, dev):
 
 def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=True):
     """BASELINE configs[4] on ONE GPU: the train.yml generator + motion-estimator step (forward of both networks in training mode,
-    L1 / codebook / equivariance losses, one backward through both on the HIP backward kernels, Adam per network on flat buffers, EMA)
-    on `batch` (source, driving) pairs.  No VGG / discriminator (SURVEY 8d config 5 allows that).  An extra key, never `value`."""
+    L1 / codebook / equivariance / multi-scale VGG19 perceptual losses, one backward through both on the HIP backward kernels, Adam per
+    network on flat buffers, EMA) on `batch` (source, driving) pairs.  No discriminator (active from iteration 5001 in the reference).
+    An extra key, never `value`."""
     from basicsr.archs import build_network
     from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
     from synergize_motion_appearance_amd.trainer import TrainStep
@@ -159,7 +160,8 @@ def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=Tr
     net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
     me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
     net_g, me = net_g.to(dev), me.to(dev)
-    topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt")}
+    topt = {k: v for k, v in cfg["train"].items() if k != "gan_opt"}
+    topt["perceptual_opt"] = dict(topt["perceptual_opt"], synthetic_vgg19=True)      # the ImageNet VGG19 weights are a download: synthetic ones of that layout
     topt["compute_dtype"] = compute_dtype
     step = TrainStep(net_g, me, topt, use_graph=use_graph)
     warmup += (step.GRAPH_WARMUP + 1) if use_graph else 0          # eager steps, then the capture
@@ -181,7 +183,8 @@ def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=Tr
                         "256x256, " +
                         ("fp32" if compute_dtype == "f32" else "bf16 compute (every convolution / Linear contraction, forward + data + weight gradient, on "
                          "v_mfma_f32_32x32x16_bf16 with operands rounded like torch.autocast(bfloat16); fp32 storage, normalisation, attention, optimiser)") +
-                        ", Adam per network + EMA inside the step; perceptual (VGG) and GAN terms not built (SURVEY 8d config 5)",
+                        ", losses: L1 pixel + codebook + motion reconstruction + equivariance + MultiScalePyramidPerceptualLoss (VGG19 layout with synthetic weights, "
+                        "on out and out_lr); Adam per network + EMA inside the step; GAN branch (from iteration 5001) not built",
             "value": round(batch / dt, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * dt, 2), "batch": batch, "steps": steps, "warmup": warmup,
             "dtype": compute_dtype, "launch": "hipGraph replay of zero_grad + forward + losses + backward (train.use_hip_graph); all-reduce / Adam / EMA outside"
             if use_graph else "eager launches", "l_g_total_last": round(total, 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

@@ -495,6 +495,18 @@ int smx_mask_deformation_bwd_f32(const float* mask_logits, int ldm, const float*
 int smx_tps_transform_frame_f32(const float* x, float* y, const float* theta, const float* control_points, const float* control_params,
                                 int ncp, int B, int C, int H, int W, void* stream);
 
+/* ---- perceptual loss pieces (csrc/train_percep.hip): MultiScalePyramidPerceptualLoss, losses/losses.py:293-387 ----
+ * AntiAliasInterpolation2d (:341-387) on NHWC: zero pad K/2, depthwise K x K Gaussian (one kernel w [K][K] for every channel), every
+ * `step`-th output kept (Ho = ceil(H / step)); and its adjoint. */
+int smx_antialias_nhwc_f32(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C, int K, int step, void* stream);
+int smx_antialias_nhwc_bwd_f32(const float* gy, int ldg, const float* w, float* dx, int ldx, int B, int H, int W, int C, int K, int step, void* stream);
+/* 2 x 2 / stride-2 max pooling of the VGG19 feature stack (torchvision cfg "E"; archs/vgg_arch.py:167-210) and its backward: the gradient
+ * goes to the first maximum of the window in scan order; x is the pooling INPUT. */
+int smx_maxpool2_f32(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, void* stream);
+int smx_maxpool2_bwd_f32(const float* x, int ldx, const float* gy, int ldg, float* dx, int ldo, int B, int H, int W, int C, void* stream);
+/* y[p][c] = x[p][c] * scale[c] + shift[c] (shift may be NULL): the (x - mean) / std input normalisation (vgg_arch.py:203) and its backward */
+int smx_chan_affine_f32(const float* x, int ldx, const float* scale, const float* shift, float* y, int ldy, int64_t P, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,11 @@ SIGNATURES = {
     "smx_partial_reduce_f32": (_i, [_p, _i, _i, _p, _i, _f, _p]),
     "smx_pack_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "smx_pack_weight_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_antialias_nhwc_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_antialias_nhwc_bwd_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_maxpool2_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_maxpool2_bwd_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "smx_chan_affine_f32": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _p]),
     "smx_winograd_u_floats": (_i64, [_i, _i]),
     "smx_pack_winograd_u_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "smx_transpose_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _p]),

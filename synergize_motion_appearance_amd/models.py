@@ -104,16 +104,21 @@ class AppMotionCompModel:
     def init_training_settings(self):
         from .trainer import TrainStep, FlatParams
         train_opt = self.opt["train"]
-        missing = [k for k in ("perceptual_opt",) if train_opt.get(k)]
+        # perceptual_opt (MultiScalePyramidPerceptualLoss) is built when it can get its VGG19 weights (perceptual_opt.vgg19_path, or
+        # synthetic_vgg19 for benchmark runs); without them: an error, or -- train.allow_missing_losses: true -- a declared skip
+        po = train_opt.get("perceptual_opt")
+        has_vgg = bool(po) and bool(dict(po).get("vgg19_path") or dict(po).get("synthetic_vgg19"))
+        missing = ["perceptual_opt"] if (po and not has_vgg) else []
         if missing and not train_opt.get("allow_missing_losses", False):
-            raise NotImplementedError(f"train.{missing[0]} (MultiScalePyramidPerceptualLoss) needs the torchvision VGG19 weights the reference "
-                                      "downloads (archs/vgg_arch.py:173); set train.allow_missing_losses: true to train without that term")
+            raise NotImplementedError("train.perceptual_opt (MultiScalePyramidPerceptualLoss) needs the torchvision VGG19 weights the reference "
+                                      "downloads (archs/vgg_arch.py:173): set perceptual_opt.vgg19_path, or train.allow_missing_losses: true to train "
+                                      "without that term")
         self.skipped_losses = missing
         self.ema_decay = float(train_opt.get("ema_decay", 0) or 0)
         me = self._ensure_motion_estimator()
         self.net_g.train()
         me.train()
-        self.train_step = TrainStep(self.net_g, me, {k: v for k, v in train_opt.items() if k not in ("perceptual_opt", "gan_opt")})
+        self.train_step = TrainStep(self.net_g, me, {k: v for k, v in train_opt.items() if k != "gan_opt" and (k != "perceptual_opt" or has_vgg)})
         self.net_g_ema, self._ema_flat = None, None
         if self.ema_decay > 0:
             self.net_g_ema = build_network(self.opt["network_g"]).to(self.device).eval()

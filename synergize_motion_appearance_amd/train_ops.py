@@ -36,7 +36,7 @@ def _param(tp, ref):
     if isinstance(ref, tuple):
         name, sl = ref
         return tp.P[name][sl], tp.G[name][sl], (name, sl.start, sl.stop)
-    return tp.P[ref], tp.G[ref], (ref, None, None)
+    return tp.P[ref], tp.G.get(ref), (ref, None, None)       # no gradient slot: a frozen parameter (the VGG19 of the perceptual loss)
 
 
 def leaf(tp, name):
@@ -146,7 +146,7 @@ def transpose(tp, x, nb, R, Cc):
 
 
 # ---- convolution / Linear -------------------------------------------------------------------------------------------------
-def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None, kind="conv", patch=None):
+def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None, kind="conv", patch=None, frozen=False):
     """y = act(conv(x) + bias) (+ res).  kind:
       "conv":    parameter [Cout,Cin,kh,kw] (or Linear [out,in] = 1x1); stride 1, or the stride-2 / pad (0,1,0,1) Downsample form;
       "patch":   Linear [Cout, p*p*C] applied as a p x p / stride-p convolution (patchify + Linear, patch=(p, C));
@@ -211,8 +211,10 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
         else:
             g2 = g if g.is_contiguous() else _dense(lib, g)
         M = B * Ho * Wo
-        # weight gradient (+ the bias gradient out of the same pass over g)
-        if kind == "patch":
+        # weight gradient (+ the bias gradient out of the same pass over g); frozen: a fixed feature extractor, data gradient only
+        if frozen:
+            pass
+        elif kind == "patch":
             _wgrad(tp, g2, x, wg, M=M, cout=cout, Hin=H, Win=W, cin=cin, Ho=Ho, Wo=Wo, kh=kh, kw=kw, stride=stride, pt=0, pl=0,
                    layout=1, ldo=kh * kw * cin, dy_ld=cout, bias_out=bg, mfma16_ok=True)
         else:
@@ -784,3 +786,64 @@ def mask_deformation(tp, mlog, sparse, K1):
         tp.acc(sparse, ds)
     tp.record(bwd)
     return deform, occ
+
+
+# ---- perceptual-loss pieces (csrc/train_percep.hip; reference losses/losses.py:293-387, archs/vgg_arch.py:167-210) -----------------------
+def antialias(tp, x, w, step):
+    """AntiAliasInterpolation2d on NHWC: zero pad K/2, depthwise Gaussian w [K,K] (device tensor, the same for every channel), every
+    `step`-th output."""
+    B, H, W, Cc = x.shape
+    K = w.shape[-1]
+    Ho, Wo = (H + step - 1) // step, (W + step - 1) // step
+    y = _empty((B, Ho, Wo, Cc), x)
+    xp, ldx, _, _ = _pix(x)
+    L.check(tp.lib.smx_antialias_nhwc_f32(xp, ldx, w.data_ptr(), y.data_ptr(), Cc, B, H, W, Cc, K, step, _stream()), "antialias_nhwc")
+
+    def bwd():
+        g = tp.take(y)
+        if g is None or not tp.needs(x):
+            return
+        g = g if g.is_contiguous() else _dense(tp.lib, g)
+        dx = _empty((B, H, W, Cc), x)
+        L.check(tp.lib.smx_antialias_nhwc_bwd_f32(g.data_ptr(), Cc, w.data_ptr(), dx.data_ptr(), Cc, B, H, W, Cc, K, step, _stream()), "antialias_nhwc_bwd")
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y
+
+
+def maxpool2(tp, x):
+    """2 x 2 / stride-2 max pooling (nn.MaxPool2d(2, 2) of the VGG19 feature stack)."""
+    B, H, W, Cc = x.shape
+    xd = x if x.is_contiguous() else _dense(tp.lib, x)
+    y = _empty((B, H // 2, W // 2, Cc), x)
+    L.check(tp.lib.smx_maxpool2_f32(xd.data_ptr(), Cc, y.data_ptr(), Cc, B, H, W, Cc, _stream()), "maxpool2")
+
+    def bwd():
+        g = tp.take(y)
+        if g is None or not tp.needs(x):
+            return
+        g = g if g.is_contiguous() else _dense(tp.lib, g)
+        dx = _empty((B, H, W, Cc), x)
+        L.check(tp.lib.smx_maxpool2_bwd_f32(xd.data_ptr(), Cc, g.data_ptr(), Cc, dx.data_ptr(), Cc, B, H, W, Cc, _stream()), "maxpool2_bwd")
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y
+
+
+def chan_affine(tp, x, scale, shift):
+    """y = x * scale[c] + shift[c] (fixed per-channel constants: the VGG input normalisation)."""
+    B, H, W, Cc = x.shape
+    y = _empty((B, H, W, Cc), x)
+    xp, ldx, P, _ = _pix(x)
+    L.check(tp.lib.smx_chan_affine_f32(xp, ldx, scale.data_ptr(), shift.data_ptr(), y.data_ptr(), Cc, P, Cc, _stream()), "chan_affine")
+
+    def bwd():
+        g = tp.take(y)
+        if g is None or not tp.needs(x):
+            return
+        g = g if g.is_contiguous() else _dense(tp.lib, g)
+        dx = _empty((B, H, W, Cc), x)
+        L.check(tp.lib.smx_chan_affine_f32(g.data_ptr(), Cc, scale.data_ptr(), None, dx.data_ptr(), Cc, P, Cc, _stream()), "chan_affine_bwd")
+        tp.acc(x, dx)
+    tp.record(bwd)
+    return y

@@ -282,6 +282,31 @@ class TrainStep:
         self.wd_m = float(om.get("weight_decay", 0))
         self.P = {**self.g.flat.P, **self.flat_m.P}
         self.G = {**self.g.flat.G, **self.flat_m.G}
+        self.percep = self._build_perceptual(self.opt.get("perceptual_opt"), next(net_g.parameters()).device)
+        if self.percep is not None:
+            self.P.update(self.percep.P)                      # frozen: values only, no gradient slots
+
+    @staticmethod
+    def _build_perceptual(po, device):
+        """`train.perceptual_opt` (MultiScalePyramidPerceptualLoss, models/appmotioncomp_model.py:170, 319-322, 374-377).  The VGG19 ImageNet
+        weights are a download the reference does at construction (archs/vgg_arch.py:173): here they come from `perceptual_opt.vgg19_path`
+        (a torch-saved state dict, torchvision `features.N.*` or reference `sliceK.N.*` keys), or -- benchmarks and tests only --
+        `perceptual_opt.synthetic_vgg19: true` (name-keyed synthetic weights).  Neither: a loud error, never a silent skip."""
+        if not po:
+            return None
+        from .perceptual import PerceptualLoss, synthetic_vgg19_state
+        po = dict(po)
+        if po.get("type", "MultiScalePyramidPerceptualLoss") != "MultiScalePyramidPerceptualLoss":
+            raise NotImplementedError(f"perceptual_opt.type {po.get('type')}: only MultiScalePyramidPerceptualLoss has a HIP plan")
+        if po.get("vgg19_path"):
+            state = torch.load(po["vgg19_path"], map_location="cpu")
+            state = state.get("state_dict", state) if isinstance(state, dict) else state
+        elif po.get("synthetic_vgg19"):
+            state = synthetic_vgg19_state()
+        else:
+            raise RuntimeError("train.perceptual_opt needs the torchvision VGG19 weights (the reference downloads them): set "
+                               "perceptual_opt.vgg19_path to a saved vgg19 state dict, or perceptual_opt.synthetic_vgg19: true for a benchmark run")
+        return PerceptualLoss(state, scales=po.get("scales", [1, 0.5, 0.25, 0.125]), loss_weights=po.get("loss_weights", [1.0] * 5), device=device)
 
     def forward_backward(self, source, driving, w=1.0, transform=None):
         g = self.g
@@ -312,9 +337,13 @@ class TrainStep:
                 tgt = tp.stop(T.scaled(tp, ops.flow_to_residual(st["flows"][i]), 1.0 / 31.5))
                 recs.append((T.l1_loss(tp, T.scale(tp, rec, 1.0 / 31.5), tgt, wr), 1.0))
             add("l_g_motion_codebook_recon", T.weighted_sum(tp, recs))
+        if self.percep is not None:
+            add("l_g_percep", self.percep(tp, st["out"], gt))
         lrw = (o.get("lr_pixel_perceptual_opt") or {}).get("loss_weight", [])
         if len(lrw) > 0 and o.get("pixel_opt"):
             add("l_g_pix_lr_0", T.l1_loss(tp, st["out_lr"], gt, g._w(o, "pixel_opt", 1.0) * float(lrw[0])))
+        if len(lrw) > 0 and self.percep is not None:
+            add("l_g_percep_lr_0", self.percep(tp, st["out_lr"], gt, float(lrw[0])))
         wa = g._w(o, "app_codebook_code_opt", 1.0)
         if wa > 0:
             add("l_g_app_codebook_code", T.weighted_sum(tp, [(l, wa) for l in st["app"][1]]))
