@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void chan_pair_partial_kernel(const float* __r
       for (long long r = r_begin + ty; r < r_end; r += rpar) {
         const float xv = x[r * ldx + c];
         if (MODE == 0) { a += xv; b += xv * xv; }
-        else { const float d = y[r * ldy + c] > 0.f ? g[r * ldg + c] : 0.f; a += d; b += d * (xv - mu) * rs; }
+        else { const float d = (!y || y[r * ldy + c] > 0.f) ? g[r * ldg + c] : 0.f; a += d; b += d * (xv - mu) * rs; }   // y null: no ReLU behind the BatchNorm
       }
     }
     __syncthreads();
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void chan_pair_partial_v4_kernel(const float* 
         a.x += xv.x; a.y += xv.y; a.z += xv.z; a.w += xv.w;
         b.x += xv.x * xv.x; b.y += xv.y * xv.y; b.z += xv.z * xv.z; b.w += xv.w * xv.w;
       } else {
-        const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+        const float4 yv = y ? *reinterpret_cast<const float4*>(y + r * ldy + c) : make_float4(1.f, 1.f, 1.f, 1.f);   // y null: no ReLU gate
         const float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + c);
         const float d0 = yv.x > 0.f ? gv.x : 0.f, d1 = yv.y > 0.f ? gv.y : 0.f, d2 = yv.z > 0.f ? gv.z : 0.f, d3 = yv.w > 0.f ? gv.w : 0.f;
         a.x += d0; a.y += d1; a.z += d2; a.w += d3;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
   const float inv_n = 1.f / (float)P;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C; const int c = (int)(i - r * C);
-    const float d = y[r * ldy + c] > 0.f ? g[r * ldg + c] : 0.f;
+    const float d = (!y || y[r * ldy + c] > 0.f) ? g[r * ldg + c] : 0.f;
     const float xh = (x[r * ldx + c] - mr[2 * c]) * mr[2 * c + 1];
     dx[r * ldo + c] = mr[2 * c + 1] * gamma[c] * (d - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
   }
@@ -411,11 +411,11 @@ extern "C" int smx_batchnorm_train_f32(const float* x, int ldx, float* y, int ld
   return smx_launch_status();
 }
 
-/* backward of y = relu(BN_train(x)) (relu: y > 0 gates g): dx; dgamma / dbeta ACCUMULATED.  ws: smx_batchnorm_ws_floats(P, C) */
+/* backward of y = relu(BN_train(x)) (relu: y > 0 gates g; y NULL: plain BatchNorm, no gate): dx; dgamma / dbeta ACCUMULATED.  ws: smx_batchnorm_ws_floats(P, C) */
 extern "C" int smx_batchnorm_train_bwd_f32(const float* x, int ldx, const float* g, int ldg, const float* y, int ldy, const float* mr,
                                            const float* gamma, float* dx, int ldo, float* dgamma, float* dbeta, int64_t P, int C, float* ws,
                                            void* stream) {
-  if (!x || !g || !y || !mr || !gamma || !dx || !dgamma || !dbeta || !ws || P <= 0 || C <= 0 || ldx < C || ldg < C || ldy < C || ldo < C) return SMX_EINVAL;
+  if (!x || !g || !mr || !gamma || !dx || !dgamma || !dbeta || !ws || P <= 0 || C <= 0 || ldx < C || ldg < C || (y && ldy < C) || ldo < C) return SMX_EINVAL;
   long long rows, nchunk; chunks(P, C, &rows, &nchunk);
   hipStream_t st = (hipStream_t)stream;
   float* sums = ws + nchunk * C * 2;

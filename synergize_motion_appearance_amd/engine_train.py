@@ -91,8 +91,12 @@ class NetGTrainEngine:
                 break
         return feats, x
 
-    def _generator(self, tp, x, hook=None):
+    def _generator(self, tp, x, hook=None, last_in=None):
+        """last_in: a list that receives the INPUT of the last block (generator.blocks[-1], the image head): the adaptive GAN weight
+        needs the gradient of two losses w.r.t. that layer's weight (models/appmotioncomp_model.py:222-228, 334-335)."""
         for i, kind in enumerate(self.gen_kinds):
+            if last_in is not None and i == len(self.gen_kinds) - 1:
+                last_in.append(x)
             x = self._block(tp, kind, f"generator.blocks.{i}", x)
             if hook is not None:
                 x = hook(i, x)
@@ -238,7 +242,9 @@ class NetGTrainEngine:
                 enc = self._one_scale(tp, st, feats[s], s)
                 t = self._fuse(tp, s, enc, t, w)
             return t
-        st["out"] = self._generator(tp, lq, fuse)
+        last_in = []
+        st["out"] = self._generator(tp, lq, fuse, last_in)
+        st["out_last_in"] = last_in[0]
         st["out_lr"] = self._generator(tp, lq)                   # x_lr_32: every generator block, no fusion (:649-659)
         if gt_nchw is not None:
             st["app"] = self.app_codebook_loss(tp, gt_nchw)

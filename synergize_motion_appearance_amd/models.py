@@ -10,11 +10,12 @@ one keypoint / dense-motion / generator launch sequence per `val.batch` frames, 
 encoded once per video.
 
 Training members (row N2, BASELINE configs[4]; `appmotioncomp_model.py:116-434, 598-605`): `init_training_settings`,
-`optimize_parameters`, `model_ema`, `update_learning_rate`, `save` drive `trainer.TrainStep` -- the generator + motion-estimator
-half of the reference step as HIP kernels with a gradient tape, Adam per network on flat parameter buffers, gradients summed over
-`torch.distributed` (RCCL) when it is initialised.  Terms that need networks the reference downloads are NOT silently dropped:
-`perceptual_opt` (VGG19) raises unless `train.allow_missing_losses` is true, and the discriminator branch (active from
-`net_d_start_iter`, 5001 in the shipped yml) raises when reached."""
+`optimize_parameters`, `model_ema`, `update_learning_rate`, `save` drive `trainer.TrainStep` -- the reference step (generator + motion
+estimator, and past `net_d_start_iter` the hinge-GAN branch with its adaptive weight and the discriminator's own update) as HIP kernels
+with a gradient tape, Adam per network on flat parameter buffers, gradients summed over `torch.distributed` (RCCL) when it is
+initialised.  The term that needs weights the reference downloads is NOT silently dropped: `perceptual_opt` (VGG19) raises unless
+`perceptual_opt.vgg19_path` is given or `train.allow_missing_losses` declares the skip -- and the GAN branch, whose adaptive weight is
+measured against the perceptual loss, raises when reached without it."""
 from collections import OrderedDict
 from copy import deepcopy
 from os import path as osp
@@ -118,7 +119,16 @@ class AppMotionCompModel:
         me = self._ensure_motion_estimator()
         self.net_g.train()
         me.train()
-        self.train_step = TrainStep(self.net_g, me, {k: v for k, v in train_opt.items() if k != "gan_opt" and (k != "perceptual_opt" or has_vgg)})
+        # the discriminator (appmotioncomp_model.py:137-160): built when the yml has network_d and train.gan_opt; its branch switches on past
+        # net_d_start_iter (adaptive weight = perceptual + pixel vs GAN gradient: it needs the perceptual term like the reference does)
+        self.net_d = None
+        if self.opt.get("network_d") and train_opt.get("gan_opt"):
+            self.net_d = build_network(self.opt["network_d"]).to(self.device)
+            path = self.opt.get("path", {})
+            if path.get("pretrain_network_d") is not None:
+                self.load_network(self.net_d, path["pretrain_network_d"], path.get("strict_load_d", True), "params_d")
+            self.net_d.train()
+        self.train_step = TrainStep(self.net_g, me, {k: v for k, v in train_opt.items() if (k != "perceptual_opt" or has_vgg)}, net_d=self.net_d)
         self.net_g_ema, self._ema_flat = None, None
         if self.ema_decay > 0:
             self.net_g_ema = build_network(self.opt["network_g"]).to(self.device).eval()
@@ -160,15 +170,17 @@ class AppMotionCompModel:
         -> optimizer_g.step(), optimizer_m.step() -> EMA; then `reduce_loss_dict`."""
         if not self.is_train:
             raise RuntimeError("optimize_parameters needs opt['is_train'] = True")
-        if current_iter > self.net_d_start_iter:
-            raise NotImplementedError("the discriminator branch (hinge GAN + adaptive weight, appmotioncomp_model.py:322-340, 408-432) starts at "
-                                      f"net_d_start_iter = {self.net_d_start_iter}: VQGANDiscriminator has no backward on the HIP path")
+        gan = current_iter > self.net_d_start_iter
+        if gan and (self.net_d is None or self.train_step.percep is None):
+            raise RuntimeError(f"iteration {current_iter} is past net_d_start_iter = {self.net_d_start_iter}: the GAN branch (appmotioncomp_model.py:324-345, "
+                               "408-432) needs network_d + train.gan_opt and the perceptual loss its adaptive weight is measured against "
+                               "(perceptual_opt.vgg19_path)")
         loss_dict = OrderedDict()
         if current_iter % self.net_d_iters == 0 and current_iter > self.net_g_start_iter:
-            losses, self.out_dict = self.train_step.step(self.source, self.gt, w=1.0)
+            losses, self.out_dict = self.train_step.step(self.source, self.gt, w=1.0, gan=gan)
             self.dense_motion = {k: self.out_dict[k] for k in ("deformation", "occlusion_map", "kp_driving", "kp_source")}
             for k, v in losses.items():
-                if k != "l_g_total":
+                if k != "l_g_total" and not k.startswith("_"):
                     loss_dict[k] = v.detach().reshape(())
         if self.ema_decay > 0:
             self.model_ema(decay=self.ema_decay)
@@ -391,9 +403,11 @@ class AppMotionCompModel:
         return self.metric_results
 
     def save(self, epoch, current_iter):
-        """appmotioncomp_model.py:598-605 (net_d and the optimizer state file are the discriminator / harness side: not written)."""
+        """appmotioncomp_model.py:598-605 (the optimizer / scheduler state file is the harness side: not written)."""
         if self.ema_decay > 0:
             self.save_network([self.net_g, self.net_g_ema], "net_g", current_iter, param_key=["params", "params_ema"])
         else:
             self.save_network(self.net_g, "net_g", current_iter)
         self.save_network(self.motion_estimator, "net_motion_estimator", current_iter)
+        if getattr(self, "net_d", None) is not None:
+            self.save_network(self.net_d, "net_d", current_iter)

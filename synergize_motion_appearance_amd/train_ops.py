@@ -663,9 +663,8 @@ def weighted_sum(tp, terms):
 # ---- motion estimator (training mode) ---------------------------------------------------------------------------------------------
 def bn_relu(tp, x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, relu=True):
     """relu(BatchNorm2d(x)) with BATCH statistics (utils/motion_estimator_util.py:214-231, 363-380 under .train()); the running
-    buffers (tensors, updated in place like F.batch_norm(training=True)) are optional."""
-    if not relu:
-        raise L.SmxError("bn_relu: the backward kernel gates on y > 0 (every BatchNorm of the hourglass is followed by a ReLU)")
+    buffers (tensors, updated in place like F.batch_norm(training=True)) are optional.  relu=False: the plain BatchNorm2d of the
+    discriminator (archs/vqgan_arch.py:546-559; its LeakyReLU is a separate `act`)."""
     gv, gg, _ = _param(tp, gamma)
     bv, bg, _ = _param(tp, beta)
     lib = tp.lib
@@ -684,7 +683,7 @@ def bn_relu(tp, x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, m
             return
         g = g if g.is_contiguous() else _dense(lib, g)
         dx = _empty(x.shape, x)
-        L.check(lib.smx_batchnorm_train_bwd_f32(xp, ldx, g.data_ptr(), Cc, y.data_ptr(), Cc, mr.data_ptr(), gv.data_ptr(), dx.data_ptr(), Cc,
+        L.check(lib.smx_batchnorm_train_bwd_f32(xp, ldx, g.data_ptr(), Cc, y.data_ptr() if relu else None, Cc, mr.data_ptr(), gv.data_ptr(), dx.data_ptr(), Cc,
                                                 gg.data_ptr(), bg.data_ptr(), P, Cc, ws.data_ptr(), _stream()), "batchnorm_train_bwd")
         tp.acc(x, dx)
     tp.record(bwd)
@@ -847,3 +846,21 @@ def chan_affine(tp, x, scale, shift):
         tp.acc(x, dx)
     tp.record(bwd)
     return y
+
+
+def torch_scalar(tp, x, fn):
+    """a scalar loss of a SMALL tensor written with torch ops (the hinge terms over a B x 30 x 30 discriminator map): value [1] on the tape,
+    gradient by torch.autograd over that one expression (a few elementwise kernels on the launch stream; capturable in the step's hipGraph)."""
+    leaf = x.detach().clone().requires_grad_()
+    with torch.enable_grad():
+        val = fn(leaf).reshape(1)
+    out = val.detach()
+
+    def bwd():
+        g = tp.take(out)
+        if g is None or not tp.needs(x):
+            return
+        (gx,) = torch.autograd.grad(val, leaf, g.reshape(1))
+        tp.acc(x, gx.contiguous())
+    tp.record(bwd)
+    return out

@@ -259,7 +259,7 @@ class TrainStep:
     motion_estimator(gt, source) in training mode -> net_g(source, dense_motion, w=1, gt=gt) -> losses -> ONE backward through both
     networks -> Adam on each (optim_g / optim_motion) -> EMA of net_g.  One tape spans both networks (their parameter names are disjoint)."""
 
-    def __init__(self, net_g, motion_estimator, train_opt, compute_dtype=None, use_graph=None):
+    def __init__(self, net_g, motion_estimator, train_opt, compute_dtype=None, use_graph=None, net_d=None):
         """use_graph (yml `train.use_hip_graph`): capture zero_grad + forward + losses + tape backward of one step in a hipGraph after
         `GRAPH_WARMUP` eager steps and replay it from then on (inputs and the equivariance transform's random parameters are copied
         into static buffers; all-reduce, Adam and EMA stay outside: they carry the step counter).  The step is launch-bound at the
@@ -282,6 +282,24 @@ class TrainStep:
         self.wd_m = float(om.get("weight_decay", 0))
         self.P = {**self.g.flat.P, **self.flat_m.P}
         self.G = {**self.g.flat.G, **self.flat_m.G}
+        # the discriminator side of optimize_parameters (models/appmotioncomp_model.py:324-345, 408-432): hinge GAN with the adaptive weight,
+        # active in `step(..., gan=True)` (the model turns it on past net_d_start_iter)
+        self.net_d, self.flat_d = net_d, None
+        if net_d is not None:
+            self.flat_d = FlatParams(net_d)
+            net_d.refresh()
+            self.d_plan, self.d_bufs = net_d._plan, dict(net_d.named_buffers())
+            od = dict(self.opt.get("optim_d") or {})
+            od.pop("type", None)
+            self.lr_d, self.betas_d, self.wd_d = float(od.get("lr", 8e-5)), tuple(od.get("betas", (0.9, 0.99))), float(od.get("weight_decay", 0))
+            self.P_d = {"net_d." + n: v for n, v in self.flat_d.P.items()}
+            self.G_d = {"net_d." + n: v for n, v in self.flat_d.G.items()}
+            self.P.update(self.P_d)
+            self.G.update(self.G_d)                           # written by the generator step's pass through net_d, zeroed before the discriminator step
+            go = dict(self.opt.get("gan_opt") or {})
+            if go.get("gan_type", "hinge") != "hinge":
+                raise NotImplementedError(f"gan_opt.gan_type {go.get('gan_type')}: the shipped train.yml uses hinge; only that has a HIP plan")
+            self.gan_scale = float(self.opt.get("scale_adaptive_gan_weight", 0.8))
         self.percep = self._build_perceptual(self.opt.get("perceptual_opt"), next(net_g.parameters()).device)
         if self.percep is not None:
             self.P.update(self.percep.P)                      # frozen: values only, no gradient slots
@@ -308,8 +326,26 @@ class TrainStep:
                                "perceptual_opt.vgg19_path to a saved vgg19 state dict, or perceptual_opt.synthetic_vgg19: true for a benchmark run")
         return PerceptualLoss(state, scales=po.get("scales", [1, 0.5, 0.25, 0.125]), loss_weights=po.get("loss_weights", [1.0] * 5), device=device)
 
-    def forward_backward(self, source, driving, w=1.0, transform=None):
+    def _disc(self, tp, x):
+        """VQGANDiscriminator.forward in train mode (archs/vqgan_arch.py:536-575): conv4x4 / LeakyReLU(0.2) / BatchNorm on BATCH statistics
+        (running buffers updated like nn.BatchNorm2d, num_batches_tracked counted).  x NHWC -> logit map [B,h,w,1]."""
+        from .lib import ACT_LRELU02, ACT_NONE
+        h = x
+        for k, (i, _, _, stride, has_bias, has_bn) in enumerate(self.d_plan):
+            oh, ow = (h.shape[1] + 2 - 4) // stride + 1, (h.shape[2] + 2 - 4) // stride + 1
+            fused = ACT_LRELU02 if (not has_bn and k != len(self.d_plan) - 1) else ACT_NONE
+            h = T.conv(tp, h, f"net_d.main.{i}.weight", f"net_d.main.{i}.bias" if has_bias else None, stride=stride, pad=(1, 1), out_hw=(oh, ow), act=fused)
+            if has_bn:
+                bn = f"main.{i + 1}"
+                h = T.bn_relu(tp, h, f"net_d.{bn}.weight", f"net_d.{bn}.bias", self.d_bufs[bn + ".running_mean"], self.d_bufs[bn + ".running_var"], relu=False)
+                self.d_bufs[bn + ".num_batches_tracked"].add_(1)
+                h = T.act(tp, h, ACT_LRELU02)
+        return h
+
+    def forward_backward(self, source, driving, w=1.0, transform=None, gan=False):
         g = self.g
+        if gan and self.flat_d is None:
+            raise RuntimeError("TrainStep(gan=True) needs net_d (the discriminator network) at construction")
         tp = Tape(self.P, self.G, mfma16=self.g.mfma16)
         src, drv = source.float().contiguous(), driving.float().contiguous()
         B = drv.shape[0]
@@ -325,8 +361,34 @@ class TrainStep:
         def add(name, t, weight=1.0):
             losses[name] = t
             terms.append((t, weight))
+        out_r, gan_state = st["out"], {}
+        if gan:
+            # adaptive GAN weight (:222-228, :334-343): d_weight = clamp(|d recon / dW| / (|d gan / dW| + 1e-4), 0, 1) * 0.8 with W the weight of the
+            # generator's last convolution and recon = perceptual + pixel loss.  Both reach W only through `out`, so the reconstruction losses
+            # read one alias of `out`, the discriminator another, and the node below -- recorded BEFORE their consumers, hence run AFTER them
+            # in the backward -- holds the two gradients apart, takes the two weight gradients of the last layer (one TN GEMM each),
+            # forms d_weight on the device and hands `out` d recon + d_weight * d gan
+            out_full = st["out"]
+            out_r, out_g = out_full.view(out_full.shape), out_full.view(out_full.shape)
+            last_in = st["out_last_in"]
+
+            def split():
+                gr, gg = tp.take(out_r), tp.take(out_g)
+                Bq, Hq, Wq, Cq = out_full.shape
+                norms = []
+                for gpart in (gr, gg):
+                    wgt = torch.empty((Cq, last_in.shape[-1], 3, 3), device=out_full.device, dtype=torch.float32)
+                    gd = gpart if gpart.is_contiguous() else gpart.contiguous()
+                    T._wgrad(tp, gd, last_in, wgt, M=Bq * Hq * Wq, cout=Cq, Hin=Hq, Win=Wq, cin=last_in.shape[-1], Ho=Hq, Wo=Wq, kh=3, kw=3,
+                             stride=1, pt=1, pl=1, layout=0, dy_ld=Cq, accumulate=False)
+                    norms.append(wgt.norm())
+                dw = (norms[0] / (norms[1] + 1e-4)).clamp(0.0, 1.0) * self.gan_scale
+                gan_state["d_weight"] = dw.reshape(1)
+                gan_state["norms"] = (norms[0].reshape(1), norms[1].reshape(1))
+                tp.acc(out_full, gr + dw * gg)
+            tp.record(split)
         if o.get("pixel_opt"):
-            add("l_g_pix", T.l1_loss(tp, st["out"], gt, g._w(o, "pixel_opt", 1.0)))
+            add("l_g_pix", T.l1_loss(tp, out_r, gt, g._w(o, "pixel_opt", 1.0)))
         wc = g._w(o, "motion_codebook_code_opt", 1.0)
         if wc:
             add("l_g_motion_codebook_code", T.weighted_sum(tp, [(l, wc) for l in st["train"]["loss_motion"]]))
@@ -338,7 +400,11 @@ class TrainStep:
                 recs.append((T.l1_loss(tp, T.scale(tp, rec, 1.0 / 31.5), tgt, wr), 1.0))
             add("l_g_motion_codebook_recon", T.weighted_sum(tp, recs))
         if self.percep is not None:
-            add("l_g_percep", self.percep(tp, st["out"], gt))
+            add("l_g_percep", self.percep(tp, out_r, gt))
+        if gan:
+            fake_pred = self._disc(tp, out_g)
+            l_gan = T.torch_scalar(tp, fake_pred, lambda p: -p.mean())     # GANLoss hinge, generator side (losses/losses.py:446-449)
+            terms.append((l_gan, 1.0))                                        # its gradient is scaled by d_weight in `split`
         lrw = (o.get("lr_pixel_perceptual_opt") or {}).get("loss_weight", [])
         if len(lrw) > 0 and o.get("pixel_opt"):
             add("l_g_pix_lr_0", T.l1_loss(tp, st["out_lr"], gt, g._w(o, "pixel_opt", 1.0) * float(lrw[0])))
@@ -369,15 +435,36 @@ class TrainStep:
         if o.get("kp_distance_opt"):
             losses["l_kpd"] = kp_distance_value(kp_d[0], kp_s[0], o["kp_distance_opt"].get("loss_weight", 1.0)).view(1)
             total_val = total_val + losses["l_kpd"]
-        losses["l_g_total"] = total_val
         tp.acc(total, torch.ones(1, device=total.device))
         tp.backward()
+        if gan:                                                # d_weight exists once the backward has passed `out`; the weighted sum above counted l_gan once
+            dw = gan_state["d_weight"]
+            losses["d_weight"], losses["l_g_gan"] = dw, dw * l_gan
+            losses["_recon_grad_norm"], losses["_gan_grad_norm"] = gan_state["norms"]     # the two last-layer gradient norms behind d_weight
+            total_val = total_val + (dw - 1.0) * l_gan
+        losses["l_g_total"] = total_val
         out = {"out": ops.nhwc_to_nchw(st["out"]), "out_lr": [ops.nhwc_to_nchw(st["out_lr"])], "deformation_list": st["flows"],
                "kp_driving": {"value": kp_d[0], "jacobian": kp_d[1]}, "kp_source": {"value": kp_s[0], "jacobian": kp_s[1]},
-               "deformation": deform, "occlusion_map": occ.view(B, 1, 64, 64), "driving_kp_heatmap_nhwc": heat}
+               "deformation": deform, "occlusion_map": occ.view(B, 1, 64, 64), "driving_kp_heatmap_nhwc": heat,
+               "_out_nhwc": st["out"], "_gt_nhwc": gt}
         if eq:
             out["kp_transformed"] = {"value": kp_t[0], "jacobian": kp_t[1]}
         return losses, out
+
+    def disc_backward(self, out_nhwc, gt_nhwc):
+        """the discriminator half (:408-430): hinge losses of net_d on the real frames and on the DETACHED generated ones (two passes: BatchNorm
+        sees each batch on its own), gradients accumulated into net_d's flat buffer (zero it first).  -> loss dict"""
+        tp = Tape(self.P_d, self.G_d, mfma16=self.g.mfma16)
+        real, fake = tp.stop(gt_nhwc), tp.stop(out_nhwc.detach())
+        pr = self._disc(tp, real)
+        l_real = T.torch_scalar(tp, pr, lambda p: torch.relu(1.0 - p).mean())
+        pf = self._disc(tp, fake)
+        l_fake = T.torch_scalar(tp, pf, lambda p: torch.relu(1.0 + p).mean())
+        one = torch.ones(1, device=out_nhwc.device)
+        tp.acc(l_real, one)
+        tp.acc(l_fake, one.clone())
+        tp.backward()
+        return {"l_d_real": l_real, "out_d_real": pr.mean().reshape(1), "l_d_fake": l_fake, "out_d_fake": pf.mean().reshape(1)}
 
     GRAPH_WARMUP = 2
 
@@ -385,10 +472,12 @@ class TrainStep:
         eq = self.opt.get("equivariance_opt")
         return EquivarianceTransform(B, **dict(eq.get("transform_params", {})), device=dev) if eq else None
 
-    def _graph_step(self, source, driving, w, transform):
+    def _graph_step(self, source, driving, w, transform, gan=False):
         """replay (capturing first) the hipGraph of zero_grad + forward_backward for this input shape."""
         st = self._static
-        key = (tuple(source.shape), tuple(driving.shape), float(w))
+        key = (tuple(source.shape), tuple(driving.shape), float(w), bool(gan))
+        if st is not None and st["key"][:3] == key[:3] and st["key"] != key:       # the GAN branch switched on (net_d_start_iter): capture anew
+            self._graph, self._static, st = None, None, None
         if st is not None and st["key"] != key:
             raise L.SmxError(f"TrainStep(use_graph): the captured step is for {st['key']}, got {key}; build another TrainStep for another shape")
         tf_new = transform if transform is not None else self._draw_transform(driving.shape[0], driving.device)
@@ -398,7 +487,7 @@ class TrainStep:
             with torch.cuda.graph(g):
                 self.g.flat.zero_grad()
                 self.flat_m.zero_grad()
-                st["losses"], st["out"] = self.forward_backward(st["src"], st["drv"], w, st["tf"])
+                st["losses"], st["out"] = self.forward_backward(st["src"], st["drv"], w, st["tf"], gan)
             self._graph, self._static = g, st
         else:
             st["src"].copy_(source)
@@ -410,17 +499,17 @@ class TrainStep:
         self._graph.replay()
         return st["losses"], st["out"]
 
-    def step(self, source, driving, w=1.0, transform=None, ema=None, ema_decay=0.0):
+    def step(self, source, driving, w=1.0, transform=None, ema=None, ema_decay=0.0, gan=False):
         """zero_grad -> forward/backward -> (all-reduce) -> Adam x2 -> (EMA).  With use_graph the returned loss / output tensors are the
         graph's static buffers: they are overwritten by the next step."""
         import torch.distributed as dist
         if self.use_graph and self._eager_steps >= self.GRAPH_WARMUP:
-            losses, out = self._graph_step(source, driving, w, transform)
+            losses, out = self._graph_step(source, driving, w, transform, gan)
         else:
             self._eager_steps += 1
             self.g.flat.zero_grad()
             self.flat_m.zero_grad()
-            losses, out = self.forward_backward(source, driving, w, transform)
+            losses, out = self.forward_backward(source, driving, w, transform, gan)
         world = 1
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             world = dist.get_world_size()
@@ -430,4 +519,10 @@ class TrainStep:
         self.flat_m.adam_step(self.lr_m, self.betas_m, 1e-8, self.wd_m, gscale=1.0 / world)
         if ema is not None and ema_decay > 0:
             self.g.flat.ema_into(ema, ema_decay)
+        if gan:                                                # optimize net_d (:408-430), after the generator / estimator update and the EMA
+            self.flat_d.zero_grad()
+            losses = dict(losses, **self.disc_backward(out["_out_nhwc"], out["_gt_nhwc"]))
+            if world > 1:
+                self.flat_d.all_reduce(dist)
+            self.flat_d.adam_step(self.lr_d, self.betas_d, 1e-8, self.wd_d, gscale=1.0 / world)
         return losses, out

@@ -106,7 +106,8 @@ def test_full_step_runs_and_updates_both_networks(run):
 
 def test_model_level_optimize_parameters(tmp_path):
     """`build_model(opt)` with is_train: feed_data -> optimize_parameters(current_iter) -> log dict / EMA / checkpoint files, the way
-    train.py:178-215 drives the reference model; perceptual_opt raises unless allow_missing_losses, the GAN branch raises when reached."""
+    train.py:178-215 drives the reference model; perceptual_opt raises unless it gets VGG19 weights or allow_missing_losses declares the skip;
+    the GAN branch (past net_d_start_iter) raises without the perceptual term and runs with it."""
     from synergize_motion_appearance_amd.models import build_model
     from synergize_motion_appearance_amd.synth import synth_clip
     cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
@@ -144,8 +145,27 @@ def test_model_level_optimize_parameters(tmp_path):
     assert os.path.exists(str(tmp_path / "models" / "net_motion_estimator_1.pth"))
     model.test()                                                                                     # validation forward on the updated weights
     assert torch.isfinite(model.out_dict["out"]).all()
-    with pytest.raises(NotImplementedError, match="discriminator"):
+    assert os.path.exists(str(tmp_path / "models" / "net_d_1.pth"))
+    with pytest.raises(RuntimeError, match="net_d_start_iter"):                                      # adaptive weight needs the perceptual term
         model.optimize_parameters(5002)
+    # with the perceptual loss (synthetic VGG19 weights: the real ones are a download) the branch past net_d_start_iter runs: GAN terms logged,
+    # the discriminator moves
+    cfg2 = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    cfg2.update(is_train=True, dist=False, rank=0, world_size=1, num_gpu=1)
+    cfg2["path"] = dict(cfg2["path"], models=str(tmp_path / "models2"))
+    cfg2["train"]["perceptual_opt"]["synthetic_vgg19"] = True
+    m2 = build_model(cfg2)
+    from synergize_motion_appearance_amd.synth import synth_state_dict
+    m2.net_g.load_state_dict(weights("network_g"), strict=True)
+    m2.motion_estimator.load_state_dict(weights("network_motion_estimator"), strict=True)
+    m2.net_d.load_state_dict(synth_state_dict([(k, tuple(v.shape)) for k, v in m2.net_d.state_dict().items()]), strict=True)
+    m2.feed_data({"source": clip[[0, 5]], "driving": clip[[3, 7]]})
+    d0 = m2.net_d.state_dict()["main.0.weight"].clone()
+    m2.optimize_parameters(5002)
+    log2 = m2.get_current_log()
+    for k in ("l_g_percep", "l_g_percep_lr_0", "l_g_gan", "d_weight", "l_d_real", "l_d_fake", "out_d_real", "out_d_fake"):
+        assert k in log2 and np.isfinite(log2[k]), k
+    assert 0.0 <= log2["d_weight"] <= 0.8 + 1e-6 and float((m2.net_d.state_dict()["main.0.weight"] - d0).abs().max()) > 1e-6
 
 
 def test_bf16_compute_step_within_the_references_own_autocast_distance():
@@ -300,3 +320,68 @@ def test_full_step_with_the_perceptual_loss_vs_reference():
         assert not bad, (tag, len(bad), bad[:10])
     with pytest.raises(RuntimeError):                                       # no weights, no silent skip
         TrainStep(net_g, me, dict(train_opt, perceptual_opt=dict(cfg["train"]["perceptual_opt"])))
+
+
+def test_full_step_with_the_gan_branch_vs_reference():
+    """optimize_parameters past net_d_start_iter (models/appmotioncomp_model.py:324-345, 408-432): the generator step with the hinge GAN term
+    through VQGANDiscriminator in train mode and the ADAPTIVE weight (ratio of the two gradient norms w.r.t. the generator's last layer,
+    clamped, x 0.8), then the discriminator's own hinge step -- against the reference's own step (tests/golden/train_step_gan.npz,
+    make_golden_r3.py train_step_gan): every loss term, d_weight and the two norms behind it, every gradient norm of net_g (472), the motion
+    estimator (88) and net_d (16), and net_d's BatchNorm running statistics after its three forward passes."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_clip, synth_state_dict
+    from synergize_motion_appearance_amd.trainer import TrainStep, EquivarianceTransform
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    net_g, me, net_d = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"]), build_network(cfg["network_d"])
+    net_g.load_state_dict(weights("network_g"), strict=True)
+    me.load_state_dict(weights("network_motion_estimator"), strict=True)
+    net_d.load_state_dict(synth_state_dict([(k, tuple(v.shape)) for k, v in net_d.state_dict().items()]), strict=True)
+    g0, g = golden("train_step_full.npz"), golden("train_step_gan.npz")
+    _, clip = synth_clip(8, seed=int(g0["clip_seed"]))
+    src, drv = clip[g0["src_frames"].tolist()].contiguous().cuda(), clip[g0["drv_frames"].tolist()].contiguous().cuda()
+    train_opt = {k: v for k, v in cfg["train"].items() if k not in ("kp_distance_opt",)}
+    train_opt["perceptual_opt"] = dict(train_opt["perceptual_opt"], synthetic_vgg19=True)
+    step = TrainStep(net_g.cuda(), me.cuda(), train_opt, net_d=net_d.cuda())
+    tf = EquivarianceTransform(2, theta=torch.from_numpy(g["theta"]), control_params=torch.from_numpy(g["control_params"]))
+    step.g.flat.zero_grad()
+    step.flat_m.zero_grad()
+    losses, out = step.forward_backward(src, drv, transform=tf, gan=True)
+    torch.cuda.synchronize()
+    for k in [f[5:] for f in g.files if f.startswith("loss_") and not f.startswith("loss_l_d_")]:
+        ref = float(g["loss_" + k])
+        assert abs(float(losses[k]) - ref) < 3e-4 * abs(ref) + 1e-6, (k, float(losses[k]), ref)
+    assert abs(float(losses["l_g_total"]) - float(g["l_g_total"])) < 3e-4 * float(g["l_g_total"])
+    assert abs(float(losses["d_weight"]) - float(g["d_weight"])) < 1e-5
+    assert abs(float(losses["_recon_grad_norm"]) - float(g["recon_grad_norm"])) < 3e-3 * float(g["recon_grad_norm"])
+    assert abs(float(losses["_gan_grad_norm"]) - float(g["gan_grad_norm"])) < 3e-3 * float(g["gan_grad_norm"])
+    for tag, G in (("me", step.flat_m.G), ("g", step.g.flat.G)):
+        names = [str(n) for n in g[f"{tag}_param_names"]]
+        ref = g[f"{tag}_grad_norms"]
+        mine = np.array([float(G[n].double().norm()) for n in names])
+        floor = 1e-6 * ref.max()
+        bad = [(n, a, b) for n, a, b in zip(names, mine, ref) if abs(a - b) > 6e-3 * b + floor]
+        assert not bad, (tag, len(bad), bad[:10])
+    # the discriminator's own step
+    step.flat_d.zero_grad()
+    dl = step.disc_backward(out["_out_nhwc"], out["_gt_nhwc"])
+    torch.cuda.synchronize()
+    for k in ("l_d_real", "l_d_fake"):
+        assert abs(float(dl[k]) - float(g["loss_" + k])) < 3e-4 * float(g["loss_" + k]), (k, float(dl[k]), float(g["loss_" + k]))
+    assert abs(float(dl["out_d_real"]) - float(g["out_d_real"])) < 1e-4 and abs(float(dl["out_d_fake"]) - float(g["out_d_fake"])) < 1e-4
+    names = [str(n) for n in g["d_param_names"]]
+    assert names == list(step.flat_d.G)
+    ref = g["d_grad_norms"]
+    mine = np.array([float(step.flat_d.G[n].double().norm()) for n in names])
+    bad = [(n, a, b) for n, a, b in zip(names, mine, ref) if abs(a - b) > 3e-3 * b + 1e-6 * ref.max()]
+    assert not bad, bad
+    sd = step.net_d.state_dict()
+    for n in ("main.3", "main.12"):
+        assert float((sd[n + ".running_mean"].cpu() - torch.from_numpy(g["d_bn_mean:" + n])).abs().max()) < 1e-4
+        assert float((sd[n + ".running_var"].cpu() - torch.from_numpy(g["d_bn_var:" + n])).abs().max()) < 1e-4 * max(1.0, float(g["d_bn_var:" + n].max()))
+        assert int(sd[n + ".num_batches_tracked"]) == int(g["d_bn_count:" + n]) == 3
+    # and a whole step through step(gan=True) moves all three networks
+    before = step.flat_d.value.clone()
+    step.step(src, drv, transform=tf, gan=True)
+    torch.cuda.synchronize()
+    assert float((step.flat_d.value - before).abs().max()) > 1e-6 and torch.isfinite(step.flat_d.value).all() and torch.isfinite(step.g.flat.value).all()
