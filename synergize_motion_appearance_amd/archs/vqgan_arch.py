@@ -3,7 +3,8 @@ train.yml `network_d`): a PatchGAN stack conv4x4/s2 + LeakyReLU, (n_layers-1) x 
 conv4x4/s1 + BN + LeakyReLU, conv4x4/s1 -> 1 logit map.  Same constructor signature and state_dict layout
 (`main.{i}.*`); the forward runs on the HIP implicit-GEMM kernel with BatchNorm in EVAL form (running statistics
 folded into the conv).  The reference only ever calls it inside the training step, in train mode
-(batch statistics + autograd): that raises here, like every other training branch."""
+(batch statistics + autograd): that form lives on the training tape (`trainer.TrainStep._disc`, the GAN branch of
+`optimize_parameters`); calling this module's forward in train mode raises."""
 import torch
 
 from .. import ops
@@ -71,8 +72,8 @@ class VQGANDiscriminator(HipArch):
     @torch.no_grad()
     def forward(self, x):
         if self.training:
-            raise NotImplementedError("VQGANDiscriminator in train mode (batch-statistics BatchNorm + autograd) belongs to the "
-                                      "training step, SURVEY row N2; call .eval() for the HIP forward")
+            raise NotImplementedError("VQGANDiscriminator in train mode (batch-statistics BatchNorm + gradients) runs inside the training "
+                                      "step (trainer.TrainStep(net_d=...)._disc, SURVEY row N2); call .eval() for the stand-alone HIP forward")
         convs = self.engine()
         h = ops.nchw_to_nhwc(x.float())
         for k, (cv, stride) in enumerate(convs):
