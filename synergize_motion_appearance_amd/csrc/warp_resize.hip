@@ -231,6 +231,89 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(const T* __restrict__ fe
   }
 }
 
+// bf16 storage, EIGHT channels (16 B) per lane: the row-chunk kernel above moves 8 B per lane and tap in bf16 -- half the bytes of the fp32
+// launch on the same number of lanes, loads and address computations, so it took the same time (317 us at 256x256x64, B=60: 3.2 TB/s
+// algorithmic).  Here a pixel is C/8 lanes, a block owns 8 * PPB' pixels... same structure, half the lanes per pixel, twice the pixels per
+// block: the taps stay packed (4 dwords) until they are blended.
+template <int LPP>
+__global__ __launch_bounds__(256) void warp_rows16_kernel(const bf16_t* __restrict__ feat, long long feat_bs,
+                                                          const float* __restrict__ flow, const float* __restrict__ occ,
+                                                          bf16_t* __restrict__ out, int H, int W, int C, int Hf, int Wf, int nframes) {
+  constexpr int PPT = 4, PPB = 256 / LPP, GPW = 64 / LPP, NPW = GPW * PPT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPP, g = lane / LPP;
+  const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int region = lin / nframes, b = lin - region * nframes;
+  const int cpr = W / (PPB * PPT);
+  const int y = region / cpr, xb = (region - y * cpr) * (PPB * PPT);
+
+  float cix = 0.f, ciy = 0.f, coc = 1.f;
+  if (lane < NPW) {
+    const int pass = lane / GPW, gg = lane % GPW;
+    const int x = xb + pass * PPB + wave * GPW + gg;
+    const float* fb = flow + (long long)b * Hf * Wf * 2;
+    const float* ob = occ ? occ + (long long)b * Hf * Wf : nullptr;
+    float fxv, fyv, ov = 1.f;
+    if (Hf == H && Wf == W) {
+      fxv = fb[(y * Wf + x) * 2]; fyv = fb[(y * Wf + x) * 2 + 1];
+      if (ob) ov = ob[y * Wf + x];
+    } else {
+      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+      ac_src(y, Hf, H, y0, y1, ly0, ly1); ac_src(x, Wf, W, x0, x1, lx0, lx1);
+      const float2 f00 = *reinterpret_cast<const float2*>(fb + (y0 * Wf + x0) * 2);
+      const float2 f01 = *reinterpret_cast<const float2*>(fb + (y0 * Wf + x1) * 2);
+      const float2 f10 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x0) * 2);
+      const float2 f11 = *reinterpret_cast<const float2*>(fb + (y1 * Wf + x1) * 2);
+      auto bil = [&](float v00, float v01, float v10, float v11) {
+#pragma clang fp contract(off)
+        return __fadd_rn(__fmul_rn(ly0, __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx1, v01))),
+                         __fmul_rn(ly1, __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx1, v11))));
+      };
+      fxv = bil(f00.x, f01.x, f10.x, f11.x);
+      fyv = bil(f00.y, f01.y, f10.y, f11.y);
+      if (ob) ov = bil(ob[y0 * Wf + x0], ob[y0 * Wf + x1], ob[y1 * Wf + x0], ob[y1 * Wf + x1]);
+    }
+    cix = ((fxv + 1.f) / 2.f) * (W - 1); ciy = ((fyv + 1.f) / 2.f) * (H - 1); coc = ov;
+  }
+  uint4 v[PPT][4]; float w[PPT][4]; float oc[PPT];
+  const bf16_t* fbase = feat + (long long)b * feat_bs + sub * 8;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int src = i * GPW + g;
+    const float ix = __shfl(cix, src, 64), iy = __shfl(ciy, src, 64);
+    oc[i] = __shfl(coc, src, 64);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float tx = ix - fx, ty = iy - fy;
+    const bool sane = ix > -2.f && ix < (float)W + 1.f && iy > -2.f && iy < (float)H + 1.f;
+    const int x0 = sane ? (int)fx : -4, y0 = sane ? (int)fy : -4;
+    w[i][0] = (1.f - tx) * (1.f - ty); w[i][1] = tx * (1.f - ty); w[i][2] = (1.f - tx) * ty; w[i][3] = tx * ty;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+      v[i][k] = make_uint4(0u, 0u, 0u, 0u);
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        v[i][k] = *reinterpret_cast<const uint4*>(fbase + (yy * W + xx) * C);
+    }
+  }
+  bf16_t* ob_ = out + ((long long)b * H * W + (long long)y * W + xb + wave * GPW + g) * C + sub * 8;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float f[8];
+      unpack8(v[i][k], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e] * w[i][k];
+    }
+    if (occ) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= oc[i];
+    }
+    *reinterpret_cast<uint4*>(ob_ + i * PPB * C) = pack8(acc);
+  }
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void resize_ac_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ y, int ldy,
                                                         long long total, int Hin, int Win, int Hout, int Wout, int C) {
@@ -335,6 +418,18 @@ int warp_launch(const T* feat, int feat_batch, const float* flow, const float* o
   // 4 pixels per thread once the launch is large (>= 8M lanes); small launches keep 1 for parallelism
   const int ppt = (npix * lpp >= (8LL << 20)) ? 4 : 1;
   dim3 grid(smx_cdiv(npix * lpp, 256 * ppt)), block(256);
+  if constexpr (sizeof(T) == 2) {
+    // bf16: 16 B per lane (8 channels) -- as many bytes per lane and tap as the fp32 launch moves
+    const int l8 = C / 8, rc8 = l8 > 0 ? 256 / l8 * 4 : 0;
+    if (C % 8 == 0 && (l8 == 8 || l8 == 16 || l8 == 32) && W % rc8 == 0 && npix / rc8 >= 256 && (long long)H * W * C < (1LL << 31) &&
+        ((((uintptr_t)feat) | ((uintptr_t)out)) & 15) == 0 && smx_tune(SMX_TUNE_WARP_ROWS)) {
+      dim3 grid8((unsigned)((long long)(H * W) / rc8 * B));
+      if (l8 == 8) SMX_LAUNCH((warp_rows16_kernel<8>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B);
+      else if (l8 == 16) SMX_LAUNCH((warp_rows16_kernel<16>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B);
+      else SMX_LAUNCH((warp_rows16_kernel<32>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B);
+      return smx_launch_status();
+    }
+  }
   // whole row chunks and enough blocks: coordinates computed once per pixel (warp_rows_kernel)
   const int rchunk = 256 / (lpp > 0 ? lpp : 1) * 4;
   if (lpp >= 16 && W % rchunk == 0 && npix / rchunk >= 256 && (long long)H * W * C < (1LL << 31) && smx_tune(SMX_TUNE_WARP_ROWS)) {
