@@ -329,6 +329,26 @@ __global__ __launch_bounds__(256) void resize_ac_kernel(const TI* __restrict__ x
   }
 }
 
+// four channels per lane (16 B fp32 / 8 B bf16 per tap) when the channel count and the row strides allow: the scalar form above spends a
+// full address computation (two divisions, the align_corners index math) per ELEMENT
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void resize_ac4_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ y, int ldy,
+                                                         long long total4, int Hin, int Win, int Hout, int Wout, int c4n) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n); long long p = i / c4n;
+    const int ox = (int)(p % Wout); p /= Wout; const int oy = (int)(p % Hout); const int b = (int)(p / Hout);
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    ac_src(oy, Hin, Hout, y0, y1, ly0, ly1); ac_src(ox, Win, Wout, x0, x1, lx0, lx1);
+    const TI* xb = x + (long long)b * Hin * Win * ldx + c4 * 4;
+    const float4 a = St<TI>::ld4(xb + ((long long)y0 * Win + x0) * ldx), bq = St<TI>::ld4(xb + ((long long)y0 * Win + x1) * ldx);
+    const float4 c = St<TI>::ld4(xb + ((long long)y1 * Win + x0) * ldx), d = St<TI>::ld4(xb + ((long long)y1 * Win + x1) * ldx);
+    // the scalar kernel's association, per channel
+    const float4 v = make_float4(ly0 * (lx0 * a.x + lx1 * bq.x) + ly1 * (lx0 * c.x + lx1 * d.x), ly0 * (lx0 * a.y + lx1 * bq.y) + ly1 * (lx0 * c.y + lx1 * d.y),
+                                 ly0 * (lx0 * a.z + lx1 * bq.z) + ly1 * (lx0 * c.z + lx1 * d.z), ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * c.w + lx1 * d.w));
+    St<TO>::st4(y + (((long long)b * Hout + oy) * Wout + ox) * ldy + c4 * 4, v);
+  }
+}
+
 // Bilinear (align_corners=True) down-sampling reads 4 taps per OUTPUT pixel: when a per-pixel op precedes
 // it (to_context: relu(conv1x1(x)) at 256x256, kept at 64x64 -- appmotioncodebook_arch.py:416-418), the op
 // only has to be evaluated at those taps (1/4 of the 256x256 pixels; exact, the op is per pixel).
@@ -456,6 +476,10 @@ template <typename TI, typename TO>
 int resize_launch(const TI* x, int ldx, TO* y, int ldy, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream) {
   if (!x || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || ldx < C || ldy < C) return SMX_EINVAL;
   const long long total = (long long)B * Hout * Wout * C;
+  if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x) & (4 * sizeof(TI) - 1)) == 0 && (((uintptr_t)y) & (4 * sizeof(TO) - 1)) == 0) {
+    SMX_LAUNCH((resize_ac4_kernel<TI, TO>), dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total / 4, Hin, Win, Hout, Wout, C / 4);
+    return smx_launch_status();
+  }
   SMX_LAUNCH((resize_ac_kernel<TI, TO>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, total, Hin, Win, Hout, Wout, C);
   return smx_launch_status();
 }
