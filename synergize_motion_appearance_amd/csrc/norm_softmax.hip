@@ -176,6 +176,38 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TS* __restrict__ x
   }
 }
 
+// four elements per lane (16 B fp32 / 8 B bf16), LPT = E / 4 lanes per token, 64 / LPT tokens per wave: E = 256 is one token per wave with
+// ONE load per lane instead of four, E = 32 packs eight tokens into a wave (the scalar form left half of it idle).  Group reductions by
+// xor shuffles below LPT.
+template <typename TS, int LPT>
+__global__ __launch_bounds__(256) void layernorm4_kernel(const TS* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ pos,
+                                                         TS* __restrict__ y, TS* __restrict__ ypos, int T, int E, int npos, float eps) {
+  constexpr int TPW = 64 / LPT;
+  const int lane = threadIdx.x & 63, sub = lane % LPT;
+  const int t = (blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW + lane / LPT;
+  const bool live = t < T;
+  const int tt = live ? t : T - 1;
+  const float4 v = St<TS>::ld4(x + (long long)tt * E + sub * 4);
+  float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+  for (int o = 1; o < LPT; o <<= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / E;
+  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+  float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+  for (int o = 1; o < LPT; o <<= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.f / sqrtf(q / E + eps);
+  if (!live) return;
+  const float4 g = *reinterpret_cast<const float4*>(gamma + sub * 4), bq = *reinterpret_cast<const float4*>(beta + sub * 4);
+  const float4 o4 = make_float4(dx * rstd * g.x + bq.x, dy * rstd * g.y + bq.y, dz * rstd * g.z + bq.z, dw * rstd * g.w + bq.w);
+  St<TS>::st4(y + (long long)t * E + sub * 4, o4);
+  if (ypos) {
+    const float4 p = *reinterpret_cast<const float4*>(pos + (long long)(t % npos) * E + sub * 4);
+    St<TS>::st4(ypos + (long long)t * E + sub * 4, make_float4(o4.x + p.x, o4.y + p.y, o4.z + p.z, o4.w + p.w));
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // masked row softmax in place: one wave per row, S <= 64*SPL
 // ---------------------------------------------------------------------------------------
@@ -462,6 +494,9 @@ int layernorm_launch(const T* x, const float* gamma, const float* beta, const fl
   if (!x || !y || !gamma || !beta || Tn <= 0 || E <= 0 || E > 512 || (y_pos && (!pos || npos <= 0))) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(smx_cdiv(Tn, 4)), block(256);
+  const bool al = ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)y_pos)) & (4 * sizeof(T) - 1)) == 0 && ((((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)pos)) & 15) == 0;
+  if (al && E == 256) { SMX_LAUNCH((layernorm4_kernel<T, 64>), grid, block, 0, st, x, gamma, beta, pos, y, y_pos, Tn, E, npos, eps); return smx_launch_status(); }
+  if (al && E == 32) { SMX_LAUNCH((layernorm4_kernel<T, 8>), dim3(smx_cdiv(Tn, 32)), block, 0, st, x, gamma, beta, pos, y, y_pos, Tn, E, npos, eps); return smx_launch_status(); }
   if (E <= 64) SMX_LAUNCH((layernorm_kernel<T, 1>), grid, block, 0, st, x, gamma, beta, pos, y, y_pos, Tn, E, npos, eps);
   else if (E <= 256) SMX_LAUNCH((layernorm_kernel<T, 4>), grid, block, 0, st, x, gamma, beta, pos, y, y_pos, Tn, E, npos, eps);
   else SMX_LAUNCH((layernorm_kernel<T, 8>), grid, block, 0, st, x, gamma, beta, pos, y, y_pos, Tn, E, npos, eps);
