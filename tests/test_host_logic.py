@@ -355,3 +355,42 @@ def test_n4_512_layout_host_side():
     for bad in (dict(img_size=512), dict(img_size=1024, attn_resolutions=[128]), dict(img_size=256, attn_resolutions=[64])):
         with pytest.raises(NotImplementedError):
             build_network(dict(type="AppMotionCompFormer", **bad))
+
+
+def test_perceptual_loss_host_side_layout_and_errors():
+    """the restated VGG19 feature stack (torchvision configuration "E", features[0:30]; reference archs/vgg_arch.py:167-200 slices it at
+    relu1_1 .. relu5_1), the pyramid kernels of AntiAliasInterpolation2d (losses/losses.py:345-377), and the loud failures: a state dict with a
+    missing or mis-shaped tensor, a perceptual_opt without weights."""
+    import pytest
+    from synergize_motion_appearance_amd import perceptual as PL
+    from synergize_motion_appearance_amd.trainer import TrainStep
+    shapes = PL.vgg19_param_shapes()
+    assert len(shapes) == 26 and shapes[0] == ("features.0.weight", (64, 3, 3, 3)) and shapes[-1] == ("features.28.bias", (512,))
+    ref_names = [n for n, _ in PL.vgg19_param_shapes("reference")]
+    assert ref_names[0] == "slice1.0.weight" and "slice2.5.weight" in ref_names and "slice4.19.bias" in ref_names and ref_names[-1] == "slice5.28.bias"
+    idx = 0
+    for n, kind, _, _ in PL.VGG19_FEATURES:                                   # conv + ReLU take two indices of nn.Sequential, a pool one
+        assert n == idx
+        idx += 1 if kind == "pool" else 2
+    assert idx == 30 and [k for _, k, _, _ in PL.VGG19_FEATURES].count("pool") == 4
+    for scale, K, step in ((0.5, 5, 2), (0.25, 13, 4), (0.125, 29, 8)):
+        k, st = PL.antialias_kernel2d(scale)
+        assert tuple(k.shape) == (K, K) and st == step and abs(float(k.sum()) - 1.0) < 1e-6 and float(k[K // 2, K // 2]) == float(k.max())
+    state = PL.synthetic_vgg19_state()
+    crit = PL.PerceptualLoss(state, device="cpu")                              # bookkeeping only: the loss itself launches HIP kernels
+    assert len(crit.P) == 26 and all(k.startswith("vgg19.features.") for k in crit.P) and sorted(crit.pyr) == [0.125, 0.25, 0.5]
+    ref_state = {rn: state[tn] for (tn, _), rn in zip(PL.vgg19_param_shapes(), ref_names)}
+    crit2 = PL.PerceptualLoss(ref_state, device="cpu")                         # the reference module's own key names load too
+    assert all(torch.equal(crit.P[k], crit2.P[k]) for k in crit.P)
+    bad = dict(state)
+    bad.pop("features.19.weight")
+    with pytest.raises(KeyError):
+        PL.PerceptualLoss(bad, device="cpu")
+    bad = dict(state, **{"features.0.weight": torch.zeros(64, 3, 5, 5)})
+    with pytest.raises(ValueError):
+        PL.PerceptualLoss(bad, device="cpu")
+    with pytest.raises(ValueError):
+        PL.PerceptualLoss(state, scales=[1, 0.3], device="cpu")
+    with pytest.raises(RuntimeError, match="vgg19_path"):
+        TrainStep._build_perceptual({"type": "MultiScalePyramidPerceptualLoss"}, "cpu")
+    assert TrainStep._build_perceptual(None, "cpu") is None
