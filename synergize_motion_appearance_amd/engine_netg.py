@@ -171,6 +171,15 @@ class NetGEngine:
         self.wsrc = {s: cv(f"warped_source_enc_{s}") for s in self.sizes}
         self.to_ctx = {s: cv(f"to_context.{int(math.log2(s)) - 5}") for s in self.sizes}
         self.bme = {n: cv("BasicMotionEncoder." + n) for n in ("convc1", "convc2", "convf1", "convf2", "conv")}
+        # bf16: BasicMotionEncoder.conv reads the 160-channel [cor | flo] concat -- 2.5 of the 64-channel slices the region-direct bf16 kernel
+        # works in, so it fell to the implicit GEMM (0.14 of its byte bound, 1.0 ms per step).  Padded to 192 input channels (zero weights, a
+        # zeroed tail in the concat buffer) it takes the region kernel
+        self.bme_conv_pad = None
+        if self.is16:
+            c = self.bme["conv"]
+            w = torch.zeros((c.cout, 9, 192), device=c.w.device, dtype=torch.float32)
+            w[:, :, :160] = c.w.view(c.cout, 9, 160)
+            self.bme_conv_pad = Conv(w.reshape(c.cout, 9 * 192).contiguous(), c.b, 3, 3, 192, c.cout)
         self.ref_c1 = cv("refine.convc1")
         self.ref_h = Conv.cat([cv("refine.conv1"), cv("refine.convo1")])      # shared input -> N=256
         # conv2 (2 <- h[:128]) and convo2 (1 <- h[128:]) as ONE block-diagonal conv 256 -> 3 writing r directly
@@ -342,13 +351,16 @@ class NetGEngine:
         for blk in self.motion_blocks:
             q = blk(q, S, self.pos_motion)
         motion_f = ops.resize(q, Fg, Fg)
-        cf = torch.empty((B, Fg, Fg, 160), device=q.device, dtype=self.adt)
+        cpad = 192 if self.bme_conv_pad is not None else 160
+        cf = torch.empty((B, Fg, Fg, cpad), device=q.device, dtype=self.adt)
+        if cpad > 160:
+            cf[..., 160:].zero_()
         cor = ops.conv(motion_f, self.bme["convc1"], act=ACT_RELU)
         ops.conv(cor, self.bme["convc2"], out=cf[..., :96], act=ACT_RELU)
         flo = ops.conv(flow_res, self.bme["convf1"], act=ACT_RELU, mfma16=self.is16)   # 7x7 pad 3 (fp32 flow in)
-        ops.conv(flo, self.bme["convf2"], out=cf[..., 96:], act=ACT_RELU)
+        ops.conv(flo, self.bme["convf2"], out=cf[..., 96:160], act=ACT_RELU)
         inp = torch.empty((B, Fg, Fg, 256), device=q.device, dtype=self.adt)
-        ops.conv(cf, self.bme["conv"], out=inp[..., :126], act=ACT_RELU)
+        ops.conv(cf, self.bme_conv_pad or self.bme["conv"], out=inp[..., :126], act=ACT_RELU)
         ops.copy_slice(flow_res, inp[..., 126:128])
         if s > 128:
             # relu(to_context(.)) is per pixel and only its 4 bilinear taps per 64x64 output pixel survive the
