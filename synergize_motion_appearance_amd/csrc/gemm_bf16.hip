@@ -390,6 +390,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GB p) {
     else rows(std::integral_constant<int, 2>{});
     return;
   }
+  // un-patchify (depth-to-space) store, aligned and inside N, no residual (the engines' to_app_feat launches): the thread's chunk column --
+  // hence its (p1, p2) sub-pixel and channel offset -- is fixed, only the token's (image, oy, ox) changes per row: the general loop below
+  // re-derived all of it per 16-B chunk with five integer divisions (0.18 of the launch's byte bound)
+  if (p.d2s_p && vec_c && al_c && !p.res && tile_n * BN + BN <= p.N && !p.bias_per_row) {
+    const int cq = tid % CPR, row0 = tid / CPR;
+    const int n0 = tile_n * BN + cq * 8;
+    const int dq = n0 / p.d2s_c, oc = n0 - dq * p.d2s_c, p1 = dq / p.d2s_p, p2 = dq - p1 * p.d2s_p;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + e] : 0.f;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int row = row0 + RSTEP * it, m = tile_m * BM + row;
+      if (m >= p.M) continue;
+      const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cq * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cq * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = apply_act(p.alpha * v[e] + bv[e], p.act);
+      const int img = m / HoWo, rem = m - img * HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const long long opix = ((long long)img * (p.Ho * p.d2s_p) + oy * p.d2s_p + p1) * (p.Wo * p.d2s_p) + ox * p.d2s_p + p2;
+      if (p.c_f32) {
+        *reinterpret_cast<float4*>(C32 + opix * p.ldc + oc) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(C32 + opix * p.ldc + oc + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        *reinterpret_cast<uint4*>(C16 + opix * p.ldc + oc) = pack8(v);
+      }
+    }
+    return;
+  }
   for (int ch = tid; ch < BM * CPR; ch += NT) {
     const int row = ch / CPR, cq = ch - row * CPR;
     const int m = tile_m * BM + row, n0 = tile_n * BN + cq * 8;
