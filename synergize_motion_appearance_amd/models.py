@@ -411,3 +411,22 @@ class AppMotionCompModel:
         self.save_network(self.motion_estimator, "net_motion_estimator", current_iter)
         if getattr(self, "net_d", None) is not None:
             self.save_network(self.net_d, "net_d", current_iter)
+        self.save_training_state(epoch, current_iter)
+
+    def save_training_state(self, epoch, current_iter):
+        """base_model.py:265-281: `{iter}.state` = {'epoch', 'iter', 'optimizers': [g, m, d], 'schedulers': [...]}, the optimizer entries in
+        torch.optim.Adam's own state_dict layout (the flat Adam buffers sliced back per parameter), so the file is interchangeable with the
+        reference's."""
+        if current_iter == -1:
+            return
+        import os
+        sched = {"milestones": list(self._milestones), "gamma": self._gamma, "last_epoch": int(current_iter)}
+        state = {"epoch": epoch, "iter": current_iter, "optimizers": self.train_step.optimizer_state_dicts(),
+                 "schedulers": [dict(sched, base_lrs=[lr]) for lr in self._base_lr] + ([dict(sched, base_lrs=[self.train_step.lr_d])] if self.net_d is not None else [])}
+        d = self.opt["path"].get("training_states") or os.path.join(self.opt["path"].get("models", "."), "..", "training_states")
+        os.makedirs(d, exist_ok=True)
+        torch.save(state, os.path.join(d, f"{current_iter}.state"))
+
+    def resume_training(self, resume_state):
+        """base_model.py:283-296: reload the Adam moments / step counts; the learning rate follows `update_learning_rate(current_iter)`."""
+        self.train_step.load_optimizer_state_dicts(resume_state["optimizers"])

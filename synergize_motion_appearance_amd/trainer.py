@@ -77,6 +77,41 @@ class FlatParams:
                                            float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.t, float(gscale),
                                            _stream()), "adam_step")
 
+    def optimizer_state_dict(self, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0):
+        """this buffer's Adam state in torch.optim.Adam's own state_dict layout (per parameter, in named_parameters order -- the order
+        the reference builds its optimizers in, models/appmotioncomp_model.py:235-270): a `.state` file written from it resumes a
+        torch.optim.Adam, and one written by the reference resumes this."""
+        state = {}
+        for i, (name, (off, n)) in enumerate(self.slots.items()):
+            shape = self.P[name].shape
+            state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[off:off + n].view(shape).detach().cpu().clone(),
+                        "exp_avg_sq": self.v[off:off + n].view(shape).detach().cpu().clone()}
+        group = {"lr": float(lr), "betas": tuple(betas), "eps": float(eps), "weight_decay": float(weight_decay), "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.slots)))}
+        return {"state": state if self.t > 0 else {}, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """-> the learning rate stored in the file (the caller's schedule decides whether to use it)."""
+        st = sd.get("state", {})
+        names = list(self.slots)
+        if st and len(st) != len(names):
+            raise ValueError(f"optimizer state has {len(st)} parameters, this network has {len(names)}")
+        self.m.zero_()
+        self.v.zero_()
+        self.t = 0
+        for i, name in enumerate(names):
+            if i not in st:
+                continue
+            off, n = self.slots[name]
+            e = st[i]
+            if tuple(e["exp_avg"].shape) != tuple(self.P[name].shape):
+                raise ValueError(f"optimizer state of parameter {i} ({name}) has shape {tuple(e['exp_avg'].shape)}, expected {tuple(self.P[name].shape)}")
+            self.m[off:off + n].copy_(e["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
+            self.v[off:off + n].copy_(e["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
+            self.t = int(float(e["step"]))
+        return float(sd["param_groups"][0]["lr"]) if sd.get("param_groups") else None
+
     def ema_into(self, other, decay):
         """other.value = decay * other.value + (1 - decay) * self.value (models/sr_model.py model_ema); same slot layout required."""
         if other.numel != self.numel:
@@ -467,6 +502,21 @@ class TrainStep:
         return {"l_d_real": l_real, "out_d_real": pr.mean().reshape(1), "l_d_fake": l_fake, "out_d_fake": pf.mean().reshape(1)}
 
     GRAPH_WARMUP = 2
+
+    def optimizer_state_dicts(self):
+        """[optimizer_g, optimizer_m (, optimizer_d)] -- the reference's `self.optimizers` order (appmotioncomp_model.py:248, 265, 270)."""
+        out = [self.g.flat.optimizer_state_dict(self.g.lr, self.g.betas, self.g.eps, self.g.wd),
+               self.flat_m.optimizer_state_dict(self.lr_m, self.betas_m, 1e-8, self.wd_m)]
+        if self.flat_d is not None:
+            out.append(self.flat_d.optimizer_state_dict(self.lr_d, self.betas_d, 1e-8, self.wd_d))
+        return out
+
+    def load_optimizer_state_dicts(self, sds):
+        flats = [self.g.flat, self.flat_m] + ([self.flat_d] if self.flat_d is not None else [])
+        if len(sds) != len(flats):
+            raise ValueError(f"Wrong lengths of optimizers: the state file has {len(sds)}, this step has {len(flats)}")
+        for f, sd in zip(flats, sds):
+            f.load_optimizer_state_dict(sd)
 
     def _draw_transform(self, B, dev):
         eq = self.opt.get("equivariance_opt")

@@ -146,6 +146,14 @@ def test_model_level_optimize_parameters(tmp_path):
     model.test()                                                                                     # validation forward on the updated weights
     assert torch.isfinite(model.out_dict["out"]).all()
     assert os.path.exists(str(tmp_path / "models" / "net_d_1.pth"))
+    state = torch.load(str(tmp_path / "training_states" / "1.state"), weights_only=False)             # base_model.py:265-281 layout
+    assert state["iter"] == 1 and len(state["optimizers"]) == 3 and len(state["optimizers"][0]["state"]) == 472
+    assert float(state["optimizers"][0]["state"][0]["step"]) == 1.0
+    m_before = model.train_step.g.flat.m.clone()
+    model.train_step.g.flat.m.zero_()
+    model.train_step.g.flat.t = 0
+    model.resume_training(state)
+    assert model.train_step.g.flat.t == 1 and torch.equal(model.train_step.g.flat.m, m_before)
     with pytest.raises(RuntimeError, match="net_d_start_iter"):                                      # adaptive weight needs the perceptual term
         model.optimize_parameters(5002)
     # with the perceptual loss (synthetic VGG19 weights: the real ones are a download) the branch past net_d_start_iter runs: GAN terms logged,

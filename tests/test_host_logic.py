@@ -394,3 +394,32 @@ def test_perceptual_loss_host_side_layout_and_errors():
     with pytest.raises(RuntimeError, match="vgg19_path"):
         TrainStep._build_perceptual({"type": "MultiScalePyramidPerceptualLoss"}, "cpu")
     assert TrainStep._build_perceptual(None, "cpu") is None
+
+
+def test_adam_state_is_interchangeable_with_torch_optim_adam():
+    """checkpoint / resume (reference base_model.py:265-296): the flat Adam buffers leave as a torch.optim.Adam state_dict
+    (per parameter, named_parameters order) and come back from one -- a `.state` file of either side resumes the other."""
+    from synergize_motion_appearance_amd.trainer import FlatParams
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    flat = FlatParams(net, allow_cpu=True)
+    flat.m.copy_(torch.arange(flat.numel, dtype=torch.float32) * 0.01)
+    flat.v.copy_(torch.arange(flat.numel, dtype=torch.float32) * 0.02 + 1.0)
+    flat.t = 7
+    sd = flat.optimizer_state_dict(8e-5, (0.9, 0.99), 1e-8, 0.0)
+    opt = torch.optim.Adam(net.parameters(), lr=1.0, betas=(0.5, 0.5))
+    opt.load_state_dict(sd)                                                  # torch accepts it as its own
+    params = list(net.parameters())
+    for i, (name, (off, n)) in enumerate(flat.slots.items()):
+        st = opt.state[params[i]]
+        assert float(st["step"]) == 7 and torch.equal(st["exp_avg"].reshape(-1), flat.m[off:off + n]) and torch.equal(st["exp_avg_sq"].reshape(-1), flat.v[off:off + n])
+    assert opt.param_groups[0]["lr"] == 8e-5 and tuple(opt.param_groups[0]["betas"]) == (0.9, 0.99)
+    other = FlatParams(torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)), allow_cpu=True)
+    lr = other.load_optimizer_state_dict(opt.state_dict())                   # and torch's own state_dict comes back
+    live = torch.zeros(flat.numel, dtype=torch.bool)
+    for off, n in flat.slots.values():
+        live[off:off + n] = True
+    assert lr == 8e-5 and other.t == 7 and torch.equal(other.m[live], flat.m[live]) and torch.equal(other.v[live], flat.v[live])
+    import pytest
+    with pytest.raises(ValueError):
+        FlatParams(torch.nn.Linear(6, 5), allow_cpu=True).load_optimizer_state_dict(sd)
+    assert FlatParams(torch.nn.Linear(2, 2), allow_cpu=True).optimizer_state_dict(1e-3)["state"] == {}    # nothing stepped yet
