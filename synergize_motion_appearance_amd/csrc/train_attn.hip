@@ -28,23 +28,28 @@ struct ABP {
   int B, H, L, S; float scale;
 };
 
+// Both kernels: 256 threads = 64 rows (queries / keys) x 4 slices of the other axis.  Thread (row r, slice g = wave index) walks the tile
+// entries j = g, g + 4, ... ; the four partial results of a row are combined through LDS in a fixed order.  (One thread per row alone left
+// B * H * L / 128 = 256 two-wave blocks for 1024 SIMDs at the training batch: latency-bound at a tenth of the VALU rate.)
 template <int DH>
-__global__ __launch_bounds__(128) void attn_bwd_q_kernel(ABP p) {
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(ABP p) {
   constexpr int TK = 64;
   __shared__ float Ks[TK * DH], Vs[TK * DH];
   __shared__ uint8_t Ms[TK];
+  __shared__ float red[4][64][DH > 4 ? DH : 4];        // statistics / dQ partials of the 4 slices
   const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
-  const int i = blockIdx.x * 128 + threadIdx.x;
+  const int rl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + rl;
   const bool ok = i < p.L;
   const int E = p.H * DH;
-  float q[DH], g[DH], acc[DH];
+  float q[DH], gd[DH], acc[DH];
   float Di = 0.f;
 #pragma unroll
   for (int d = 0; d < DH; ++d) {
     q[d] = ok ? p.q[(long long)b * p.q_bs + (long long)i * p.ldq + h * DH + d] * p.scale : 0.f;
-    g[d] = ok ? p.d_o[((long long)b * p.L + i) * E + h * DH + d] : 0.f;
+    gd[d] = ok ? p.d_o[((long long)b * p.L + i) * E + h * DH + d] : 0.f;
     const float ov = ok ? p.o[((long long)b * p.L + i) * E + h * DH + d] : 0.f;
-    Di += g[d] * ov; acc[d] = 0.f;
+    Di += gd[d] * ov; acc[d] = 0.f;
   }
   const float* Kb = p.k + (long long)b * p.k_bs + h * DH;
   const float* Vb = p.v + (long long)b * p.v_bs + h * DH;
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(128) void attn_bwd_q_kernel(ABP p) {
     const float il = pass ? 1.f / l : 0.f;
     for (int j0 = 0; j0 < p.S; j0 += TK) {
       __syncthreads();
-      for (int t = threadIdx.x; t < TK * DH; t += 128) {
+      for (int t = threadIdx.x; t < TK * DH; t += 256) {
         const int r = t / DH, d = t - r * DH;
         const bool in = j0 + r < p.S;
         Ks[t] = in ? Kb[(long long)(j0 + r) * p.ldk + d] : 0.f;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(128) void attn_bwd_q_kernel(ABP p) {
       if (threadIdx.x < TK) Ms[threadIdx.x] = (j0 + threadIdx.x < p.S) ? (p.mask ? p.mask[(long long)b * p.S + j0 + threadIdx.x] : 0) : 1;
       __syncthreads();
       const int n = min(TK, p.S - j0);
-      for (int r = 0; r < n; ++r) {
+      for (int r = g; r < n; r += 4) {
         if (Ms[r]) continue;
         float s = 0.f;
 #pragma unroll
@@ -73,31 +78,46 @@ __global__ __launch_bounds__(128) void attn_bwd_q_kernel(ABP p) {
           const float pij = expf(s - m) * il;
           float dp = 0.f;
 #pragma unroll
-          for (int d = 0; d < DH; ++d) dp += g[d] * Vs[r * DH + d];
+          for (int d = 0; d < DH; ++d) dp += gd[d] * Vs[r * DH + d];
           const float ds = pij * (dp - Di);
 #pragma unroll
           for (int d = 0; d < DH; ++d) acc[d] += ds * Ks[r * DH + d];
         }
       }
     }
-  }
-  if (ok) {
+    if (!pass) {                                          // the row's (m, l) over ALL keys from the four slices' (m_g, l_g)
+      red[g][rl][0] = m; red[g][rl][1] = l;
+      __syncthreads();
+      float mm = fmaxf(fmaxf(red[0][rl][0], red[1][rl][0]), fmaxf(red[2][rl][0], red[3][rl][0]));
+      float ll = 0.f;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) p.dq[((long long)b * p.L + i) * E + h * DH + d] = acc[d] * p.scale;
+      for (int k = 0; k < 4; ++k) ll += (red[k][rl][0] == -INFINITY) ? 0.f : red[k][rl][1] * expf(red[k][rl][0] - mm);
+      m = mm; l = ll;
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DH; ++d) red[g][rl][d] = acc[d];
+  __syncthreads();
+  if (g == 0 && ok) {
+#pragma unroll
+    for (int d = 0; d < DH; ++d)
+      p.dq[((long long)b * p.L + i) * E + h * DH + d] = ((red[0][rl][d] + red[1][rl][d]) + (red[2][rl][d] + red[3][rl][d])) * p.scale;
     float* st = p.stats + (((long long)b * p.H + h) * p.L + i) * 3;
     st[0] = m; st[1] = 1.f / l; st[2] = Di;
   }
 }
 
 template <int DH>
-__global__ __launch_bounds__(128) void attn_bwd_kv_kernel(ABP p) {
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(ABP p) {
   constexpr int TQ = 64;
   __shared__ float Qs[TQ * DH], Gs[TQ * DH], St[TQ * 3];
+  __shared__ float red[4][64][2 * DH];                 // dK | dV partials of the 4 slices
   // grid.y = B * H: one (sample, head) per block row also when the context is shared by the batch (k_bs = v_bs = 0) -- the per-sample
-  // dK / dV are then summed over the batch by the caller's fixed-order batch sum; looping the batch inside a (head, key-tile) block
-  // left 8 x H blocks for 256 CUs
+  // dK / dV are then summed over the batch by the caller's fixed-order batch sum
   const int bb = blockIdx.y / p.H, h = blockIdx.y - bb * p.H;
-  const int j = blockIdx.x * 128 + threadIdx.x;
+  const int rl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + rl;
   const bool ok = j < p.S;
   const int E = p.H * DH;
   float kk[DH], vv[DH], dk[DH], dv[DH];
@@ -112,20 +132,20 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(ABP p) {
     const bool masked = p.mask && ok && p.mask[(long long)b * p.S + j];
     for (int i0 = 0; i0 < p.L; i0 += TQ) {
       __syncthreads();
-      for (int t = threadIdx.x; t < TQ * DH; t += 128) {
+      for (int t = threadIdx.x; t < TQ * DH; t += 256) {
         const int r = t / DH, d = t - r * DH;
         const bool in = i0 + r < p.L;
         Qs[t] = in ? p.q[(long long)b * p.q_bs + (long long)(i0 + r) * p.ldq + h * DH + d] * p.scale : 0.f;
         Gs[t] = in ? p.d_o[((long long)b * p.L + i0 + r) * E + h * DH + d] : 0.f;
       }
-      for (int t = threadIdx.x; t < TQ * 3; t += 128) {
+      for (int t = threadIdx.x; t < TQ * 3; t += 256) {
         const int r = t / 3;
         St[t] = (i0 + r < p.L) ? p.stats[(((long long)b * p.H + h) * p.L + i0 + r) * 3 + (t - r * 3)] : 0.f;
       }
       __syncthreads();
       if (!ok || masked) continue;
       const int n = min(TQ, p.L - i0);
-      for (int r = 0; r < n; ++r) {
+      for (int r = g; r < n; r += 4) {
         float s = 0.f, dp = 0.f;
 #pragma unroll
         for (int d = 0; d < DH; ++d) { s += Qs[r * DH + d] * kk[d]; dp += Gs[r * DH + d] * vv[d]; }
@@ -136,11 +156,15 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(ABP p) {
       }
     }
   }
-  if (ok) {
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < DH; ++d) { red[g][rl][d] = dk[d]; red[g][rl][DH + d] = dv[d]; }
+  __syncthreads();
+  if (g == 0 && ok) {
 #pragma unroll
     for (int d = 0; d < DH; ++d) {
-      p.dk[((long long)bb * p.S + j) * E + h * DH + d] = dk[d];
-      p.dv[((long long)bb * p.S + j) * E + h * DH + d] = dv[d];
+      p.dk[((long long)bb * p.S + j) * E + h * DH + d] = (red[0][rl][d] + red[1][rl][d]) + (red[2][rl][d] + red[3][rl][d]);
+      p.dv[((long long)bb * p.S + j) * E + h * DH + d] = (red[0][rl][DH + d] + red[1][rl][DH + d]) + (red[2][rl][DH + d] + red[3][rl][DH + d]);
     }
   }
 }
@@ -362,9 +386,9 @@ int launch(ABP& p, int shared, hipStream_t st) {
     SMX_LAUNCH(attn_bwd_kv_mfma_kernel, dim3(p.S / 128, p.B * p.H), dim3(256), 0, st, p);
     return smx_launch_status();
   }
-  SMX_LAUNCH(attn_bwd_q_kernel<DH>, dim3(smx_cdiv(p.L, 128), p.B * p.H), dim3(128), 0, st, p);
+  SMX_LAUNCH(attn_bwd_q_kernel<DH>, dim3(smx_cdiv(p.L, 64), p.B * p.H), dim3(256), 0, st, p);
   (void)shared;
-  SMX_LAUNCH(attn_bwd_kv_kernel<DH>, dim3(smx_cdiv(p.S, 128), p.B * p.H), dim3(128), 0, st, p);
+  SMX_LAUNCH(attn_bwd_kv_kernel<DH>, dim3(smx_cdiv(p.S, 64), p.B * p.H), dim3(256), 0, st, p);
   return smx_launch_status();
 }
 
