@@ -97,10 +97,19 @@ __global__ __launch_bounds__(256) void chan_pair_partial_v4_kernel(const float* 
 // F.batch_norm(training=True)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nchunk, int C, long long n, float eps, float momentum,
                                                           float* __restrict__ mr, float* __restrict__ run_mean, float* __restrict__ run_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  // 32 channels per block, 8 lanes per channel walking the (up to 1024) chunk partials interleaved, fixed-order finish in double through
+  // LDS: one thread per channel walked them alone (66 us per launch)
+  __shared__ double red[2][8][32];
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + l;
   double s = 0.0, q = 0.0;
-  for (int k = 0; k < nchunk; ++k) { s += part[((long long)k * C + c) * 2]; q += part[((long long)k * C + c) * 2 + 1]; }
+  if (c < C)
+    for (int k = g; k < nchunk; k += 8) { s += part[((long long)k * C + c) * 2]; q += part[((long long)k * C + c) * 2 + 1]; }
+  red[0][g][l] = s; red[1][g][l] = q;
+  __syncthreads();
+  if (g != 0 || c >= C) return;
+  s = ((red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l])) + ((red[0][4][l] + red[0][5][l]) + (red[0][6][l] + red[0][7][l]));
+  q = ((red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l])) + ((red[1][4][l] + red[1][5][l]) + (red[1][6][l] + red[1][7][l]));
   const double mean = s / (double)n;
   double var = q / (double)n - mean * mean; if (var < 0.0) var = 0.0;
   mr[2 * c] = (float)mean; mr[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -122,10 +131,17 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
 // backward finish: sums[c] = {sum dy', sum dy' xh}; dgamma += sum dy' xh; dbeta += sum dy'
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunk, int C, float* __restrict__ sums,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[2][8][32];
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + l;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < nchunk; ++k) { a += part[((long long)k * C + c) * 2]; b += part[((long long)k * C + c) * 2 + 1]; }
+  if (c < C)
+    for (int k = g; k < nchunk; k += 8) { a += part[((long long)k * C + c) * 2]; b += part[((long long)k * C + c) * 2 + 1]; }
+  red[0][g][l] = a; red[1][g][l] = b;
+  __syncthreads();
+  if (g != 0 || c >= C) return;
+  a = ((red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l])) + ((red[0][4][l] + red[0][5][l]) + (red[0][6][l] + red[0][7][l]));
+  b = ((red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l])) + ((red[1][4][l] + red[1][5][l]) + (red[1][6][l] + red[1][7][l]));
   sums[2 * c] = (float)a; sums[2 * c + 1] = (float)b;
   dgamma[c] += (float)b; dbeta[c] += (float)a;
 }
@@ -406,7 +422,7 @@ extern "C" int smx_batchnorm_train_f32(const float* x, int ldx, float* y, int ld
   else
     SMX_LAUNCH(chan_pair_partial_kernel<0>, dim3((unsigned)nchunk), dim3(256), 0, st, x, ldx, (const float*)nullptr, 0, (const float*)nullptr, 0,
                (const float*)nullptr, (long long)P, C, (int)rows, ws);
-  SMX_LAUNCH(bn_finalize_kernel, dim3(smx_cdiv(C, 256)), dim3(256), 0, st, ws, (int)nchunk, C, (long long)P, eps, momentum, mr, running_mean, running_var);
+  SMX_LAUNCH(bn_finalize_kernel, dim3(smx_cdiv(C, 32)), dim3(256), 0, st, ws, (int)nchunk, C, (long long)P, eps, momentum, mr, running_mean, running_var);
   SMX_LAUNCH(bn_relu_apply_kernel, dim3(grid_for((long long)P * C)), dim3(256), 0, st, x, ldx, y, ldy, mr, gamma, beta, (long long)P, C, relu);
   return smx_launch_status();
 }
@@ -423,7 +439,7 @@ extern "C" int smx_batchnorm_train_bwd_f32(const float* x, int ldx, const float*
     SMX_LAUNCH(chan_pair_partial_v4_kernel<1>, dim3((unsigned)nchunk, (C + 63) / 64), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, mr, (long long)P, C, (int)rows, ws);
   else
     SMX_LAUNCH(chan_pair_partial_kernel<1>, dim3((unsigned)nchunk), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, mr, (long long)P, C, (int)rows, ws);
-  SMX_LAUNCH(bn_bwd_finalize_kernel, dim3(smx_cdiv(C, 256)), dim3(256), 0, st, ws, (int)nchunk, C, sums, dgamma, dbeta);
+  SMX_LAUNCH(bn_bwd_finalize_kernel, dim3(smx_cdiv(C, 32)), dim3(256), 0, st, ws, (int)nchunk, C, sums, dgamma, dbeta);
   SMX_LAUNCH(bn_relu_bwd_apply_kernel, dim3(grid_for((long long)P * C)), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, mr, sums, gamma, dx, ldo, (long long)P, C);
   return smx_launch_status();
 }
