@@ -307,9 +307,16 @@ class FramePipeline:
     pinned host memory one byte per sample, are resized / normalised ON the device, rendered in batches, and the uint8 result
     frames return to pinned host memory, with the H2D copy of batch i+1 and the D2H copy of batch i-1 overlapping the
     compute of batch i on three HIP streams (double-buffered staging on both sides).  `run` accepts any CPU uint8 tensor /
-    numpy array [N,H,W,3] (or an iterable of such chunks) and returns / yields uint8 [n,256,256,3] host tensors."""
+    numpy array [N,H,W,3] (or an iterable of such chunks) and returns / yields uint8 [n,256,256,3] host tensors.
 
-    def __init__(self, net_g, motion_estimator, batch=60, frame_hw=(256, 256), swap_rb=False, relative=True, adapt_movement_scale=True):
+    use_graph (default on): the per-batch launch sequence (uint8 -> fp32 normalise, keypoints, dense motion, generator, uint8 pack: ~700
+    launches behind Python + ctypes) is captured ONCE in a hipGraph over static input / output / source-state buffers and replayed per full
+    batch.  In fp32 the GPU step (110 ms) hides the host; in bf16 (42 ms) the host thread -- launches plus the pinned-memory copies and
+    waits of this pipeline -- was the bound: 946 frames/s host-to-host against 1437 device-resident.  A new source is a copy of its packed
+    state into the static buffer (the unpacked tensors are views of it); a ragged last batch runs eagerly."""
+
+    def __init__(self, net_g, motion_estimator, batch=60, frame_hw=(256, 256), swap_rb=False, relative=True, adapt_movement_scale=True,
+                 use_graph=True):
         self.net_g, self.me, self.B = net_g, motion_estimator, int(batch)
         self.hw, self.swap_rb, self.relative, self.adapt = tuple(frame_hw), swap_rb, relative, adapt_movement_scale
         dev = next(net_g.parameters()).device
@@ -321,7 +328,43 @@ class FramePipeline:
         self.pin_in = [torch.empty((self.B, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.dev_in = [torch.empty((self.B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.pin_out = [torch.empty((self.B, self.img, self.img, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.dev_out = [torch.empty((self.B, self.img, self.img, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.s_h2d, self.s_d2h = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.use_graph = bool(use_graph)
+        self._graph = None           # (CUDAGraph, static uint8 input, static uint8 output, static packed state, its unpacked SourceState, dtype)
+        self._graph_src = None       # the SourceState object whose values the static state currently holds
+
+    def _render_eager(self, state, u8):
+        x = ops.frames_u8_to_nchw(u8, (self.img, self.img), self.swap_rb)
+        return render_frames(state, x, self.net_g, self.me, self.relative, self.adapt, batch=self.B)
+
+    def _render(self, state, u8):
+        """uint8 device frames [n,H,W,3] -> uint8 device frames [n,img,img,3]; full batches through the captured graph."""
+        n = u8.shape[0]
+        adt = self.net_g.engine().adt
+        if not self.use_graph or n != self.B:
+            return self._render_eager(state, u8)
+        if self._graph is not None and self._graph[5] != adt:      # the networks switched compute dtype: the captured launches are stale
+            self._graph, self._graph_src = None, None
+        if self._graph is None:
+            flat = (state.flat if state.flat is not None else pack_source_state(state.cache, state.src64, state.kp_source, state.kp_initial, state.scale)).clone()
+            gstate = unpack_source_state(flat, adt, self.img)
+            gin = torch.empty_like(self.dev_in[0])
+            gin.copy_(u8)
+            self._render_eager(gstate, gin)                          # warm-up outside the capture (one-time attribute calls, allocator pools)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                gout = self._render_eager(gstate, gin)
+            self._graph, self._graph_src = (g, gin, gout, flat, gstate, adt), state
+        g, gin, gout, flat, gstate, _ = self._graph
+        if self._graph_src is not state:
+            src_flat = state.flat if state.flat is not None else pack_source_state(state.cache, state.src64, state.kp_source, state.kp_initial, state.scale)
+            flat.copy_(src_flat)
+            self._graph_src = state
+        gin.copy_(u8)
+        g.replay()
+        return gout
 
     @torch.no_grad()
     def stream(self, state: SourceState, frames):
@@ -349,16 +392,15 @@ class FramePipeline:
                 h2d = torch.cuda.Event()
                 h2d.record()
             cur.wait_event(h2d)
-            x = ops.frames_u8_to_nchw(self.dev_in[k][:n], (self.img, self.img), self.swap_rb)
+            out = self._render(state, self.dev_in[k][:n])
             in_free[k] = torch.cuda.Event()
             in_free[k].record(cur)
-            out = render_frames(state, x, self.net_g, self.me, self.relative, self.adapt, batch=B)
+            self.dev_out[k][:n].copy_(out)                       # off the (possibly static) render output: the next batch may overwrite it
             done = torch.cuda.Event()
             done.record(cur)
-            with torch.cuda.stream(self.s_d2h):                  # pin_out[k] was handed out (and consumed) one iteration ago
+            with torch.cuda.stream(self.s_d2h):                  # pin_out[k] / dev_out[k] were handed out (and consumed) one iteration ago
                 self.s_d2h.wait_event(done)
-                self.pin_out[k][:n].copy_(out, non_blocking=True)
-                out.record_stream(self.s_d2h)
+                self.pin_out[k][:n].copy_(self.dev_out[k][:n], non_blocking=True)
                 out_ready[k] = torch.cuda.Event()
                 out_ready[k].record()
             if pending is not None:                              # hand batch i-1 to the caller while batch i runs

@@ -267,6 +267,15 @@ def test_frame_pipeline_host_to_host_equals_device_resident_run(nets):
     assert got.dtype == torch.uint8 and not got.is_cuda and torch.equal(got, want.cpu())
     again = torch.cat([c.clone() for _, c in pipe.stream(st, u8.numpy())])                    # numpy in, chunks out, buffers recycled
     assert torch.equal(again, got)
+    # the full batches above went through the captured hipGraph (use_graph default), the ragged last one eagerly: bit-identical either way,
+    # also without the graph, for a SECOND source through the same pipeline (its packed state copied into the static buffer) and back
+    assert pipe._graph is not None
+    assert torch.equal(driver.FramePipeline(net_g, me, batch=4, use_graph=False).run(st, u8), got)
+    src2, _ = synth_clip(1, seed=10)
+    st2 = driver.encode_source_state(net_g, me, src2.cuda(), x[0:1], True)
+    want2 = driver.render_frames(st2, x, net_g, me, True, True, batch=4)
+    assert torch.equal(pipe.run(st2, u8), want2.cpu()) and not torch.equal(want2, want)
+    assert torch.equal(pipe.run(st, u8), got)
     # resize branch: 300x340 frames -> 256x256
     big = (torch.rand((2, 300, 340, 3), generator=torch.Generator().manual_seed(3)) * 255).to(torch.uint8)
     y = ops.frames_u8_to_nchw(big.cuda(), (256, 256))
