@@ -302,6 +302,18 @@ def make_animation(source_image, driving_video, net_g, motion_estimator, relativ
     return preds, list(drv8)
 
 
+def _host_copy(dst, src):
+    """CPU tensor -> CPU tensor as ONE plain memcpy.  `Tensor.copy_` between host tensors goes through ATen's parallel copy kernel: its
+    OpenMP team (one thread per host CPU) spins after the region, and on a CPU-quota'd container that spinning throttles the very thread
+    that issues the next batch's kernel launches -- measured: a 0.8 MB copy per batch made the following ~450 launches take 32 ms instead of
+    8 (tools/pipe_prof.py)."""
+    if dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and not dst.is_cuda and not src.is_cuda:
+        import numpy as np
+        np.copyto(dst.numpy(), src.numpy())
+    else:
+        dst.copy_(src)
+
+
 class FramePipeline:
     """N3 -- the host I/O around the loop (demo.py:166-185 in, :222 out) as an MI355X pipeline: uint8 driving frames leave
     pinned host memory one byte per sample, are resized / normalised ON the device, rendered in batches, and the uint8 result
@@ -310,9 +322,8 @@ class FramePipeline:
     numpy array [N,H,W,3] (or an iterable of such chunks) and returns / yields uint8 [n,256,256,3] host tensors.
 
     use_graph (default on): the per-batch launch sequence (uint8 -> fp32 normalise, keypoints, dense motion, generator, uint8 pack: ~700
-    launches behind Python + ctypes) is captured ONCE in a hipGraph over static input / output / source-state buffers and replayed per full
-    batch.  In fp32 the GPU step (110 ms) hides the host; in bf16 (42 ms) the host thread -- launches plus the pinned-memory copies and
-    waits of this pipeline -- was the bound: 946 frames/s host-to-host against 1437 device-resident.  A new source is a copy of its packed
+    launches, ~8 ms of Python + ctypes) is captured ONCE in a hipGraph over static input / output / source-state buffers and replayed per
+    full batch: it matters where a batch's GPU work is shorter than that (small batches in bf16).  A new source is a copy of its packed
     state into the static buffer (the unpacked tensors are views of it); a ragged last batch runs eagerly."""
 
     def __init__(self, net_g, motion_estimator, batch=60, frame_hw=(256, 256), swap_rb=False, relative=True, adapt_movement_scale=True,
@@ -386,7 +397,7 @@ class FramePipeline:
             a, n, k = i * B, min(B, N - i * B), i & 1
             if in_free[k] is not None:
                 in_free[k].synchronize()                         # compute has consumed the device copy staged from this host buffer
-            self.pin_in[k][:n].copy_(frames[a:a + n])            # host memcpy into pinned memory (a decoder would write here directly)
+            _host_copy(self.pin_in[k][:n], frames[a:a + n])      # host memcpy into pinned memory (a decoder would write here directly)
             with torch.cuda.stream(self.s_h2d):
                 self.dev_in[k][:n].copy_(self.pin_in[k][:n], non_blocking=True)
                 h2d = torch.cuda.Event()
@@ -419,5 +430,5 @@ class FramePipeline:
         if out is None:
             out = torch.empty((frames.shape[0], self.img, self.img, 3), dtype=torch.uint8)
         for a, chunk in self.stream(state, frames):
-            out[a:a + chunk.shape[0]].copy_(chunk)
+            _host_copy(out[a:a + chunk.shape[0]], chunk)
         return out
