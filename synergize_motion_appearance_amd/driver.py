@@ -208,7 +208,7 @@ def broadcast_source_state(net_g, motion_estimator, source=None, initial_frame=N
 
 
 def render_frames(state: SourceState, frames, net_g, motion_estimator, relative=True, adapt_movement_scale=True,
-                  batch=8, want="uint8", w=1.0):
+                  batch=30, want="uint8", w=1.0):
     """frames [n,3,H,W] (any subset of a clip, in any order: frames are independent given `state`) -> uint8 [n,H,W,3]
     / fp32 NCHW [n,3,H,W] / both."""
     eng_g, eng_m = net_g.engine(), motion_estimator.engine()
@@ -233,7 +233,7 @@ def render_frames(state: SourceState, frames, net_g, motion_estimator, relative=
 
 
 @torch.no_grad()
-def animate_sharded(source, driving, net_g, motion_estimator, relative=True, adapt_movement_scale=True, batch=8,
+def animate_sharded(source, driving, net_g, motion_estimator, relative=True, adapt_movement_scale=True, batch=30,
                     root=0, anchor_idx=0, gather=True, group=None):
     """The N>1 form of `animate_batched` (one process per GPU, torch.distributed initialised): rank `root` encodes the
     source (+ the anchor frame's keypoints and the hull scale) and broadcasts the packed state once; every rank
@@ -269,7 +269,7 @@ def animate_sharded(source, driving, net_g, motion_estimator, relative=True, ada
 
 @torch.no_grad()
 def animate_batched(source, driving, net_g, motion_estimator, relative=True, adapt_movement_scale=True,
-                    batch=8, kp_source=None, kp_driving_initial=None, source_cache=None, want="uint8", anchor_idx=0, w=1.0):
+                    batch=30, kp_source=None, kp_driving_initial=None, source_cache=None, want="uint8", anchor_idx=0, w=1.0):
     """source [3,H,W] / [1,3,H,W], driving [N,3,H,W] device tensors in [-1,1].
     -> uint8 frames [N,H,W,3] (want='uint8'), fp32 NCHW [N,3,H,W] ('float'), or both ('both').
     anchor_idx: the frame whose keypoints are `kp_driving_initial`.  The reference's dataset path
@@ -290,7 +290,7 @@ def animate_batched(source, driving, net_g, motion_estimator, relative=True, ada
 
 @torch.no_grad()
 def make_animation(source_image, driving_video, net_g, motion_estimator, relative=True,
-                   adapt_movement_scale=True, cpu=False, batch=8):
+                   adapt_movement_scale=True, cpu=False, batch=30):
     """demo.py:103-134 signature; returns (predictions, driving_imgs) as lists of uint8 HWC arrays."""
     if cpu:
         raise RuntimeError("the MI355X-native path has no CPU mode")
