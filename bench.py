@@ -73,7 +73,7 @@ def _pin_process_to(cpus):
 
 
 def _idle_cpus(allowed, want, dt=0.3):
-    """the `want` least busy of the allowed CPUs over a short /proc/stat window: on a shared 256-CPU host everybody's pinned jobs sit on
+    """the least busy window of `want` consecutive allowed CPUs over a short /proc/stat sample: on a shared 256-CPU host everybody's pinned jobs sit on
     CPUs 0..31, and a baseline confined there measured 0.22 fps on one box and 0.91 on another."""
     def snap():
         out = {}
@@ -88,9 +88,17 @@ def _idle_cpus(allowed, want, dt=0.3):
         time.sleep(dt)
         b = snap()
         busy = {c: 1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in allowed if c in a and c in b}
-        order = sorted(busy, key=lambda c: (round(busy[c], 2), c))
+        order = sorted(busy)
         if len(order) >= want:
-            return sorted(order[:want])
+            # the quietest WINDOW of `want` consecutive CPUs (step 8: CCX granularity), not the `want` quietest CPUs anywhere: threads scattered
+            # over sockets / CCXs lose more to cache and NUMA traffic than they gain from idleness
+            best, best_load = None, None
+            for i in range(0, len(order) - want + 1, 8):
+                win = order[i:i + want]
+                load = sum(busy[c] for c in win) / want
+                if best is None or load < best_load - 1e-9:
+                    best, best_load = win, load
+            return sorted(best)
     except (OSError, ValueError, IndexError):
         pass
     return sorted(allowed)[:want]
