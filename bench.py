@@ -506,13 +506,13 @@ def main():
     ap.add_argument("--profile-only", action="store_true", help="the command the rocprofv3 passes wrap: timed steps only (no B=1 re-renders, "
                                                                  "no roofline / PCIe / CPU / bf16 legs)")
     ap.add_argument("--img-size", type=int, default=256, choices=[256, 512], help="512: BASELINE configs[3] (options/test_512.yml, DESIGN N4: every grid x2; "
-                                                                                    "default --batch 15; no bf16 / CPU legs); never the headline")
+                                                                                    "default --batch 75; no bf16 / CPU legs); never the headline")
     ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")
     args = ap.parse_args()
     if args.img_size != 256:
         args.no_cpu_baseline = args.no_bf16_leg = args.no_train_leg = True
         if "--batch" not in sys.argv:
-            args.batch = 15
+            args.batch = 75
     if args.profile_only:
         args.no_cpu_baseline = args.no_roofline = args.no_d2h = args.no_bf16_leg = args.no_consistency = args.no_train_leg = True
 
