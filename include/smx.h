@@ -307,10 +307,12 @@ int smx_winograd43_conv3x3_f32(const float* x, int lda, const float* u43, const 
 /* ---------------------------------------------------------------------------------------
  * A12: VectorQuantizer.forward (archs/vqgan_arch.py:33-93), fused: d = |z|^2 + |e|^2 - 2 z.e
  * over the first Ks rows, first-minimum argmin, gather, z_q = z + (e - z).
- * z tokens [N][D]; codebook [Ks..][D]; idx int64 [N]; zq [N][D]; dmin [N] (min distance, optional);
- * sqerr: one float, = sum (zq-z)^2 (optional; written, not accumulated), computed WITHOUT atomics: per-block partials in
- * sq_ws (smx_vq_ws_floats(N) floats, required with sqerr) summed in a fixed order -> the codebook loss is bit-reproducible.
- * z, codebook, zq 16-byte aligned.
+ * z tokens [N][D]; codebook [Ks..][D]; idx int64 [N]; zq [N][D]; dmin [N] (min distance, optional); Ks <= 4096.
+ * sq_ws: REQUIRED workspace of smx_vq_ws_floats(N) floats, 16-byte aligned: the code norms |e|^2 (computed once per call by a small
+ * kernel of their own, then read by every block) followed by the per-block partials of sqerr.
+ * sqerr: one float, = sum (zq-z)^2 (optional; written, not accumulated), computed WITHOUT atomics: the per-block partials are
+ * summed in a fixed order -> the codebook loss is bit-reproducible.  z is read from HBM once (the gather epilogue reuses the
+ * MFMA operand fragments).  z, codebook, zq 16-byte aligned.
  * ------------------------------------------------------------------------------------- */
 int64_t smx_vq_ws_floats(int N);
 int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, float* zq, float* dmin,

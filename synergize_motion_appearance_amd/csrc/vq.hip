@@ -3,15 +3,23 @@
 //
 // The reference materialises two [N][K] fp32 matrices (d and the one-hot); here the z.e
 // contraction runs on the fp32 MFMA (32 tokens x 32 codes per wave-tile, exact fp32), the
-// running (min, index) lives in registers in the MFMA C layout, the L2 reduction over the
-// codebook axis finishes with wavefront shuffles, and nothing but z, the codebook, the
-// indices and z_q touches HBM.  z fragments stay in registers for the whole codebook sweep;
+// running (min, index) lives in registers in the MFMA C layout, and nothing but z, the codebook,
+// the indices and z_q touches HBM.  z fragments stay in registers for the whole codebook sweep;
 // code tiles (32 x D) are double-buffered in LDS (row stride D+4 dwords: conflict-free ds_read_b128),
 // the next tile streamed through a few registers in chunks inside the current tile's MFMA loop (one barrier per tile);
 // sum (z_q - z)^2 leaves as per-block partials summed in a fixed order (bit-reproducible loss).
+//
+// Everything outside the MFMA loop is kept short: a CU holds two blocks, and whenever one is in its prologue or epilogue the other
+// has the SIMDs to itself but nobody to hide its own latencies (s_memtime stamps, tools/vq_phase.py: the first form of this kernel
+// spent 37 % of a block's life outside the loop, and a block alone ran its loop at 0.71 of the pipe).  So: the code norms |e|^2 come
+// from a tiny kernel of their own (every block used to recompute all Ks of them: 1 MB of L2 reads and 32 dependent round trips per
+// block, 23 % of its life); the argmin over the 32 code lanes goes through an LDS transpose (8 ds_read_b128 per lane instead of 160
+// dependent ds_bpermute); the gather epilogue takes z from the MFMA operand fragments every lane still HOLDS (through LDS, so its
+// HBM lines are whole) -- z is read exactly once; and the loop reads each B slice one slice ahead of its MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include "smx.h"
 #include "smx_common.h"
 
@@ -19,19 +27,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-template <int D>
-__global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+constexpr int VQ_MAX_CODES = 4096;     // the norms' share of the workspace (and of LDS: 16 KB)
+
+// |e|^2 of every code, once per call: 8 lanes per code, fixed summation order
+__global__ __launch_bounds__(256) void vq_code_norms_kernel(const float* __restrict__ cb, float* __restrict__ norms, int D, int Ks, int ks_pad) {
+  const int code = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7; float s = 0.f;
+  if (code < Ks) {
+    const float* cp = cb + (long long)code * D;
+    for (int c = part * 4; c < D; c += 32) { const float4 v = *reinterpret_cast<const float4*>(cp + c); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+  }
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (part == 0 && code < ks_pad) norms[code] = s;
+}
+
+template <int D, bool PROF>
+__global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb, const float* __restrict__ norms,
                                                  int64_t* __restrict__ idx_out, float* __restrict__ zq,
                                                  float* __restrict__ dmin_out, float* __restrict__ sq_part, int N, int Ks) {
   // 32 codes per tile, two LDS buffers: the next tile's global loads are issued DURING the current tile's MFMAs and land in
   // registers while the matrix pipe works; they go to the other buffer a quarter tile later -> ONE barrier per tile and no
   // exposed HBM/L2 round trip (the single-buffered form had a load -> barrier -> compute -> barrier sequence per 64 codes)
-  constexpr int LD = D + 4, KS = D / 8, CT = 32;
+  constexpr int LD = D + 4, KS = D / 8, CT = 32, TLD = 36;   // TLD: row stride of the argmin transpose (16-B aligned rows)
   constexpr int PF = CT * (D / 4) / 256;               // float4 per thread per tile (D=256: 8, D=32: 1)
   static_assert(CT * (D / 4) % 256 == 0, "tile must split evenly over the block");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* cs = sm;                       // [2][CT][LD] code tiles
-  float* ee = sm + 2 * CT * LD;         // [Ks rounded up to CT] all code norms, computed once per block
+  float* ee = sm + (2 * CT * LD > 4 * 32 * TLD * 2 ? 2 * CT * LD : 4 * 32 * TLD * 2);   // [Ks rounded up to CT] the code norms
   const int ks_pad = (Ks + CT - 1) / CT * CT;
   float* zzs = ee + ks_pad;             // [4][32] token norms per wave
   int* bis = reinterpret_cast<int*>(zzs + 128);   // [4][32] best index per wave
@@ -41,6 +62,8 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
   const int myrow = row0 + (lane & 31);
   const bool rok = myrow < N;
 
+  unsigned long long ts[6], wall0 = 0;
+  if (PROF) { ts[0] = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
   // z fragments: lane l holds token (l&31), k = 8*kk + 4*(l>>5) + j
   float4 af[KS]; float zz = 0.f;
 #pragma unroll
@@ -50,16 +73,8 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
   }
   zz += __shfl_xor(zz, 32, 64);
   if (lane < 32) zzs[wave * 32 + lane] = zz;
-  // all code norms once per block (Ks*D MACs: <1% of the block's 128*Ks*D): 8 lanes per code
-  for (int c0 = 0; c0 < ks_pad; c0 += 32) {
-    const int code = c0 + (threadIdx.x >> 3), part = threadIdx.x & 7; float s = 0.f;
-    if (code < Ks) {
-      const float* cp = cb + (long long)code * D;
-      for (int c = part * 4; c < D; c += 32) { const float4 v = *reinterpret_cast<const float4*>(cp + c); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
-    }
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    if (part == 0) ee[code] = s;
-  }
+  for (int i = threadIdx.x; i < ks_pad; i += 256) ee[i] = norms[i];
+  if (PROF) ts[1] = __builtin_readcyclecounter();
   // the next tile travels global -> registers -> LDS in NCH chunks INSIDE the current tile's MFMA loop (chunk q is requested at
   // kk = q*KS/NCH and written to the other buffer KS/NCH steps later): only PF/NCH float4 are live at a time -- the whole-tile
   // prefetch cost 32 VGPRs at D = 256 and dropped the kernel to one wave per SIMD
@@ -93,23 +108,29 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
   for (int r = 0; r < 16; ++r) { bestd[r] = INFINITY; besti[r] = 0; }
 
   const int ntiles = ks_pad / CT;
+  if (PROF) ts[2] = __builtin_readcyclecounter();
   for (int t = 0; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* bp = cs + ((t & 1) * CT + (lane & 31)) * LD + (lane >> 5) * 4;
+    float4 bq[2];                                      // the slice after this one is read while this one's MFMAs run: a block whose
+    bq[0] = *reinterpret_cast<const float4*>(bp);      // partner is in its prologue / epilogue has nobody to hide the LDS latency
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
+      if (kk + 1 < KS) bq[(kk + 1) & 1] = *reinterpret_cast<const float4*>(bp + (kk + 1) * 8);
       if (kk % KSTEP == 0) {                           // compile-time positions (the loop is fully unrolled)
         if (kk > 0 && more) stash((t + 1) & 1, (kk / KSTEP - 1) * PC);   // the buffer tile t-1 used: free since the barrier that ended t-1
         if (more) fetch(t + 1, (kk / KSTEP) * PC);
       }
-      const float4 bf = *reinterpret_cast<const float4*>(bp + kk * 8);
+      const float4 bf = bq[kk & 1];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf.w, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the next slice's ds_read first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then this slice's four MFMAs
     }
     if (more) stash((t + 1) & 1, (NCH - 1) * PC);
     const int code = t * CT + (lane & 31);
@@ -123,17 +144,32 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
     }
     __syncthreads();
   }
-  // reduce over the 32 code lanes (same lane>>5 half): smaller d, ties -> smaller index
+  if (PROF) ts[3] = __builtin_readcyclecounter();
+  // argmin over the 32 code lanes: (d, index) pairs transposed through LDS (the code tiles are dead: the loop's last barrier is behind
+  // every wave), then each lane folds 16 codes of one token -- smaller d, ties -> smaller index -- and meets its neighbour once
+  float* td = cs + wave * (2 * 32 * TLD);
+  int* ti = reinterpret_cast<int*>(td + 32 * TLD);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    float d = bestd[r]; int i = besti[r];
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    td[row * TLD + (lane & 31)] = bestd[r];
+    ti[row * TLD + (lane & 31)] = besti[r];
+  }
+  __syncthreads();
+  {
+    const int row = lane >> 1, hc = lane & 1;
+    const float4* dp = reinterpret_cast<const float4*>(td + row * TLD + hc * 16);
+    const int4* ip = reinterpret_cast<const int4*>(ti + row * TLD + hc * 16);
+    float d = INFINITY; int i = 0x7fffffff;
+    auto fold = [&](float d2, int i2) { if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; } };
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      const float d2 = __shfl_xor(d, o, 64); const int i2 = __shfl_xor(i, o, 64);
-      if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+    for (int j = 0; j < 4; ++j) {
+      const float4 dv = dp[j]; const int4 iv = ip[j];
+      fold(dv.x, iv.x); fold(dv.y, iv.y); fold(dv.z, iv.z); fold(dv.w, iv.w);
     }
-    if ((lane & 31) == 0) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    fold(__shfl_xor(d, 1, 64), __shfl_xor(i, 1, 64));
+    if (i == 0x7fffffff) i = 0;                            // a row of NaN distances: index 0, as torch.argmin of an all-NaN row is not relied on
+    if (hc == 0) {
       bis[wave * 32 + row] = i;
       if (row0 + row < N) {
         idx_out[row0 + row] = (int64_t)i;
@@ -142,18 +178,32 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
     }
   }
   __syncthreads();
-  // gather: z_q = z + (e[idx] - z)  (straight-through form, vqgan_arch.py:76); 16 B per lane, D/4 lanes per token
-  constexpr int LPR = D / 4, RPI = 64 / LPR;           // lanes per row, rows per iteration (D=256: 64 / 1, D=32: 8 / 8)
+  if (PROF) ts[4] = __builtin_readcyclecounter();
+  // gather: z_q = z + (e[idx] - z)  (straight-through form, vqgan_arch.py:76).  z is NOT read again: every lane still holds its operand
+  // fragments, which go through LDS CP columns at a time ([32 tokens][CP + 4] per wave, in the dead code tiles) and come back a token
+  // row per 64 / (CP/4) lanes, so the codebook reads and the z_q stores are whole 128-byte lines (16 B per lane, CP*4 bytes per row)
+  constexpr int CP = D < 64 ? D : 64, TL = CP + 4, LPRW = CP / 4, RPI = 64 / LPRW, KP = CP / 8;
+  float* tz = cs + wave * (32 * TL);
   float err = 0.f;
-#pragma unroll 4
-  for (int r = lane / LPR; r < 32; r += RPI) {
-    const int row = row0 + r; if (row >= N) break;
-    const int c = (lane % LPR) * 4;
-    const float4 e = *reinterpret_cast<const float4*>(cb + (long long)bis[wave * 32 + r] * D + c);
-    const float4 zv = *reinterpret_cast<const float4*>(z + (long long)row * D + c);
-    const float4 df = make_float4(e.x - zv.x, e.y - zv.y, e.z - zv.z, e.w - zv.w);
-    if (zq) *reinterpret_cast<float4*>(zq + (long long)row * D + c) = make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w);
-    err += (df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w);
+#pragma unroll
+  for (int ps = 0; ps < D / CP; ++ps) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      *reinterpret_cast<float4*>(tz + (lane & 31) * TL + k * 8 + (lane >> 5) * 4) = af[ps * KP + k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < 32 / RPI; ++rr) {
+      const int r = rr * RPI + lane / LPRW, c = (lane % LPRW) * 4;
+      const int row = row0 + r;
+      const float4 zv = *reinterpret_cast<const float4*>(tz + r * TL + c);
+      const float4 e = *reinterpret_cast<const float4*>(cb + (long long)bis[wave * 32 + r] * D + ps * CP + c);
+      const float4 df = make_float4(e.x - zv.x, e.y - zv.y, e.z - zv.z, e.w - zv.w);
+      if (row < N) {
+        if (zq) *reinterpret_cast<float4*>(zq + (long long)row * D + ps * CP + c) = make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w);
+        err += (df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   if (sq_part) {
     // deterministic: fixed shuffle tree per wave, the block's four waves added in order, one partial per block; the host-visible
@@ -163,6 +213,21 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
     if (lane == 0) wsum[wave] = err;
     __syncthreads();
     if (threadIdx.x == 0) sq_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  }
+  if (PROF) {                                              // tools/vq_phase.py: phase lengths in shader clocks, in place of eight dmin values
+    ts[5] = __builtin_readcyclecounter();
+    __syncthreads();
+    if (threadIdx.x == 0 && dmin_out && row0 + 16 <= N) {
+#pragma unroll
+      for (int k = 1; k < 6; ++k) dmin_out[row0 + k - 1] = (float)(ts[k] - ts[k - 1]);
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      dmin_out[row0 + 6] = (float)(((xcc & 7) << 8) | ((hw >> 8) & 0xff));          // CU key
+      dmin_out[row0 + 7] = (float)(ts[0] & 0xffffff); dmin_out[row0 + 8] = (float)((ts[0] >> 24) & 0xffffff);   // start (shader clock)
+      dmin_out[row0 + 9] = (float)(ts[5] & 0xffffff); dmin_out[row0 + 10] = (float)((ts[5] >> 24) & 0xffffff);  // end
+      dmin_out[row0 + 11] = (float)(wall0 & 0xffffff); dmin_out[row0 + 12] = (float)(wall_clock64() & 0xffffff); // 100 MHz wall clock
+    }
   }
 }
 
@@ -180,24 +245,37 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
   if (threadIdx.x == 0) *sqerr = red[0];
 }
 
-template <int D>
-int launch_vq(const float* z, const float* cb, int64_t* idx, float* zq, float* dmin, float* sqerr, float* sq_ws, int N, int Ks, hipStream_t st) {
-  const size_t lds = (size_t)(2 * 32 * (D + 4) + (Ks + 31) / 32 * 32 + 128 + 128 + 4) * sizeof(float);
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vq_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <int D, bool PROF>
+int launch_vq_p(const float* z, const float* cb, int64_t* idx, float* zq, float* dmin, float* sqerr, float* ws, int N, int Ks, hipStream_t st) {
+  const int ks_pad = (Ks + 31) / 32 * 32;
+  const int tile_floats = 2 * 32 * (D + 4) > 4 * 32 * 36 * 2 ? 2 * 32 * (D + 4) : 4 * 32 * 36 * 2;
+  const size_t lds = (size_t)(tile_floats + ks_pad + 128 + 128 + 4) * sizeof(float);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vq_kernel<D, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nblk = smx_cdiv(N, 128);
-  SMX_LAUNCH(vq_kernel<D>, dim3(nblk), dim3(256), lds, st, z, cb, idx, zq, dmin, sqerr ? sq_ws : nullptr, N, Ks);
-  if (sqerr) SMX_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, sq_ws, nblk, sqerr);
+  float* norms = ws; float* part = ws + VQ_MAX_CODES;
+  SMX_LAUNCH(vq_code_norms_kernel, dim3(ks_pad / 32), dim3(256), 0, st, cb, norms, D, Ks, ks_pad);
+  SMX_LAUNCH((vq_kernel<D, PROF>), dim3(nblk), dim3(256), lds, st, z, cb, (const float*)norms, idx, zq, dmin, sqerr ? part : nullptr, N, Ks);
+  if (sqerr) SMX_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, part, nblk, sqerr);
   return smx_launch_status();
+}
+
+template <int D>
+int launch_vq(const float* z, const float* cb, int64_t* idx, float* zq, float* dmin, float* sqerr, float* ws, int N, int Ks, hipStream_t st) {
+#ifdef SMX_TOOLS
+  static const bool prof = getenv("SMX_VQ_PROF") != nullptr;
+  if (prof) return launch_vq_p<D, true>(z, cb, idx, zq, dmin, sqerr, ws, N, Ks, st);
+#endif
+  return launch_vq_p<D, false>(z, cb, idx, zq, dmin, sqerr, ws, N, Ks, st);
 }
 
 }  // namespace
 
-extern "C" int64_t smx_vq_ws_floats(int N) { return N > 0 ? (int64_t)smx_cdiv(N, 128) : 0; }
+extern "C" int64_t smx_vq_ws_floats(int N) { return N > 0 ? (int64_t)VQ_MAX_CODES + smx_cdiv(N, 128) : 0; }
 
 extern "C" int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, float* zq, float* dmin,
                                   float* sqerr, float* sq_ws, int N, int D, int Ks, void* stream) {
-  if (!z || !codebook || !idx || N <= 0 || Ks <= 0 || (sqerr && !sq_ws)) return SMX_EINVAL;
-  if ((((uintptr_t)z) | ((uintptr_t)codebook) | ((uintptr_t)zq)) & 15) return SMX_EINVAL;
+  if (!z || !codebook || !idx || !sq_ws || N <= 0 || Ks <= 0 || Ks > VQ_MAX_CODES) return SMX_EINVAL;
+  if ((((uintptr_t)z) | ((uintptr_t)codebook) | ((uintptr_t)zq) | ((uintptr_t)sq_ws)) & 15) return SMX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   switch (D) {
     case 32: return launch_vq<32>(z, codebook, idx, zq, dmin, sqerr, sq_ws, N, Ks, st);

@@ -750,7 +750,7 @@ def vq_nearest(z_tokens, codebook, Ks, want_zq=True):
     zq = torch.empty_like(z_tokens) if want_zq else None
     dmin = torch.empty((N,), device=z_tokens.device, dtype=torch.float32)
     sq = torch.empty((1,), device=z_tokens.device, dtype=torch.float32)
-    ws = torch.empty((int(L.load().smx_vq_ws_floats(N)),), device=z_tokens.device, dtype=torch.float32)   # per-block partials (no atomics)
+    ws = torch.empty((int(L.load().smx_vq_ws_floats(N)),), device=z_tokens.device, dtype=torch.float32)   # code norms + per-block loss partials (no atomics)
     meta = {"bytes": 8.0 * N * D + 4.0 * Ks * D + 8.0 * N, "flops": 2.0 * N * Ks * D}
     L.check(_timed("vq", meta, L.load().smx_vq_nearest_f32, z_tokens.contiguous().data_ptr(), codebook.contiguous().data_ptr(),
                    idx.data_ptr(), None if zq is None else zq.data_ptr(), dmin.data_ptr(), sq.data_ptr(), ws.data_ptr(), N, D, Ks,
