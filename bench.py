@@ -197,10 +197,11 @@ def init_distributed(rank, world, dev):
     return dist, "gloo (explicitly requested via SMX_BENCH_BACKEND)"
 
 
-def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=True):
+def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=True, gan=False):
     """BASELINE configs[4] on ONE GPU: the train.yml generator + motion-estimator step (forward of both networks in training mode,
     L1 / codebook / equivariance / multi-scale VGG19 perceptual losses, one backward through both on the HIP backward kernels, Adam per
-    network on flat buffers, EMA) on `batch` (source, driving) pairs.  No discriminator (active from iteration 5001 in the reference).
+    network on flat buffers, EMA) on `batch` (source, driving) pairs.  gan=True: the form the reference runs from iteration 5001 -- the
+    discriminator's score of `out` with the adaptive weight in the generator loss, then the discriminator's own hinge step.
     An extra key, never `value`."""
     from basicsr.archs import build_network
     from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
@@ -210,20 +211,25 @@ def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=Tr
     net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
     me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
     net_g, me = net_g.to(dev), me.to(dev)
-    topt = {k: v for k, v in cfg["train"].items() if k != "gan_opt"}
+    net_d = None
+    if gan:
+        net_d = build_network(cfg["network_d"])
+        net_d.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_d.state_dict().items()]), strict=True)
+        net_d = net_d.to(dev)
+    topt = {k: v for k, v in cfg["train"].items() if gan or k != "gan_opt"}
     topt["perceptual_opt"] = dict(topt["perceptual_opt"], synthetic_vgg19=True)      # the ImageNet VGG19 weights are a download: synthetic ones of that layout
     topt["compute_dtype"] = compute_dtype
-    step = TrainStep(net_g, me, topt, use_graph=use_graph)
+    step = TrainStep(net_g, me, topt, use_graph=use_graph, net_d=net_d)
     warmup += (step.GRAPH_WARMUP + 1) if use_graph else 0          # eager steps, then the capture
     _, clip = synth_clip(2 * batch, seed=321)
     src, drv = clip[:batch].contiguous().to(dev), clip[batch:].contiguous().to(dev)
     torch.cuda.reset_peak_memory_stats()
     for _ in range(warmup):
-        step.step(src, drv)
+        step.step(src, drv, gan=gan)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses, _ = step.step(src, drv)
+        losses, _ = step.step(src, drv, gan=gan)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     total = float(losses["l_g_total"])
@@ -234,7 +240,9 @@ def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=Tr
                         ("fp32" if compute_dtype == "f32" else "bf16 compute (every convolution / Linear contraction, forward + data + weight gradient, on "
                          "v_mfma_f32_32x32x16_bf16 with operands rounded like torch.autocast(bfloat16); fp32 storage, normalisation, attention, optimiser)") +
                         ", losses: L1 pixel + codebook + motion reconstruction + equivariance + MultiScalePyramidPerceptualLoss (VGG19 layout with synthetic weights, "
-                        "on out and out_lr); Adam per network + EMA inside the step; GAN branch (from iteration 5001) not built",
+                        "on out and out_lr)" + (" + hinge GAN term with the adaptive weight, then the discriminator's own hinge step (the form from iteration 5001)" if gan else
+                                                "; the form of iterations 1..5000 (no discriminator yet; `gan_step` times the later form)") +
+                        "; Adam per network + EMA inside the step",
             "value": round(batch / dt, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * dt, 2), "batch": batch, "steps": steps, "warmup": warmup,
             "dtype": compute_dtype, "launch": "hipGraph replay of zero_grad + forward + losses + backward (train.use_hip_graph); all-reduce / Adam / EMA outside"
             if use_graph else "eager launches", "l_g_total_last": round(total, 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
@@ -641,6 +649,9 @@ def main():
         result["configs4_train"]["eager_ms_per_step"] = train_leg(dev, use_graph=False)["ms_per_step"]
         torch.cuda.empty_cache()
         result["configs4_train"]["bf16_compute"] = train_leg(dev, compute_dtype="bf16")
+        torch.cuda.empty_cache()
+        g = train_leg(dev, gan=True)                             # iterations past net_d_start_iter: + discriminator forward / backward / Adam
+        result["configs4_train"]["gan_step"] = {k: g[k] for k in ("workload", "value", "unit", "ms_per_step", "l_g_total_last", "peak_mem_GB")}
         torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_train_leg:

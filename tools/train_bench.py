@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--perceptual", action="store_true", help="+ MultiScalePyramidPerceptualLoss on out and out_lr (VGG19 layout, synthetic weights)")
+    ap.add_argument("--gan", action="store_true", help="the form past net_d_start_iter: discriminator term with the adaptive weight + the discriminator's own step")
     ap.add_argument("--graph", action="store_true", help="train.use_hip_graph: replay the captured step")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: convolution / Linear contractions on the bf16 MFMA (train.compute_dtype)")
     a = ap.parse_args()
@@ -30,22 +31,27 @@ def main():
     net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
     me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
     net_g, me = net_g.cuda(), me.cuda()
-    topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt")}
+    topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt",) + (() if a.gan else ("gan_opt",))}
+    net_d = None
+    if a.gan:
+        net_d = build_network(cfg["network_d"])
+        net_d.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_d.state_dict().items()]), strict=True)
+        net_d = net_d.cuda()
     if a.perceptual:
         topt["perceptual_opt"] = dict(cfg["train"]["perceptual_opt"], synthetic_vgg19=True)
     topt["compute_dtype"] = a.dtype
-    step = TrainStep(net_g, me, topt, use_graph=a.graph)
+    step = TrainStep(net_g, me, topt, use_graph=a.graph, net_d=net_d)
     _, clip = synth_clip(2 * a.batch, seed=321)
     src, drv = clip[:a.batch].contiguous().cuda(), clip[a.batch:].contiguous().cuda()
     for _ in range(a.warmup + (3 if a.graph else 0)):
-        step.step(src, drv)
+        step.step(src, drv, gan=a.gan)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        losses, _ = step.step(src, drv)
+        losses, _ = step.step(src, drv, gan=a.gan)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"what": f"train.yml generator + motion-estimator step ({'with' if a.perceptual else 'no'} perceptual loss, no GAN), compute {a.dtype}{', hipGraph replay' if a.graph else ''}, 1 GPU", "batch": a.batch, "ms_per_step": round(1e3 * dt, 2),
+    print(json.dumps({"what": f"train.yml generator + motion-estimator step ({'with' if a.perceptual else 'no'} perceptual loss, {'with the GAN branch' if a.gan else 'no GAN'}), compute {a.dtype}{', hipGraph replay' if a.graph else ''}, 1 GPU", "batch": a.batch, "ms_per_step": round(1e3 * dt, 2),
                       "pairs_per_s": round(a.batch / dt, 2), "l_g_total": float(losses["l_g_total"]),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
 
