@@ -405,6 +405,17 @@ int smx_pack_weight_bf16(const float* w_oihw, void* packed, int Cout, int Cin, i
  * the training step's 3x3 forward and data-gradient convolutions run on the fused Winograd kernel with the current weights */
 int64_t smx_winograd_u_floats(int N, int C);
 int smx_pack_winograd_u_f32(const float* w_oihw, float* u, int Cout, int Cin, int mode, void* stream);
+/* All of a step's packings in one launch.  items_dev: DEVICE array of n_items descriptors sorted by first_block; item i owns blocks
+ * [first_block, first_block + ceil(total / 1024)), n_blocks = the sum.  kind: which of the three packings above (same arguments, same
+ * results bit for bit); total = output elements (Cout*Cin*kh*kw, or smx_winograd_u_floats(N, C) for SMX_PACK_WINOGRAD_U). */
+enum { SMX_PACK_F32 = 0, SMX_PACK_BF16 = 1, SMX_PACK_WINOGRAD_U = 2 };
+typedef struct smx_pack_item {
+  const float* w;      /* OIHW parameter */
+  void* out;
+  int64_t total;
+  int32_t cout, cin, kh, kw, mode, kind, first_block, reserved;
+} smx_pack_item;
+int smx_pack_batch(const smx_pack_item* items_dev, int n_items, int n_blocks, void* stream);
 /* batched y[g][c][r] = x[g][r][c] */
 int smx_transpose_f32(const float* x, int ldx, int64_t x_bs, float* y, int ldy, int64_t y_bs, int nb, int R, int C, void* stream);
 /* y = act(x) as its own pass (training keeps the pre-activation of GELU / swish / sigmoid for the backward) */

@@ -382,20 +382,23 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __rest
 // mode 0: OIHW -> [Cout][(ky,kx,ci)]            (the forward operand)
 // mode 1: OIHW -> [Cin][(kh-1-ky, kw-1-kx, co)] (the data-gradient operand: transposed channels, flipped taps)
 template <typename TO>
+__device__ __forceinline__ void pack_weight_elem(const float* __restrict__ w, TO* __restrict__ o, long long i, int Cout, int Cin, int kh, int kw, int mode) {
+  // i indexes the OUTPUT so that writes are coalesced
+  if (mode == 0) {
+    const int K = kh * kw * Cin; const int co = (int)(i / K), k = (int)(i - (long long)co * K);
+    const int tap = k / Cin, ci = k - tap * Cin;
+    St<TO>::st(o + i, w[((long long)co * Cin + ci) * kh * kw + tap]);
+  } else {
+    const int K = kh * kw * Cout; const int ci = (int)(i / K), k = (int)(i - (long long)ci * K);
+    const int tap = k / Cout, co = k - tap * Cout; const int ky = kh - 1 - tap / kw, kx = kw - 1 - tap % kw;
+    St<TO>::st(o + i, w[((long long)co * Cin + ci) * kh * kw + ky * kw + kx]);
+  }
+}
+
+template <typename TO>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, TO* __restrict__ o, int Cout, int Cin, int kh, int kw, int mode) {
   const long long total = (long long)Cout * Cin * kh * kw;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    // i indexes the OUTPUT so that writes are coalesced
-    if (mode == 0) {
-      const int K = kh * kw * Cin; const int co = (int)(i / K), k = (int)(i - (long long)co * K);
-      const int tap = k / Cin, ci = k - tap * Cin;
-      St<TO>::st(o + i, w[((long long)co * Cin + ci) * kh * kw + tap]);
-    } else {
-      const int K = kh * kw * Cout; const int ci = (int)(i / K), k = (int)(i - (long long)ci * K);
-      const int tap = k / Cout, co = k - tap * Cout; const int ky = kh - 1 - tap / kw, kx = kw - 1 - tap % kw;
-      St<TO>::st(o + i, w[((long long)co * Cin + ci) * kh * kw + ky * kw + kx]);
-    }
-  }
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) pack_weight_elem<TO>(w, o, i, Cout, Cin, kh, kw, mode);
 }
 
 // Winograd-domain weights U = G g G^T of F(2x2,3x3) in the fragment order winograd.hip reads ([16 f][N/32][C/8][2][32][4]:
@@ -403,28 +406,47 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 //   mode 0 (forward):       N = Cout, C = Cin,  g[n][a][b][c] = w[n][c][a][b]
 //   mode 1 (data gradient): N = Cin,  C = Cout, g[n][a][b][c] = w[c][n][2-a][2-b]
 // so the training step's 3x3 convolutions (forward AND data gradient) run on the fused Winograd kernel with this step's weights
-__global__ __launch_bounds__(256) void pack_winograd_u_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int mode, long long total) {
+__device__ __forceinline__ void pack_winograd_u_elem(const float* __restrict__ w, float* __restrict__ u, long long i, int Cout, int Cin, int mode) {
   const int N = mode ? Cin : Cout, Cc = mode ? Cout : Cin;
   const int n32 = (N + 31) / 32, c8 = Cc / 8;
   const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    long long t = i;
-    const int e = (int)(t & 3); t >>= 2; const int r = (int)(t & 31); t >>= 5; const int hh = (int)(t & 1); t >>= 1;
-    const int s = (int)(t % c8); t /= c8; const int nt = (int)(t % n32); const int f = (int)(t / n32);
-    float out = 0.f;
-    if (f < 16) {
-      const int n = nt * 32 + r, c = 8 * s + 4 * hh + e, fi = f >> 2, fj = f & 3;
-      if (n < N) {
-        double acc = 0.0;
-        for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) {
-            const float g = mode ? w[((long long)c * Cin + n) * 9 + (2 - a) * 3 + (2 - b)] : w[((long long)n * Cin + c) * 9 + a * 3 + b];
-            acc += G[fi][a] * (double)g * G[fj][b];
-          }
-        out = (float)acc;
-      }
+  long long t = i;
+  const int e = (int)(t & 3); t >>= 2; const int r = (int)(t & 31); t >>= 5; const int hh = (int)(t & 1); t >>= 1;
+  const int s = (int)(t % c8); t /= c8; const int nt = (int)(t % n32); const int f = (int)(t / n32);
+  float out = 0.f;
+  if (f < 16) {
+    const int n = nt * 32 + r, c = 8 * s + 4 * hh + e, fi = f >> 2, fj = f & 3;
+    if (n < N) {
+      double acc = 0.0;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+          const float g = mode ? w[((long long)c * Cin + n) * 9 + (2 - a) * 3 + (2 - b)] : w[((long long)n * Cin + c) * 9 + a * 3 + b];
+          acc += G[fi][a] * (double)g * G[fj][b];
+        }
+      out = (float)acc;
     }
-    u[i] = out;                                             // f >= 16: the prefetch pad behind the last fragment (zeros)
+  }
+  u[i] = out;                                             // f >= 16: the prefetch pad behind the last fragment (zeros)
+}
+
+__global__ __launch_bounds__(256) void pack_winograd_u_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int mode, long long total) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) pack_winograd_u_elem(w, u, i, Cout, Cin, mode);
+}
+
+// every packing of a step in ONE launch: a table of items (sorted by first_block), block b works on the item whose block range holds it,
+// 1024 output elements per block.  The per-layer launches were ~660 per training step at 6-11 us each, most of it launch latency.
+__global__ __launch_bounds__(256) void pack_batch_kernel(const smx_pack_item* __restrict__ items, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const smx_pack_item it = items[lo];
+  const long long base = (long long)((int)blockIdx.x - it.first_block) * 1024;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long long i = base + e * 256 + threadIdx.x;
+    if (i >= it.total) break;
+    if (it.kind == SMX_PACK_F32) pack_weight_elem<float>(it.w, (float*)it.out, i, it.cout, it.cin, it.kh, it.kw, it.mode);
+    else if (it.kind == SMX_PACK_BF16) pack_weight_elem<bf16_t>(it.w, (bf16_t*)it.out, i, it.cout, it.cin, it.kh, it.kw, it.mode);
+    else pack_winograd_u_elem(it.w, (float*)it.out, i, it.cout, it.cin, it.mode);
   }
 }
 
@@ -613,6 +635,12 @@ extern "C" int smx_pack_winograd_u_f32(const float* w_oihw, float* u, int Cout, 
   if (Cc % 8 != 0) return SMX_EINVAL;
   const long long total = smx_winograd_u_floats(N, Cc);
   SMX_LAUNCH(pack_winograd_u_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, mode, total);
+  return smx_launch_status();
+}
+
+extern "C" int smx_pack_batch(const smx_pack_item* items_dev, int n_items, int n_blocks, void* stream) {
+  if (!items_dev || n_items <= 0 || n_blocks <= 0) return SMX_EINVAL;
+  SMX_LAUNCH(pack_batch_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
   return smx_launch_status();
 }
 

@@ -138,6 +138,7 @@ SIGNATURES = {
     "smx_chan_affine_f32": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _p]),
     "smx_winograd_u_floats": (_i64, [_i, _i]),
     "smx_pack_winograd_u_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "smx_pack_batch": (_i, [_p, _i, _i, _p]),
     "smx_transpose_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _p]),
     "smx_act_f32": (_i, [_p, _i, _p, _i, _i64, _i, _i, _p]),
     "smx_act_bwd_f32": (_i, [_p, _i, _p, _i, _p, _i, _i64, _i, _i, _p]),

@@ -23,7 +23,7 @@ from . import lib as L
 
 
 class Tape:
-    def __init__(self, params, grads, mfma16=False):
+    def __init__(self, params, grads, mfma16=False, plan=None):
         """params / grads: {name: device tensor}; grads[name] has the parameter's shape (usually a view of one flat buffer) and is
         ACCUMULATED into by the weight-gradient kernels (zero it before the step).
         mfma16: the bf16-compute training mode (BASELINE configs[4] "bf16"): every convolution / Linear contraction -- forward, data
@@ -38,6 +38,9 @@ class Tape:
         self._stop = set()
         self.packed = {}        # per-step cache of packed weights: (key, mode) -> tensor
         self.lib = L.load()
+        self.plan = plan        # train_ops.PackPlan (optional): all packings it has seen are refreshed by ONE launch, now
+        if plan is not None:
+            plan.begin(self)
 
     # ---- graph ----
     def record(self, fn):

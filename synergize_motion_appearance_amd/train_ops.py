@@ -11,6 +11,7 @@ from it): conv / Linear `F.conv2d`, `nn.Linear`; `normalize`+`swish` archs/vqgan
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import lib as L
@@ -56,27 +57,79 @@ def leaf(tp, name):
     return t
 
 
+class PackPlan:
+    """The weight packings of a training step, remembered across steps.  The step asks for them one by one, lazily, where a layer runs
+    (`_packed`, `_packed16`, `_packed_u`: ~660 launches of 6-11 us); a plan attached to the Tape records each request the first time
+    (the parameter view, the persistent output buffer, the packing's arguments), and from the next step on ONE `smx_pack_batch`
+    launch at tape creation refreshes all of them from the current parameter values and hands them to the tape's cache.  Frozen
+    parameters (no gradient slot: the perceptual loss' VGG19) are packed once and never again.  The plan is tied to one parameter
+    dict (flat buffers do not move); a different dict resets it."""
+    F32, BF16, WINO_U = 0, 1, 2
+    ITEM = np.dtype([("w", "<u8"), ("out", "<u8"), ("total", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("kh", "<i4"), ("kw", "<i4"),
+                     ("mode", "<i4"), ("kind", "<i4"), ("first_block", "<i4"), ("reserved", "<i4")])   # == smx_pack_item (include/smx.h)
+
+    def __init__(self):
+        self.items = {}          # cache key -> (out tensor, w tensor, total, cout, cin, kh, kw, mode, kind, frozen)
+        self._owner = None
+        self._table = None
+        self._n = self._blocks = 0
+        self._dirty = False
+
+    def add(self, ck, w, out, total, cout, cin, kh, kw, mode, kind, frozen):
+        self.items[ck] = (out, w, int(total), cout, cin, kh, kw, mode, kind, bool(frozen))
+        self._dirty = self._dirty or not frozen
+
+    def begin(self, tp):
+        if self._owner != id(tp.P):
+            self.items, self._owner, self._table, self._n, self._dirty = {}, id(tp.P), None, 0, False
+            return
+        if not self.items:
+            return
+        if self._dirty:
+            live = [it for it in self.items.values() if not it[9]]
+            tab = np.zeros(len(live), dtype=self.ITEM)
+            blk = 0
+            for r, (out, w, total, cout, cin, kh, kw, mode, kind, _) in zip(tab, live):
+                r["w"], r["out"], r["total"] = w.data_ptr(), out.data_ptr(), total
+                r["cout"], r["cin"], r["kh"], r["kw"], r["mode"], r["kind"], r["first_block"] = cout, cin, kh, kw, mode, kind, blk
+                blk += (total + 1023) // 1024
+            dev = live[0][0].device if live else None
+            self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev) if live else None
+            self._n, self._blocks, self._dirty = len(live), blk, False
+        if self._n:
+            L.check(tp.lib.smx_pack_batch(self._table.data_ptr(), self._n, self._blocks, _stream()), "pack_batch")
+        for ck, it in self.items.items():
+            tp.packed[ck] = it[0]
+
+
+def _plan_add(tp, ck, w, wc, out, total, cout, cin, kh, kw, mode, kind, frozen):
+    if tp.plan is not None and wc is w:                   # a non-contiguous view was copied: nothing stable to point the table at
+        tp.plan.add(ck, w, out, total, cout, cin, kh, kw, mode, kind, frozen)
+
+
 def _packed(tp, ref, mode, cout, cin, kh, kw):
     """per-step cache of a packed weight: mode 0 forward [Cout][(ky,kx,ci)], mode 1 data gradient [Cin][(flipped taps, co)]."""
-    w, _, key = _param(tp, ref)
+    w, gslot, key = _param(tp, ref)
     ck = (key, mode)
     if ck not in tp.packed:
         wc = w if w.is_contiguous() else w.contiguous()
         out = torch.empty((cout, kh * kw * cin) if mode == 0 else (cin, kh * kw * cout), device=w.device, dtype=F32)
         L.check(tp.lib.smx_pack_weight_f32(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, mode, _stream()), "pack_weight")
         tp.packed[ck] = out
+        _plan_add(tp, ck, w, wc, out, out.numel(), cout, cin, kh, kw, mode, PackPlan.F32, gslot is None)
     return tp.packed[ck]
 
 
 def _packed16(tp, ref, mode, cout, cin, kh, kw):
     """per-step cache of a packed weight rounded to bfloat16 (bf16-compute mode: pack and convert in one launch)."""
-    w, _, key = _param(tp, ref)
+    w, gslot, key = _param(tp, ref)
     ck = (key, "bf16", mode)
     if ck not in tp.packed:
         wc = w if w.is_contiguous() else w.contiguous()
         out = torch.empty((cout, kh * kw * cin) if mode == 0 else (cin, kh * kw * cout), device=w.device, dtype=torch.bfloat16)
         L.check(tp.lib.smx_pack_weight_bf16(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, mode, _stream()), "pack_weight_bf16")
         tp.packed[ck] = out
+        _plan_add(tp, ck, w, wc, out, out.numel(), cout, cin, kh, kw, mode, PackPlan.BF16, gslot is None)
     return tp.packed[ck]
 
 
@@ -89,7 +142,7 @@ def _conv16(w16, bias, kh, kw, cin, cout):
 
 def _packed_u(tp, ref, mode, cout, cin):
     """per-step cache of the Winograd-domain weights of a 3x3 parameter (mode 0 forward, 1 data gradient)."""
-    w, _, key = _param(tp, ref)
+    w, gslot, key = _param(tp, ref)
     ck = (key, "u", mode)
     if ck not in tp.packed:
         wc = w if w.is_contiguous() else w.contiguous()
@@ -97,6 +150,7 @@ def _packed_u(tp, ref, mode, cout, cin):
         out = torch.empty((int(tp.lib.smx_winograd_u_floats(n, c)),), device=w.device, dtype=F32)
         L.check(tp.lib.smx_pack_winograd_u_f32(wc.data_ptr(), out.data_ptr(), cout, cin, mode, _stream()), "pack_winograd_u")
         tp.packed[ck] = out
+        _plan_add(tp, ck, w, wc, out, out.numel(), cout, cin, 3, 3, mode, PackPlan.WINO_U, gslot is None)
     return tp.packed[ck]
 
 

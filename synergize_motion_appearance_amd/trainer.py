@@ -132,6 +132,7 @@ class NetGTrainStep:
         if compute_dtype not in ("f32", "bf16"):
             raise ValueError(f"compute_dtype {compute_dtype!r}: f32 or bf16")
         self.mfma16 = compute_dtype == "bf16"
+        self._pack_plan = T.PackPlan()          # this step's weight packings, refreshed by one launch per step from the second step on
         self.flat = FlatParams(net_g)
         net_g.refresh()                                      # the inference engine's packed copies are stale from now on
         self.engine = NetGTrainEngine(net_g.cfg)
@@ -154,7 +155,7 @@ class NetGTrainStep:
         'out', gradients w.r.t. the three dense-motion inputs in their own layouts).  Parameter gradients accumulate into
         `self.flat.grad` (call `flat.zero_grad()` first)."""
         flat = self.flat
-        tp = Tape(flat.P, flat.G, mfma16=self.mfma16)
+        tp = Tape(flat.P, flat.G, mfma16=self.mfma16, plan=self._pack_plan)
         B = driving.shape[0]
         defo = dense_motion["deformation"].float().contiguous()
         occ = dense_motion["occlusion_map"].float().reshape(B, 64, 64).contiguous()
@@ -316,6 +317,7 @@ class TrainStep:
         self.lr_m, self.betas_m = float(om.get("lr", 8e-5)), tuple(om.get("betas", (0.9, 0.99)))
         self.wd_m = float(om.get("weight_decay", 0))
         self.P = {**self.g.flat.P, **self.flat_m.P}
+        self._pack_plan, self._pack_plan_d = T.PackPlan(), T.PackPlan()     # generator-side tape (incl. its pass through net_d) / discriminator step
         self.G = {**self.g.flat.G, **self.flat_m.G}
         # the discriminator side of optimize_parameters (models/appmotioncomp_model.py:324-345, 408-432): hinge GAN with the adaptive weight,
         # active in `step(..., gan=True)` (the model turns it on past net_d_start_iter)
@@ -381,7 +383,7 @@ class TrainStep:
         g = self.g
         if gan and self.flat_d is None:
             raise RuntimeError("TrainStep(gan=True) needs net_d (the discriminator network) at construction")
-        tp = Tape(self.P, self.G, mfma16=self.g.mfma16)
+        tp = Tape(self.P, self.G, mfma16=self.g.mfma16, plan=self._pack_plan)
         src, drv = source.float().contiguous(), driving.float().contiguous()
         B = drv.shape[0]
         eng = self.me_engine
@@ -489,7 +491,7 @@ class TrainStep:
     def disc_backward(self, out_nhwc, gt_nhwc):
         """the discriminator half (:408-430): hinge losses of net_d on the real frames and on the DETACHED generated ones (two passes: BatchNorm
         sees each batch on its own), gradients accumulated into net_d's flat buffer (zero it first).  -> loss dict"""
-        tp = Tape(self.P_d, self.G_d, mfma16=self.g.mfma16)
+        tp = Tape(self.P_d, self.G_d, mfma16=self.g.mfma16, plan=self._pack_plan_d)
         real, fake = tp.stop(gt_nhwc), tp.stop(out_nhwc.detach())
         pr = self._disc(tp, real)
         l_real = T.torch_scalar(tp, pr, lambda p: torch.relu(1.0 - p).mean())

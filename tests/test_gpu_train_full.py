@@ -393,3 +393,47 @@ def test_full_step_with_the_gan_branch_vs_reference():
     step.step(src, drv, transform=tf, gan=True)
     torch.cuda.synchronize()
     assert float((step.flat_d.value - before).abs().max()) > 1e-6 and torch.isfinite(step.flat_d.value).all() and torch.isfinite(step.g.flat.value).all()
+
+
+def test_pack_plan_steps_equal_per_layer_packing():
+    """The step's weight packings go through one batched launch from the second step on (train_ops.PackPlan).  After two optimiser steps
+    (the plan is recorded in the first, batched from the second), at IDENTICAL parameters: losses and both flat gradient buffers with the
+    batched refresh equal those with per-layer packing (plan detached) to the run-to-run noise of the warp-backward atomics, measured
+    by running the per-layer form twice."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_clip
+    from synergize_motion_appearance_amd.trainer import TrainStep, EquivarianceTransform
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    train_opt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt", "kp_distance_opt")}
+    _, clip = synth_clip(8, seed=77)
+    batches = [(clip[[0, 1]].contiguous().cuda(), clip[[2, 3]].contiguous().cuda()), (clip[[4, 5]].contiguous().cuda(), clip[[6, 7]].contiguous().cuda()),
+               (clip[[1, 6]].contiguous().cuda(), clip[[3, 0]].contiguous().cuda())]
+    gen = torch.Generator().manual_seed(11)
+    tfs = [EquivarianceTransform(2, sigma_affine=0.05, sigma_tps=0.005, points_tps=5, generator=gen) for _ in batches]
+    net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+    net_g.load_state_dict(weights("network_g"), strict=True)
+    me.load_state_dict(weights("network_motion_estimator"), strict=True)
+    step = TrainStep(net_g.cuda(), me.cuda(), train_opt, use_graph=False)
+    for b, tf in zip(batches[:2], tfs[:2]):
+        step.step(*b, transform=tf)
+    plan = step._pack_plan
+    assert plan._n > 300 and plan._blocks > plan._n, "the plan never batched anything"
+    bn = {k: v.clone() for k, v in step.bufs.items()}                       # BatchNorm running statistics move in the forward: rewind between runs
+
+    def grads(with_plan):
+        for k, v in step.bufs.items():
+            v.copy_(bn[k])
+        step._pack_plan = plan if with_plan else None
+        step.g.flat.zero_grad()
+        step.flat_m.zero_grad()
+        losses, _ = step.forward_backward(*batches[2], transform=tfs[2])
+        torch.cuda.synchronize()
+        return float(losses["l_g_total"]), step.g.flat.grad.clone(), step.flat_m.grad.clone()
+
+    a, b, c = grads(True), grads(False), grads(False)
+    step._pack_plan = plan
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) + 3 * abs(b[0] - c[0])
+    for x, y, z in zip(a[1:], b[1:], c[1:]):
+        noise = float((y - z).norm())
+        assert float((x - y).norm()) <= 3 * noise + 1e-7 * float(y.norm()), (float((x - y).norm()), noise, float(y.norm()))

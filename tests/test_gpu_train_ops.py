@@ -494,3 +494,47 @@ def test_conv_backward_bf16_compute_mode(T, B, Cin, Cout, H, k, stride, pad, up2
     wf = w.clone().requires_grad_()
     lin(x, wf).backward(gm)
     assert rel(tp.G["w"], wf.grad) > 1e-4, tag
+
+
+def test_batched_weight_packing_equals_the_per_layer_launches():
+    """smx_pack_batch (one launch, a device table of items) against smx_pack_weight_f32 / _bf16 / smx_pack_winograd_u_f32 layer by layer:
+    bit for bit, for both modes, odd sizes and totals that end inside a 1024-element block -- through train_ops.PackPlan, the way the
+    training step drives it (first tape records, second tape refreshes everything in one launch after the parameters moved)."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from synergize_motion_appearance_amd import train_ops as T
+    from synergize_motion_appearance_amd.tape import Tape
+    g = torch.Generator().manual_seed(5)
+    shapes = {"a": (64, 32, 3, 3), "b": (17, 35, 7, 7), "c": (256, 128, 1, 1), "d": (128, 128, 3, 3), "e": (3, 8, 3, 3), "f": (96, 64, 4, 4)}
+    P = {k: torch.randn(*v, generator=g).cuda() for k, v in shapes.items()}
+    G = {k: torch.zeros_like(v) for k, v in P.items() if k != "e"}              # "e" has no gradient slot: frozen, packed once
+    plan = T.PackPlan()
+
+    def ask(tp):
+        out = {}
+        for k, (co, ci, kh, kw) in shapes.items():
+            for mode in (0, 1):
+                out[k, "f32", mode] = T._packed(tp, k, mode, co, ci, kh, kw)
+                out[k, "bf16", mode] = T._packed16(tp, k, mode, co, ci, kh, kw)
+                if kh == 3 and kw == 3 and (ci if mode == 0 else co) % 8 == 0:
+                    out[k, "u", mode] = T._packed_u(tp, k, mode, co, ci)
+        return out
+
+    first = ask(Tape(P, G, plan=plan))                                          # owner set by begin(); every request packs by itself and is recorded
+    assert plan._n == 0 and len(plan.items) == len(first)
+    for k in P:
+        if k != "e":
+            P[k].mul_(1.5).add_(0.25)                                           # "the optimiser stepped"
+    tp2 = Tape(P, G, plan=plan)                                                 # one launch refreshes all recorded packings
+    assert plan._n == len([1 for it in plan.items.values() if not it[9]]) and plan._n < len(plan.items)
+    assert all(ck in tp2.packed for ck in plan.items)
+    batched = {k: v.clone() for k, v in ask(tp2).items()}
+    ref = ask(Tape(P, G))                                                       # no plan: the per-layer launches at the same parameter values
+    torch.cuda.synchronize()
+    assert set(ref) == set(batched)
+    for k in ref:
+        a, b = ref[k], batched[k]
+        assert a.dtype == b.dtype and a.shape == b.shape
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), k
+    # a tape over a different parameter dict resets the plan instead of packing from stale pointers
+    Tape(dict(P), G, plan=plan)
+    assert not plan.items
