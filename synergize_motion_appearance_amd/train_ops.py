@@ -74,32 +74,32 @@ class PackPlan:
         self._table = None
         self._n = self._blocks = 0
         self._dirty = False
+        self._ready = {}         # cache key -> out tensor of everything the current table refreshes (+ the frozen ones)
 
     def add(self, ck, w, out, total, cout, cin, kh, kw, mode, kind, frozen):
         self.items[ck] = (out, w, int(total), cout, cin, kh, kw, mode, kind, bool(frozen))
-        self._dirty = self._dirty or not frozen
+        self._dirty = True
 
     def begin(self, tp):
         if self._owner != id(tp.P):
-            self.items, self._owner, self._table, self._n, self._dirty = {}, id(tp.P), None, 0, False
+            self.items, self._owner, self._table, self._n, self._dirty, self._ready = {}, id(tp.P), None, 0, False, {}
             return
         if not self.items:
             return
-        if self._dirty:
-            live = [it for it in self.items.values() if not it[9]]
+        if self._dirty and not torch.cuda.is_current_stream_capturing():      # (the table upload is a host copy: not inside a capture --
+            live = [(ck, it) for ck, it in self.items.items() if not it[9]]   #  requests recorded since the last table keep packing by themselves)
             tab = np.zeros(len(live), dtype=self.ITEM)
             blk = 0
-            for r, (out, w, total, cout, cin, kh, kw, mode, kind, _) in zip(tab, live):
+            for r, (_, (out, w, total, cout, cin, kh, kw, mode, kind, _f)) in zip(tab, live):
                 r["w"], r["out"], r["total"] = w.data_ptr(), out.data_ptr(), total
                 r["cout"], r["cin"], r["kh"], r["kw"], r["mode"], r["kind"], r["first_block"] = cout, cin, kh, kw, mode, kind, blk
                 blk += (total + 1023) // 1024
-            dev = live[0][0].device if live else None
-            self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev) if live else None
+            self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(live[0][1][0].device) if live else None
             self._n, self._blocks, self._dirty = len(live), blk, False
+            self._ready = {ck: it[0] for ck, it in self.items.items()}        # in the table, or frozen and packed once
         if self._n:
             L.check(tp.lib.smx_pack_batch(self._table.data_ptr(), self._n, self._blocks, _stream()), "pack_batch")
-        for ck, it in self.items.items():
-            tp.packed[ck] = it[0]
+        tp.packed.update(self._ready)
 
 
 def _plan_add(tp, ck, w, wc, out, total, cout, cin, kh, kw, mode, kind, frozen):

@@ -526,7 +526,7 @@ def test_batched_weight_packing_equals_the_per_layer_launches():
             P[k].mul_(1.5).add_(0.25)                                           # "the optimiser stepped"
     tp2 = Tape(P, G, plan=plan)                                                 # one launch refreshes all recorded packings
     assert plan._n == len([1 for it in plan.items.values() if not it[9]]) and plan._n < len(plan.items)
-    assert all(ck in tp2.packed for ck in plan.items)
+    assert all(ck in tp2.packed for ck in plan.items) and set(plan._ready) == set(plan.items)
     batched = {k: v.clone() for k, v in ask(tp2).items()}
     ref = ask(Tape(P, G))                                                       # no plan: the per-layer launches at the same parameter values
     torch.cuda.synchronize()
