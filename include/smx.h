@@ -309,7 +309,9 @@ int smx_winograd43_conv3x3_f32(const float* x, int lda, const float* u43, const 
  * over the first Ks rows, first-minimum argmin, gather, z_q = z + (e - z).
  * z tokens [N][D]; codebook [Ks..][D]; idx int64 [N]; zq [N][D]; dmin [N] (min distance, optional); Ks <= 4096.
  * sq_ws: REQUIRED workspace of smx_vq_ws_floats(N) floats, 16-byte aligned: the code norms |e|^2 (computed once per call by a small
- * kernel of their own, then read by every block) followed by the per-block partials of sqerr.
+ * kernel of their own, then read by every block), the per-block partials of sqerr, and -- for launches of few tokens (fewer 128-token
+ * blocks than half the CUs), where the codebook sweep is split over up to 8 shares per token block and a second kernel folds the
+ * shares' (distance, index) pairs and does the gather (tuning knob "vq_split"; same indices / distances / z_q bit for bit) -- the shares.
  * sqerr: one float, = sum (zq-z)^2 (optional; written, not accumulated), computed WITHOUT atomics: the per-block partials are
  * summed in a fixed order -> the codebook loss is bit-reproducible.  z is read from HBM once (the gather epilogue reuses the
  * MFMA operand fragments).  z, codebook, zq 16-byte aligned.

@@ -21,6 +21,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"attn4_mfma", "SMX_ATTN4_MFMA", 1},          // d_head 4 attention: 1 = 4x4x1 (16-block) MFMA kernel, 0 = VALU kernel
   {"conv16_slab", "SMX_CONV16_SLAB", 1},        // bf16 region conv, 16x16 tiles: 1 = 32-channel slices with all nine taps' weights in LDS, 0 = one weight tile per tap
   {"attn_bwd_mfma", "SMX_ATTN_BWD_MFMA", 1},    // training, d_head 32 attention backward: 1 = fp32 MFMA kernels, 0 = the per-thread VALU kernels
+  {"vq_split", "SMX_VQ_SPLIT", 1},              // VQ, few tokens (< half a chip of 128-token blocks): codebook sweep split over blockIdx.y + a combine kernel
 };
 bool g_init = false;
 void init_once() {

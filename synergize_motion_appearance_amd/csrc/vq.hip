@@ -40,10 +40,13 @@ __global__ __launch_bounds__(256) void vq_code_norms_kernel(const float* __restr
   if (part == 0 && code < ks_pad) norms[code] = s;
 }
 
-template <int D, bool PROF>
+template <int D, bool PROF, bool SPLIT>
 __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb, const float* __restrict__ norms,
                                                  int64_t* __restrict__ idx_out, float* __restrict__ zq,
-                                                 float* __restrict__ dmin_out, float* __restrict__ sq_part, int N, int Ks) {
+                                                 float* __restrict__ dmin_out, float* __restrict__ sq_part, int N, int Ks,
+                                                 int tiles_per_split, float* __restrict__ pd, int* __restrict__ pi) {
+  // SPLIT (few tokens: the launch would leave most CUs idle): blockIdx.y sweeps only its share of the code tiles and leaves each token's
+  // (min distance, index) over that share in pd / pi [split][N]; vq_combine_kernel folds the shares and does the gather.
   // 32 codes per tile, two LDS buffers: the next tile's global loads are issued DURING the current tile's MFMAs and land in
   // registers while the matrix pipe works; they go to the other buffer a quarter tile later -> ONE barrier per tile and no
   // exposed HBM/L2 round trip (the single-buffered form had a load -> barrier -> compute -> barrier sequence per 64 codes)
@@ -96,8 +99,11 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
       *reinterpret_cast<float4*>(cs + (buf * CT + r) * LD + c4 * 4) = pf[q];
     }
   };
+  const int ntiles = ks_pad / CT;
+  const int tb = SPLIT ? (int)blockIdx.y * tiles_per_split : 0;
+  const int te = SPLIT ? (tb + tiles_per_split < ntiles ? tb + tiles_per_split : ntiles) : ntiles;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) { fetch(0, c * PC); stash(0, c * PC); }
+  for (int c = 0; c < NCH; ++c) { fetch(tb, c * PC); stash(0, c * PC); }
   __syncthreads();
   float zzr[16];
 #pragma unroll
@@ -107,21 +113,21 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
 #pragma unroll
   for (int r = 0; r < 16; ++r) { bestd[r] = INFINITY; besti[r] = 0; }
 
-  const int ntiles = ks_pad / CT;
   if (PROF) ts[2] = __builtin_readcyclecounter();
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
+  for (int t = tb; t < te; ++t) {
+    const bool more = t + 1 < te;
+    const int cur = (t - tb) & 1;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* bp = cs + ((t & 1) * CT + (lane & 31)) * LD + (lane >> 5) * 4;
+    const float* bp = cs + (cur * CT + (lane & 31)) * LD + (lane >> 5) * 4;
     float4 bq[2];                                      // the slice after this one is read while this one's MFMAs run: a block whose
     bq[0] = *reinterpret_cast<const float4*>(bp);      // partner is in its prologue / epilogue has nobody to hide the LDS latency
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       if (kk + 1 < KS) bq[(kk + 1) & 1] = *reinterpret_cast<const float4*>(bp + (kk + 1) * 8);
       if (kk % KSTEP == 0) {                           // compile-time positions (the loop is fully unrolled)
-        if (kk > 0 && more) stash((t + 1) & 1, (kk / KSTEP - 1) * PC);   // the buffer tile t-1 used: free since the barrier that ended t-1
+        if (kk > 0 && more) stash(cur ^ 1, (kk / KSTEP - 1) * PC);   // the buffer tile t-1 used: free since the barrier that ended t-1
         if (more) fetch(t + 1, (kk / KSTEP) * PC);
       }
       const float4 bf = bq[kk & 1];
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the next slice's ds_read first ...
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then this slice's four MFMAs
     }
-    if (more) stash((t + 1) & 1, (NCH - 1) * PC);
+    if (more) stash(cur ^ 1, (NCH - 1) * PC);
     const int code = t * CT + (lane & 31);
     if (code < Ks) {
       const float e2 = ee[code];
@@ -169,6 +175,10 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
     }
     fold(__shfl_xor(d, 1, 64), __shfl_xor(i, 1, 64));
     if (i == 0x7fffffff) i = 0;                            // a row of NaN distances: index 0, as torch.argmin of an all-NaN row is not relied on
+    if (SPLIT) {
+      if (hc == 0 && row0 + row < N) { pd[(long long)blockIdx.y * N + row0 + row] = d; pi[(long long)blockIdx.y * N + row0 + row] = i; }
+      return;
+    }
     if (hc == 0) {
       bis[wave * 32 + row] = i;
       if (row0 + row < N) {
@@ -231,6 +241,41 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, co
   }
 }
 
+// the second half of the SPLIT form: per token fold the splits' (distance, index) pairs -- smaller d, ties -> smaller index, the order the
+// one-sweep kernel resolves them in -- then index / distance / z_q = z + (e - z) / the block's share of sum (z_q - z)^2.  128 tokens per block
+// (the partial count of the one-sweep form), D/4 lanes per token.
+template <int D>
+__global__ __launch_bounds__(256) void vq_combine_kernel(const float* __restrict__ z, const float* __restrict__ cb, const float* __restrict__ pd,
+                                                         const int* __restrict__ pi, int splits, int64_t* __restrict__ idx_out,
+                                                         float* __restrict__ zq, float* __restrict__ dmin_out, float* __restrict__ sq_part, int N) {
+  constexpr int LPR = D / 4, TPP = 256 / LPR;             // lanes per token, tokens per pass
+  __shared__ float wsum[4];
+  const int g = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
+  float err = 0.f;
+  for (int t0 = 0; t0 < 128; t0 += TPP) {
+    const int row = blockIdx.x * 128 + t0 + g;
+    if (row >= N) break;                                   // rows ascend with t0 and g: nothing valid follows for this thread
+    float d = pd[row]; int i = pi[row];
+    for (int sidx = 1; sidx < splits; ++sidx) {
+      const float d2 = pd[(long long)sidx * N + row]; const int i2 = pi[(long long)sidx * N + row];
+      if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+    }
+    if (c == 0) { idx_out[row] = (int64_t)i; if (dmin_out) dmin_out[row] = d; }
+    const float4 e = *reinterpret_cast<const float4*>(cb + (long long)i * D + c);
+    const float4 zv = *reinterpret_cast<const float4*>(z + (long long)row * D + c);
+    const float4 df = make_float4(e.x - zv.x, e.y - zv.y, e.z - zv.z, e.w - zv.w);
+    if (zq) *reinterpret_cast<float4*>(zq + (long long)row * D + c) = make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w);
+    err += (df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w);
+  }
+  if (sq_part) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) err += __shfl_xor(err, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = err;
+    __syncthreads();
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  }
+}
+
 // sqerr = sum of the per-block partials in a FIXED order (one block: strided per-thread sums, then a fixed LDS tree)
 __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ sqerr) {
   __shared__ float red[256];
@@ -245,16 +290,34 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
   if (threadIdx.x == 0) *sqerr = red[0];
 }
 
+constexpr int VQ_SPLIT_MAX = 8, VQ_SPLIT_TOKENS = 16384;   // the split form's share of the workspace: 2 x 8 x min(N, 16384) floats
+
 template <int D, bool PROF>
 int launch_vq_p(const float* z, const float* cb, int64_t* idx, float* zq, float* dmin, float* sqerr, float* ws, int N, int Ks, hipStream_t st) {
-  const int ks_pad = (Ks + 31) / 32 * 32;
+  const int ks_pad = (Ks + 31) / 32 * 32, ntiles = ks_pad / 32;
   const int tile_floats = 2 * 32 * (D + 4) > 4 * 32 * 36 * 2 ? 2 * 32 * (D + 4) : 4 * 32 * 36 * 2;
   const size_t lds = (size_t)(tile_floats + ks_pad + 128 + 128 + 4) * sizeof(float);
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vq_kernel<D, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nblk = smx_cdiv(N, 128);
   float* norms = ws; float* part = ws + VQ_MAX_CODES;
+  static int cus = 0;
+  if (!cus) { int dev = 0, n = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; } cus = n; }
   SMX_LAUNCH(vq_code_norms_kernel, dim3(ks_pad / 32), dim3(256), 0, st, cb, norms, D, Ks, ks_pad);
-  SMX_LAUNCH((vq_kernel<D, PROF>), dim3(nblk), dim3(256), lds, st, z, cb, (const float*)norms, idx, zq, dmin, sqerr ? part : nullptr, N, Ks);
+  // few tokens (one frame is 8 blocks, a training batch of four 32): split the codebook sweep over blockIdx.y so the launch covers the chip
+  int splits = 1;
+  if (!PROF && smx_tune(SMX_TUNE_VQ_SPLIT) && nblk * 2 <= cus && N <= VQ_SPLIT_TOKENS && ntiles >= 8) {
+    splits = cus / nblk; if (splits > VQ_SPLIT_MAX) splits = VQ_SPLIT_MAX; if (splits > ntiles / 4) splits = ntiles / 4;   // >= 4 tiles per share: below that
+  }                                                                                                                        // the second launch costs what the split saves
+  if (splits > 1) {
+    const int tps = smx_cdiv(ntiles, splits); splits = smx_cdiv(ntiles, tps);
+    float* pd = part + nblk; int* pi = reinterpret_cast<int*>(pd + (size_t)VQ_SPLIT_MAX * (N < VQ_SPLIT_TOKENS ? N : VQ_SPLIT_TOKENS));
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vq_kernel<D, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SMX_LAUNCH((vq_kernel<D, false, true>), dim3(nblk, splits), dim3(256), lds, st, z, cb, (const float*)norms, idx, zq, dmin, (float*)nullptr, N, Ks, tps, pd, pi);
+    SMX_LAUNCH(vq_combine_kernel<D>, dim3(nblk), dim3(256), 0, st, z, cb, (const float*)pd, (const int*)pi, splits, idx, zq, dmin, sqerr ? part : nullptr, N);
+  } else {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vq_kernel<D, PROF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SMX_LAUNCH((vq_kernel<D, PROF, false>), dim3(nblk), dim3(256), lds, st, z, cb, (const float*)norms, idx, zq, dmin, sqerr ? part : nullptr, N, Ks, ntiles,
+               (float*)nullptr, (int*)nullptr);
+  }
   if (sqerr) SMX_LAUNCH(vq_finalize_kernel, dim3(1), dim3(256), 0, st, part, nblk, sqerr);
   return smx_launch_status();
 }
@@ -270,7 +333,7 @@ int launch_vq(const float* z, const float* cb, int64_t* idx, float* zq, float* d
 
 }  // namespace
 
-extern "C" int64_t smx_vq_ws_floats(int N) { return N > 0 ? (int64_t)VQ_MAX_CODES + smx_cdiv(N, 128) : 0; }
+extern "C" int64_t smx_vq_ws_floats(int N) { return N > 0 ? (int64_t)VQ_MAX_CODES + smx_cdiv(N, 128) + 2LL * VQ_SPLIT_MAX * (N < VQ_SPLIT_TOKENS ? N : VQ_SPLIT_TOKENS) : 0; }
 
 extern "C" int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, float* zq, float* dmin,
                                   float* sqerr, float* sq_ws, int N, int D, int Ks, void* stream) {

@@ -672,6 +672,27 @@ def test_vq_ties_and_ragged(ops):
         assert float((d[bad, got[bad]] - d[bad, ref[bad]]).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("N,D,Ks", [(1024, 256, 1024), (4096, 256, 1000), (1000, 32, 1024), (4133, 64, 300), (16384, 128, 256), (130, 32, 513)])
+def test_vq_split_sweep_equals_one_sweep(ops, tuning, N, D, Ks):
+    """few tokens: the codebook sweep is split over blockIdx.y and a combine kernel folds the shares (knob vq_split).  Same distances, same
+    tie rule: indices, minimum distances and z_q must equal the one-sweep kernel's bit for bit (ragged N, Ks not a multiple of 32, a
+    codebook with exact duplicates in different shares); the loss differs only by its summation order."""
+    cb = rnd(f"vqs_cb{D}", (1024, D))
+    if Ks > 70:
+        cb[Ks - 3] = cb[5]
+        cb[Ks // 2] = cb[5]
+    z = rnd(f"vqs_z{N}_{D}", (N, D))
+    z[:7] = cb[5] + 1e-3
+    tuning("vq_split", 0)
+    a = ops.vq_nearest(z.cuda(), cb.cuda(), Ks)
+    tuning("vq_split", 1)
+    b = ops.vq_nearest(z.cuda(), cb.cuda(), Ks)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert abs(float(a[3]) - float(b[3])) <= 2e-6 * abs(float(a[3]))
+    if Ks > 70:
+        assert b[0][:7].tolist() == [5] * 7
+
+
 @pytest.mark.parametrize("B,C,H,W,nw", [(2, 64, 32, 32, 1), (2, 64, 32, 32, 2), (3, 128, 16, 32, 2), (1, 96, 8, 16, 1)])
 def test_conv_sft_epilogue_equals_conv_then_sft_combine(ops, B, C, H, W, nw, tuning):
     """Fuse_sft_block's `dec + w * (dec * scale + shift)` as the epilogue of the shift branch's 3x3 conv
