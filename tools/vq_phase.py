@@ -45,11 +45,11 @@ for N in (1228800, 245760):
     k0 = key.unique()[3]
     m = key == k0
     st0 = start[m].min()
-    rows = sorted(zip((start[m] - st0).tolist(), t[m].tolist(), raw[m, 5].tolist()))[:10]
-    print("  one CU's first blocks: [slot] start | MFMA loop from .. to | end   (shader clocks since the CU's first block)")
-    for st_, ph, sl in rows:
+    rows = sorted(zip((start[m] - st0).tolist(), t[m].tolist()))[:10]
+    print("  one CU's first blocks: start | MFMA loop from .. to | end   (shader clocks since the CU's first block)")
+    for st_, ph in rows:
         a = st_ + ph[0] + ph[1]
-        print(f"    [{int(sl):2d}] {st_:9.0f} | {a:9.0f} .. {a + ph[2]:9.0f} | {st_ + sum(ph):9.0f}")
+        print(f"    {st_:9.0f} | {a:9.0f} .. {a + ph[2]:9.0f} | {st_ + sum(ph):9.0f}")
     print(f"CUs seen {len(key.unique())}; mean blocks resident per CU over its span {busy / span:.2f}; "
           f"end -> next start on the same CU: mean {g.mean():.0f} clocks, median {g.median():.0f}, max {g.max():.0f}")
     names = ["z load + norms", "first code tile", "MFMA loop", "argmin over lanes", "gather + store"]
