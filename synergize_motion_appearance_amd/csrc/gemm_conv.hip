@@ -440,6 +440,7 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
     if (d->N <= 32) tile = 3;
     else if (d->N % 128 == 0 && (long long)d->M * nb >= 49152 && d->K <= 256 && d->N <= 512 && !d->d2s_p) tile = 12;   // short K, big M: 256x128, 16 waves
     else if (d->N % 128 == 0 && (long long)d->M * nb >= 24576) tile = 8;
+    else if (d->N > 64 && d->N < 128 && d->K >= 1024 && (long long)d->M * nb >= 24576) tile = 8;   // the 7x7 keypoint / jacobian head (N = 76, K = 1764): 4.8 -> 4.0 ms at B = 300
     else tile = 5;
   }
   switch (tile) {
