@@ -173,7 +173,10 @@ def cpu_baseline(Pg, Pm, src, drv, frames=20, warmup=2, threads=None, budget_s=1
             "sample": f"median (p10/p90 beside it) of {len(t_ref)} / {len(t_cached)} per-frame times after {warmup} warm-up frames of the same 256x256 clip, B=1 sequential, "
                       f"torch CPU fp32, {cores} threads confined to {cores} CPUs of a {host}-CPU host; value: source re-encoded per frame "
                       f"(demo.py:117-131 semantics), value_cached_encoder: source encoder computed once; "
-                      f"{sum(t_ref) + sum(t_cached):.1f} s of timed CPU work"}
+                      f"{sum(t_ref) + sum(t_cached):.1f} s of timed CPU work",
+            "caveat": "context only: the GPU box's host is a SHARED many-core machine -- the spread between p10 and p90 (and the cached-encoder variant, which "
+                      "removes 16 % of the flops, not separating from the plain one) shows the figure is bound by contention from other tenants, not by the "
+                      "reference path; it says nothing about kernel quality (the roofline fraction does)"}
 
 
 def init_distributed(rank, world, dev):
@@ -249,6 +252,89 @@ def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=Tr
             "parity": ("tests/test_gpu_train_full.py: every parameter-gradient norm and sampled gradients / Adam updates vs the reference's own backward"
                        if compute_dtype == "f32" else "tests/test_gpu_train_full.py::test_bf16_compute_step...: gradient-norm deviation from the fp32 "
                        "fixture within 1.25x of the reference's own torch.autocast(bfloat16) step (tests/golden/train_step_autocast.npz)")}
+
+
+def train_bench(args, world, rank, dev, dist, collective):
+    """`bench.py --train [--gpus N]`: BASELINE configs[4] as a job of its own -- the train.yml step (generator + motion estimator + perceptual
+    loss) data-parallel over N ranks, `--batch` (default 4) pairs PER RANK (weak scaling), bf16 compute unless --dtype f32.  The reference wraps
+    its networks in DDP (models/base_model.py:71-74); here every rank all-reduces two flat gradient buffers over RCCL, net_g's issued when
+    its backward ends and overlapped with the motion estimator's backward (trainer.TrainStep.overlap_allreduce), the step replayed from two
+    hipGraphs cut at that point.  Timed like the headline (barrier | K steps | barrier, max over ranks); afterwards the replicas'
+    parameters are compared (they must be bit-identical) -- prints ONE JSON line on rank 0."""
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
+    from synergize_motion_appearance_amd.trainer import TrainStep
+    B, K, W = args.batch, args.steps, args.warmup
+    cdt = args.dtype
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+    net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
+    me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
+    if rank != 0:                                            # a replica that did NOT start from rank 0's weights: the constructor's broadcast must fix it
+        with torch.no_grad():
+            next(net_g.parameters()).mul_(1.0 + 1e-3 * rank)
+    net_g, me = net_g.to(dev), me.to(dev)
+    net_d = None
+    if args.gan:
+        net_d = build_network(cfg["network_d"])
+        net_d.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_d.state_dict().items()]), strict=True)
+        net_d = net_d.to(dev)
+    topt = {k: v for k, v in cfg["train"].items() if args.gan or k != "gan_opt"}
+    topt["perceptual_opt"] = dict(topt["perceptual_opt"], synthetic_vgg19=True)
+    topt["compute_dtype"] = cdt
+    topt["overlap_allreduce"] = not args.no_overlap
+    step = TrainStep(net_g, me, topt, use_graph=not args.eager, net_d=net_d)
+    W += (step.GRAPH_WARMUP + 1) if not args.eager else 0
+    _, clip = synth_clip(2 * B, seed=321 + rank)             # every rank its own pairs (a DistributedSampler shard)
+    src, drv = clip[:B].contiguous().to(dev), clip[B:].contiguous().to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(W):
+        step.step(src, drv, gan=args.gan)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        losses, _ = step.step(src, drv, gan=args.gan)
+    torch.cuda.synchronize()
+    my_dt = time.perf_counter() - t0
+    barrier()
+    dt = time.perf_counter() - t0
+    total = float(losses["l_g_total"])
+    if not (total == total and abs(total) < 1e6):
+        raise SystemExit(f"[bench --train] non-finite / exploding loss {total} on rank {rank}")
+    chk = torch.tensor([float(step.g.flat.value.double().sum()), float(step.flat_m.value.double().sum()),
+                        float(step.g.flat.m.double().sum()), my_dt, dt], dtype=torch.float64)
+    rows = [chk]
+    if dist is not None:
+        cdev = dev if collective == "RCCL" else "cpu"
+        rows = [torch.zeros_like(chk, device=cdev) for _ in range(world)]
+        dist.all_gather(rows, chk.to(cdev))
+        rows = [r.cpu() for r in rows]
+        dt = max(float(r[4]) for r in rows)
+    identical = all(bool(torch.equal(r[:3], rows[0][:3])) for r in rows)
+    if not identical:
+        raise SystemExit(f"[bench --train] replicas diverged: checksums {[r[:3].tolist() for r in rows]}")
+    if rank != 0:
+        return None
+    grad_mb = 4 * (step.g.flat.numel + step.flat_m.numel) / 1e6
+    return {"metric": "training pairs/sec at 256x256 (BASELINE configs[4]: train.yml step, dense-motion + VQ + perceptual loss)",
+            "value": round(world * B * K / dt, 3), "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cdt, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[4]: options/train.yml generator + motion-estimator step, {B} (source, driving) pairs per GPU x {world} GPU(s), "
+                                   + ("bf16 compute (conv / Linear contractions on v_mfma_f32_32x32x16_bf16 with autocast's operand rounding; fp32 storage / optimiser)"
+                                      if cdt == "bf16" else "fp32") + ", losses: L1 + codebook + motion reconstruction + equivariance + multi-scale VGG19-layout perceptual"
+                                   + (" + hinge GAN branch" if args.gan else ""), "pairs_per_gpu": B, "global_batch": world * B,
+                       "parallelism": (f"dp{world}: gradient all-reduce of two flat fp32 buffers ({grad_mb:.0f} MB) over {collective} in 64 MB buckets; net_g's issued at the end "
+                                       f"of its backward and {'overlapped with' if not args.no_overlap else 'NOT overlapped with (--no-overlap)'} the motion estimator's backward; "
+                                       "parameters / Adam state / BatchNorm buffers broadcast from rank 0 at construction") if world > 1 else "1 GPU",
+                       "launch": "eager launches" if args.eager else ("two hipGraphs cut where net_g's gradients are final" if world > 1 and not args.no_overlap else "one hipGraph per step")},
+            "rank_times_s": {"per_rank": [round(float(r[3]), 4) for r in rows]},
+            "replicas_bit_identical": identical, "l_g_total_last": round(total, 5),
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
 
 
 def load_profile_json(name):
@@ -403,7 +489,7 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
              "gemm_bf16": "gemm_bf16_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom)
     if dom.startswith("attention"):
         peak = PEAK_F32_MFMA_TFLOPS                      # the attention cores run on the fp32 MFMA in both storage modes
-    # traffic: the B=60 launches of the dominant kernel ALONE (the wide block shape for the Winograd family), paired with the
+    # traffic: the full-batch launches of the dominant kernel ALONE (the wide block shape for the Winograd family), paired with the
     # event-timed duration of exactly those launches
     tkey = "winograd_wide" if (dom == "winograd" and "winograd_wide" in tfam and "winograd_wide" in fam) else dom
     roof = {
@@ -414,8 +500,9 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
         "note": ("achieved/frac = flops the matrix cores EXECUTE in this kernel (2*M*N*16/4*Cin per launch for F(2x2,3x3): 16 multiplies per "
                  "2x2 output tile and channel) / its summed launch time; achieved_algorithmic = the direct convolution's 2*M*N*9*Cin over "
                  "the same time (2.25x the executed rate by construction, not a utilisation)") if dom == "winograd" else
-                ("achieved = 2*M*N*K of the launches / their summed time (executed == algorithmic: a direct convolution); in bf16 no layer of "
-                 "this network is MFMA-bound -- see kernels.*.algorithmic_GBps for the byte side"),
+                ("achieved = 2*M*N*K of the launches / their summed time (executed == algorithmic: a direct convolution).  By arithmetic intensity "
+                 "(bf16 bytes of input + output per pixel against a 2500 TF / 8 TB/s = 312 flop/B ridge) the C_in >= 128 layers are MFMA-bound "
+                 "(128->128 3x3: 576 flop/B), the 64->64 @ 256^2 layers sit at the ridge (288 flop/B) -- see kernels.*.algorithmic_GBps for the byte side"),
         "launches_per_step": g["calls"] // nprof, "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
         "share_of_step_time": round(g["ms"] / nprof / step_ms, 3),
         "method": f"HIP events around every launch on the launch stream, {nprof} instrumented steps after the timed region"}
@@ -424,13 +511,13 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
         roof["traffic_launches"] = tkey
         roof["traffic_GBps"] = round(tfam[tkey]["hbm_bytes_per_launch"] / (tl["ms"] * 1e-3 / tl["calls"]) / 1e9, 1)
         roof["traffic_note"] = (f"HBM-side bytes per launch of the `{tkey}` launches only (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of the guide), from "
-                                f"separate rocprofv3 --pmc passes of `bench.py --profile-only` at B=60 committed under profiles/{PROFILE_TAG}_traffic_pmc{sfx}.json "
+                                f"separate rocprofv3 --pmc passes of `bench.py --profile-only` (B={DEFAULT_BATCH} frames per step) committed under profiles/{PROFILE_TAG}_traffic_pmc{sfx}.json "
                                 "(not measured in this run); traffic_GBps pairs it with this run's event-timed duration of the same launches")
     if mfma_pmc and dom in mfma_pmc.get("kernels", {}):
-        roof["mfma_pmc"] = dict(mfma_pmc["kernels"][dom], source=f"profiles/{PROFILE_TAG}_mfma_pmc{sfx}.json (rocprofv3 --pmc pass of this command, B=60; "
+        roof["mfma_pmc"] = dict(mfma_pmc["kernels"][dom], source=f"profiles/{PROFILE_TAG}_mfma_pmc{sfx}.json (rocprofv3 --pmc pass of `bench.py --profile-only`, B={DEFAULT_BATCH} frames per step; "
                                                                      "all launches of the family, the B=1 source-encoder ones included)")
         if dom == "winograd" and "winograd_wide" in mfma_pmc["kernels"]:
-            roof["mfma_pmc_b60_launches"] = mfma_pmc["kernels"]["winograd_wide"]          # the wide kernel = the B=60 launches alone
+            roof["mfma_pmc_batch_launches"] = mfma_pmc["kernels"]["winograd_wide"]        # the wide kernel = the full-batch (B = 300) launches alone
     mm = ("winograd", "gemm_conv", "gemm_bf16", "conv3x3_bf16")          # every convolution / GEMM family of either dtype
     conv_ms = max(sum(fam[k]["ms"] for k in mm if k in fam), 1e-9)
     conv_fl = sum(fam[k]["flops"] for k in mm if k in fam)
@@ -450,7 +537,7 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
             e["TFLOPs_executed"] = round(f["mfma_flops"] / (f["ms"] * 1e-3) / 1e12, 2)
         pf = "attention" if name.startswith("attention") else name
         if pf in tfam and not name.startswith("attention") and name != "winograd":
-            # the counter summary holds the B=60 launches only (bench.py --profile-only skips the B=1 re-render check; the B=1
+            # the counter summary holds the full-batch launches only (bench.py --profile-only skips the B=1 re-render check; the B=1
             # source-encoder launches are separated by block shape / grid size in tools/pmc_traffic.py)
             e["pmc_hbm_bytes_per_launch"] = round(tfam[pf]["hbm_bytes_per_launch"])
             e["pmc_hbm_GBps"] = round(tfam[pf]["hbm_bytes_per_launch"] / avg_s / 1e9, 1)
@@ -516,7 +603,17 @@ def main():
     ap.add_argument("--img-size", type=int, default=256, choices=[256, 512], help="512: BASELINE configs[3] (options/test_512.yml, DESIGN N4: every grid x2; "
                                                                                     "default --batch 75; no bf16 / CPU legs); never the headline")
     ap.add_argument("--dump-shapes", default=None, help="write the per-shape GEMM timing table (instrumented pass) here")
+    ap.add_argument("--train", action="store_true", help="BASELINE configs[4] as its own job: the train.yml step, data-parallel over --gpus ranks, --batch pairs per "
+                                                          "rank (default 4), bf16 compute unless --dtype f32 is given; prints its own JSON line (pairs/s)")
+    ap.add_argument("--gan", action="store_true", help="--train: the step past net_d_start_iter (discriminator branch)")
+    ap.add_argument("--eager", action="store_true", help="--train: eager launches instead of hipGraph replay")
+    ap.add_argument("--no-overlap", action="store_true", help="--train: all-reduce both flat buffers after the whole backward (A/B against the overlapped default)")
     args = ap.parse_args()
+    if args.train:
+        if "--batch" not in sys.argv:
+            args.batch = 4
+        if "--dtype" not in sys.argv:
+            args.dtype = "bf16"
     if args.img_size != 256:
         args.no_cpu_baseline = args.no_bf16_leg = args.no_train_leg = True
         if "--batch" not in sys.argv:
@@ -536,6 +633,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist, collective = (None, None) if world == 1 else init_distributed(rank, world, dev)
+
+    if args.train:
+        res = train_bench(args, world, rank, dev, dist, collective)
+        if rank == 0:
+            if one_device:
+                res["config"]["one_device_test_knob"] = True
+            print(json.dumps(res), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from synergize_motion_appearance_amd import ops, driver
     from synergize_motion_appearance_amd.synth import synth_clip

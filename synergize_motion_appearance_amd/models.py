@@ -143,7 +143,8 @@ class AppMotionCompModel:
         self.net_d_start_iter = train_opt.get("net_d_start_iter", 0)
         sch = dict(train_opt.get("scheduler") or {})
         self._milestones, self._gamma = list(sch.get("milestones", [])), float(sch.get("gamma", 1.0))
-        self._base_lr = (self.train_step.g.lr, self.train_step.lr_m)
+        # one base rate per optimizer, the reference's order [g, m (, d)] (appmotioncomp_model.py:248, 265, 270): MultiStepLR decays all three
+        self._base_lr = [self.train_step.g.lr, self.train_step.lr_m] + ([self.train_step.lr_d] if self.net_d is not None else [])
         self.log_dict = OrderedDict()
 
     def model_ema(self, decay=0.999):
@@ -158,9 +159,16 @@ class AppMotionCompModel:
         if 0 < current_iter < warmup_iter:
             f *= current_iter / warmup_iter
         self.train_step.g.lr, self.train_step.lr_m = self._base_lr[0] * f, self._base_lr[1] * f
+        if self.net_d is not None:
+            self.train_step.lr_d = self._base_lr[2] * f
 
     def get_current_learning_rate(self):
+        """base_model.py:167-168: the FIRST optimizer's param-group rates (what train.py logs)."""
         return [self.train_step.g.lr]
+
+    def get_current_learning_rates(self):
+        """one rate per optimizer, the reference's order [g, m (, d)]."""
+        return [self.train_step.g.lr, self.train_step.lr_m] + ([self.train_step.lr_d] if self.net_d is not None else [])
 
     def get_current_log(self):
         return self.log_dict
@@ -422,7 +430,7 @@ class AppMotionCompModel:
         import os
         sched = {"milestones": list(self._milestones), "gamma": self._gamma, "last_epoch": int(current_iter)}
         state = {"epoch": epoch, "iter": current_iter, "optimizers": self.train_step.optimizer_state_dicts(),
-                 "schedulers": [dict(sched, base_lrs=[lr]) for lr in self._base_lr] + ([dict(sched, base_lrs=[self.train_step.lr_d])] if self.net_d is not None else [])}
+                 "schedulers": [dict(sched, base_lrs=[lr]) for lr in self._base_lr]}
         d = self.opt["path"].get("training_states") or os.path.join(self.opt["path"].get("models", "."), "..", "training_states")
         os.makedirs(d, exist_ok=True)
         torch.save(state, os.path.join(d, f"{current_iter}.state"))
@@ -430,3 +438,4 @@ class AppMotionCompModel:
     def resume_training(self, resume_state):
         """base_model.py:283-296: reload the Adam moments / step counts; the learning rate follows `update_learning_rate(current_iter)`."""
         self.train_step.load_optimizer_state_dicts(resume_state["optimizers"])
+        self.train_step.sync_replicas()                      # multi-rank: every replica continues from rank 0's parameters / moments / buffers

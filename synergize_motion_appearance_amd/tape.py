@@ -86,10 +86,14 @@ class Tape:
             _axpy(self.lib, g, s, 1.0)
             e[0], e[1] = s, True
 
-    def backward(self):
-        for fn in reversed(self.nodes):
-            fn()
-        self.nodes = []
+    def mark(self):
+        """a position in the recording: `backward(stop_at=mark)` runs exactly the nodes recorded after it."""
+        return len(self.nodes)
+
+    def backward(self, stop_at=0):
+        """run the recorded closures in reverse, down to (not including) position `stop_at`; a later call continues from there."""
+        while len(self.nodes) > stop_at:
+            self.nodes.pop()()
 
 
 def _stream():

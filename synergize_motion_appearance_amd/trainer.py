@@ -52,22 +52,45 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
-    def all_reduce(self, dist, group=None, bucket_mb=64):
-        """sum the flat gradient over the ranks in a few large buckets (async, then one wait); the 1/world factor is applied
-        inside the Adam kernel (gscale)."""
+    def all_reduce_start(self, dist, group=None, bucket_mb=64):
+        """issue the sum of the flat gradient over the ranks in a few large buckets and return the pending work handles: RCCL runs them
+        on its own stream behind everything already queued on the current one, so kernels launched AFTER this call (the other
+        network's backward) overlap the collective.  `all_reduce_wait` joins them.  The 1/world factor is applied inside the Adam
+        kernel (gscale).  gloo carrying device tensors (the one-device tests) is host-staged and completes here."""
         n = max(1, int(bucket_mb * (1 << 20) // 4))
         cpu = dist.get_backend(group) == "gloo" and self.grad.is_cuda
         works = []
         for a in range(0, self.numel, n):
             chunk = self.grad[a:a + n]
-            if cpu:                                         # gloo with device tensors (tests on one device): host-staged
+            if cpu:
                 h = chunk.cpu()
                 dist.all_reduce(h, group=group)
                 chunk.copy_(h)
             else:
                 works.append(dist.all_reduce(chunk, group=group, async_op=True))
+        return works
+
+    @staticmethod
+    def all_reduce_wait(works):
         for w in works:
             w.wait()
+
+    def all_reduce(self, dist, group=None, bucket_mb=64):
+        self.all_reduce_wait(self.all_reduce_start(dist, group, bucket_mb))
+
+    def broadcast(self, dist, src=0, group=None):
+        """every rank takes `src`'s parameters, Adam moments and step counter (what DDP's constructor does for the parameters,
+        models/base_model.py:71-74; the moments and the counter matter after a resume that only `src` performed)."""
+        cpu = dist.get_backend(group) == "gloo" and self.value.is_cuda
+        t = torch.tensor([float(self.t)], dtype=torch.float64, device="cpu" if (cpu or not self.value.is_cuda) else self.value.device)
+        for buf in (self.value, self.m, self.v, t):
+            if cpu and buf.is_cuda:
+                h = buf.cpu()
+                dist.broadcast(h, src=src, group=group)
+                buf.copy_(h)
+            else:
+                dist.broadcast(buf, src=src, group=group)
+        self.t = int(t.item())
 
     def adam_step(self, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, gscale=1.0):
         if self.lib is None:
@@ -95,8 +118,9 @@ class FlatParams:
         """-> the learning rate stored in the file (the caller's schedule decides whether to use it)."""
         st = sd.get("state", {})
         names = list(self.slots)
-        if st and len(st) != len(names):
+        if st and (len(st) > len(names) or any(int(i) >= len(names) for i in st)):
             raise ValueError(f"optimizer state has {len(st)} parameters, this network has {len(names)}")
+        # torch.optim.Adam omits the entry of a parameter that never received a gradient: a missing index = zero moments
         self.m.zero_()
         self.v.zero_()
         self.t = 0
@@ -303,7 +327,7 @@ class TrainStep:
         from .engine_motion_train import MotionTrainEngine
         compute_dtype = compute_dtype or str(dict(train_opt).get("compute_dtype", "f32"))
         self.use_graph = bool(dict(train_opt).get("use_hip_graph", False)) if use_graph is None else bool(use_graph)
-        self._graph, self._static, self._eager_steps = None, None, 0
+        self._graph, self._graph2, self._static, self._eager_steps = None, None, None, 0
         self.g = NetGTrainStep(net_g, train_opt, compute_dtype)
         self.me = motion_estimator
         self.flat_m = FlatParams(motion_estimator)
@@ -336,10 +360,59 @@ class TrainStep:
             go = dict(self.opt.get("gan_opt") or {})
             if go.get("gan_type", "hinge") != "hinge":
                 raise NotImplementedError(f"gan_opt.gan_type {go.get('gan_type')}: the shipped train.yml uses hinge; only that has a HIP plan")
+            if float(go.get("loss_weight", 1.0)) != 1.0:
+                raise NotImplementedError(f"gan_opt.loss_weight {go.get('loss_weight')}: the shipped train.yml uses 1.0 (the adaptive weight scales the term); "
+                                          "only that has a HIP plan")
+            # models/appmotioncomp_model.py:209 reads `fix_generator` with default TRUE (adaptive weight from fuse_convs_dict[largest].shift[-1].weight,
+            # :337-340); the shipped train.yml sets false (generator.blocks[-1].weight, :333-335) -- the only form built here
+            if self.opt.get("fix_generator", True):
+                raise NotImplementedError("train.fix_generator true (the reference's default when the key is absent): the adaptive GAN weight would be "
+                                          "taken at fuse_convs_dict[...].shift[-1].weight; only `fix_generator: false` (the shipped train.yml) has a HIP plan")
             self.gan_scale = float(self.opt.get("scale_adaptive_gan_weight", 0.8))
+        eq = dict(self.opt.get("equivariance_opt") or {})
+        if eq and not (eq.get("use_value", True) and eq.get("use_jacobian", True)):
+            raise NotImplementedError("equivariance_opt.use_value / use_jacobian false: the shipped train.yml uses both terms (losses/losses.py:540-560); "
+                                      "only that has a HIP plan")
         self.percep = self._build_perceptual(self.opt.get("perceptual_opt"), next(net_g.parameters()).device)
         if self.percep is not None:
             self.P.update(self.percep.P)                      # frozen: values only, no gradient slots
+        # overlap_allreduce: net_g's flat gradient is complete when the tape's backward has passed the start of net_g's forward; its
+        # all-reduce is issued there and runs under the estimator's backward (DDP's overlap, models/base_model.py:71-74, at network
+        # granularity).  Under the hipGraph the step is captured as TWO graphs cut at that point.
+        self.overlap_allreduce = bool(self.opt.get("overlap_allreduce", True))
+        self._pending = []
+        self.sync_replicas()
+
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist
+        return None
+
+    def sync_replicas(self, src=0):
+        """rank `src`'s parameters, Adam state and BatchNorm buffers on every rank: what DDP does at construction (parameters) and in every
+        forward (buffers: `broadcast_buffers`), models/base_model.py:71-74.  Called by the constructor and after a resume; from then on the
+        replicas stay bit-identical because every rank applies the same all-reduced gradient (BatchNorm running statistics are
+        per-rank batch statistics exactly as under DDP without SyncBN -- only rank 0's are saved)."""
+        dist = self._dist()
+        if dist is None:
+            return False
+        flats = [self.g.flat, self.flat_m] + ([self.flat_d] if self.flat_d is not None else [])
+        for f in flats:
+            f.broadcast(dist, src)
+        bufs = list(self.bufs.values()) + (list(self.d_bufs.values()) if self.flat_d is not None else [])
+        host = dist.get_backend() == "gloo"
+        for b in bufs:
+            if host and b.is_cuda:
+                h = b.cpu()
+                dist.broadcast(h, src=src)
+                b.copy_(h)
+            else:
+                dist.broadcast(b, src=src)
+        self.g.net_g.refresh()
+        self.me.refresh()
+        return True
 
     @staticmethod
     def _build_perceptual(po, device):
@@ -379,7 +452,10 @@ class TrainStep:
                 h = T.act(tp, h, ACT_LRELU02)
         return h
 
-    def forward_backward(self, source, driving, w=1.0, transform=None, gan=False):
+    def forward_backward(self, source, driving, w=1.0, transform=None, gan=False, on_cut=None):
+        """on_cut: called once in the middle of the backward, when every gradient of net_g (and of the discriminator pass) is final and
+        only the motion estimator's backward remains -- the place the generator's gradient all-reduce is issued from (and where the
+        hipGraph capture of the step is cut in two)."""
         g = self.g
         if gan and self.flat_d is None:
             raise RuntimeError("TrainStep(gan=True) needs net_d (the discriminator network) at construction")
@@ -390,6 +466,7 @@ class TrainStep:
         kp_d = eng.kp_detector(tp, drv)
         kp_s = eng.kp_detector(tp, src)
         deform, occ, heat, aux = eng.dense_motion(tp, src, kp_d, kp_s)
+        cut = tp.mark()                                       # backward position: everything of net_g (and the losses) is behind it
         st = g.engine.forward(tp, src, deform, occ, heat, float(w), gt_nchw=drv)
         gt = tp.stop(ops.nchw_to_nhwc(drv))
         o = self.opt
@@ -473,6 +550,9 @@ class TrainStep:
             losses["l_kpd"] = kp_distance_value(kp_d[0], kp_s[0], o["kp_distance_opt"].get("loss_weight", 1.0)).view(1)
             total_val = total_val + losses["l_kpd"]
         tp.acc(total, torch.ones(1, device=total.device))
+        if on_cut is not None:
+            tp.backward(stop_at=cut)
+            on_cut()
         tp.backward()
         if gan:                                                # d_weight exists once the backward has passed `out`; the weighted sum above counted l_gan once
             dw = gan_state["d_weight"]
@@ -524,23 +604,34 @@ class TrainStep:
         eq = self.opt.get("equivariance_opt")
         return EquivarianceTransform(B, **dict(eq.get("transform_params", {})), device=dev) if eq else None
 
-    def _graph_step(self, source, driving, w, transform, gan=False):
-        """replay (capturing first) the hipGraph of zero_grad + forward_backward for this input shape."""
+    def _graph_step(self, source, driving, w, transform, gan=False, on_cut=None):
+        """replay (capturing first) the hipGraph of zero_grad + forward_backward for this input shape.  With `on_cut` the step is TWO
+        graphs sharing one memory pool -- [zero_grad, forwards, losses, backward of net_g] and [backward of the motion estimator] --
+        and `on_cut()` (the generator's gradient all-reduce) is issued between their replays."""
         st = self._static
-        key = (tuple(source.shape), tuple(driving.shape), float(w), bool(gan))
+        key = (tuple(source.shape), tuple(driving.shape), float(w), bool(gan), on_cut is not None)
         if st is not None and st["key"][:3] == key[:3] and st["key"] != key:       # the GAN branch switched on (net_d_start_iter): capture anew
-            self._graph, self._static, st = None, None, None
+            self._graph, self._graph2, self._static, st = None, None, None, None
         if st is not None and st["key"] != key:
             raise L.SmxError(f"TrainStep(use_graph): the captured step is for {st['key']}, got {key}; build another TrainStep for another shape")
         tf_new = transform if transform is not None else self._draw_transform(driving.shape[0], driving.device)
         if st is None:
             st = {"key": key, "src": source.float().contiguous().clone(), "drv": driving.float().contiguous().clone(), "tf": tf_new}
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            g, g2 = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if on_cut is not None else None)
+            cap = {"ctx": torch.cuda.graph(g)}
+
+            def cut_capture():                                 # end graph 1 here, continue recording into graph 2 (same pool, replayed in order)
+                cap["ctx"].__exit__(None, None, None)
+                cap["ctx"] = torch.cuda.graph(g2, pool=g.pool())
+                cap["ctx"].__enter__()
+            cap["ctx"].__enter__()
+            try:
                 self.g.flat.zero_grad()
                 self.flat_m.zero_grad()
-                st["losses"], st["out"] = self.forward_backward(st["src"], st["drv"], w, st["tf"], gan)
-            self._graph, self._static = g, st
+                st["losses"], st["out"] = self.forward_backward(st["src"], st["drv"], w, st["tf"], gan, on_cut=cut_capture if g2 is not None else None)
+            finally:
+                cap["ctx"].__exit__(None, None, None)
+            self._graph, self._graph2, self._static = g, g2, st      # (the capture executed nothing: the replay below is this step)
         else:
             st["src"].copy_(source)
             st["drv"].copy_(driving)
@@ -549,24 +640,33 @@ class TrainStep:
                 if st["tf"].tps:
                     st["tf"].control_params.copy_(tf_new.control_params)
         self._graph.replay()
+        if self._graph2 is not None:
+            on_cut()
+            self._graph2.replay()
         return st["losses"], st["out"]
 
     def step(self, source, driving, w=1.0, transform=None, ema=None, ema_decay=0.0, gan=False):
         """zero_grad -> forward/backward -> (all-reduce) -> Adam x2 -> (EMA).  With use_graph the returned loss / output tensors are the
         graph's static buffers: they are overwritten by the next step."""
-        import torch.distributed as dist
+        dist = self._dist()
+        world = dist.get_world_size() if dist is not None else 1
+        pending = []
+
+        def start_g():                                         # net_g's gradients are final: their all-reduce runs under the estimator's backward
+            pending.extend(self.g.flat.all_reduce_start(dist))
+        on_cut = start_g if (dist is not None and self.overlap_allreduce) else None
         if self.use_graph and self._eager_steps >= self.GRAPH_WARMUP:
-            losses, out = self._graph_step(source, driving, w, transform, gan)
+            losses, out = self._graph_step(source, driving, w, transform, gan, on_cut)
         else:
             self._eager_steps += 1
             self.g.flat.zero_grad()
             self.flat_m.zero_grad()
-            losses, out = self.forward_backward(source, driving, w, transform, gan)
-        world = 1
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            world = dist.get_world_size()
-            self.g.flat.all_reduce(dist)
-            self.flat_m.all_reduce(dist)
+            losses, out = self.forward_backward(source, driving, w, transform, gan, on_cut)
+        if dist is not None:
+            if on_cut is None:
+                start_g()
+            pending.extend(self.flat_m.all_reduce_start(dist))
+            FlatParams.all_reduce_wait(pending)
         self.g.flat.adam_step(self.g.lr, self.g.betas, self.g.eps, self.g.wd, gscale=1.0 / world)
         self.flat_m.adam_step(self.lr_m, self.betas_m, 1e-8, self.wd_m, gscale=1.0 / world)
         if ema is not None and ema_decay > 0:

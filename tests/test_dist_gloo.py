@@ -171,18 +171,27 @@ def _flat_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from synergize_motion_appearance_amd.trainer import FlatParams
-    torch.manual_seed(0)
+    torch.manual_seed(rank)                                       # replicas that start apart (BasicSR seeds rank r with seed + r)
     net = torch.nn.Sequential(torch.nn.Linear(37, 101), torch.nn.Linear(101, 5))
     flat = FlatParams(net, allow_cpu=True)
+    flat.m.fill_(float(rank)), flat.v.fill_(2.0 * rank)
+    flat.t = 7 * (1 - rank)
+    before = flat.value.clone()
+    flat.broadcast(dist, src=0)                                   # DDP's construction-time broadcast (+ the Adam state, for a resume)
+    synced = (rank == 0 and torch.equal(before, flat.value)) or (rank == 1 and not torch.equal(before, flat.value))
+    synced = synced and float(flat.m.abs().sum()) == 0.0 and float(flat.v.abs().sum()) == 0.0 and flat.t == 7
+    synced = synced and all(p.data_ptr() == flat.P[n].data_ptr() for n, p in net.named_parameters())
     # parameters alias the flat buffer (checkpoint names / shapes intact), slots are 256-B aligned
     assert all(p.data_ptr() == flat.P[n].data_ptr() for n, p in net.named_parameters())
     assert all(o % FlatParams.ALIGN == 0 for o, _ in flat.slots.values())
     for n, g in flat.G.items():
         g.fill_(float(rank + 1))                                  # rank r contributes r+1 everywhere
-    flat.all_reduce(dist, bucket_mb=0.001)                        # 262-float buckets: many collectives, same result
-    ok = all(bool((g == 3.0).all()) for g in flat.G.values())     # 1 + 2
+    works = flat.all_reduce_start(dist, bucket_mb=0.001)          # 262-float buckets: many collectives in flight, joined later
+    other = torch.ones(5) * rank                                  # "the other network's backward" runs meanwhile
+    flat.all_reduce_wait(works)
+    ok = all(bool((g == 3.0).all()) for g in flat.G.values()) and len(works) > 4 and float(other.sum()) == 5.0 * rank     # 1 + 2
     pad_untouched = float(flat.grad.sum()) == 3.0 * sum(n for _, n in flat.slots.values())
-    q.put((rank, ok, pad_untouched, [tuple(p.grad.shape) for p in net.parameters()]))
+    q.put((rank, ok and synced, pad_untouched, [tuple(p.grad.shape) for p in net.parameters()], float(flat.value.double().sum())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -197,6 +206,7 @@ def test_world2_flat_gradient_all_reduce():
     res = sorted(q.get(timeout=120) for _ in range(world))
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    for rank, ok, pad, shapes in res:
+    for rank, ok, pad, shapes, chk in res:
         assert ok and pad, rank
         assert shapes == [(101, 37), (101,), (5, 101), (5,)]
+    assert res[0][4] == res[1][4]                                 # identical replicas after the broadcast

@@ -139,9 +139,16 @@ def _ddp_worker(rank, world, port, q):
         net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
         net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
         me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
+        if rank == 1:                                          # a replica that starts elsewhere (BasicSR seeds rank r with seed + r): the constructor's
+            with torch.no_grad():                              # rank-0 broadcast (DDP's, models/base_model.py:71-74) must bring it back
+                net_g.state_dict()["generator.blocks.18.weight"].mul_(1.5)
+                me.state_dict()["kp_detector.kp.weight"].add_(0.25)
+                me.state_dict()["kp_detector.predictor.encoder.down_blocks.0.norm.running_mean"].add_(3.0)
         net_g, me = net_g.cuda(), me.cuda()
         topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt", "kp_distance_opt")}
         step = TrainStep(net_g, me, topt)
+        start = [float(step.g.flat.value.double().sum()), float(step.flat_m.value.double().sum()),
+                 float(step.bufs["kp_detector.predictor.encoder.down_blocks.0.norm.running_mean"].double().sum())]
         _, clip = synth_clip(8, seed=321)
         # each rank owns ONE different (source, driving) pair (a DistributedSampler shard)
         src, drv = clip[[0, 5][rank]][None].cuda(), clip[[3, 7][rank]][None].cuda()
@@ -159,9 +166,13 @@ def _ddp_worker(rank, world, port, q):
         summed_probe = step.g.flat.G["generator.blocks.18.weight"].clone()
         step.g.flat.adam_step(8e-5, gscale=1.0 / world)
         step.flat_m.adam_step(8e-5, gscale=1.0 / world)
+        # then two whole steps through TrainStep.step: net_g's all-reduce is issued from inside the backward (overlap_allreduce)
+        for _ in range(2):
+            step.step(src, drv, transform=tf)
         torch.cuda.synchronize()
+        after = [float(step.g.flat.value.double().sum()), float(step.flat_m.value.double().sum()), step.g.flat.t]
         # numpy, not tensors: a tensor in a Queue travels as a shared-memory handle that dies with this process
-        q.put({"rank": rank, "local": local, "summed": summed, "local_probe": local_probe.cpu().numpy(), "summed_probe": summed_probe.cpu().numpy(),
+        q.put({"rank": rank, "local": local, "summed": summed, "start": start, "after": after, "local_probe": local_probe.cpu().numpy(), "summed_probe": summed_probe.cpu().numpy(),
                "w": step.g.flat.P["generator.blocks.18.weight"].cpu().numpy(), "wm": step.flat_m.P["kp_detector.kp.weight"].cpu().numpy(),
                "chk": [float(step.g.flat.value.double().sum()), float(step.flat_m.value.double().sum())]})
     finally:
@@ -192,3 +203,40 @@ def test_two_ranks_training_step_sums_gradients_and_keeps_replicas_identical():
     for i in range(2):
         assert abs(r0["summed"][i] - (r0["local"][i] + r1["local"][i])) < 1e-4 * (abs(r0["summed"][i]) + 1e-3)
     assert np.array_equal(r0["w"], r1["w"]) and np.array_equal(r0["wm"], r1["wm"]) and r0["chk"] == r1["chk"]   # replicas identical after Adam
+    assert r0["start"] == r1["start"]                  # rank 1's perturbed parameters / BatchNorm buffer were replaced by rank 0's at construction
+    assert r0["after"] == r1["after"] and r0["after"][2] == 3 and r0["after"][:2] != r0["chk"]          # and stay identical through TrainStep.step
+
+
+@pytest.mark.parametrize("extra", [(), ("--eager", "--dtype", "f32"), ("--no-overlap",)])
+def test_bench_train_two_ranks_on_one_device(extra):
+    """`bench.py --train --gpus 2` (BASELINE configs[4] as the driver would launch it on an N-GPU node): two ranks on this box's one device, gloo
+    carrying the flat buffers.  Default form = bf16 compute, the step replayed from TWO hipGraphs with net_g's gradient all-reduce issued between
+    them; rank 1 starts from perturbed weights, so `replicas_bit_identical` also proves the construction-time broadcast."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    env = dict(os.environ, SMX_BENCH_ONE_DEVICE="1", SMX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--train", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "1", *extra]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["unit"] == "pairs/s" and j["value"] > 0 and j["replicas_bit_identical"] is True
+    assert j["config"]["global_batch"] == 2 and j["dtype"] == ("f32" if "f32" in extra else "bf16")
+    assert len(j["rank_times_s"]["per_rank"]) == 2
+    if not extra:
+        assert "two hipGraphs" in j["config"]["launch"]
+
+
+def test_bench_512_two_ranks_on_one_device():
+    """`bench.py --img-size 512 --gpus 2` (BASELINE configs[3] "1 then 8 GPUs"): the 512 variant through the same shard / broadcast path (113.5 MB of
+    packed source state per broadcast)."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    env = dict(os.environ, SMX_BENCH_ONE_DEVICE="1", SMX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--img-size", "512", "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch", "2", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "512x512" in j["metric"] and j["config"]["sources"] == 2
+    assert j["batch_consistency"]["max_lsb_vs_b1"] <= 1

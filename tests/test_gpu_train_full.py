@@ -139,6 +139,8 @@ def test_model_level_optimize_parameters(tmp_path):
     assert torch.allclose(e1, 0.995 * e0 + 0.005 * w1, atol=1e-7)                                    # ema_decay 0.995
     model.update_learning_rate(200001)
     assert abs(model.get_current_learning_rate()[0] - 4e-5) < 1e-12                                  # MultiStepLR milestone, gamma 0.5
+    assert all(abs(r - 4e-5) < 1e-12 for r in model.get_current_learning_rates()) and len(model.get_current_learning_rates()) == 3   # g, m AND d decay
+    assert abs(model.train_step.lr_d - 4e-5) < 1e-12
     model.save(0, 1)
     ck = torch.load(str(tmp_path / "models" / "net_g_1.pth"))
     assert set(ck) == {"params", "params_ema"} and torch.equal(ck["params"]["generator.blocks.18.weight"], w1.cpu())

@@ -423,3 +423,39 @@ def test_adam_state_is_interchangeable_with_torch_optim_adam():
     with pytest.raises(ValueError):
         FlatParams(torch.nn.Linear(6, 5), allow_cpu=True).load_optimizer_state_dict(sd)
     assert FlatParams(torch.nn.Linear(2, 2), allow_cpu=True).optimizer_state_dict(1e-3)["state"] == {}    # nothing stepped yet
+
+
+def test_partial_adam_state_and_tape_cut():
+    """(i) torch.optim.Adam omits the state of a parameter that never received a gradient: a `.state` file with fewer entries than parameters
+    loads (missing index = zero moments), one with MORE is refused.  (ii) `Tape.mark()` / `backward(stop_at)`: the backward can be run in two
+    pieces -- the cut the trainer issues net_g's gradient all-reduce from (models/base_model.py:71-74's overlap at network granularity)."""
+    import pytest
+    from synergize_motion_appearance_amd.trainer import FlatParams
+    from synergize_motion_appearance_amd.tape import Tape
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    flat = FlatParams(net, allow_cpu=True)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    net[0].weight.grad.fill_(1.0)
+    net[0].bias.grad, net[1].weight.grad, net[1].bias.grad = torch.ones(5), None, None      # only the first layer ever got a gradient
+    opt.step()
+    sd = opt.state_dict()
+    assert len(sd["state"]) == 2
+    other = FlatParams(torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)), allow_cpu=True)
+    assert other.load_optimizer_state_dict(sd) == 2e-4 and other.t == 1
+    off, n = other.slots["0.weight"]
+    assert float(other.m[off:off + n].abs().sum()) > 0
+    off, n = other.slots["1.weight"]
+    assert float(other.m[off:off + n].abs().sum()) == 0 and float(other.v[off:off + n].abs().sum()) == 0
+    sd["state"][9] = sd["state"][0]
+    with pytest.raises(ValueError):
+        other.load_optimizer_state_dict(sd)
+    tp = Tape({}, {})
+    order = []
+    tp.record(lambda: order.append("a"))
+    cut = tp.mark()
+    tp.record(lambda: order.append("b"))
+    tp.record(lambda: order.append("c"))
+    tp.backward(stop_at=cut)
+    assert order == ["c", "b"] and len(tp.nodes) == 1
+    tp.backward()
+    assert order == ["c", "b", "a"] and tp.nodes == []

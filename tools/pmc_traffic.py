@@ -22,7 +22,7 @@ def load(d, counter):
 
 
 def variant(name):
-    """finer key beside the family: the Winograd block shapes separately -- the 4-wave 'wide' block is what the B=60 launches of the
+    """finer key beside the family: the Winograd block shapes separately -- the 4-wave 'wide' block is what the full-batch (B = 300 by default) launches of the
     big layers run, `winograd_kernel<1>` the B=1 source-encoder / small launches (same split as tools/pmc_mfma.py)."""
     if "winograd_wide_kernel" in name:
         return "winograd_wide"
@@ -64,8 +64,8 @@ def main(fetch_dir, write_dir, out):
         res["conv_gemm_family"] = {"launches_profiled": nl,
                                    "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in conv.values()) / nl}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 "
-                         "--profile-only` (timed steps only: no B=1 re-render check, so every warp / attention / layernorm launch is a B=60 "
-                         "launch; the B=1 source-encoder convolutions are separated by block shape: winograd_wide = the B=60 launches); "
+                         "--profile-only` (timed steps only: no B=1 re-render check, so every warp / attention / layernorm launch is a full-batch (B = 300 by default) "
+                         "launch; the B=1 source-encoder convolutions are separated by block shape: winograd_wide = the full-batch (B = 300 by default) launches); "
                          "FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B)",
                "families": res}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
