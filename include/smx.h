@@ -334,6 +334,18 @@ int smx_vq_nearest_f32(const float* z, const float* codebook, int64_t* idx, floa
 int smx_conv3x3_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32, int ldres,
                      void* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
                      float* stats_part, int tile_h, void* stream);
+/* The big-launch form of smx_conv3x3_bf16 (csrc/conv3x3_bf16_t32.hip; same call sites, same semantics): 16 x 32-pixel output tiles x 64
+ * channels per workgroup, 16-channel slices through a double-buffered LDS stage, weights by LDS-DMA from a FRAGMENT-ORDERED pack
+ * `wp` = [ceil(Cout/64)][Cin/16][9 taps][2][64 lanes][8] bf16 built once per layer by smx_conv3x3_bf16_t32_pack from the
+ * [Cout][ldw >= 9*Cin] layout smx_conv3x3_bf16 takes (smx_conv3x3_bf16_t32_pack_elems = its element count, -1 on bad arguments).
+ * H % 16 == 0, W % 32 == 0, Cin % 16 == 0; stats_part = {mean, M2} per 16 x 32-pixel tile: [B][(H/16)*(W/32)][Cout][2]. */
+long long smx_conv3x3_bf16_t32_pack_elems(int Cin, int Cout);
+int smx_conv3x3_bf16_t32_pack(const void* w, int ldw, void* wp, int Cin, int Cout, void* stream);
+int smx_conv3x3_bf16_t32(const void* x, int lda, const void* wp, const float* bias, const void* res, int res_f32, int ldres, void* y, int ldc,
+                         int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish, float* stats_part,
+                         void* stream);
+int smx_conv3x3_sft_bf16_t32(const void* x, int lda, const void* wp, const float* bias, const void* dec, int lddec, const void* scale,
+                             int ldscale, float sft_w, void* y, int ldc, int B, int H, int W, int Cin, int Cout, void* stream);
 /* The bf16 counterpart of smx_winograd_conv3x3_sft_f32: y = dec + w * (dec * scale + conv3x3(x)) as the convolution's epilogue
  * (Fuse_sft_block, archs/appmotioncodebook_arch.py:49-51); dec / scale / y bf16 NHWC with 16 B-aligned rows, Cout % 8 == 0. */
 int smx_conv3x3_sft_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* dec, int lddec,

@@ -68,6 +68,10 @@ SIGNATURES = {
     "smx_get_tuning": (_i, [C.c_char_p, C.POINTER(_i)]),
     "smx_gemm_conv_f32": (_i, [C.POINTER(GemmDesc), _p]),
     "smx_gemm_conv_bf16": (_i, [C.POINTER(Gemm16Desc), _p]),
+    "smx_conv3x3_bf16_t32_pack_elems": (_i64, [_i, _i]),
+    "smx_conv3x3_bf16_t32_pack": (_i, [_p, _i, _p, _i, _i, _p]),
+    "smx_conv3x3_bf16_t32": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "smx_conv3x3_sft_bf16_t32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
     "smx_winograd_conv3x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "smx_winograd43_conv3x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "smx_winograd_conv3x3_sft_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i, _i, _i, _i, _i, _p, _p]),

@@ -113,13 +113,28 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
         self._u = None
         self._w16 = None
         self._u43 = None
+        self._w16t = None
+
+    @property
+    def w16_t32(self):
+        """fragment-ordered bf16 pack of a 3x3 layer for the 16x32-tile region kernel (smx_conv3x3_bf16_t32_pack), built once per layer."""
+        if self._w16t is None:
+            lib = L.load()
+            n = int(lib.smx_conv3x3_bf16_t32_pack_elems(self.cin, self.cout))
+            if n <= 0 or self.kh != 3 or self.kw != 3:
+                raise L.SmxError(f"w16_t32: not a 3x3 layer with Cin % 16 == 0 ({self.kh}x{self.kw}, Cin {self.cin})")
+            wp = torch.empty(n, device=self.w.device, dtype=BF16)
+            w16 = self.w16
+            L.check(lib.smx_conv3x3_bf16_t32_pack(w16.data_ptr(), w16.shape[1], wp.data_ptr(), self.cin, self.cout, _stream()), "smx_conv3x3_bf16_t32_pack")
+            self._w16t = wp
+        return self._w16t
 
     @property
     def w16(self):
@@ -199,6 +214,15 @@ REGION3X3 = not _os.environ.get("SMX_NO_REGION3X3")
 CONV16_TILE_H = int(_os.environ.get("SMX_CONV16_TILE_H", "0"))      # 0 = auto, 8 | 16 = forced (tools / tests)
 
 
+CONV16_T32 = int(_os.environ.get("SMX_CONV16_T32", "1"))           # 16x32-tile kernel (csrc/conv3x3_bf16_t32.hip) for the big launches; 0 = off
+CONV16_T32_MIN_BLOCKS = 1024                                         # two resident rounds of the chip's 512 block slots; tests lower it
+
+
+def _conv16_t32_ok(B, Ho, Wo, Cin, cout):
+    return (CONV16_T32 and Ho % 16 == 0 and Wo % 32 == 0 and Cin % 16 == 0 and
+            B * (Ho // 16) * (Wo // 32) * ((cout + 63) // 64) >= CONV16_T32_MIN_BLOCKS)
+
+
 def _conv16_tile_h(Cin, Ho, nblk16=0):
     """output tile height of the region-direct bf16 3x3 kernel (measured per shape, tools/conv16_bench.py): 16x16 tiles (2 workgroups
     per CU) once the launch has >= 1024 of them -- 5-15 % over 8x16 tiles at every B=60 shape since the loader normalises at store
@@ -229,6 +253,20 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
         return out
     if getattr(out, "_gn_part", None) is not None:
         out._gn_part = None
+    if (REGION3X3 and tile == 0 and x.dtype == BF16 and out.dtype == BF16 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1)
+            and not d2s and (Ho, Wo) == ((2 * H, 2 * W) if up2 else (H, W)) and lda % 8 == 0 and a_ptr % 16 == 0
+            and _conv16_t32_ok(B, Ho, Wo, Cin, cv.cout)):
+        # the big launches: 16x32-pixel tiles, 16-channel slices through a double-buffered stage, weights by LDS-DMA from the fragment-ordered pack
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1, "t32": 1,
+                "bytes": 2.0 * B * Ho * Wo * (Cin / (4.0 if up2 else 1.0) + cv.cout * (2 if res is not None else 1))} if _PROFILE is not None else None
+        part = torch.empty((B, (Ho // 16) * (Wo // 32), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
+        L.check(_timed("conv3x3_bf16", meta, L.load().smx_conv3x3_bf16_t32, a_ptr, lda, cv.w16_t32.data_ptr(),
+                       None if cv.b is None else cv.b.data_ptr(), r_ptr, int(res is not None and res.dtype == torch.float32), ldr,
+                       c_ptr, ldc, B, Ho, Wo, Cin, cv.cout, int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish),
+                       None if part is None else part.data_ptr(), _stream()), "smx_conv3x3_bf16_t32")
+        if part is not None:
+            out._gn_part = part
+        return out
     if (REGION3X3 and tile == 0 and x.dtype == BF16 and out.dtype == BF16 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1)
             and not d2s and Cin % 64 == 0 and Ho % 16 == 0 and Wo % 16 == 0 and (Ho, Wo) == ((2 * H, 2 * W) if up2 else (H, W))
             and lda % 8 == 0 and a_ptr % 16 == 0):
@@ -662,6 +700,13 @@ def conv_sft(x, cv, dec, scale, w=1.0):
         s_ptr, lds_ = _pix(scale, "conv_sft scale")
         if lda % 8 == 0 and ldd % 8 == 0 and lds_ % 8 == 0 and (a_ptr | d_ptr | s_ptr) % 16 == 0:
             out = torch.empty((B, H, W, cv.cout), device=x.device, dtype=BF16)
+            if _conv16_t32_ok(B, H, W, Cin, cv.cout):
+                meta = {"flops": 2.0 * B * H * W * cv.cout * 9 * Cin, "M": B * H * W, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1, "t32": 1,
+                        "bytes": 2.0 * B * H * W * (Cin + 3 * cv.cout)} if _PROFILE is not None else None
+                L.check(_timed("conv3x3_bf16", meta, L.load().smx_conv3x3_sft_bf16_t32, a_ptr, lda, cv.w16_t32.data_ptr(),
+                               None if cv.b is None else cv.b.data_ptr(), d_ptr, ldd, s_ptr, lds_, float(w), out.data_ptr(), cv.cout,
+                               B, H, W, Cin, cv.cout, _stream()), "smx_conv3x3_sft_bf16_t32")
+                return out
             th = _conv16_tile_h(Cin, H, B * (H // 16) * (W // 16) * ((cv.cout + 63) // 64))
             meta = {"flops": 2.0 * B * H * W * cv.cout * 9 * Cin, "M": B * H * W, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1,
                     "bytes": 2.0 * B * H * W * (Cin + 3 * cv.cout)} if _PROFILE is not None else None

@@ -167,13 +167,41 @@ R3_CASES = [(2, 64, 64, 32, 32, False, 0, None), (1, 128, 128, 64, 32, False, 3,
             (3, 64, 3 * 64, 16, 32, False, 0, None)]
 
 
+# the 16x32-tile form (csrc/conv3x3_bf16_t32.hip): W % 32 == 0, C_in % 16 == 0 (48 and 160 are not multiples of 64), ragged C_out (96, 126),
+# 8 slices (C_in 128) and an odd slice count (C_in 48: the two-stage loop ends on stage 0), x2 upsampling folded into the loader
+T32_CASES = [(2, 64, 64, 32, 32, False, 0, None), (1, 128, 128, 64, 32, False, 3, "bf16"), (2, 256, 128, 16, 32, False, 1, "f32"),
+             (2, 64, 64, 32, 64, True, 0, "bf16"), (1, 128, 96, 32, 64, False, 0, None), (1, 512, 256, 32, 32, False, 4, None),
+             (3, 64, 3 * 64, 16, 32, False, 0, None), (2, 48, 64, 32, 32, False, 2, "bf16"), (1, 160, 126, 16, 64, False, 0, None)]
+
+
+def _case_id(c):
+    return f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_up{int(c[5])}_act{c[6]}_res{c[7]}"
+
+
+@pytest.mark.parametrize("case", T32_CASES, ids=[_case_id(c) for c in T32_CASES])
+def test_conv3x3_region_direct_bf16_t32(ops, case, monkeypatch):
+    """the big-launch form of the region-direct kernel (16x32-pixel tiles, 16-channel slices through a double-buffered LDS stage, weights by
+    LDS-DMA from the fragment-ordered pack, A fragments shared by the three ky taps): same checks as the 16x16 / 8x16 forms below."""
+    _region_direct_case(ops, case, 32, monkeypatch)
+
+
 @pytest.mark.parametrize("tile_h", [16, 116, 8], ids=["16x16_slab", "16x16_per_tap", "8x16"])
-@pytest.mark.parametrize("case", R3_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_up{int(c[5])}_act{c[6]}_res{c[7]}" for c in R3_CASES])
+@pytest.mark.parametrize("case", R3_CASES, ids=[_case_id(c) for c in R3_CASES])
 def test_conv3x3_region_direct_bf16(ops, case, tile_h, monkeypatch):
     """the region-direct 3x3 kernel (input region staged once per 64-channel slice, nine taps read from LDS) against conv2d on
     the bf16-rounded operands, against the implicit-GEMM bf16 kernel on the same operands, through channel-slice views, with
     the fused GroupNorm+swish loader, and with the Welford partials it emits for the next GroupNorm."""
+    _region_direct_case(ops, case, tile_h, monkeypatch)
+
+
+def _region_direct_case(ops, case, tile_h, monkeypatch):
     B, Cin, Cout, H, W, up2, act, resk = case
+    t32 = tile_h == 32
+    monkeypatch.setattr(ops, "CONV16_T32", int(t32))
+    monkeypatch.setattr(ops, "CONV16_T32_MIN_BLOCKS", 1)
+    tw = 32 if t32 else 16
+    if t32:
+        tile_h = 16
     ops.set_tuning("conv16_slab", 0 if tile_h > 100 else 1)     # 16x16 tiles: all nine taps' weights of a 32-channel slice in LDS | one tile per tap
     tile_h %= 100
     monkeypatch.setattr(ops, "CONV16_TILE_H", tile_h)
@@ -182,7 +210,7 @@ def test_conv3x3_region_direct_bf16(ops, case, tile_h, monkeypatch):
     b = rnd(f"r3b{case}", (Cout,), 0.1)
     xe = F.interpolate(x, scale_factor=2.0, mode="nearest") if up2 else x
     ref = F.conv2d(xe.double(), r16(w).double(), b.double(), padding=1)
-    ref = {0: lambda t: t, 1: F.relu, 3: O.swish, 4: F.gelu}[act](ref).float()
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: O.swish, 4: F.gelu}[act](ref).float()
     res = r16(rnd(f"r3r{case}", tuple(ref.shape))) if resk else None
     if res is not None:
         ref = ref + res
@@ -193,7 +221,7 @@ def test_conv3x3_region_direct_bf16(ops, case, tile_h, monkeypatch):
     rt = None if res is None else (nhwc16(res) if resk == "bf16" else res.permute(0, 2, 3, 1).contiguous().cuda())
     with ops.profile() as rec:
         y = ops.conv(xin[..., 8:8 + Cin], cv, out=out[..., 8:8 + Cout], up2=up2, act=act, res=rt, want_stats=True)
-    assert [r[0] for r in rec.rows] == ["conv3x3_bf16"]
+    assert [r[0] for r in rec.rows] == ["conv3x3_bf16"] and bool(rec.rows[0][1].get("t32")) == t32
     ok, worst = close16(nchw32(y), ref, ulps=1.0)
     assert ok, worst
     assert float(out[..., :8].float().min()) == 5.0 and float(out[..., 8 + Cout:].float().max()) == 5.0
@@ -202,9 +230,9 @@ def test_conv3x3_region_direct_bf16(ops, case, tile_h, monkeypatch):
     assert ok, worst
     # Welford partials of the stored tile: {mean, M2} per 16x16 pixels and channel
     part = y._gn_part
-    assert part is not None and tuple(part.shape) == (B, (H // tile_h) * (W // 16), Cout, 2)
+    assert part is not None and tuple(part.shape) == (B, (H // tile_h) * (W // tw), Cout, 2)
     yc = y.float().cpu().double()
-    blocks = yc.view(B, H // tile_h, tile_h, W // 16, 16, Cout).permute(0, 1, 3, 5, 2, 4).reshape(B, -1, Cout, tile_h * 16)
+    blocks = yc.view(B, H // tile_h, tile_h, W // tw, tw, Cout).permute(0, 1, 3, 5, 2, 4).reshape(B, -1, Cout, tile_h * tw)
     bm = blocks.mean(-1)
     assert maxabs(part[..., 0].cpu(), bm) < 5e-6 * max(1.0, float(bm.abs().max()))
     assert maxabs(part[..., 1].cpu(), ((blocks - bm[..., None]) ** 2).sum(-1)) < 1e-3
@@ -218,7 +246,9 @@ def test_conv3x3_region_direct_bf16(ops, case, tile_h, monkeypatch):
         w2 = rnd(f"r3w2{case}", (64, Cout, 3, 3), 1.0 / math.sqrt(9 * Cout))
         hn = r16(O.swish(F.group_norm(nchw32(y), 32, g.cpu(), bt.cpu(), 1e-6)))
         ref2 = F.conv2d(hn.double(), r16(w2).double(), None, padding=1).float()
-        y2 = ops.conv(y, ops.Conv.from_torch(w2.cuda(), None), in_ss=ss, in_swish=True)
+        with ops.profile() as rec2:
+            y2 = ops.conv(y, ops.Conv.from_torch(w2.cuda(), None), in_ss=ss, in_swish=True)
+        assert bool(rec2.rows[0][1].get("t32")) == t32
         ok, worst = close16(nchw32(y2), ref2, ulps=2.0, floor=4e-3)
         assert ok, worst
 
@@ -464,12 +494,14 @@ def test_bf16_batched_driver_and_packed_state_roundtrip(nets16):
     assert float(d.mean()) < 1.5 * rmean * 127.5 and float(d.max()) <= rmax * 127.5, (float(d.mean()), float(d.max()))
 
 
-@pytest.mark.parametrize("B,C,H,W,tile_h", [(2, 64, 32, 32, 16), (2, 128, 16, 32, 8), (1, 64, 16, 16, 8)])
+@pytest.mark.parametrize("B,C,H,W,tile_h", [(2, 64, 32, 32, 16), (2, 128, 16, 32, 8), (1, 64, 16, 16, 8), (2, 64, 32, 32, 32), (1, 128, 16, 64, 32)])
 def test_conv_sft_epilogue_bf16(ops, B, C, H, W, tile_h, monkeypatch):
     """Fuse_sft_block's `dec + w * (dec * scale + shift)` as the epilogue of the shift branch's 3x3 conv on the bf16 region kernel
     (smx_conv3x3_sft_bf16), operands being channel slices of wider bf16 buffers as in the engine: against conv2d + the formula in
     fp32 on the bf16-rounded operands (one rounding of the result), and it must not run a separate sft_combine pass."""
-    monkeypatch.setattr(ops, "CONV16_TILE_H", tile_h)
+    monkeypatch.setattr(ops, "CONV16_T32", int(tile_h == 32))          # 32: the 16x32-tile kernel (smx_conv3x3_sft_bf16_t32)
+    monkeypatch.setattr(ops, "CONV16_T32_MIN_BLOCKS", 1)
+    monkeypatch.setattr(ops, "CONV16_TILE_H", 16 if tile_h == 32 else tile_h)
     ss = r16(rnd(f"bs{C}{H}", (B, H, W, 2 * C)))
     cat = r16(rnd(f"bc{C}{H}", (B, H, W, 2 * C)))
     scale = r16(rnd(f"bq{C}{H}", (B, H, W, C)))
@@ -479,7 +511,7 @@ def test_conv_sft_epilogue_bf16(ops, B, C, H, W, tile_h, monkeypatch):
     ssd, catd = ss.cuda().to(BF), cat.cuda().to(BF)
     with ops.profile() as rec:
         y = ops.conv_sft(ssd[..., C:], cv, catd[..., C:], scale.cuda().to(BF), 0.7)
-    assert [r[0] for r in rec.rows] == ["conv3x3_bf16"] and y.dtype == BF
+    assert [r[0] for r in rec.rows] == ["conv3x3_bf16"] and y.dtype == BF and bool(rec.rows[0][1].get("t32")) == (tile_h == 32)
     shift = F.conv2d(ss[..., C:].permute(0, 3, 1, 2).double(), r16(w).double(), b.double(), padding=1).permute(0, 2, 3, 1).float()
     dec = cat[..., C:]
     ok, worst = close16(y.float().cpu(), dec + 0.7 * (dec * scale + shift), ulps=1.0)

@@ -166,6 +166,8 @@ def _ddp_worker(rank, world, port, q):
         summed_probe = step.g.flat.G["generator.blocks.18.weight"].clone()
         step.g.flat.adam_step(8e-5, gscale=1.0 / world)
         step.flat_m.adam_step(8e-5, gscale=1.0 / world)
+        chk = [float(step.g.flat.value.double().sum()), float(step.flat_m.value.double().sum())]
+        w_probe, wm_probe = step.g.flat.P["generator.blocks.18.weight"].cpu().numpy(), step.flat_m.P["kp_detector.kp.weight"].cpu().numpy()
         # then two whole steps through TrainStep.step: net_g's all-reduce is issued from inside the backward (overlap_allreduce)
         for _ in range(2):
             step.step(src, drv, transform=tf)
@@ -173,8 +175,7 @@ def _ddp_worker(rank, world, port, q):
         after = [float(step.g.flat.value.double().sum()), float(step.flat_m.value.double().sum()), step.g.flat.t]
         # numpy, not tensors: a tensor in a Queue travels as a shared-memory handle that dies with this process
         q.put({"rank": rank, "local": local, "summed": summed, "start": start, "after": after, "local_probe": local_probe.cpu().numpy(), "summed_probe": summed_probe.cpu().numpy(),
-               "w": step.g.flat.P["generator.blocks.18.weight"].cpu().numpy(), "wm": step.flat_m.P["kp_detector.kp.weight"].cpu().numpy(),
-               "chk": [float(step.g.flat.value.double().sum()), float(step.flat_m.value.double().sum())]})
+               "w": w_probe, "wm": wm_probe, "chk": chk})
     finally:
         dist.barrier()
         dist.destroy_process_group()

@@ -459,3 +459,19 @@ def test_partial_adam_state_and_tape_cut():
     assert order == ["c", "b"] and len(tp.nodes) == 1
     tp.backward()
     assert order == ["c", "b", "a"] and tp.nodes == []
+
+
+def test_t32_kernel_isa_keeps_its_hands_off_registers_with_requests_in_flight():
+    """csrc/conv3x3_bf16_t32.hip issues its region requests from inline asm that hipcc does not count; the data is valid only behind the
+    matching `t32-claim` wait one step later.  The compiler is free to copy / spill / reuse those registers in between (it believes they
+    were written at the request) -- a silent race that passes on a lucky schedule.  tools/t32_isa_audit.py compiles the kernel to gfx950
+    ISA (no GPU needed) and walks every K loop twice in issue order: no instruction may name a register with a request in flight, and
+    every request must meet its claim."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("t32_isa_audit", os.path.join(REPO, "tools", "t32_isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels, requests, claims, loops, bad = mod.audit(mod.compile_isa())
+    assert kernels == 1 and loops == 3, (kernels, loops)            # one shipped instantiation, one K loop per loader mode (raw / GN / GN + swish)
+    assert requests == claims and requests >= 45, (requests, claims)
+    assert not bad, bad[:5]

@@ -35,6 +35,16 @@ for cin, cout, s in SHAPES:
     fl = 2.0 * B * s * s * cout * 9 * cin
     by = 2.0 * B * s * s * (cin + cout)
     ops.CONV16_TILE_H = 16
+    ops.CONV16_T32 = 1
+    t_t = timed(lambda: ops.conv(x, cv, out=out))
+    t_tn = timed(lambda: ops.conv(x, cv, out=out, in_ss=ss, in_swish=True))
+    t_ts = timed(lambda: ops.conv(x, cv, out=out, want_stats=True))
+    res = torch.randn((B, s, s, cout), device="cuda").to(BF)
+    t_tr = timed(lambda: ops.conv(x, cv, out=out, res=res, in_ss=ss, in_swish=True, want_stats=True))
+    ops.CONV16_T32 = 0
+    t_or = timed(lambda: ops.conv(x, cv, out=out, res=res, in_ss=ss, in_swish=True, want_stats=True))
+    print(f"{cin:4d} {cout:4d} {s:4d} : t32 {1e3 * t_t:8.1f} us ({fl / t_t / 1e9:6.0f} TF, {by / t_t / 1e6:6.0f} GB/s)  +GN {1e3 * t_tn:8.1f} ({fl / t_tn / 1e9:6.0f} TF)  +stats {1e3 * t_ts:8.1f}  "
+          f"GN+res+stats {1e3 * t_tr:8.1f} ({fl / t_tr / 1e9:6.0f} TF)  [16x16 form: {1e3 * t_or:8.1f} ({fl / t_or / 1e9:6.0f} TF)]")
     t_r = timed(lambda: ops.conv(x, cv, out=out))
     ops.CONV16_TILE_H = 8
     t_8 = timed(lambda: ops.conv(x, cv, out=out))
