@@ -83,14 +83,25 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // region requests that are meant to stay in flight for a whole step.
 // One LDS-DMA: 64 lanes x 16 B from `gsrc` (per lane) to LDS [lds_dst, lds_dst + 1 KB) (wave-uniform).  M0 carries the LDS base and is
 // compiler-reserved: saved and restored inside the statement.
+#ifndef T32_RPOL
+#define T32_RPOL ""                 // cache policy of the REGION requests (tools/conv_t32_ablate.py builds "nt" / "sc1" variants)
+#endif
+__device__ __forceinline__ void glds16r(const void* gsrc, unsigned lds_dst) {   // the same for a region chunk
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " T32_RPOL "\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#ifndef T32_WPOL
+#define T32_WPOL ""                 // cache policy of the WEIGHT requests
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " T32_WPOL "\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 // a 16-B global load hipcc does not know about: the destination holds garbage until a `claim` whose count covers it
 __device__ __forceinline__ void gload16(u32x4& dst, const void* gsrc) {
-  asm volatile("global_load_dwordx4 %0, %1, off ; t32-request" : "=v"(dst) : "v"(gsrc) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off " T32_RPOL " ; t32-request" : "=v"(dst) : "v"(gsrc) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void claim(u32x4& r) {                          // wait until at most N requests are in flight; r is valid (and opaque) from here
@@ -139,6 +150,24 @@ __device__ __forceinline__ void t32_stage_chunk(KState& st, unsigned char* __res
   *reinterpret_cast<uint4*>(Rn + off) = v;
 }
 
+// Without a GroupNorm loader (MODE 0: SFT / fuse / Upsample / conv-FFN convolutions) the region needs no registers at all: the raw slice
+// goes global -> LDS by DMA like the weights (5 more wave-instructions per wave and step), straight into the stage.  Thread t's DMA lane
+// of round k fills LDS slot t + 256 k; the slot order carries the swizzle, so KState::goff is the offset of THAT slot's chunk (same
+// pixel as the chunk the thread owns, possibly the other 16-B half).  Conv padding: the owner of a chunk outside the image overwrites
+// it with zeros once the wave's DMAs have landed (the partner lane that may have filled the slot is in the same wave).
+__device__ __forceinline__ void t32_region_dma(KState& st, const bf16_t* __restrict__ Xs, unsigned dst_stage, int wave, int tid) {
+  const unsigned rdst = dst_stage + wave * 1024;
+#pragma unroll
+  for (int k = 0; k < NIT; ++k)
+    if (k < NIT - 1 || tid < TAIL_T) glds16r(Xs + st.goff[k], rdst + k * (NT * 16));
+}
+__device__ __forceinline__ void t32_zero_padding(KState& st, unsigned char* __restrict__ Rn, int tid, int sink_base) {
+  if (st.okmask == 0x1fu) return;                                           // (interior tiles: nothing to do)
+#pragma unroll
+  for (int k = 0; k < NIT; ++k)
+    if (!((st.okmask >> k) & 1u) && (k < NIT - 1 || tid < TAIL_T)) *reinterpret_cast<uint4*>(Rn + st.loff[k]) = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // One step = one 16-channel slice: 72 MFMAs out of stage Rd, while the other stage is filled for slice s+1 --
 //   * weights: five LDS-DMAs per wave, issued first: a whole step to land;
 //   * region: chunk-wise software pipeline.  Chunk k of slice s+1 was requested exactly one step ago; behind MFMA unit U_k it is
@@ -166,10 +195,12 @@ __device__ __forceinline__ void t32_step(KState& st, int s, const bf16_t* __rest
       glds16(src + q * 1024, dst + q * 1024);
     }
   }
+  if (MODE == 0 && NEXT && !(ABL & 1)) t32_region_dma(st, X + (s + 1) * CSL, lds0 + nxt, wave, tid);   // no loader transform: the raw region IS the stage
   const unsigned char* Wt = Rd + REGION_B + st.boff;
   const bf16x8 abl_frag = __builtin_bit_cast(bf16x8, make_uint4(0x3c003c00u + tid, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u));
   auto chunk = [&](auto kc) __attribute__((always_inline)) {
     constexpr int K = decltype(kc)::value;
+    if (MODE == 0) return;
     // the sink of a thread without a 5th chunk sits behind both stages: 2 * STAGE_B from smem
     if (NEXT && !(ABL & 4)) t32_stage_chunk<K, MODE, (ABL & 3) ? 0 : (NEXT2 ? 9 : 9 - K)>(st, Rn, SSl, (s + 1) * CSL, tid, 2 * STAGE_B - nxt);
     if (NEXT && (ABL & 4)) claim<(ABL & 3) ? 0 : (NEXT2 ? 9 : 9 - K)>(st.rreg[K]);   // (a request without its claim would land in registers hipcc has given to something else)
@@ -205,8 +236,9 @@ __device__ __forceinline__ void t32_step(KState& st, int s, const bf16_t* __rest
       if (u == 7) chunk(std::integral_constant<int, 4>{});
     }
   }
-  if (NEXT2 && !(ABL & 3)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // this wave's share of the weights of slice s+1 has landed
+  if (MODE != 0 && NEXT2 && !(ABL & 3)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // this wave's share of the weights of slice s+1 has landed
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (MODE == 0 && NEXT && !(ABL & 4)) t32_zero_padding(st, Rn, tid, 2 * STAGE_B - nxt);
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);                                         // nothing of the next step above this line
 }
@@ -216,8 +248,11 @@ __device__ __forceinline__ void t32_k_loop(KState& st, const CP& p, int img, int
                                            unsigned char* smem, int wave, int tid) {
   const unsigned lds0 = (unsigned)(uintptr_t)((lds_void*)smem);
   const float* SSl = reinterpret_cast<const float*>(smem + SS_OFF) + (tid & 1) * 16;
+  if (MODE == 0) t32_region_dma(st, X, lds0, wave, tid);
+  else {
 #pragma unroll
-  for (int k = 0; k < NIT; ++k) gload16(st.rreg[k], X + st.goff[k]);
+    for (int k = 0; k < NIT; ++k) gload16(st.rreg[k], X + st.goff[k]);
+  }
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int q = min(wave + 4 * k, 17);
@@ -228,14 +263,19 @@ __device__ __forceinline__ void t32_k_loop(KState& st, const CP& p, int img, int
     for (int c = tid; c < p.Cin; c += NT) reinterpret_cast<float2*>(smem + SS_OFF)[c] = sp[c];
     __syncthreads();
   }
-  t32_stage_chunk<0, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);           // vmcnt(0): the first slice's region AND weights
-  t32_stage_chunk<1, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);
-  t32_stage_chunk<2, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);
-  t32_stage_chunk<3, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);
-  t32_stage_chunk<4, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);
-  if (nsl > 1) {
+  if (MODE == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t32_zero_padding(st, smem, tid, 2 * STAGE_B);
+  } else {
+    t32_stage_chunk<0, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);         // vmcnt(0): the first slice's region AND weights
+    t32_stage_chunk<1, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);
+    t32_stage_chunk<2, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);
+    t32_stage_chunk<3, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);
+    t32_stage_chunk<4, MODE, 0>(st, smem, SSl, 0, tid, 2 * STAGE_B);
+    if (nsl > 1) {
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) gload16(st.rreg[k], X + st.goff[k] + CSL);  // in flight across the barrier
+      for (int k = 0; k < NIT; ++k) gload16(st.rreg[k], X + st.goff[k] + CSL);  // in flight across the barrier
+    }
   }
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
@@ -247,7 +287,7 @@ __device__ __forceinline__ void t32_k_loop(KState& st, const CP& p, int img, int
 
 // ABL (tools builds only, -DSMX_TOOLS; tools/conv_t32_ablate.py): timing-only variants with one phase compiled out -- 1: no region global
 // loads after the first slices, 2: no weight DMA after the first slice, 4: no region transform / LDS store after the first slice, 8: no MFMAs
-// (fragment reads kept), 16: no fragment reads (MFMAs on stale registers), 32: no epilogue global traffic.  Results are garbage for ABL != 0.
+// (fragment reads kept), 16: no fragment reads (MFMAs on stale registers), 32: no epilogue global traffic, 64: no epilogue.  Results are garbage for ABL != 0.
 template <int ABL>
 __global__ __launch_bounds__(NT, 2) void conv3x3_t32_kernel(CP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -279,7 +319,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_t32_kernel(CP p) {
     int iy = by * TH - 1 + ry, ix = bx * TW - 1 + rx;
     const bool ok = item < RPX * 2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     if (p.up2) { iy >>= 1; ix >>= 1; }
-    st.goff[k] = ok ? (iy * Ws_ + ix) * p.lda + half * 8 : 0;              // a padding chunk loads a valid address and is zeroed at store time
+    // a padding chunk loads a valid address and is zeroed at store time; without a loader (DMA'd region) the chunk is the one of LDS slot
+    // tid + 256 k: same pixel, 16-B half taken from the slot's parity
+    st.goff[k] = ok ? (iy * Ws_ + ix) * p.lda + (p.in_ss ? half : half ^ ((rx >> 3) & 1)) * 8 : 0;
     st.loff[k] = ry * ROWB + rx * PXB + ((half ^ ((rx >> 3) & 1)) << 4);
     st.okmask |= (ok ? 1u : 0u) << k;
   }
@@ -438,7 +480,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_t32_kernel(CP p) {
     else if (p.res_f32) all_fast(act_c, std::integral_constant<int, 3>{});
     else all_fast(act_c, std::integral_constant<int, 1>{});
   };
-  if (fast && p.mul) all_fast(std::integral_constant<int, SMX_ACT_NONE>{}, std::integral_constant<int, 2>{});      // SFT: the launcher guarantees the fast layout
+  if (ABL & 64) {                                                          // (tools) no epilogue at all; every accumulator stays live
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(acc[i][0])); asm volatile("" :: "v"(acc[i][1])); }
+  }
+  else if (fast && p.mul) all_fast(std::integral_constant<int, SMX_ACT_NONE>{}, std::integral_constant<int, 2>{});      // SFT: the launcher guarantees the fast layout
   else if (fast) {
     switch (p.act) {
       case SMX_ACT_NONE: by_res(std::integral_constant<int, SMX_ACT_NONE>{}); break;
@@ -539,7 +585,7 @@ static int conv3x3_t32_launch(const void* x, int lda, const void* wp, const floa
 #ifdef SMX_TOOLS
 #define T32_ABL_CASE(A) case A: { static bool at = false; if (!at) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_t32_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)); at = true; } \
     SMX_LAUNCH(conv3x3_t32_kernel<A>, dim3((unsigned)blocks), dim3(NT), LDS_B, (hipStream_t)stream, p); return smx_launch_status(); }
-  switch (abl) { T32_ABL_CASE(1) T32_ABL_CASE(2) T32_ABL_CASE(3) T32_ABL_CASE(4) T32_ABL_CASE(7) T32_ABL_CASE(8) T32_ABL_CASE(16) T32_ABL_CASE(24) T32_ABL_CASE(32) T32_ABL_CASE(39) T32_ABL_CASE(63) T32_ABL_CASE(31)
+  switch (abl) { T32_ABL_CASE(1) T32_ABL_CASE(2) T32_ABL_CASE(3) T32_ABL_CASE(4) T32_ABL_CASE(7) T32_ABL_CASE(8) T32_ABL_CASE(16) T32_ABL_CASE(24) T32_ABL_CASE(32) T32_ABL_CASE(39) T32_ABL_CASE(63) T32_ABL_CASE(31) T32_ABL_CASE(127) T32_ABL_CASE(64) T32_ABL_CASE(103)
     case 0: break; default: return SMX_EINVAL; }
 #else
   if (abl) return SMX_EINVAL;

@@ -472,6 +472,6 @@ def test_t32_kernel_isa_keeps_its_hands_off_registers_with_requests_in_flight():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     kernels, requests, claims, loops, bad = mod.audit(mod.compile_isa())
-    assert kernels == 1 and loops == 3, (kernels, loops)            # one shipped instantiation, one K loop per loader mode (raw / GN / GN + swish)
-    assert requests == claims and requests >= 45, (requests, claims)
+    assert kernels == 1 and loops == 2, (kernels, loops)            # one shipped instantiation; one register-staged K loop per GroupNorm loader mode (GN / GN + swish;
+    assert requests == claims and requests >= 30, (requests, claims)   # without a loader the region goes by LDS-DMA and no register is ever in flight)
     assert not bad, bad[:5]

@@ -8,10 +8,12 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(REPO, "tools", "conv_t32_tools.bin")
+POL = os.environ.get("T32_RPOL", "")                       # region-request cache policy variant: "", "nt", "sc1", "sc0 sc1"
+WPOL = os.environ.get("T32_WPOL", "")                     # weight-DMA cache policy variant
+SO = os.path.join(REPO, "tools", "conv_t32_tools" + ("_" + POL.replace(" ", "") if POL else "") + ("_w" + WPOL.replace(" ", "") if WPOL else "") + ".bin")
 SRC = os.path.join(REPO, "synergize_motion_appearance_amd", "csrc", "conv3x3_bf16_t32.hip")
 if "--build" in sys.argv:
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DSMX_TOOLS",
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DSMX_TOOLS", f'-DT32_RPOL="{POL}"', f'-DT32_WPOL="{WPOL}"',
                            "-I", os.path.join(REPO, "include"), "-I", os.path.dirname(SRC), SRC, "-o", SO])
     print("built", SO)
     sys.exit(0)
@@ -26,7 +28,7 @@ B = int([a for a in sys.argv[1:] if a.isdigit()][0]) if [a for a in sys.argv[1:]
 BF = torch.bfloat16
 SHAPES = [(64, 64, 256), (128, 128, 128), (256, 128, 64), (512, 256, 32)]
 ABL = [(0, "full"), (1, "-region loads"), (2, "-weight DMA"), (3, "-loads -DMA"), (4, "-region store"), (7, "-loads -DMA -store"), (8, "-MFMA"), (16, "-frag reads"),
-       (24, "-MFMA -reads"), (32, "-epilogue traffic"), (39, "-all staging -epilogue"), (31, "epilogue only (+prologue)"), (63, "skeleton")]
+       (24, "-MFMA -reads"), (32, "-epilogue traffic"), (39, "-all staging -epilogue"), (31, "epilogue only (+prologue)"), (63, "skeleton"), (64, "-epilogue"), (103, "-staging -epilogue (prologue + MFMA + reads)"), (127, "skeleton -epilogue (launch + prologue + barriers)")]
 
 
 def timed(fn, n=5):
