@@ -238,7 +238,8 @@ def train_leg(dev, batch=4, steps=4, warmup=2, compute_dtype="f32", use_graph=Tr
     total = float(losses["l_g_total"])
     if not (total == total and abs(total) < 1e6):
         raise SystemExit(f"[bench] training leg: non-finite / exploding loss {total}")
-    return {"workload": f"BASELINE.json configs[4] on ONE GPU: options/train.yml generator + motion-estimator step, {batch} (source, driving) pairs at "
+    roof = train_roofline(step, src, drv, gan, compute_dtype, dt)
+    return {"roofline": roof, "workload": f"BASELINE.json configs[4] on ONE GPU: options/train.yml generator + motion-estimator step, {batch} (source, driving) pairs at "
                         "256x256, " +
                         ("fp32" if compute_dtype == "f32" else "bf16 compute (every convolution / Linear contraction, forward + data + weight gradient, on "
                          "v_mfma_f32_32x32x16_bf16 with operands rounded like torch.autocast(bfloat16); fp32 storage, normalisation, attention, optimiser)") +
@@ -335,6 +336,51 @@ def train_bench(args, world, rank, dev, dist, collective):
             "rank_times_s": {"per_rank": [round(float(r[3]), 4) for r in rows]},
             "replicas_bit_identical": identical, "l_g_total_last": round(total, 5),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+
+
+def train_roofline(step, src, drv, gan, compute_dtype, dt):
+    """one EAGER forward + backward of the step just timed under ops.profile() (HIP events around every convolution / Linear /
+    weight-gradient launch on the launch stream): the step's algorithmic contraction flops (forward, data gradient and weight gradient of
+    every convolution and Linear; attention, normalisation and element-wise work is not counted), the time those launches take, and
+    the dominant family's rate against the matrix peak of the pipe it runs on."""
+    from synergize_motion_appearance_amd import ops
+    step.g.flat.zero_grad()
+    step.flat_m.zero_grad()
+    with ops.profile() as rec:
+        step.forward_backward(src, drv, gan=gan)
+    fam = {}
+    for name, meta, ms in rec.rows:
+        meta = meta or {}
+        if not meta.get("flops"):
+            continue
+        key = "winograd" if meta.get("wino") else name
+        f = fam.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "mfma_flops": 0.0, "bf16": int(bool(meta.get("bf16")))})
+        f["calls"] += 1
+        f["ms"] += ms
+        f["flops"] += meta["flops"]
+        f["mfma_flops"] += meta.get("mfma_flops", meta["flops"])
+    flops = sum(f["flops"] for f in fam.values())
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    d = fam[dom]
+    peak = PEAK_BF16_MFMA_TFLOPS if d["bf16"] else PEAK_F32_MFMA_TFLOPS
+    tf = d["mfma_flops"] / (d["ms"] * 1e-3) / 1e12
+    return {"kernel": {"wgrad": "wgrad_kernel<false,64,64> (weight gradient: TN GEMM over the pixels, v_mfma_f32_32x32x2_f32)",
+                       "wgrad_bf16": "wgrad_kernel<true,64,64> (weight gradient, operands rounded to bf16, v_mfma_f32_32x32x16_bf16)",
+                       "winograd": "winograd_kernel / winograd_wide_kernel (forward and data gradient of the 3x3 convolutions, F(2x2,3x3), v_mfma_f32_32x32x2_f32)",
+                       "gemm_conv": "gemm_conv_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                       "gemm_bf16": "gemm_bf16_kernel (implicit GEMM forward / data gradient, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom),
+            "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+            "launches_per_step": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
+            "share_of_step_time": round(d["ms"] * 1e-3 / dt, 3),
+            "step_algorithmic_gflop": round(flops / 1e9, 1),
+            "step_algorithmic_TFLOPs": round(flops / dt / 1e12, 2),
+            "families": {k: {"calls": v["calls"], "ms_per_step": round(v["ms"], 3), "algorithmic_gflop": round(v["flops"] / 1e9, 1),
+                             "TFLOPs_executed": round(v["mfma_flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                             "frac_of_its_pipe": round(v["mfma_flops"] / (v["ms"] * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if v["bf16"] else PEAK_F32_MFMA_TFLOPS), 4)}
+                         for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+            "method": "HIP events around every convolution / Linear / weight-gradient launch of ONE eager forward + backward after the timed (graph-replayed) steps; "
+                      "achieved = the dominant family's executed flops / its summed launch time; share_of_step_time = that time / the timed step; "
+                      "step_algorithmic_TFLOPs = all contraction flops / the timed step (the step is far from MFMA-bound: ~4,000 launches of 5-100 us at 4 pairs)"}
 
 
 def load_profile_json(name):

@@ -170,10 +170,13 @@ def _wgrad(tp, dy, x, out, *, nb=1, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stri
     ws = torch.empty((n,), device=out.device, dtype=F32)
     dyp, ldy = (dy.data_ptr(), dy_ld) if dy_ld is not None else _pix(dy)[:2]
     xp, ldx = (x.data_ptr(), x_ld) if x_ld is not None else _pix(x)[:2]
-    fn = tp.lib.smx_wgrad_mfma16_f32 if (tp.mfma16 and mfma16_ok) else tp.lib.smx_wgrad_f32
-    L.check(fn(dyp, ldy, dy_bs, xp, ldx, x_bs, nb, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, int(up2),
-                                 ws.data_ptr(), ms.value, out.data_ptr(), out_bs, layout, ldo, int(accumulate), float(alpha),
-                                 None if bias_out is None else bias_out.data_ptr(), _stream()), "wgrad")
+    bf = bool(tp.mfma16 and mfma16_ok)
+    fn = tp.lib.smx_wgrad_mfma16_f32 if bf else tp.lib.smx_wgrad_f32
+    K = kh * kw * cin
+    meta = {"flops": 2.0 * nb * M * cout * K, "M": M, "N": cout, "K": K, "nb": nb, "k": kh, "bf16": int(bf)} if ops._PROFILE is not None else None
+    L.check(ops._timed("wgrad_bf16" if bf else "wgrad", meta, fn, dyp, ldy, dy_bs, xp, ldx, x_bs, nb, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl,
+                       int(up2), ws.data_ptr(), ms.value, out.data_ptr(), out_bs, layout, ldo, int(accumulate), float(alpha),
+                       None if bias_out is None else bias_out.data_ptr(), _stream()), "wgrad")
 
 
 def act_bwd(tp, g, ref, act):

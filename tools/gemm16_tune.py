@@ -10,6 +10,7 @@ from synergize_motion_appearance_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
 # (M, N, K) as 1x1 convolutions over M pixels
+SCALE = int(sys.argv[1]) if len(sys.argv) > 1 else 1        # 5: the B = 300 launches
 SHAPES = [(61440, 256, 256), (3932160, 64, 128), (61440, 512, 256), (61440, 4096, 256), (983040, 192, 128), (983040, 192, 64),
           (61440, 32, 32), (983040, 128, 256), (61440, 2048, 256), (245760, 128, 32), (61440, 64, 288), (245760, 128, 256), (245760, 192, 128),
           (61440, 256, 4096), (61440, 256, 1024)]
@@ -29,6 +30,7 @@ def timed(fn, n=8):
 
 print("M N K : auto us | tile1 128x128/8w  tile2 128x64/4w  tile3 64x64/4w  tile4 128x32  tile5 64x128  tile6 256x64/8w  tile7 128x128/4w   (GB/s of the best)")
 for M, N, K in SHAPES:
+    M *= SCALE
     x = torch.randn((1, M // 256, 256, K), device="cuda").to(BF)
     cv = ops.Conv.from_torch(torch.randn((N, K, 1, 1), device="cuda") / K ** 0.5, torch.randn(N, device="cuda") * 0.1)
     out = torch.empty((1, M // 256, 256, N), device="cuda", dtype=BF)
