@@ -46,7 +46,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: v_mfma_f32_32x32x16_bf16 dense pe
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
 CLIP = 300                       # frames of the driving clip (BASELINE.json configs[1])
 DEFAULT_BATCH = 300              # frames per step: the whole clip in flight (HBM holds it many times over); 60 until round 3 (545 -> 565 frames/s)
-PROFILE_TAG = "r03"              # profiles/<tag>_{traffic,mfma}_pmc[_bf16].json: the committed counter summaries this run quotes
+PROFILE_TAG = "r04"              # profiles/<tag>_{traffic,mfma}_pmc[_bf16].json: the committed counter summaries this run quotes
 
 
 def build_nets(device, img_size=256):
@@ -530,7 +530,8 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     tf_exec = g["mfma_flops"] / (g["ms"] * 1e-3) / 1e12
     tf_alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
     kname = {"winograd": "winograd_wide_kernel / winograd_kernel<..> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
-             "conv3x3_bf16": "conv3x3_bf16_kernel<TH> (region-direct 3x3/s1/p1 convolution, v_mfma_f32_32x32x16_bf16)",
+             "conv3x3_bf16": "conv3x3_t32_kernel (16x32-pixel tiles, 16-channel slices, LDS-DMA weights; the big launches) / conv3x3_bf16_kernel<TH> (the small ones): "
+                             "region-direct 3x3/s1/p1 convolution, v_mfma_f32_32x32x16_bf16",
              "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x2_f32)",
              "gemm_bf16": "gemm_bf16_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom)
     if dom.startswith("attention"):

@@ -28,6 +28,9 @@
 //   * epilogue: wave-private exchange through LDS (no block barrier inside), 16-B stores of 8 channels, bias / activation /
 //     residual / SFT fused, Welford partials {mean, M2} per 16x32-pixel tile for the next GroupNorm.
 // (n-block, tile) pairs are adjacent in the XCD-ordered block walk, so the second n-block of a tile finds the region in L2.
+// Measured and left out (profiles/r04_t32_*.txt): s_setprio 1 around the MFMA groups (0 to -7 %), nt / sc1 cache policies on the region or
+// weight requests and non-temporal output stores (nt on the region: -20 %: the 32-B-per-pixel slices of one 128-B line live off L1 hits), persistent blocks with and
+// without the next tile's first requests issued ahead of the epilogue (-5 % ... 0: see DESIGN section 4b).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -228,6 +231,7 @@ __device__ __forceinline__ void t32_step(KState& st, int s, const bf16_t* __rest
         st.acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a[i + ky], st.acc[i][0], 0, 0, 0);   // A = weights: the tile is [n][pixel]
         st.acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a[i + ky], st.acc[i][1], 0, 0, 0);
       }
+
       const int u = kx * 3 + ky;                                             // MFMA unit (8 MFMAs) just issued
       if (u == 0) chunk(std::integral_constant<int, 0>{});
       if (u == 2) chunk(std::integral_constant<int, 1>{});

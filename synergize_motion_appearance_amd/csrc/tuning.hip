@@ -22,6 +22,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"conv16_slab", "SMX_CONV16_SLAB", 1},        // bf16 region conv, 16x16 tiles: 1 = 32-channel slices with all nine taps' weights in LDS, 0 = one weight tile per tap
   {"attn_bwd_mfma", "SMX_ATTN_BWD_MFMA", 1},    // training, d_head 32 attention backward: 1 = fp32 MFMA kernels, 0 = the per-thread VALU kernels
   {"vq_split", "SMX_VQ_SPLIT", 1},              // VQ, few tokens (< half a chip of 128-token blocks): codebook sweep split over blockIdx.y + a combine kernel
+  {"warp_nt", "SMX_WARP_NT", 1},                // warp row-chunk kernels: non-temporal output stores (write-once stream: 6.5 -> 8.3 TB/s algorithmic at B = 300; 0 = plain stores)
 };
 bool g_init = false;
 void init_once() {

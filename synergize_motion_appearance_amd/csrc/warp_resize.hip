@@ -154,7 +154,13 @@ __global__ __launch_bounds__(256) void warp_kernel(const T* __restrict__ feat, l
 // row and x-base are block-uniform (scalar ALU); lane j < NPW of each wave computes the sampling
 // position of the wave's j-th pixel ONCE and the pixel's lane group fetches it with three
 // wavefront shuffles.  Arithmetic and association order are those of the scalar path of warp_kernel.
-template <typename T, int LPP>
+// NTS: non-temporal output stores (the output stream is write-once: the verdict's "write-rate fix" experiment, knob `warp_nt`)
+typedef float f32x4nt __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2nt __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float* p, float4 v) { __builtin_nontemporal_store(f32x4nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4nt*>(p)); }
+__device__ __forceinline__ void st4_nt(bf16_t* p, float4 v) { const uint2 q = pack4(v.x, v.y, v.z, v.w); __builtin_nontemporal_store(u32x2nt{q.x, q.y}, reinterpret_cast<u32x2nt*>(p)); }
+template <typename T, int LPP, bool NTS = false>
 __global__ __launch_bounds__(256) void warp_rows_kernel(const T* __restrict__ feat, long long feat_bs,
                                                         const float* __restrict__ flow, const float* __restrict__ occ,
                                                         T* __restrict__ out, int H, int W, int C, int Hf, int Wf,
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(const T* __restrict__ fe
       acc.x += v[i][k].x * w[i][k]; acc.y += v[i][k].y * w[i][k]; acc.z += v[i][k].z * w[i][k]; acc.w += v[i][k].w * w[i][k];
     }
     if (occ) { acc.x *= oc[i]; acc.y *= oc[i]; acc.z *= oc[i]; acc.w *= oc[i]; }
-    St<T>::st4(ob_ + i * PPB * C, acc);
+    if (NTS) st4_nt(ob_ + i * PPB * C, acc); else St<T>::st4(ob_ + i * PPB * C, acc);
   }
 }
 
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(const T* __restrict__ fe
 template <int LPP>
 __global__ __launch_bounds__(256) void warp_rows16_kernel(const bf16_t* __restrict__ feat, long long feat_bs,
                                                           const float* __restrict__ flow, const float* __restrict__ occ,
-                                                          bf16_t* __restrict__ out, int H, int W, int C, int Hf, int Wf, int nframes) {
+                                                          bf16_t* __restrict__ out, int H, int W, int C, int Hf, int Wf, int nframes, int nts) {
   constexpr int PPT = 4, PPB = 256 / LPP, GPW = 64 / LPP, NPW = GPW * PPT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPP, g = lane / LPP;
   const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void warp_rows16_kernel(const bf16_t* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] *= oc[i];
     }
-    *reinterpret_cast<uint4*>(ob_ + i * PPB * C) = pack8(acc);
+    { const uint4 pk_ = pack8(acc); if (nts) __builtin_nontemporal_store(u32x4nt{pk_.x, pk_.y, pk_.z, pk_.w}, reinterpret_cast<u32x4nt*>(ob_ + i * PPB * C)); else *reinterpret_cast<uint4*>(ob_ + i * PPB * C) = pk_; }
   }
 }
 
@@ -444,9 +450,9 @@ int warp_launch(const T* feat, int feat_batch, const float* flow, const float* o
     if (C % 8 == 0 && (l8 == 8 || l8 == 16 || l8 == 32) && W % rc8 == 0 && npix / rc8 >= 256 && (long long)H * W * C < (1LL << 31) &&
         ((((uintptr_t)feat) | ((uintptr_t)out)) & 15) == 0 && smx_tune(SMX_TUNE_WARP_ROWS)) {
       dim3 grid8((unsigned)((long long)(H * W) / rc8 * B));
-      if (l8 == 8) SMX_LAUNCH((warp_rows16_kernel<8>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B);
-      else if (l8 == 16) SMX_LAUNCH((warp_rows16_kernel<16>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B);
-      else SMX_LAUNCH((warp_rows16_kernel<32>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B);
+      if (l8 == 8) SMX_LAUNCH((warp_rows16_kernel<8>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B, smx_tune(SMX_TUNE_WARP_NT));
+      else if (l8 == 16) SMX_LAUNCH((warp_rows16_kernel<16>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B, smx_tune(SMX_TUNE_WARP_NT));
+      else SMX_LAUNCH((warp_rows16_kernel<32>), grid8, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, B, smx_tune(SMX_TUNE_WARP_NT));
       return smx_launch_status();
     }
   }
@@ -455,7 +461,12 @@ int warp_launch(const T* feat, int feat_batch, const float* flow, const float* o
   if (lpp >= 16 && W % rchunk == 0 && npix / rchunk >= 256 && (long long)H * W * C < (1LL << 31) && smx_tune(SMX_TUNE_WARP_ROWS)) {
     const int cpi2 = (H * W) / rchunk;
     dim3 grid2(cpi2 * B);
-    if (lpp == 16) SMX_LAUNCH((warp_rows_kernel<T, 16>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+    if (smx_tune(SMX_TUNE_WARP_NT)) {
+      if (lpp == 16) SMX_LAUNCH((warp_rows_kernel<T, 16, true>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+      else if (lpp == 32) SMX_LAUNCH((warp_rows_kernel<T, 32, true>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+      else SMX_LAUNCH((warp_rows_kernel<T, 64, true>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
+    }
+    else if (lpp == 16) SMX_LAUNCH((warp_rows_kernel<T, 16>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
     else if (lpp == 32) SMX_LAUNCH((warp_rows_kernel<T, 32>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
     else SMX_LAUNCH((warp_rows_kernel<T, 64>), grid2, block, 0, st, feat, feat_bs, flow, occ, out, H, W, C, Hf, Wf, cpi2, B);
     return smx_launch_status();

@@ -10,10 +10,11 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 POL = os.environ.get("T32_RPOL", "")                       # region-request cache policy variant: "", "nt", "sc1", "sc0 sc1"
 WPOL = os.environ.get("T32_WPOL", "")                     # weight-DMA cache policy variant
-SO = os.path.join(REPO, "tools", "conv_t32_tools" + ("_" + POL.replace(" ", "") if POL else "") + ("_w" + WPOL.replace(" ", "") if WPOL else "") + ".bin")
+XDEF = os.environ.get("T32_DEFS", "")                      # extra -D flags of an experiment build, e.g. "T32_SETPRIO"
+SO = os.path.join(REPO, "tools", "conv_t32_tools" + ("_" + POL.replace(" ", "") if POL else "") + ("_w" + WPOL.replace(" ", "") if WPOL else "") + ("_" + XDEF.replace(" ", "_") if XDEF else "") + ".bin")
 SRC = os.path.join(REPO, "synergize_motion_appearance_amd", "csrc", "conv3x3_bf16_t32.hip")
 if "--build" in sys.argv:
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DSMX_TOOLS", f'-DT32_RPOL="{POL}"', f'-DT32_WPOL="{WPOL}"',
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DSMX_TOOLS", f'-DT32_RPOL="{POL}"', f'-DT32_WPOL="{WPOL}"'] + ["-D" + d for d in XDEF.split()] + [
                            "-I", os.path.join(REPO, "include"), "-I", os.path.dirname(SRC), SRC, "-o", SO])
     print("built", SO)
     sys.exit(0)
