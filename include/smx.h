@@ -394,6 +394,12 @@ int smx_nhwc_to_nchw_bf16(const void* x, int ldx, float* y, int B, int C, int H,
  * bias_out (nullable): the BIAS gradient sum_m dY[m][co] comes out of the same pass (the dY tiles stream through the k-tile-0 blocks anyway;
  * their column sums are finished in a fixed order) -- same accumulate / alpha. */
 int64_t smx_wgrad_ws_floats(int nb, int M, int Cout, int K, int* msplit_out);
+/* workspace / pixel split for a CONVOLUTION's weight gradient: as smx_wgrad_ws_floats, but told the geometry, so that 3x3 / stride 1 /
+ * pad 1 layers with 64-multiple channel counts (and 32-multiple output widths) get the split of the region kernel (one block holds all
+ * nine taps of a 64 x 64 (co, ci) tile and walks down a 32-pixel strip: csrc/train_wgrad_region.hip).  smx_wgrad_*_f32 pick the kernel
+ * from the same geometry and the msplit passed. */
+int64_t smx_wgrad_conv_ws_floats(int nb, int M, int Cout, int Cin, int Hin, int Win, int Ho, int Wo, int kh, int kw, int stride,
+                                 int pad_t, int pad_l, int up2, int* msplit_out);
 int smx_wgrad_f32(const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
                   int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
                   float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,

@@ -34,7 +34,13 @@ static inline int smx_launch_status() {
 
 // tuning table (tuning.hip): plain ints read by the launchers; set via smx_set_tuning / SMX_* env at first use
 enum { SMX_TUNE_WINO_NW = 0, SMX_TUNE_WINO_ABLATE, SMX_TUNE_GEMM_VARIANT, SMX_TUNE_GEMM_XCD_SWIZZLE,
-       SMX_TUNE_WARP_ROWS, SMX_TUNE_WARP_REORDER, SMX_TUNE_ATTN16, SMX_TUNE_WINO_WIDE, SMX_TUNE_WINO_NT, SMX_TUNE_ATTN4_MFMA, SMX_TUNE_CONV16_SLAB, SMX_TUNE_ATTN_BWD_MFMA, SMX_TUNE_VQ_SPLIT, SMX_TUNE_WARP_NT, SMX_TUNE_COUNT };
+       SMX_TUNE_WARP_ROWS, SMX_TUNE_WARP_REORDER, SMX_TUNE_ATTN16, SMX_TUNE_WINO_WIDE, SMX_TUNE_WINO_NT, SMX_TUNE_ATTN4_MFMA, SMX_TUNE_CONV16_SLAB, SMX_TUNE_ATTN_BWD_MFMA, SMX_TUNE_VQ_SPLIT, SMX_TUNE_WARP_NT, SMX_TUNE_WGRAD_REGION, SMX_TUNE_WGRAD_SLOTS, SMX_TUNE_COUNT };
 int smx_tune(int key);
 
 static inline int smx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// region form of the 3x3 / s1 / p1 weight gradient (train_wgrad_region.hip), dispatched by train_gemm.hip's wgrad_launch
+bool smx_wgrad_region_shape_ok(int nb, int Cout, int Cin, int Hin, int Win, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2);
+int smx_wgrad_region_split(int M, int Cout, int Cin, int Ho, int Wo, int* uper_out);
+int smx_wgrad_region_launch(bool bf16, const float* dy, int ldy, const float* x, int ldx, int M, int Cout, int Hin, int Win, int Cin, int Ho, int Wo,
+                            int up2, float* ws, float* bias_ws, int msplit, void* stream);

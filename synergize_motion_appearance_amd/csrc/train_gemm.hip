@@ -308,7 +308,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (i < total) {
       g = (int)(i / per); j = i - (long long)g * per;
       const float* w = ws + (long long)g * msplit * per + j;
-      for (int zz = q; zz < msplit; zz += 8) {
+      int zz = q;
+      if (VEC == 4) {                        // four partial rows in flight per lane (the region kernel's splits run to 512: one dependent
+        for (; zz + 24 < msplit; zz += 32) { // HBM round trip per split was most of this kernel); the order of the additions is unchanged
+          const float4 v0 = *reinterpret_cast<const float4*>(w + (long long)zz * per);
+          const float4 v1 = *reinterpret_cast<const float4*>(w + (long long)(zz + 8) * per);
+          const float4 v2 = *reinterpret_cast<const float4*>(w + (long long)(zz + 16) * per);
+          const float4 v3 = *reinterpret_cast<const float4*>(w + (long long)(zz + 24) * per);
+          s[0] += v0.x; s[VEC > 1 ? 1 : 0] += v0.y; s[VEC > 2 ? 2 : 0] += v0.z; s[VEC > 3 ? 3 : 0] += v0.w;
+          s[0] += v1.x; s[VEC > 1 ? 1 : 0] += v1.y; s[VEC > 2 ? 2 : 0] += v1.z; s[VEC > 3 ? 3 : 0] += v1.w;
+          s[0] += v2.x; s[VEC > 1 ? 1 : 0] += v2.y; s[VEC > 2 ? 2 : 0] += v2.z; s[VEC > 3 ? 3 : 0] += v2.w;
+          s[0] += v3.x; s[VEC > 1 ? 1 : 0] += v3.y; s[VEC > 2 ? 2 : 0] += v3.z; s[VEC > 3 ? 3 : 0] += v3.w;
+        }
+      }
+      for (; zz < msplit; zz += 8) {
         if (VEC == 4) {
           const float4 v = *reinterpret_cast<const float4*>(w + (long long)zz * per);
           s[0] += v.x; s[VEC > 1 ? 1 : 0] += v.y; s[VEC > 2 ? 2 : 0] += v.z; s[VEC > 3 ? 3 : 0] += v.w;
@@ -528,6 +541,19 @@ extern "C" int64_t smx_wgrad_ws_floats(int nb, int M, int Cout, int K, int* mspl
   return (int64_t)nb * ms * Cout * K + (int64_t)nb * ms * Cout;      // weight partials + the bias-gradient partials
 }
 
+/* the same, told the convolution's geometry: 3x3 / stride 1 / pad 1 layers with 64-multiple channel counts and 32-multiple widths go to
+ * the region kernel (train_wgrad_region.hip), which wants more, smaller pixel splits (one block owns all nine taps of a 64 x 64 tile) */
+extern "C" int64_t smx_wgrad_conv_ws_floats(int nb, int M, int Cout, int Cin, int Hin, int Win, int Ho, int Wo, int kh, int kw, int stride,
+                                            int pad_t, int pad_l, int up2, int* msplit_out) {
+  if (nb <= 0 || M <= 0 || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  if (M % (Ho * Wo) == 0 && smx_wgrad_region_shape_ok(nb, Cout, Cin, Hin, Win, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2)) {
+    const int ms = smx_wgrad_region_split(M, Cout, Cin, Ho, Wo, nullptr);
+    if (msplit_out) *msplit_out = ms;
+    return (int64_t)ms * Cout * 9 * Cin + (int64_t)ms * Cout;
+  }
+  return smx_wgrad_ws_floats(nb, M, Cout, kh * kw * Cin, msplit_out);
+}
+
 static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
                         int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
                         float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
@@ -553,7 +579,12 @@ static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, cons
   const long long tiles = (long long)smx_cdiv(Cout, 64) * p.tiles_k;
   if (tiles > 2147483647LL) return SMX_EINVAL;
   const dim3 grid((unsigned)tiles, nb, msplit);
-  if (bf16) SMX_LAUNCH((wgrad_kernel<true, 64, 64>), grid, dim3(256), 0, st, p);
+  const bool region = smx_wgrad_region_shape_ok(nb, Cout, Cin, Hin, Win, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2) && p.vec_x && p.vec_y &&
+                      (((uintptr_t)ws) & 15) == 0 && msplit == smx_wgrad_region_split(M, Cout, Cin, Ho, Wo, nullptr);
+  if (region) {
+    const int rc = smx_wgrad_region_launch(bf16, dy, ldy, x, ldx, M, Cout, Hin, Win, Cin, Ho, Wo, up2, ws, p.bias_ws, msplit, stream);
+    if (rc != SMX_OK) return rc;
+  } else if (bf16) SMX_LAUNCH((wgrad_kernel<true, 64, 64>), grid, dim3(256), 0, st, p);
   else SMX_LAUNCH((wgrad_kernel<false, 64, 64>), grid, dim3(256), 0, st, p);
   const long long per_g = (long long)Cout * p.K;
   if (per_g % 4 == 0 && (((uintptr_t)ws) & 15) == 0)

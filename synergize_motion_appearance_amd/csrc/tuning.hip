@@ -23,6 +23,8 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"attn_bwd_mfma", "SMX_ATTN_BWD_MFMA", 1},    // training, d_head 32 attention backward: 1 = fp32 MFMA kernels, 0 = the per-thread VALU kernels
   {"vq_split", "SMX_VQ_SPLIT", 1},              // VQ, few tokens (< half a chip of 128-token blocks): codebook sweep split over blockIdx.y + a combine kernel
   {"warp_nt", "SMX_WARP_NT", 1},                // warp row-chunk kernels: non-temporal output stores (write-once stream: 6.5 -> 8.3 TB/s algorithmic at B = 300; 0 = plain stores)
+  {"wgrad_region", "SMX_WGRAD_REGION", 1},      // training: 3x3 / s1 / p1 weight gradients with 64-multiple channels on the region kernel (0 = the generic TN GEMM)
+  {"wgrad_slots", "SMX_WGRAD_SLOTS", 256},      // region weight gradient: blocks the pixel split aims at (device sweep profiles/r04_wgrad_region.txt: 256 = one block per CU beats 512 -- half the partials to write and reduce, twice the rows per run -- and 128)
 };
 bool g_init = false;
 void init_once() {

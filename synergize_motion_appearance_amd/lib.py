@@ -128,6 +128,7 @@ SIGNATURES = {
     "smx_vq_nearest_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     # ---- training step ----
     "smx_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, C.POINTER(_i)]),
+    "smx_wgrad_conv_ws_floats": (_i64, [_i] * 14 + [C.POINTER(_i)]),
     "smx_wgrad_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p, _p]),
     "smx_wgrad_mfma16_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p, _p]),
     "smx_colsum_ws_floats": (_i64, [_i64, _i]),

@@ -166,7 +166,7 @@ def _colsum(tp, x2d_ptr, ld, P, Cc, out, accumulate=True, alpha=1.0):
 def _wgrad(tp, dy, x, out, *, nb=1, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl, up2=0, layout=0, ldo=0, accumulate=True,
            alpha=1.0, dy_ld=None, x_ld=None, dy_bs=0, x_bs=0, out_bs=0, bias_out=None, mfma16_ok=False):
     ms = C.c_int(1)
-    n = int(tp.lib.smx_wgrad_ws_floats(nb, M, cout, kh * kw * cin, C.byref(ms)))
+    n = int(tp.lib.smx_wgrad_conv_ws_floats(nb, M, cout, cin, Hin, Win, Ho, Wo, kh, kw, stride, pt, pl, int(up2), C.byref(ms)))
     ws = torch.empty((n,), device=out.device, dtype=F32)
     dyp, ldy = (dy.data_ptr(), dy_ld) if dy_ld is not None else _pix(dy)[:2]
     xp, ldx = (x.data_ptr(), x_ld) if x_ld is not None else _pix(x)[:2]

@@ -57,6 +57,10 @@ CONV_BWD = [
     (2, 64, 64, 8, 3, 1, 1, True, 0, False, "Upsample nearest x2 + conv"),
     (2, 128, 3, 16, 3, 1, 1, False, 0, False, "3x3 128->3 (image head)"),
     (2, 256, 2, 16, 3, 1, 1, False, 0, False, "3x3 256->2 (RefineFlow head)"),
+    # Wo % 32 == 0 and 64-multiple channels: the weight gradient runs on the region kernel (train_wgrad_region.hip)
+    (2, 64, 64, 32, 3, 1, 1, False, 0, False, "region 64->64 @32"),
+    (1, 128, 64, 64, 3, 1, 1, False, 0, True, "region 128->64 @64 + residual (two strips per row)"),
+    (3, 64, 128, 16, 3, 1, 1, True, 0, False, "region Upsample x2 + conv 64->128 @16->32"),
 ]
 
 
@@ -440,7 +444,8 @@ def test_gelu_and_adam_and_ema(T):
 
 
 BF16_CONV = [c for c in CONV_BWD if c[-1] in ("3x3", "3x3 relu", "1x1", "7x7 pad 3 relu", "7x7 valid (kp head)", "3x3 160->126 lrelu (odd Cout)",
-                                              "Downsample pad(0,1,0,1) stride 2", "Upsample nearest x2 + conv", "3x3 128->3 (image head)")]
+                                              "Downsample pad(0,1,0,1) stride 2", "Upsample nearest x2 + conv", "3x3 128->3 (image head)",
+                                              "region 64->64 @32", "region Upsample x2 + conv 64->128 @16->32")]
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,k,stride,pad,up2,act,res,tag", BF16_CONV, ids=[c[-1] for c in BF16_CONV])
@@ -494,6 +499,49 @@ def test_conv_backward_bf16_compute_mode(T, B, Cin, Cout, H, k, stride, pad, up2
     wf = w.clone().requires_grad_()
     lin(x, wf).backward(gm)
     assert rel(tp.G["w"], wf.grad) > 1e-4, tag
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,up2,bf16", [(4, 128, 128, 64, 64, 0, 0), (2, 64, 192, 40, 96, 0, 0), (1, 256, 64, 7, 32, 0, 1), (2, 64, 64, 24, 32, 1, 1),
+                                                     (5, 64, 64, 3, 32, 0, 0)])
+def test_region_weight_gradient_equals_the_generic_kernel(B, Cin, Cout, H, W, up2, bf16):
+    """csrc/train_wgrad_region.hip against the generic TN GEMM it replaces (same entry point, `wgrad_region` knob 1 / 0) on operands that are
+    CHANNEL SLICES of wider buffers (ld > C, 16-byte-aligned offsets), non-square grids, runs that cross strip / image boundaries, accumulate +
+    alpha, and the bias gradient from the same pass.  Both sum the same products in different orders: 1e-5 relative (bf16 mode: the same
+    rounded operands, fp32 accumulation)."""
+    import ctypes as C
+    from synergize_motion_appearance_amd import lib as L
+    lib = L.load()
+    Hin, Win = (H // 2, W // 2) if up2 else (H, W)
+    xw = (rnd("rg_x", (B, Hin, Win, Cin + 8)) * 1.0).cuda()
+    dyw = rnd("rg_dy", (B, H, W, Cout + 12)).cuda()
+    x, dy = xw[..., 4:4 + Cin], dyw[..., 8:8 + Cout]
+    M = B * H * W
+    st = torch.cuda.current_stream().cuda_stream
+    fn = lib.smx_wgrad_mfma16_f32 if bf16 else lib.smx_wgrad_f32
+    outs = []
+    try:
+        for knob in (1, 0):
+            L.check(lib.smx_set_tuning(b"wgrad_region", knob), "knob")
+            ms = C.c_int(0)
+            n = int(lib.smx_wgrad_conv_ws_floats(1, M, Cout, Cin, Hin, Win, H, W, 3, 3, 1, 1, 1, up2, C.byref(ms)))
+            ws = torch.empty(n, device="cuda")
+            out = torch.full((Cout, Cin, 3, 3), 0.25, device="cuda")
+            bias = torch.full((Cout,), -0.5, device="cuda")
+            L.check(fn(dy.data_ptr(), Cout + 12, 0, x.data_ptr(), Cin + 8, 0, 1, M, Cout, Hin, Win, Cin, H, W, 3, 3, 1, 1, 1, up2, ws.data_ptr(), ms.value,
+                       out.data_ptr(), 0, 0, 0, 1, 0.5, bias.data_ptr(), st), "wgrad")
+            torch.cuda.synchronize()
+            outs.append((out.cpu(), bias.cpu(), ms.value))
+    finally:
+        L.check(lib.smx_set_tuning(b"wgrad_region", 1), "knob")
+    assert rel(outs[0][0], outs[1][0]) < 1e-5 and rel(outs[0][1], outs[1][1]) < 1e-5
+    # and against autograd (fp32 mode)
+    if not bf16:
+        xr = x.cpu().permute(0, 3, 1, 2)
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest") if up2 else xr
+        w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+        F.conv2d(xr, w, padding=1).backward(dy.cpu().permute(0, 3, 1, 2))
+        assert rel(outs[0][0] - 0.25, 0.5 * w.grad) < 2e-4
+        assert rel(outs[0][1] + 0.5, 0.5 * dy.cpu().sum((0, 1, 2))) < 2e-4
 
 
 def test_batched_weight_packing_equals_the_per_layer_launches():
