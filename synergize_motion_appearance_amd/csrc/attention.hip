@@ -437,6 +437,90 @@ __global__ __launch_bounds__(256) void attn_mfma4_kernel(AP<T> p) {
   }
 }
 
+// d_head = 4 on bf16 storage (configs[2]): the same swapped-product scheme on v_mfma_f32_4x4x4_16B_bf16 -- K = 4 is the whole head
+// dimension for S^T = K Q^T and four keys for O^T += V^T P^T, so a 4-key group costs TWO matrix instructions instead of eight
+// (4x4x1 fp32: one per d and one per key).  The operands are the stored bf16 values themselves (a K row of this head is the 8-byte A
+// fragment, the lane's q row the B fragment: no conversion, no pre-scaling -- the softmax scale enters as the fma in front of v_exp_f32);
+// P is rounded to bf16 for the second product like in the d_head = 32 bf16 kernel, the row sum keeps the unrounded values.  32 keys per
+// step (one max / rescale per 32 keys).  Scores, statistics and accumulators stay lane-local fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool MASK>
+__global__ __launch_bounds__(256) void attn_mfma4_bf16_kernel(AP<bf16_t> p) {
+  extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+  uint2* Ks = reinterpret_cast<uint2*>(smem4);                   // [S] key-major: K[key][0..3] (4 x bf16)
+  bf16_t* Vt = reinterpret_cast<bf16_t*>(Ks + p.S);              // [4][S] d-major
+  float* Mf = reinterpret_cast<float*>(Vt + 4 * p.S);            // [S] (MASK) 0 / -inf per key
+  float* part = Mf + (MASK ? p.S : 0);                           // [4][64][6]
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l4 = lane & 3;
+  const int qrow = blockIdx.x * 64 + lane;
+  const s16x4 qf = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(p.q + b * p.q_bs + (long long)qrow * p.ldq + h * 4));
+  const float sc = p.scale * 1.44269504088896340736f;
+  const bf16_t* K = p.k + b * p.k_bs + h * 4;
+  const bf16_t* V = p.v + b * p.v_bs + h * 4;
+  const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
+  for (int i = threadIdx.x; i < p.S; i += 256) {
+    Ks[i] = *reinterpret_cast<const uint2*>(K + (long long)i * p.ldk);
+    const uint2 v = *reinterpret_cast<const uint2*>(V + (long long)i * p.ldv);
+    Vt[i] = (bf16_t)(v.x & 0xffffu); Vt[p.S + i] = (bf16_t)(v.x >> 16); Vt[2 * p.S + i] = (bf16_t)(v.y & 0xffffu); Vt[3 * p.S + i] = (bf16_t)(v.y >> 16);
+    if (MASK) Mf[i] = M[i] ? -INFINITY : 0.f;
+  }
+  __syncthreads();
+  float m = -INFINITY, l = 0.f;
+  f32x4m acc[2] = {f32x4m{0.f, 0.f, 0.f, 0.f}, f32x4m{0.f, 0.f, 0.f, 0.f}};
+  const int per = p.S >> 2, g0 = wave * per;
+  const bf16_t* vrow = Vt + l4 * p.S;
+  for (int g = g0; g < g0 + per; g += 32) {
+    f32x4m s[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const s16x4 kf = __builtin_bit_cast(s16x4, Ks[g + 4 * c + l4]);
+      f32x4m c0 = f32x4m{0.f, 0.f, 0.f, 0.f};
+      if (MASK) { const float4 mf = *reinterpret_cast<const float4*>(Mf + g + 4 * c); c0 = f32x4m{mf.x, mf.y, mf.z, mf.w}; }
+      s[c] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(kf, qf, c0, 0, 0, 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tmax = fmaxf(tmax, s[c][i]);
+    const float m_new = fmaxf(m, tmax * sc);
+    if (MASK && m_new == -INFINITY) continue;                    // every key so far masked (per lane: keep the state)
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[c][i] = __builtin_amdgcn_exp2f(fmaf(s[c][i], sc, -m_new)); ps += s[c][i]; }
+    acc[0] *= alpha; acc[1] *= alpha;
+    l = l * alpha + ps; m = m_new;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const s16x4 vf = __builtin_bit_cast(s16x4, *reinterpret_cast<const uint2*>(vrow + g + 4 * c));   // A: V^T[d = lane & 3][keys g+4c .. +3]
+      const s16x4 pf = __builtin_bit_cast(s16x4, pack4(s[c][0], s[c][1], s[c][2], s[c][3]));           // B: this lane's p for those keys
+      acc[c & 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(vf, pf, acc[c & 1], 0, 0, 0);
+    }
+  }
+  const f32x4m a4 = acc[0] + acc[1];
+  float* pp = part + (wave * 64 + lane) * 6;
+  pp[0] = m; pp[1] = l; pp[2] = a4[0]; pp[3] = a4[1]; pp[4] = a4[2]; pp[5] = a4[3];
+  __syncthreads();
+  if (wave == 0) {
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, part[(w * 64 + lane) * 6]);
+    float ll = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* q6 = part + (w * 64 + lane) * 6;
+      const float f = (q6[0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(q6[0] - mm);
+      ll += q6[1] * f; a.x += q6[2] * f; a.y += q6[3] * f; a.z += q6[4] * f; a.w += q6[5] * f;
+    }
+    // ll == 0 (every key masked) -> 0/0 = NaN like the reference
+    St<bf16_t>::st4(p.o + b * p.o_bs + (long long)qrow * p.ldo + h * 4, make_float4(a.x / ll, a.y / ll, a.z / ll, a.w / ll));
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -459,6 +543,21 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 36 + 4 * 64 * 6 * (int)sizeof(float));
     });
     if (attr_err != hipSuccess) return SMX_ELAUNCH;
+    if constexpr (sizeof(T) == 2) {
+      if (smx_tune(SMX_TUNE_ATTN4_MFMA) == 1 && S % 128 == 0) {          // bf16 storage: the 4x4x4 bf16 MFMA form (knob 2: the fp32 4x4x1 form on bf16 storage)
+        static std::once_flag attr16_once;
+        static hipError_t attr16_err = hipSuccess;
+        std::call_once(attr16_once, [] {
+          const void* fns[] = {(const void*)(attn_mfma4_bf16_kernel<true>), (const void*)(attn_mfma4_bf16_kernel<false>)};
+          for (const void* f : fns)
+            if (attr16_err == hipSuccess) attr16_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 20 + 4 * 64 * 6 * (int)sizeof(float));
+        });
+        if (attr16_err != hipSuccess) return SMX_ELAUNCH;
+        if (key_mask) SMX_LAUNCH(attn_mfma4_bf16_kernel<true>, dim3(L / 64, B * H), dim3(256), (size_t)S * 20 + 4 * 64 * 6 * sizeof(float), st, p);
+        else SMX_LAUNCH(attn_mfma4_bf16_kernel<false>, dim3(L / 64, B * H), dim3(256), (size_t)S * 16 + 4 * 64 * 6 * sizeof(float), st, p);
+        return smx_launch_status();
+      }
+    }
     if (smx_tune(SMX_TUNE_ATTN4_MFMA) && S % 64 == 0) {
       if (key_mask) SMX_LAUNCH((attn_mfma4_kernel<T, true>), dim3(L / 64, B * H), dim3(256), (size_t)S * 36 + 4 * 64 * 6 * sizeof(float), st, p);
       else SMX_LAUNCH((attn_mfma4_kernel<T, false>), dim3(L / 64, B * H), dim3(256), (size_t)S * 32 + 4 * 64 * 6 * sizeof(float), st, p);

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(WG p) {
 //   layout 0: OIHW parameter  out[co][ci][ky][kx]           (k = (ky*kw + kx)*Cin + ci)
 //   layout 1: row-major       out[g][co * ldo + k]          (Linear [out][in]; patch-embedding Linear [out][(p1 p2 c)]; batched GEMM C)
 //   layout 2: transposed      out[g][k * ldo + co]
-template <int VEC>
+template <int VEC, int NG = 8>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long out_bs,
                                                            int nb, int msplit, int Cout, int K, int Cin, int khw, int layout, int ldo,
                                                            int accumulate, float alpha, const float* __restrict__ bias_ws, float* __restrict__ bias_out) {
@@ -297,9 +297,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   // ~100 partial tiles) interleaved, finished through LDS in a FIXED order.  (One thread per element walking all splits alone left a
   // 36,864-element layer on 144 blocks: 21 us per launch; 4-byte loads of 128-B rows: 19 us.)  VEC = 1: the scalar form for layers whose
   // element count per group is not a multiple of 4.
-  __shared__ float red[8][32 * VEC];
-  const int l = threadIdx.x & 31, q = threadIdx.x >> 5;
-  for (long long base = blockIdx.x * (32LL * VEC); base < total; base += (long long)gridDim.x * (32 * VEC)) {
+  // NG = 32: 8 lanes x float4 = one 128-B line per partial row and 32 groups over the splits -- the region weight gradient leaves up to 256
+  // partials of a 36,864-element layer: four times the blocks, a quarter of the dependent loads per thread.
+  constexpr int LG = 256 / NG;
+  __shared__ float red[NG][LG * VEC];
+  const int l = threadIdx.x % LG, q = threadIdx.x / LG;
+  for (long long base = blockIdx.x * ((long long)LG * VEC); base < total; base += (long long)gridDim.x * (LG * VEC)) {
     const long long i = base + (long long)l * VEC;                // VEC == 4: per % 4 == 0, so the 4 elements share g and are contiguous
     float s[VEC];
 #pragma unroll
@@ -310,18 +313,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       const float* w = ws + (long long)g * msplit * per + j;
       int zz = q;
       if (VEC == 4) {                        // four partial rows in flight per lane (the region kernel's splits run to 512: one dependent
-        for (; zz + 24 < msplit; zz += 32) { // HBM round trip per split was most of this kernel); the order of the additions is unchanged
+        for (; zz + 3 * NG < msplit; zz += 4 * NG) { // HBM round trip per split was most of this kernel); the order of the additions is unchanged
           const float4 v0 = *reinterpret_cast<const float4*>(w + (long long)zz * per);
-          const float4 v1 = *reinterpret_cast<const float4*>(w + (long long)(zz + 8) * per);
-          const float4 v2 = *reinterpret_cast<const float4*>(w + (long long)(zz + 16) * per);
-          const float4 v3 = *reinterpret_cast<const float4*>(w + (long long)(zz + 24) * per);
+          const float4 v1 = *reinterpret_cast<const float4*>(w + (long long)(zz + NG) * per);
+          const float4 v2 = *reinterpret_cast<const float4*>(w + (long long)(zz + 2 * NG) * per);
+          const float4 v3 = *reinterpret_cast<const float4*>(w + (long long)(zz + 3 * NG) * per);
           s[0] += v0.x; s[VEC > 1 ? 1 : 0] += v0.y; s[VEC > 2 ? 2 : 0] += v0.z; s[VEC > 3 ? 3 : 0] += v0.w;
           s[0] += v1.x; s[VEC > 1 ? 1 : 0] += v1.y; s[VEC > 2 ? 2 : 0] += v1.z; s[VEC > 3 ? 3 : 0] += v1.w;
           s[0] += v2.x; s[VEC > 1 ? 1 : 0] += v2.y; s[VEC > 2 ? 2 : 0] += v2.z; s[VEC > 3 ? 3 : 0] += v2.w;
           s[0] += v3.x; s[VEC > 1 ? 1 : 0] += v3.y; s[VEC > 2 ? 2 : 0] += v3.z; s[VEC > 3 ? 3 : 0] += v3.w;
         }
       }
-      for (; zz < msplit; zz += 8) {
+      for (; zz < msplit; zz += NG) {
         if (VEC == 4) {
           const float4 v = *reinterpret_cast<const float4*>(w + (long long)zz * per);
           s[0] += v.x; s[VEC > 1 ? 1 : 0] += v.y; s[VEC > 2 ? 2 : 0] += v.z; s[VEC > 3 ? 3 : 0] += v.w;
@@ -337,7 +340,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const int c = l * VEC + e;
-        float t = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+        float t = 0.f;
+#pragma unroll
+        for (int o8 = 0; o8 < NG; o8 += 8)
+          t += ((red[o8][c] + red[o8 + 1][c]) + (red[o8 + 2][c] + red[o8 + 3][c])) + ((red[o8 + 4][c] + red[o8 + 5][c]) + (red[o8 + 6][c] + red[o8 + 7][c]));
         t *= alpha;
         const long long je = j + e;
         const int co = (int)(je / K), k = (int)(je - (long long)co * K);
@@ -587,7 +593,10 @@ static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, cons
   } else if (bf16) SMX_LAUNCH((wgrad_kernel<true, 64, 64>), grid, dim3(256), 0, st, p);
   else SMX_LAUNCH((wgrad_kernel<false, 64, 64>), grid, dim3(256), 0, st, p);
   const long long per_g = (long long)Cout * p.K;
-  if (per_g % 4 == 0 && (((uintptr_t)ws) & 15) == 0)
+  if (per_g % 4 == 0 && (((uintptr_t)ws) & 15) == 0 && msplit >= 64 && (long long)nb * per_g <= (1LL << 19))
+    SMX_LAUNCH((wgrad_reduce_kernel<4, 32>), dim3(grid_for((long long)nb * per_g * 8)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
+               Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha, p.bias_ws, bias_out);
+  else if (per_g % 4 == 0 && (((uintptr_t)ws) & 15) == 0)
     SMX_LAUNCH(wgrad_reduce_kernel<4>, dim3(grid_for((long long)nb * per_g * 2)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
                Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha, p.bias_ws, bias_out);
   else

@@ -18,7 +18,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"attn16", "SMX_ATTN16", 1},                  // bf16 storage, d_head 32: bf16 MFMA kernel (0 = fp32 MFMA kernel on bf16 storage)
   {"wino_wide", "SMX_WINO_WIDE", 1},            // Winograd big launches: 1 = 4-wave "wide" blocks, 64 n per wave (default), 0 = 8-wave blocks, 5 = wide at one block per CU (tools)
   {"wino_nt", "SMX_WINO_NT", 0},                // wide Winograd epilogue: non-temporal residual loads / output stores
-  {"attn4_mfma", "SMX_ATTN4_MFMA", 1},          // d_head 4 attention: 1 = 4x4x1 (16-block) MFMA kernel, 0 = VALU kernel
+  {"attn4_mfma", "SMX_ATTN4_MFMA", 1},          // d_head 4 attention: 1 = MFMA kernels (fp32 storage: 4x4x1 f32; bf16 storage: 4x4x4 bf16), 2 = the 4x4x1 f32 kernel on either storage, 0 = VALU kernel
   {"conv16_slab", "SMX_CONV16_SLAB", 1},        // bf16 region conv, 16x16 tiles: 1 = 32-channel slices with all nine taps' weights in LDS, 0 = one weight tile per tap
   {"attn_bwd_mfma", "SMX_ATTN_BWD_MFMA", 1},    // training, d_head 32 attention backward: 1 = fp32 MFMA kernels, 0 = the per-thread VALU kernels
   {"vq_split", "SMX_VQ_SPLIT", 1},              // VQ, few tokens (< half a chip of 128-token blocks): codebook sweep split over blockIdx.y + a combine kernel

@@ -333,11 +333,53 @@ def test_elementwise_bf16_variants(ops):
 def test_attention_bf16_storage(ops):
     """bf16 storage on the fp32-MFMA attention kernels (d_head 4 always; d_head 32 with the bf16-MFMA kernel switched off):
     the stored result is the correctly rounded fp32 result."""
-    old = ops.set_tuning("attn16", 0)
+    old, old4 = ops.set_tuning("attn16", 0), ops.set_tuning("attn4_mfma", 2)
     try:
         _attention_bf16_storage(ops)
     finally:
         ops.set_tuning("attn16", old)
+        ops.set_tuning("attn4_mfma", old4)
+
+
+def test_attention_d4_bf16_mfma_kernel(ops):
+    """d_head 4 on v_mfma_f32_4x4x4_16B_bf16 (attn_mfma4_bf16_kernel: stored bf16 operands straight into the matrix instruction, P rounded
+    to bf16 before the PV product): against the fp32 4x4x1 kernel on the same bf16-rounded q / k / v, same error model as the d_head 32
+    bf16 kernel (|err| <= 2^-9 max|v| + the output rounding); masked keys, a key count the 32-key step does not divide (falls back to the
+    fp32 form: identical result), fully masked rows NaN."""
+    B, H, N, dh = 2, 8, 1024, 4
+    E = H * dh
+    assert ops.set_tuning("attn4_mfma", 1) == 1
+    for S, shared in ((1024, False), (512, True), (256, True), (768, True), (320, True)):
+        q = r16(rnd(f"d4q{S}", (B, N, E)) * 2.0).cuda()
+        kv = r16(rnd(f"d4k{S}", ((1 if shared else B), S, 2 * E)) * 2.0).cuda()
+        mask = None
+        if not shared:
+            mask = torch.zeros((B, S), dtype=torch.uint8)
+            mask[1, ::5] = 1
+            mask[0, 100:200] = 1
+            mask = mask.cuda()
+        k32, v32 = (kv[..., :E], kv[..., E:]) if not shared else (kv[0, :, :E], kv[0, :, E:])
+        ref = ops.attention(q, k32, v32, H, dh, S, k_shared=shared, mask=mask)
+        kv16 = kv.to(BF)
+        k16, v16 = (kv16[..., :E], kv16[..., E:]) if not shared else (kv16[0, :, :E], kv16[0, :, E:])
+        got = ops.attention(q.to(BF), k16, v16, H, dh, S, k_shared=shared, mask=mask)
+        assert got.dtype == BF
+        vmax = float(kv[..., E:].abs().max())
+        err = float((got.float() - ref).abs().max())
+        assert err <= (2.0 ** -9 + 2.0 ** -8) * vmax, (S, shared, err, vmax)
+        assert float((got.float() - ref).abs().mean()) < 1e-3 * vmax
+        old = ops.set_tuning("attn4_mfma", 2)
+        try:
+            f32form = ops.attention(q.to(BF), k16, v16, H, dh, S, k_shared=shared, mask=mask)
+        finally:
+            ops.set_tuning("attn4_mfma", old)
+        assert torch.equal(f32form, got) == (S % 128 != 0), S      # the bf16-MFMA form really ran where it applies (and only there)
+    mask = torch.zeros((B, 1024), dtype=torch.uint8)
+    mask[1] = 1
+    q = r16(rnd("d4qn", (B, N, E))).cuda().to(BF)
+    kv = r16(rnd("d4kn", (B, 1024, 2 * E))).cuda().to(BF)
+    o = ops.attention(q, kv[..., :E], kv[..., E:], H, dh, 1024, mask=mask.cuda())
+    assert bool(torch.isnan(o[1].float()).all()) and bool(torch.isfinite(o[0].float()).all())
 
 
 def test_attention_bf16_mfma_kernel(ops):

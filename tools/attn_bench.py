@@ -26,7 +26,7 @@ def timed(fn, n=10):
 
 
 H, N = 8, 1024
-for dh, E in ((4, 32), (32, 256)):
+for dh, E in (((4, 32), (32, 256)) if __name__ == "__main__" else ()):
     for S, shared, masked in ((1024, False, True), (1024, False, False), (256, True, False), (512, True, False), (768, True, False), (1024, True, False)):
         q = torch.randn((B, N, E), device="cuda")
         kv = torch.randn(((1 if shared else B), 1024, 2 * E), device="cuda")
