@@ -364,8 +364,8 @@ def train_roofline(step, src, drv, gan, compute_dtype, dt):
     d = fam[dom]
     peak = PEAK_BF16_MFMA_TFLOPS if d["bf16"] else PEAK_F32_MFMA_TFLOPS
     tf = d["mfma_flops"] / (d["ms"] * 1e-3) / 1e12
-    return {"kernel": {"wgrad": "wgrad_kernel<false,64,64> (weight gradient: TN GEMM over the pixels, v_mfma_f32_32x32x2_f32)",
-                       "wgrad_bf16": "wgrad_kernel<true,64,64> (weight gradient, operands rounded to bf16, v_mfma_f32_32x32x16_bf16)",
+    return {"kernel": {"wgrad": "wgrad_region_kernel<false> (3x3/s1 layers with 64-multiple channels: nine taps per block, strip walk, LDS-DMA) / wgrad_kernel<false,64,64> (the rest): weight gradient as a TN GEMM over the pixels, v_mfma_f32_32x32x2_f32",
+                       "wgrad_bf16": "wgrad_region_kernel<true> / wgrad_kernel<true,64,64> (weight gradient, operands rounded to bf16, v_mfma_f32_32x32x16_bf16)",
                        "winograd": "winograd_kernel / winograd_wide_kernel (forward and data gradient of the 3x3 convolutions, F(2x2,3x3), v_mfma_f32_32x32x2_f32)",
                        "gemm_conv": "gemm_conv_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)",
                        "gemm_bf16": "gemm_bf16_kernel (implicit GEMM forward / data gradient, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom),

@@ -351,6 +351,12 @@ int smx_conv3x3_sft_bf16_t32(const void* x, int lda, const void* wp, const float
 int smx_conv3x3_sft_bf16(const void* x, int lda, const void* w, int ldw, const float* bias, const void* dec, int lddec,
                          const void* scale, int ldscale, float sft_w, void* y, int ldc, int B, int H, int W, int Cin, int Cout,
                          int tile_h, void* stream);
+/* the same region-direct kernel on fp32 STORAGE (x, res, y fp32; w the bf16 [Cout][9*Cin] pack): inputs rounded to bf16 (RNE) while
+ * staged, fp32 accumulate and output -- torch.autocast(bfloat16)'s arithmetic for F.conv2d; the forward and data gradient of the
+ * 3x3 / stride 1 / pad 1 convolutions in the bf16-compute training mode (BASELINE configs[4]).  Cin % 64 == 0, H % tile_h == 0
+ * (tile_h 8 | 16), W % 16 == 0; no fused GroupNorm loader / statistics in this form. */
+int smx_conv3x3_mfma16_f32(const float* x, int lda, const void* w, int ldw, const float* bias, const float* res, int ldres,
+                           float* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, int tile_h, void* stream);
 int smx_groupnorm_swish_nhwc_bf16(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int B, int HW,
                                   int C, int groups, float eps, int swish, float* ws, void* stream);
 int smx_groupnorm_stats_bf16(const void* x, int ldx, const float* gamma, const float* beta, float* ss, int B, int HW, int C,
@@ -412,6 +418,19 @@ int smx_wgrad_mfma16_f32(const float* dy, int ldy, int64_t dy_bs, const float* x
                          float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
                          float* bias_out, void* stream);
 /* out[c] (+)= alpha * sum_p x[p*ld + c]  (bias gradients); ws: smx_colsum_ws_floats(P, C) floats; two fixed-order stages */
+/* DEFERRED split reduce.  `accumulate | 2` in smx_wgrad_f32 / smx_wgrad_mfma16_f32 (nb == 1) leaves the raw partials in `ws` and skips
+ * the reduce launch; smx_wgrad_reduce_describe fills the item the skipped launch would have been (host side, no launch; `first_block`
+ * is the caller's: the running sum of `nblocks` in table order), and ONE smx_wgrad_reduce_batch launch over a device table of such
+ * items finishes all of them (bit-identical to the per-layer launches).  Items of one launch must have distinct outputs.  The
+ * workspaces must stay untouched between the weight-gradient launch and the batch. */
+typedef struct smx_reduce_item {
+  const float* ws; float* out; const float* bias_ws; float* bias_out;
+  int32_t msplit, Cout, K, Cin, khw, layout, ldo, accumulate;
+  float alpha; int32_t kind, first_block, nblocks;
+} smx_reduce_item;
+int smx_wgrad_reduce_describe(const float* ws, int msplit, float* out, int Cout, int Cin, int kh, int kw, int layout, int ldo,
+                              int accumulate, float alpha, float* bias_out, smx_reduce_item* item);
+int smx_wgrad_reduce_batch(const smx_reduce_item* items_dev, int n_items, int n_blocks, void* stream);
 int64_t smx_colsum_ws_floats(int64_t P, int C);
 int smx_colsum_f32(const float* x, int ld, int64_t P, int C, float* ws, float* out, int accumulate, float alpha, void* stream);
 int smx_partial_reduce_f32(const float* part, int nchunk, int C, float* out, int accumulate, float alpha, void* stream);

@@ -65,7 +65,10 @@ __device__ __forceinline__ float c_act(float v, int act) {
 // tap-streaming form (one [64 n][64 k] weight tile, one barrier, one store/load phase per tap = per 16 MFMAs) read: compute
 // 1.25k cycles, weight store / next request / barrier 1.05k, loop overhead 0.35k per step -- the matrix pipe idled through more
 // than half of every step, and neither deeper weight prefetch, nor skipping the barriers, nor pipelining the LDS reads moved it.
-template <int TH, bool SLAB = false>
+// F32: fp32 STORAGE on both sides (the bf16-compute training mode, `smx_conv3x3_mfma16_f32`): the region is read as fp32 and rounded to
+// bf16 (RNE) on its way into LDS, the output (and the residual) are fp32 -- torch.autocast(bfloat16)'s arithmetic for F.conv2d on fp32
+// tensors; no fused GroupNorm loader / statistics in this form.
+template <int TH, bool SLAB = false, bool F32 = false>
 __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p) {
   constexpr int RPX = Geo<TH>::RPX, TI = TH / 8;                                 // TI: 32-pixel A fragments per wave
   constexpr int CSL = SLAB ? 32 : CS;                                            // channels per staged slice
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   const int by = logical % p.tiles_y; const int img = logical / p.tiles_y;
   const int n0 = blockIdx.y * BN;
   const int Hs = p.up2 ? p.H >> 1 : p.H, Ws_ = p.up2 ? p.W >> 1 : p.W;
-  const bf16_t* __restrict__ X = p.x + (long long)img * Hs * Ws_ * p.lda;
+  const bf16_t* __restrict__ X = p.x + (F32 ? 0LL : (long long)img * Hs * Ws_ * p.lda);
+  const float* __restrict__ Xf = reinterpret_cast<const float*>(p.x) + (F32 ? (long long)img * Hs * Ws_ * p.lda : 0LL);
 
   // ---- region staging: RPX * 8 chunks of 16 B per slice, 256 threads -> 11 chunks per thread (the last partially) -----
   constexpr int NCH = (RPX * CPP + NT - 1) / NT;
@@ -119,7 +123,13 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
     for (int k = 0; k < NCH; ++k) {
       int g; const bool ok = chunk_ok(k, g);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *reinterpret_cast<const uint4*>(X + g + c0);
+      if (F32) {
+        if (ok) {
+          const float4 a = *reinterpret_cast<const float4*>(Xf + g + c0), b = *reinterpret_cast<const float4*>(Xf + g + c0 + 4);
+          const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          v = pack8(f);
+        }
+      } else if (ok) v = *reinterpret_cast<const uint4*>(X + g + c0);
       rreg[k] = v;
     }
   };
@@ -307,14 +317,15 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   const int cq = tid & 7;                                                // this thread's 8-channel chunk (same for all its pixels)
   const int nc = n0 + cq * 8;
   const bool full = nc + 7 < p.Cout;
-  const bool al = (p.ldc % 8 == 0) && ((((uintptr_t)p.y) & 15) == 0) &&
+  const bool al = (p.ldc % (F32 ? 4 : 8) == 0) && ((((uintptr_t)p.y) & 15) == 0) &&
                   (!p.res || (p.res_f32 ? ((p.ldres % 4 == 0) && ((((uintptr_t)p.res) & 15) == 0)) : ((p.ldres % 8 == 0) && ((((uintptr_t)p.res) & 15) == 0))));
   // per-image bases (64-bit once, wave-uniform); per-value offsets are 32-bit (H*W*ld < 2^31, launcher check)
   const long long ipix = (long long)img * p.H * p.W;
   const bf16_t* __restrict__ R16 = reinterpret_cast<const bf16_t*>(p.res) + ipix * p.ldres;
   const float* __restrict__ R32 = reinterpret_cast<const float*>(p.res) + ipix * p.ldres;
   const bf16_t* __restrict__ M16 = p.mul + ipix * p.ldmul;
-  bf16_t* __restrict__ Y16 = p.y + ipix * p.ldc;
+  bf16_t* __restrict__ Y16 = p.y + (F32 ? 0LL : ipix * p.ldc);
+  float* __restrict__ Y32 = reinterpret_cast<float*>(p.y) + (F32 ? ipix * p.ldc : 0LL);
   constexpr int NPASS = TH * TW / 32;                                    // pixels of the tile, 32 per pass
   // a bf16 residual is requested for ALL passes before the accumulators go through LDS: one HBM round trip overlapped with the
   // exchange instead of NPASS of them in sequence behind it
@@ -385,14 +396,20 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
               for (int e = 0; e < 8; ++e) v[e] += q[e];
             }
           }
-          const uint4 pk = pack8(v);
-          *reinterpret_cast<uint4*>(Y16 + opix * p.ldc + nc) = pk;
-          if (p.stats) unpack8(pk, v);                                   // statistics of the values as STORED (bf16-rounded)
+          if (F32) {
+            *reinterpret_cast<float4*>(Y32 + opix * p.ldc + nc) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(Y32 + opix * p.ldc + nc + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            const uint4 pk = pack8(v);
+            *reinterpret_cast<uint4*>(Y16 + opix * p.ldc + nc) = pk;
+            if (p.stats) unpack8(pk, v);                                 // statistics of the values as STORED (bf16-rounded)
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             if (nc + e >= p.Cout) { v[e] = 0.f; continue; }
             if (p.res) v[e] += p.res_f32 ? R32[opix * p.ldres + nc + e] : bf2f(R16[opix * p.ldres + nc + e]);
+            if (F32) { Y32[opix * p.ldc + nc + e] = v[e]; continue; }
             const bf16_t h = f2bf(v[e]);
             Y16[opix * p.ldc + nc + e] = h;
             v[e] = bf2f(h);
@@ -442,12 +459,13 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
 
 static int conv3x3_bf16_launch(const void* x, int lda, const void* w, int ldw, const float* bias, const void* res, int res_f32,
                                int ldres, const void* mul, int ldmul, float sft_w, void* y, int ldc, int B, int H, int W, int Cin, int Cout,
-                               int up2, int act, const float* in_ss, int in_swish, float* stats_part, int tile_h, void* stream) {
+                               int up2, int act, const float* in_ss, int in_swish, float* stats_part, int tile_h, void* stream, bool f32io = false) {
+  if (f32io && (in_ss || stats_part || mul || (res && !res_f32) || lda % 4 != 0)) return SMX_EINVAL;
   if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (tile_h != 8 && tile_h != 16)) return SMX_EINVAL;
   if (mul && (!res || res_f32 || Cout % 8 || ldc % 8 || ldres % 8 || ldmul % 8 || ldmul < Cout || act != SMX_ACT_NONE ||
               ((((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)mul)) & 15))) return SMX_EINVAL;
   const int TH = tile_h;
-  if (H % TH != 0 || W % TW != 0 || Cin % CS != 0 || lda % 8 != 0 || lda < Cin || ldc < Cout || ldw < 9 * Cin || ldw % 8 != 0) return SMX_EINVAL;
+  if (H % TH != 0 || W % TW != 0 || Cin % CS != 0 || (!f32io && lda % 8 != 0) || lda < Cin || ldc < Cout || ldw < 9 * Cin || ldw % 8 != 0) return SMX_EINVAL;
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (in_ss && ((uintptr_t)in_ss & 15)) || (res && ldres < Cout)) return SMX_EINVAL;
   if (up2 && ((H & 1) || (W & 1))) return SMX_EINVAL;
   CP p;
@@ -465,6 +483,13 @@ static int conv3x3_bf16_launch(const void* x, int lda, const void* w, int ldw, c
   p.ntiles = (int)blocks; p.tpb = 1;
   dim3 grid((unsigned)blocks, (Cout + BN - 1) / BN);
   constexpr int SLAB_LDS = Geo<16>::RPX * 80 + 9 * BN * 80;            // 72,000 B (>= the 69,632 B epilogue exchange)
+  if (f32io) {
+    static bool attr3 = false;
+    if (!attr3) { SMX_HIP(hipFuncSetAttribute((const void*)(conv3x3_bf16_kernel<16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS)); attr3 = true; }
+    if (TH == 16) SMX_LAUNCH((conv3x3_bf16_kernel<16, true, true>), grid, dim3(NT), SLAB_LDS, (hipStream_t)stream, p);
+    else SMX_LAUNCH((conv3x3_bf16_kernel<8, false, true>), grid, dim3(NT), Geo<8>::LDS_B, (hipStream_t)stream, p);
+    return smx_launch_status();
+  }
   if (TH == 16 && Cin % 32 == 0 && smx_tune(SMX_TUNE_CONV16_SLAB)) {
     static bool attr2 = false;
     if (!attr2) { SMX_HIP(hipFuncSetAttribute((const void*)(conv3x3_bf16_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS)); attr2 = true; }
@@ -488,4 +513,12 @@ extern "C" int smx_conv3x3_sft_bf16(const void* x, int lda, const void* w, int l
   if (!dec || !scale) return SMX_EINVAL;
   return conv3x3_bf16_launch(x, lda, w, ldw, bias, dec, 0, lddec, scale, ldscale, sft_w, y, ldc, B, H, W, Cin, Cout, 0, SMX_ACT_NONE, nullptr, 0,
                              nullptr, tile_h, stream);
+}
+
+/* fp32 storage, bf16 MFMA: the region-direct kernel for the bf16-COMPUTE training mode (forward and data gradient of the 3x3 / s1 / p1
+ * convolutions on fp32 activations: inputs rounded to bf16 while staged, fp32 accumulate, fp32 output / residual). */
+extern "C" int smx_conv3x3_mfma16_f32(const float* x, int lda, const void* w, int ldw, const float* bias, const float* res, int ldres,
+                                      float* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, int tile_h, void* stream) {
+  return conv3x3_bf16_launch(x, lda, w, ldw, bias, res, 1, ldres, nullptr, 0, 0.f, y, ldc, B, H, W, Cin, Cout, up2, act, nullptr, 0, nullptr, tile_h,
+                             stream, true);
 }

@@ -278,14 +278,15 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(WG p) {
 //   layout 0: OIHW parameter  out[co][ci][ky][kx]           (k = (ky*kw + kx)*Cin + ci)
 //   layout 1: row-major       out[g][co * ldo + k]          (Linear [out][in]; patch-embedding Linear [out][(p1 p2 c)]; batched GEMM C)
 //   layout 2: transposed      out[g][k * ldo + co]
-template <int VEC, int NG = 8>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long out_bs,
-                                                           int nb, int msplit, int Cout, int K, int Cin, int khw, int layout, int ldo,
-                                                           int accumulate, float alpha, const float* __restrict__ bias_ws, float* __restrict__ bias_out) {
+template <int VEC, int NG>
+__device__ __forceinline__ void wgrad_reduce_body(float* __restrict__ red_raw, const int bid, const int nblk,
+                                                  const float* __restrict__ ws, float* __restrict__ out, long long out_bs,
+                                                  int nb, int msplit, int Cout, int K, int Cin, int khw, int layout, int ldo,
+                                                  int accumulate, float alpha, const float* __restrict__ bias_ws, float* __restrict__ bias_out) {
   const long long per = (long long)Cout * K, total = per * nb;
   // the bias gradient rides in the same launch (it was a third launch of ~10 us per layer, 450 per step): the LAST block also sums
   // the nb * msplit column-sum partials per channel, in a fixed order
-  if (bias_out && blockIdx.x == gridDim.x - 1) {
+  if (bias_out && bid == nblk - 1) {
     for (int c = threadIdx.x; c < Cout; c += 256) {
       float t = 0.f;
       for (int k = 0; k < nb * msplit; ++k) t += bias_ws[(long long)k * Cout + c];
@@ -300,9 +301,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   // NG = 32: 8 lanes x float4 = one 128-B line per partial row and 32 groups over the splits -- the region weight gradient leaves up to 256
   // partials of a 36,864-element layer: four times the blocks, a quarter of the dependent loads per thread.
   constexpr int LG = 256 / NG;
-  __shared__ float red[NG][LG * VEC];
+  float (*red)[LG * VEC] = reinterpret_cast<float (*)[LG * VEC]>(red_raw);       // [NG][LG * VEC] <= 1024 floats
   const int l = threadIdx.x % LG, q = threadIdx.x / LG;
-  for (long long base = blockIdx.x * ((long long)LG * VEC); base < total; base += (long long)gridDim.x * (LG * VEC)) {
+  for (long long base = bid * ((long long)LG * VEC); base < total; base += (long long)nblk * (LG * VEC)) {
     const long long i = base + (long long)l * VEC;                // VEC == 4: per % 4 == 0, so the 4 elements share g and are contiguous
     float s[VEC];
 #pragma unroll
@@ -357,6 +358,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     __syncthreads();
   }
+}
+
+template <int VEC, int NG = 8>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long out_bs,
+                                                           int nb, int msplit, int Cout, int K, int Cin, int khw, int layout, int ldo,
+                                                           int accumulate, float alpha, const float* __restrict__ bias_ws, float* __restrict__ bias_out) {
+  __shared__ float red[1024];
+  wgrad_reduce_body<VEC, NG>(red, (int)blockIdx.x, (int)gridDim.x, ws, out, out_bs, nb, msplit, Cout, K, Cin, khw, layout, ldo, accumulate, alpha, bias_ws, bias_out);
+}
+
+// Every split reduce of a backward pass in ONE launch (smx_wgrad_reduce_batch): a device table of items sorted by first_block; block b
+// finishes the item whose block range holds it exactly as the per-layer launch would have (same block count, same order of additions:
+// bit-identical results).  The per-layer reduces were ~460 launches of 5-50 us per training step (7.7 ms), most of it launch latency
+// and tails.  Items of one launch must not share an output (the host plan puts a parameter's second call site into the next launch).
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const smx_reduce_item* __restrict__ items, int n) {
+  __shared__ float red[1024];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const smx_reduce_item it = items[lo];
+  const int bid = (int)blockIdx.x - it.first_block;
+  if (bid >= it.nblocks) return;
+  if (it.kind == 2) wgrad_reduce_body<4, 32>(red, bid, it.nblocks, it.ws, it.out, 0, 1, it.msplit, it.Cout, it.K, it.Cin, it.khw, it.layout, it.ldo, it.accumulate, it.alpha, it.bias_ws, it.bias_out);
+  else if (it.kind == 1) wgrad_reduce_body<4, 8>(red, bid, it.nblocks, it.ws, it.out, 0, 1, it.msplit, it.Cout, it.K, it.Cin, it.khw, it.layout, it.ldo, it.accumulate, it.alpha, it.bias_ws, it.bias_out);
+  else wgrad_reduce_body<1, 8>(red, bid, it.nblocks, it.ws, it.out, 0, 1, it.msplit, it.Cout, it.K, it.Cin, it.khw, it.layout, it.ldo, it.accumulate, it.alpha, it.bias_ws, it.bias_out);
 }
 
 // ---- column sums: part[chunk][C] = sum over the chunk's rows; then out[c] (+)= sum_chunk part[chunk][c] (fixed order) ----
@@ -560,6 +585,14 @@ extern "C" int64_t smx_wgrad_conv_ws_floats(int nb, int M, int Cout, int Cin, in
   return smx_wgrad_ws_floats(nb, M, Cout, kh * kw * Cin, msplit_out);
 }
 
+// which reduce form a (workspace, split, size) gets and on how many blocks: shared by the per-layer launch and smx_wgrad_reduce_describe
+static int reduce_kind(const float* ws, int nb, int msplit, long long per_g, int* nblk) {
+  if (per_g % 4 == 0 && (((uintptr_t)ws) & 15) == 0 && msplit >= 64 && (long long)nb * per_g <= (1LL << 19)) { *nblk = grid_for((long long)nb * per_g * 8); return 2; }
+  if (per_g % 4 == 0 && (((uintptr_t)ws) & 15) == 0) { *nblk = grid_for((long long)nb * per_g * 2); return 1; }
+  *nblk = grid_for((long long)nb * per_g * 8);
+  return 0;
+}
+
 static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, const float* x, int ldx, int64_t x_bs, int nb, int M, int Cout,
                         int Hin, int Win, int Cin, int Ho, int Wo, int kh, int kw, int stride, int pad_t, int pad_l, int up2,
                         float* ws, int msplit, float* out, int64_t out_bs, int layout, int ldo, int accumulate, float alpha,
@@ -592,16 +625,37 @@ static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, cons
     if (rc != SMX_OK) return rc;
   } else if (bf16) SMX_LAUNCH((wgrad_kernel<true, 64, 64>), grid, dim3(256), 0, st, p);
   else SMX_LAUNCH((wgrad_kernel<false, 64, 64>), grid, dim3(256), 0, st, p);
+  if (accumulate & 2) return nb == 1 ? smx_launch_status() : SMX_EINVAL;      // deferred: the partials stay in ws for smx_wgrad_reduce_batch
   const long long per_g = (long long)Cout * p.K;
-  if (per_g % 4 == 0 && (((uintptr_t)ws) & 15) == 0 && msplit >= 64 && (long long)nb * per_g <= (1LL << 19))
-    SMX_LAUNCH((wgrad_reduce_kernel<4, 32>), dim3(grid_for((long long)nb * per_g * 8)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
+  int nblk = 0;
+  const int kind = reduce_kind(ws, nb, msplit, per_g, &nblk);
+  if (kind == 2)
+    SMX_LAUNCH((wgrad_reduce_kernel<4, 32>), dim3(nblk), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
                Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha, p.bias_ws, bias_out);
-  else if (per_g % 4 == 0 && (((uintptr_t)ws) & 15) == 0)
-    SMX_LAUNCH(wgrad_reduce_kernel<4>, dim3(grid_for((long long)nb * per_g * 2)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
+  else if (kind == 1)
+    SMX_LAUNCH(wgrad_reduce_kernel<4>, dim3(nblk), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
                Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha, p.bias_ws, bias_out);
   else
-    SMX_LAUNCH(wgrad_reduce_kernel<1>, dim3(grid_for((long long)nb * per_g * 8)), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
+    SMX_LAUNCH(wgrad_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, ws, out, (long long)out_bs, nb, msplit,
                Cout, p.K, Cin, kh * kw, layout, ldo, accumulate, alpha, p.bias_ws, bias_out);
+  return smx_launch_status();
+}
+
+extern "C" int smx_wgrad_reduce_describe(const float* ws, int msplit, float* out, int Cout, int Cin, int kh, int kw, int layout, int ldo,
+                                         int accumulate, float alpha, float* bias_out, smx_reduce_item* item) {
+  if (!ws || !out || !item || msplit < 1 || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || layout < 0 || layout > 2) return SMX_EINVAL;
+  const int K = kh * kw * Cin;
+  item->ws = ws; item->out = out; item->bias_out = bias_out;
+  item->bias_ws = bias_out ? ws + (long long)msplit * Cout * K : nullptr;
+  item->msplit = msplit; item->Cout = Cout; item->K = K; item->Cin = Cin; item->khw = kh * kw; item->layout = layout; item->ldo = ldo;
+  item->accumulate = accumulate & 1; item->alpha = alpha; item->first_block = 0;
+  item->kind = reduce_kind(ws, 1, msplit, (long long)Cout * K, &item->nblocks);
+  return SMX_OK;
+}
+
+extern "C" int smx_wgrad_reduce_batch(const smx_reduce_item* items_dev, int n_items, int n_blocks, void* stream) {
+  if (!items_dev || n_items <= 0 || n_blocks <= 0) return SMX_EINVAL;
+  SMX_LAUNCH(wgrad_reduce_batch_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
   return smx_launch_status();
 }
 

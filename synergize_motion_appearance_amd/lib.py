@@ -108,6 +108,7 @@ SIGNATURES = {
     "smx_to_uint8_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
     "smx_conv3x3_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     "smx_conv3x3_sft_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_conv3x3_mfma16_f32": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i] + [_i] * 8 + [_p]),
     "smx_groupnorm_swish_nhwc_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
     "smx_groupnorm_stats_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
     "smx_groupnorm_apply_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -128,6 +129,8 @@ SIGNATURES = {
     "smx_vq_nearest_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     # ---- training step ----
     "smx_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, C.POINTER(_i)]),
+    "smx_wgrad_reduce_describe": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "smx_wgrad_reduce_batch": (_i, [_p, _i, _i, _p]),
     "smx_wgrad_conv_ws_floats": (_i64, [_i] * 14 + [C.POINTER(_i)]),
     "smx_wgrad_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p, _p]),
     "smx_wgrad_mfma16_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _f, _p, _p]),

@@ -214,6 +214,9 @@ REGION3X3 = not _os.environ.get("SMX_NO_REGION3X3")
 CONV16_TILE_H = int(_os.environ.get("SMX_CONV16_TILE_H", "0"))      # 0 = auto, 8 | 16 = forced (tools / tests)
 
 
+CONV16_F32_REGION = int(_os.environ.get("SMX_CONV16_F32_REGION", "1"))   # fp32-storage form of the region kernel (bf16-compute training); 0 = implicit GEMM
+
+
 CONV16_T32 = int(_os.environ.get("SMX_CONV16_T32", "1"))           # 16x32-tile kernel (csrc/conv3x3_bf16_t32.hip) for the big launches; 0 = off
 CONV16_T32_MIN_BLOCKS = 1024                                         # two resident rounds of the chip's 512 block slots; tests lower it
 
@@ -281,6 +284,18 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
                        None if part is None else part.data_ptr(), th, _stream()), "smx_conv3x3_bf16")
         if part is not None:
             out._gn_part = part
+        return out
+    if (REGION3X3 and CONV16_F32_REGION and tile == 0 and x.dtype == torch.float32 and out.dtype == torch.float32 and cv.kh == 3 and cv.kw == 3
+            and stride == 1 and (pt, pl) == (1, 1) and not d2s and in_ss is None and not want_stats and (res is None or res.dtype == torch.float32)
+            and Cin % 64 == 0 and Ho % 8 == 0 and Wo % 16 == 0 and (Ho, Wo) == ((2 * H, 2 * W) if up2 else (H, W)) and lda % 4 == 0
+            and a_ptr % 16 == 0 and cv.w16.data_ptr() % 16 == 0):
+        # bf16-compute training mode (fp32 storage): the region-direct kernel instead of the implicit GEMM (9 shifted copies through LDS)
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1,
+                "bytes": 4.0 * B * Ho * Wo * (Cin / (4.0 if up2 else 1.0) + cv.cout * (2 if res is not None else 1))} if _PROFILE is not None else None
+        th = _conv16_tile_h(Cin, Ho, B * (Ho // 16) * (Wo // 16) * ((cv.cout + 63) // 64))
+        L.check(_timed("conv3x3_mfma16", meta, L.load().smx_conv3x3_mfma16_f32, a_ptr, lda, cv.w16.data_ptr(), cv.w16.shape[1],
+                       None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, Ho, Wo, Cin, cv.cout, int(up2), act, th, _stream()),
+                "smx_conv3x3_mfma16_f32")
         return out
     M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
     ksplit, ws = 1, None

@@ -23,7 +23,7 @@ from . import lib as L
 
 
 class Tape:
-    def __init__(self, params, grads, mfma16=False, plan=None):
+    def __init__(self, params, grads, mfma16=False, plan=None, reduce_plan=None):
         """params / grads: {name: device tensor}; grads[name] has the parameter's shape (usually a view of one flat buffer) and is
         ACCUMULATED into by the weight-gradient kernels (zero it before the step).
         mfma16: the bf16-compute training mode (BASELINE configs[4] "bf16"): every convolution / Linear contraction -- forward, data
@@ -41,6 +41,9 @@ class Tape:
         self.plan = plan        # train_ops.PackPlan (optional): all packings it has seen are refreshed by ONE launch, now
         if plan is not None:
             plan.begin(self)
+        self.reduce_plan = reduce_plan      # train_ops.ReducePlan (optional): the weight gradients' split reduces, one launch per backward piece
+        if reduce_plan is not None:
+            reduce_plan.begin(self)
 
     # ---- graph ----
     def record(self, fn):
@@ -94,6 +97,8 @@ class Tape:
         """run the recorded closures in reverse, down to (not including) position `stop_at`; a later call continues from there."""
         while len(self.nodes) > stop_at:
             self.nodes.pop()()
+        if self.reduce_plan is not None:
+            self.reduce_plan.flush(self)
 
 
 def _stream():

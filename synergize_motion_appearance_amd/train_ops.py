@@ -102,6 +102,88 @@ class PackPlan:
         tp.packed.update(self._ready)
 
 
+class ReducePlan:
+    """The split reduces of a backward pass, remembered across steps (the weight-gradient counterpart of PackPlan).  Every weight
+    gradient is two launches: the TN GEMM that leaves `msplit` raw partial tiles in a workspace and the fixed-order reduce that adds them
+    into the parameter's .grad (~460 reduce launches of 5-50 us per step).  The first step that runs with a plan attached to its Tape
+    RECORDS: each `_wgrad` gets a persistent workspace, reduces immediately as before and leaves its item (smx_reduce_item) in the
+    current segment; `Tape.backward()` closes a segment each time it returns (the step runs its backward in one or two pieces).  From
+    the next step on the plan REPLAYS: `_wgrad` finds its workspace by position, launches the GEMM with the reduce deferred, and the end
+    of each backward piece finishes the segment's items with ONE `smx_wgrad_reduce_batch` launch per wave (a parameter's second call
+    site goes to the next wave: items of one launch must not share an output).  The plan belongs to one gradient dict and one call
+    sequence (`key`); a request that does not match the recording raises -- a step variant needs its own plan."""
+    ITEM = np.dtype([("ws", "<u8"), ("out", "<u8"), ("bias_ws", "<u8"), ("bias_out", "<u8"), ("msplit", "<i4"), ("Cout", "<i4"), ("K", "<i4"),
+                     ("Cin", "<i4"), ("khw", "<i4"), ("layout", "<i4"), ("ldo", "<i4"), ("accumulate", "<i4"), ("alpha", "<f4"), ("kind", "<i4"),
+                     ("first_block", "<i4"), ("nblocks", "<i4")])                          # == smx_reduce_item (include/smx.h)
+
+    def __init__(self):
+        self._owner = None
+        self.segs = []           # recorded: [{"items": [(sig, ws, record)], "waves": [(device table, n items, n blocks)]}]
+        self.cur = []
+        self.replay = False
+        self.seg_i = self.item_i = 0
+
+    def begin(self, tp):
+        if self._owner != id(tp.G):
+            self._owner, self.segs, self.cur, self.replay = id(tp.G), [], [], False
+        else:
+            self.replay = bool(self.segs) and not self.cur
+        self.seg_i = self.item_i = 0
+
+    def request(self, tp, sig, n_floats, device):
+        """-> (workspace, deferred?)"""
+        if not self.replay:
+            ws = torch.empty((n_floats,), device=device, dtype=F32)
+            self.cur.append([sig, ws, None])
+            return ws, False
+        seg = self.segs[self.seg_i] if self.seg_i < len(self.segs) else None
+        if seg is None or self.item_i >= len(seg["items"]) or seg["items"][self.item_i][0] != sig:
+            raise L.SmxError("ReducePlan: this backward asks for a weight gradient the recorded step did not have at this position "
+                             f"(segment {self.seg_i}, item {self.item_i}: {sig}) -- a step variant (e.g. the GAN branch) needs its own plan")
+        ws = seg["items"][self.item_i][1]
+        self.item_i += 1
+        return ws, True
+
+    def describe(self, tp, ws, msplit, out, cout, cin, kh, kw, layout, ldo, alpha, bias_out):
+        rec = np.zeros(1, dtype=self.ITEM)
+        L.check(tp.lib.smx_wgrad_reduce_describe(ws.data_ptr(), msplit, out.data_ptr(), cout, cin, kh, kw, layout, ldo, 1, float(alpha),
+                                                 None if bias_out is None else bias_out.data_ptr(), rec.ctypes.data), "wgrad_reduce_describe")
+        self.cur[-1][2] = rec
+
+    def flush(self, tp):
+        """the end of a piece of the backward: close the recorded segment / finish the deferred items of this one."""
+        if not self.replay:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.SmxError("ReducePlan: the recording step must run eagerly (the table upload is a host copy)")
+            items, self.cur = self.cur, []
+            waves, seen = {}, {}
+            for sig, ws, rec in items:
+                wv = seen.get(int(rec["out"][0]), 0)
+                seen[int(rec["out"][0])] = wv + 1
+                waves.setdefault(wv, []).append(rec)
+            tabs = []
+            for wv in sorted(waves):
+                tab = np.concatenate(waves[wv])
+                blk = 0
+                for r in tab:
+                    r["first_block"] = blk
+                    blk += int(r["nblocks"])
+                tabs.append((torch.from_numpy(tab.view(np.uint8).copy()).to(items[0][1].device), len(tab), blk))
+            self.segs.append({"items": items, "waves": tabs})
+            return
+        if self.seg_i >= len(self.segs):
+            if self.item_i:
+                raise L.SmxError("ReducePlan: more backward pieces than recorded")
+            return
+        seg = self.segs[self.seg_i]
+        if self.item_i != len(seg["items"]):
+            raise L.SmxError(f"ReducePlan: segment {self.seg_i} ran {self.item_i} of its {len(seg['items'])} recorded weight gradients")
+        for tab, n, blk in seg["waves"]:
+            L.check(tp.lib.smx_wgrad_reduce_batch(tab.data_ptr(), n, blk, _stream()), "wgrad_reduce_batch")
+        self.seg_i += 1
+        self.item_i = 0
+
+
 def _plan_add(tp, ck, w, wc, out, total, cout, cin, kh, kw, mode, kind, frozen):
     if tp.plan is not None and wc is w:                   # a non-contiguous view was copied: nothing stable to point the table at
         tp.plan.add(ck, w, out, total, cout, cin, kh, kw, mode, kind, frozen)
@@ -167,7 +249,14 @@ def _wgrad(tp, dy, x, out, *, nb=1, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stri
            alpha=1.0, dy_ld=None, x_ld=None, dy_bs=0, x_bs=0, out_bs=0, bias_out=None, mfma16_ok=False):
     ms = C.c_int(1)
     n = int(tp.lib.smx_wgrad_conv_ws_floats(nb, M, cout, cin, Hin, Win, Ho, Wo, kh, kw, stride, pt, pl, int(up2), C.byref(ms)))
-    ws = torch.empty((n,), device=out.device, dtype=F32)
+    rp = getattr(tp, "reduce_plan", None)
+    planned = rp is not None and nb == 1 and accumulate and out_bs == 0
+    deferred = False
+    if planned:
+        sig = (out.data_ptr(), None if bias_out is None else bias_out.data_ptr(), M, cout, cin, kh, kw, stride, layout, ldo, n, ms.value, float(alpha))
+        ws, deferred = rp.request(tp, sig, n, out.device)
+    else:
+        ws = torch.empty((n,), device=out.device, dtype=F32)
     dyp, ldy = (dy.data_ptr(), dy_ld) if dy_ld is not None else _pix(dy)[:2]
     xp, ldx = (x.data_ptr(), x_ld) if x_ld is not None else _pix(x)[:2]
     bf = bool(tp.mfma16 and mfma16_ok)
@@ -175,8 +264,10 @@ def _wgrad(tp, dy, x, out, *, nb=1, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stri
     K = kh * kw * cin
     meta = {"flops": 2.0 * nb * M * cout * K, "M": M, "N": cout, "K": K, "nb": nb, "k": kh, "bf16": int(bf)} if ops._PROFILE is not None else None
     L.check(ops._timed("wgrad_bf16" if bf else "wgrad", meta, fn, dyp, ldy, dy_bs, xp, ldx, x_bs, nb, M, cout, Hin, Win, cin, Ho, Wo, kh, kw, stride, pt, pl,
-                       int(up2), ws.data_ptr(), ms.value, out.data_ptr(), out_bs, layout, ldo, int(accumulate), float(alpha),
+                       int(up2), ws.data_ptr(), ms.value, out.data_ptr(), out_bs, layout, ldo, int(accumulate) | (2 if deferred else 0), float(alpha),
                        None if bias_out is None else bias_out.data_ptr(), _stream()), "wgrad")
+    if planned and not deferred:
+        rp.describe(tp, ws, ms.value, out, cout, cin, kh, kw, layout, ldo, alpha, bias_out)
 
 
 def act_bwd(tp, g, ref, act):

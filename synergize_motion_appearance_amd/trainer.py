@@ -342,6 +342,9 @@ class TrainStep:
         self.wd_m = float(om.get("weight_decay", 0))
         self.P = {**self.g.flat.P, **self.flat_m.P}
         self._pack_plan, self._pack_plan_d = T.PackPlan(), T.PackPlan()     # generator-side tape (incl. its pass through net_d) / discriminator step
+        # the weight gradients' split reduces, one launch per backward piece from the second step on (train.batched_wgrad_reduce, default on);
+        # one plan per call sequence: (GAN branch?, backward cut in two for the overlapped all-reduce?) and the discriminator's own step
+        self._reduce_plans = {} if self.g.opt.get("batched_wgrad_reduce", True) else None
         self.G = {**self.g.flat.G, **self.flat_m.G}
         # the discriminator side of optimize_parameters (models/appmotioncomp_model.py:324-345, 408-432): hinge GAN with the adaptive weight,
         # active in `step(..., gan=True)` (the model turns it on past net_d_start_iter)
@@ -459,7 +462,8 @@ class TrainStep:
         g = self.g
         if gan and self.flat_d is None:
             raise RuntimeError("TrainStep(gan=True) needs net_d (the discriminator network) at construction")
-        tp = Tape(self.P, self.G, mfma16=self.g.mfma16, plan=self._pack_plan)
+        rp = None if self._reduce_plans is None else self._reduce_plans.setdefault((bool(gan), on_cut is not None), T.ReducePlan())
+        tp = Tape(self.P, self.G, mfma16=self.g.mfma16, plan=self._pack_plan, reduce_plan=rp)
         src, drv = source.float().contiguous(), driving.float().contiguous()
         B = drv.shape[0]
         eng = self.me_engine
@@ -571,7 +575,8 @@ class TrainStep:
     def disc_backward(self, out_nhwc, gt_nhwc):
         """the discriminator half (:408-430): hinge losses of net_d on the real frames and on the DETACHED generated ones (two passes: BatchNorm
         sees each batch on its own), gradients accumulated into net_d's flat buffer (zero it first).  -> loss dict"""
-        tp = Tape(self.P_d, self.G_d, mfma16=self.g.mfma16, plan=self._pack_plan_d)
+        rp = None if self._reduce_plans is None else self._reduce_plans.setdefault("d", T.ReducePlan())
+        tp = Tape(self.P_d, self.G_d, mfma16=self.g.mfma16, plan=self._pack_plan_d, reduce_plan=rp)
         real, fake = tp.stop(gt_nhwc), tp.stop(out_nhwc.detach())
         pr = self._disc(tp, real)
         l_real = T.torch_scalar(tp, pr, lambda p: torch.relu(1.0 - p).mean())

@@ -488,10 +488,16 @@ def test_conv_backward_bf16_compute_mode(T, B, Cin, Cout, H, k, stride, pad, up2
     tp = Tape(P, {n: torch.zeros_like(v) for n, v in P.items()}, mfma16=True)
     xd = nhwc(x).cuda()
     kw = dict(stride=2, pad=(0, 0), out_hw=(H // 2, H // 2)) if stride == 2 else dict(pad=(pad, pad)) if pad != k // 2 else {}
-    yd = T.conv(tp, xd, "w", "b", up2=up2, act=act, **kw)
-    assert yd.dtype == torch.float32 and rel(nchw(yd), y_ref) < 2e-4, tag
-    tp.acc(yd, nhwc(g).cuda())
-    tp.backward()
+    from synergize_motion_appearance_amd import ops
+    with ops.profile() as rec:
+        yd = T.conv(tp, xd, "w", "b", up2=up2, act=act, **kw)
+        assert yd.dtype == torch.float32 and rel(nchw(yd), y_ref) < 2e-4, tag
+        tp.acc(yd, nhwc(g).cuda())
+        tp.backward()
+    names = [r[0] for r in rec.rows]
+    if k == 3 and stride == 1 and Cin % 64 == 0:
+        # forward on the fp32-storage form of the region-direct kernel (smx_conv3x3_mfma16_f32); the data gradient too when C_out % 64 == 0
+        assert names.count("conv3x3_mfma16") == (2 if Cout % 64 == 0 else 1), (tag, names)
     assert rel(tp.G["w"], dW) < 2e-4, tag
     assert rel(nchw(tp.grad(xd)), dX) < 2e-4, tag
     assert rel(tp.G["b"], gm.sum((0, 2, 3))) < 2e-4, tag
@@ -542,6 +548,57 @@ def test_region_weight_gradient_equals_the_generic_kernel(B, Cin, Cout, H, W, up
         F.conv2d(xr, w, padding=1).backward(dy.cpu().permute(0, 3, 1, 2))
         assert rel(outs[0][0] - 0.25, 0.5 * w.grad) < 2e-4
         assert rel(outs[0][1] + 0.5, 0.5 * dy.cpu().sum((0, 1, 2))) < 2e-4
+
+
+def test_batched_split_reduce_equals_the_per_layer_launches(T):
+    """train_ops.ReducePlan: the step after the recording one defers every weight gradient's split reduce and finishes a backward piece's
+    items with ONE smx_wgrad_reduce_batch launch per wave -- gradients bit-identical to the per-layer launches, including a parameter used at
+    two call sites (second wave), the bias gradients, a backward run in two pieces, and a changed call sequence raising instead of
+    silently reducing the wrong workspace."""
+    from synergize_motion_appearance_amd.tape import Tape
+    from synergize_motion_appearance_amd import lib as L
+    P = {"w1": rnd("rp_w1", (64, 64, 3, 3), 0.05), "b1": rnd("rp_b1", (64,), 0.1), "w2": rnd("rp_w2", (128, 64, 3, 3), 0.05),
+         "b2": rnd("rp_b2", (128,), 0.1), "w3": rnd("rp_w3", (32, 128), 0.1), "b3": rnd("rp_b3", (32,), 0.1)}
+    P = {k: v.cuda().contiguous() for k, v in P.items()}
+    x = nhwc(rnd("rp_x", (2, 64, 32, 32))).cuda()
+    gy = nhwc(rnd("rp_g", (2, 32, 32, 32))).cuda()
+
+    def run(plan, pieces=1, extra=False):
+        G = run.G if plan is not None else {k: torch.zeros_like(v) for k, v in P.items()}
+        for v in G.values():
+            v.zero_()
+        tp = Tape(P, G, reduce_plan=plan)
+        tp.stop(x)
+        h = T.conv(tp, x, "w1", "b1", act=1)
+        h = T.conv(tp, h, "w1", "b1")                      # the same parameter again: its reduce goes to the second wave
+        cut = tp.mark()
+        h = T.conv(tp, h, "w2", "b2", act=2)
+        if extra:
+            h = T.conv(tp, h, "w3", "b3")
+        y = T.conv(tp, h, "w3", "b3")
+        tp.acc(y, gy.clone())
+        if pieces == 2:
+            tp.backward(stop_at=cut)
+        tp.backward()
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in G.items()}
+    ref = run(None)
+    for pieces in (1, 2):
+        plan = T.ReducePlan()
+        run.G = {k: torch.zeros_like(v) for k, v in P.items()}
+        rec = run(plan, pieces)                               # records (reduces at once)
+        assert not plan.replay and len(plan.segs) == pieces
+        rep = run(plan, pieces)                               # replays: deferred, one batch launch per wave and piece
+        assert plan.replay
+        rep2 = run(plan, pieces)
+        for k in P:
+            assert torch.equal(rec[k], ref[k]) and torch.equal(rep[k], ref[k]) and torch.equal(rep2[k], ref[k]), (pieces, k)
+    assert len(plan.segs[1]["waves"]) == 2                # piece 2 (recorded last = the first convs) holds w1 twice
+    with pytest.raises(L.SmxError):
+        Tp = T.ReducePlan()
+        run.G = {k: torch.zeros_like(v) for k, v in P.items()}
+        run(Tp)
+        run(Tp, extra=True)
 
 
 def test_batched_weight_packing_equals_the_per_layer_launches():
