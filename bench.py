@@ -368,7 +368,9 @@ def train_roofline(step, src, drv, gan, compute_dtype, dt):
                        "wgrad_bf16": "wgrad_region_kernel<true> / wgrad_kernel<true,64,64> (weight gradient, operands rounded to bf16, v_mfma_f32_32x32x16_bf16)",
                        "winograd": "winograd_kernel / winograd_wide_kernel (forward and data gradient of the 3x3 convolutions, F(2x2,3x3), v_mfma_f32_32x32x2_f32)",
                        "gemm_conv": "gemm_conv_kernel (implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                       "gemm_bf16": "gemm_bf16_kernel (implicit GEMM forward / data gradient, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom),
+                       "gemm_bf16": "gemm_bf16_kernel (implicit GEMM forward / data gradient, v_mfma_f32_32x32x16_bf16)",
+                       "conv3x3_mfma16": "conv3x3_bf16_kernel<TH, SLAB, F32=true> (region-direct 3x3 forward / data gradient on fp32 storage, operands rounded to bf16 "
+                                         "while staged, v_mfma_f32_32x32x16_bf16)"}.get(dom, dom),
             "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
             "launches_per_step": d["calls"], "avg_launch_us": round(1e3 * d["ms"] / d["calls"], 2),
             "share_of_step_time": round(d["ms"] * 1e-3 / dt, 3),

@@ -117,6 +117,15 @@ typedef struct smx_gemm16_desc {
 } smx_gemm16_desc;
 
 int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream);
+/* Short-K Linear / 1x1 convolution on bf16 storage, row-panel form (csrc/gemm_rp_bf16.hip): c[M][N] = act(a[M][K] w^T + bias) (+ res),
+ * K = 128 | 256, N % 128 == 0, M % 32 == 0 (smx_gemm_rp_bf16_ok).  Persistent blocks stream 32-row tiles of `a` through LDS by LDS-DMA
+ * while every wave keeps its weight fragments in registers; `wp` = the [N/32][K/16][64 lanes][8] fragment-ordered pack built once per
+ * layer by smx_gemm_rp_bf16_pack from the [N][ldw >= K] bf16 layout smx_gemm_conv_bf16 takes ((N/32)*(K/16)*512 elements).
+ * Replaces smx_gemm_conv_bf16 at the token Linears of the transformer layers (archs/appmotioncodebook_arch.py:69-70,101-115). */
+int smx_gemm_rp_bf16_ok(long long M, int N, int K);
+int smx_gemm_rp_bf16_pack(const void* w, int ldw, void* wp, int N, int K, void* stream);
+int smx_gemm_rp_bf16(const void* a, int lda, const void* wp, const float* bias, const void* res, int ldres, void* c, int ldc,
+                     long long M, int N, int K, int act, void* stream);
 
 /* Fused Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 convolutions (same call sites as above for
  * the eligible layers: ResBlock / Upsample / SFT / FFN / RefineFlow 3x3 convs): 2.25x fewer MFMA

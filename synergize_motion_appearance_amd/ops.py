@@ -113,7 +113,7 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -121,6 +121,17 @@ class Conv:
         self._w16 = None
         self._u43 = None
         self._w16t = None
+        self._w16rp = None
+
+    @property
+    def w16_rp(self):
+        """fragment-ordered bf16 pack of a 1x1 layer for the row-panel kernel (smx_gemm_rp_bf16_pack), built once per layer."""
+        if self._w16rp is None:
+            w16 = self.w16
+            wp = torch.empty((self.cout // 32) * (self.cin // 16) * 512, device=w16.device, dtype=BF16)
+            L.check(L.load().smx_gemm_rp_bf16_pack(w16.data_ptr(), w16.shape[1], wp.data_ptr(), self.cout, self.cin, _stream()), "smx_gemm_rp_bf16_pack")
+            self._w16rp = wp
+        return self._w16rp
 
     @property
     def w16_t32(self):
@@ -217,6 +228,21 @@ CONV16_TILE_H = int(_os.environ.get("SMX_CONV16_TILE_H", "0"))      # 0 = auto, 
 CONV16_F32_REGION = int(_os.environ.get("SMX_CONV16_F32_REGION", "1"))   # fp32-storage form of the region kernel (bf16-compute training); 0 = implicit GEMM
 
 
+GEMM16_RP = int(_os.environ.get("SMX_GEMM16_RP", "1"))               # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
+GEMM16_RP_MIN_ROWS = 16384                                           # below: too few 32-row tiles to fill the persistent blocks (tests lower it)
+
+
+def _rows_dense(t):
+    """all leading dims collapse to ONE row index at a common stride (what a [M][ld] view needs)."""
+    ld = t.stride(-2) if t.dim() > 1 else t.shape[-1]
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] > 1 and t.stride(d) != exp:
+            return False
+        exp *= t.shape[d]
+    return True
+
+
 CONV16_T32 = int(_os.environ.get("SMX_CONV16_T32", "1"))           # 16x32-tile kernel (csrc/conv3x3_bf16_t32.hip) for the big launches; 0 = off
 CONV16_T32_MIN_BLOCKS = 1024                                         # two resident rounds of the chip's 512 block slots; tests lower it
 
@@ -298,6 +324,16 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
                 "smx_conv3x3_mfma16_f32")
         return out
     M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
+    if (GEMM16_RP and tile == 0 and x.dtype == BF16 and out.dtype == BF16 and cv.kh == 1 and cv.kw == 1 and stride == 1 and (pt, pl) == (0, 0)
+            and not up2 and not d2s and in_ss is None and (Ho, Wo) == (H, W) and (res is None or res.dtype == BF16) and M >= GEMM16_RP_MIN_ROWS
+            and cv.w is not None and L.load().smx_gemm_rp_bf16_ok(M, cv.cout, K) and lda % 8 == 0 and ldc % 8 == 0 and a_ptr % 16 == 0
+            and c_ptr % 16 == 0 and (res is None or (ldr % 8 == 0 and r_ptr % 16 == 0)) and _rows_dense(x) and _rows_dense(out)
+            and (res is None or _rows_dense(res))):
+        # short-K token Linears: persistent row-panel kernel (weights in registers, rows by LDS-DMA)
+        meta = {"flops": 2.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "bf16": 1, "rp": 1} if _PROFILE is not None else None
+        L.check(_timed("gemm_bf16", meta, L.load().smx_gemm_rp_bf16, a_ptr, lda, cv.w16_rp.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       r_ptr, ldr, c_ptr, ldc, M, cv.cout, K, act, _stream()), "smx_gemm_rp_bf16")
+        return out
     ksplit, ws = 1, None
     if not d2s and K >= 2048:
         blocks = ((M + 63) // 64) * ((cv.cout + 63) // 64)

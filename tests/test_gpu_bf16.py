@@ -117,7 +117,9 @@ def test_gemm_conv_bf16(ops, case):
         y = ops.conv(xin, cv, stride=stride, pad=pad, out_hw=out_hw, up2=up2, act=act, tile=tile, mfma16=True,
                      out_dtype=torch.float32 if c_f32 else None)
     names = [r[0] for r in rec.rows]
-    assert names in (["gemm_bf16"], ["conv3x3_bf16"]) and (tile == 0 or names == ["gemm_bf16"])   # a forced tile always means the implicit GEMM
+    assert names in (["gemm_bf16"], ["conv3x3_bf16"], ["conv3x3_mfma16"]) and (tile == 0 or names == ["gemm_bf16"])   # a forced tile always means the implicit GEMM
+    if a_f32 and c_f32 and k == 3 and stride == 1 and Cin % 64 == 0 and H % 8 == 0 and tile == 0:
+        assert names == ["conv3x3_mfma16"], names              # fp32 storage on both sides: the region-direct kernel's F32 form
     assert y.dtype == (torch.float32 if c_f32 else BF)
     if c_f32:
         assert maxabs(nchw32(y), ref) < 2e-4 * max(1.0, float(ref.abs().max())), tag
@@ -436,6 +438,45 @@ def _attention_bf16_storage(ops):
         assert got.dtype == BF
         ok, worst = close16(got.float().cpu(), ref.cpu(), ulps=1.0, floor=1e-6)
         assert ok, (dh, S, shared, worst)
+
+
+@pytest.mark.parametrize("B,K,N,act,with_res,sliced", [(8, 256, 256, 0, True, False), (4, 256, 512, 4, False, True), (8, 128, 128, 0, False, False),
+                                                      (4, 128, 256, 1, True, True), (5, 256, 128, 0, True, False)])
+def test_row_panel_gemm_bf16(ops, B, K, N, act, with_res, sliced):
+    """csrc/gemm_rp_bf16.hip (persistent row-panel kernel for the K = 128 / 256 1x1 layers) == the fp32 product of the bf16-rounded operands,
+    bias / activation / residual in fp32, ONE rounding at the store; on channel-slice views (ld > C) too; and it is the kernel that ran."""
+    H = W = 64
+    rows = ops.GEMM16_RP_MIN_ROWS
+    ops.GEMM16_RP_MIN_ROWS = 1024
+    try:
+        xw = r16(rnd(f"rpx{K}{N}", (B, H, W, K + (24 if sliced else 0)))).cuda().to(BF)
+        x = xw[..., 8:8 + K] if sliced else xw
+        w = rnd(f"rpw{K}{N}", (N, K), 1.0 / math.sqrt(K))
+        b = rnd(f"rpb{K}{N}", (N,), 0.2)
+        rw = r16(rnd(f"rpr{K}{N}", (B, H, W, N + (16 if sliced else 0)))).cuda().to(BF)
+        res = (rw[..., 16:] if sliced else rw) if with_res else None
+        cv = ops.Conv(w.cuda().contiguous(), b.cuda(), 1, 1, K, N)
+        with ops.profile() as rec:
+            y = ops.conv(x, cv, act=act, res=res)
+        assert [r[1].get("rp") for r in rec.rows] == [1], rec.rows
+        ref = x.float().cpu().reshape(-1, K).double() @ r16(w).double().T + b.double()
+        ref = ref.float()
+        if act == 1:
+            ref = torch.relu(ref)
+        elif act == 4:
+            ref = F.gelu(ref)
+        if res is not None:
+            ref = ref + res.float().cpu().reshape(-1, N)
+        ok, worst = close16(y.float().cpu().reshape(-1, N), ref, ulps=1.02, floor=2e-3)
+        assert ok, worst
+        ops.GEMM16_RP = 0
+        try:
+            y0 = ops.conv(x, cv, act=act, res=res)
+        finally:
+            ops.GEMM16_RP = 1
+        assert float((y0.float() - y.float()).abs().max()) <= 2.0 ** -7 * float(y0.float().abs().max())      # the implicit GEMM: same values up to the last bf16 bit
+    finally:
+        ops.GEMM16_RP_MIN_ROWS = rows
 
 
 def test_conv3x3_small_n_bf16_input(ops):
