@@ -122,6 +122,10 @@ int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream);
  * while every wave keeps its weight fragments in registers; `wp` = the [N/32][K/16][64 lanes][8] fragment-ordered pack built once per
  * layer by smx_gemm_rp_bf16_pack from the [N][ldw >= K] bf16 layout smx_gemm_conv_bf16 takes ((N/32)*(K/16)*512 elements).
  * Replaces smx_gemm_conv_bf16 at the token Linears of the transformer layers (archs/appmotioncodebook_arch.py:69-70,101-115). */
+int smx_gemm_rp_f32_ok(long long M, int N, int K);      /* the fp32 form (csrc/gemm_rp_f32.hip): fp32 MFMA, weights [N/32][K/8][64 lanes][4] */
+int smx_gemm_rp_f32_pack(const float* w, int ldw, float* wp, int N, int K, void* stream);
+int smx_gemm_rp_f32(const float* a, int lda, const float* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
+                    long long M, int N, int K, int act, void* stream);
 int smx_gemm_rp_bf16_ok(long long M, int N, int K);
 int smx_gemm_rp_bf16_pack(const void* w, int ldw, void* wp, int N, int K, void* stream);
 int smx_gemm_rp_bf16(const void* a, int lda, const void* wp, const float* bias, const void* res, int ldres, void* c, int ldc,
@@ -375,6 +379,11 @@ int smx_layernorm_pos_bf16(const void* x, const float* gamma, const float* beta,
                            int npos, float eps, void* stream);
 int smx_attention_bf16(const void* q, int ldq, int64_t q_bs, const void* k, int ldk, int64_t k_bs, const void* v, int ldv, int64_t v_bs,
                        void* o, int ldo, int64_t o_bs, const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream);
+/* The vqgan AttnBlock core (archs/vqgan_arch.py:229-253) on bf16 storage as ONE kernel: o[b][l][:] = softmax_s(q[b][l].k[b][s] * scale) v[b][s],
+ * one head of d = 256; `vt` is V TRANSPOSED ([d][ldvt >= S] per image, what the value projection writes with its per-row bias).  The
+ * [B][L][S] score tensor of the three-launch form (QK^T GEMM, softmax_rows, PV GEMM) never exists.  L % 128 == 0, S % 32 == 0. */
+int smx_attnblock_bf16(const void* q, int ldq, int64_t q_bs, const void* k, int ldk, int64_t k_bs, const void* vt, int ldvt, int64_t vt_bs,
+                       void* o, int ldo, int64_t o_bs, int B, int L, int S, int d, float scale, void* stream);
 int smx_softmax_rows_bf16(void* s, int ld, int R, int S, float scale, const uint8_t* mask, int rows_per_mask, void* stream);
 int smx_warp_nhwc_bf16(const void* feat, int feat_batch, const float* flow, const float* occ, void* out, int B, int H, int W, int C,
                        int Hf, int Wf, void* stream);

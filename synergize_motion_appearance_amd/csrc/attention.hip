@@ -273,6 +273,124 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AP<bf16_t> p) {
   }
 }
 
+// The vqgan AttnBlock core (archs/vqgan_arch.py:229-253: ONE head of d = C = 256 over the 32 x 32 tokens) on bf16 storage, fused:
+// softmax(q k^T / sqrt(C)) v as one kernel, the [B, N, N] score tensor never exists (the three-launch form wrote and re-read 1.26 GB of
+// fp32 scores per call at B = 300).  Same swapped-product scheme as attn_mfma16_kernel with the d axis 8 tiles wide: Q^T fragments
+// (16 k-steps) and the eight O^T accumulator tiles live in registers (64 + 128 VGPRs), K tiles [32 keys][256] and V^T tiles
+// [256][32 keys] stream global -> LDS by LDS-DMA (no staging registers: Q^T + O^T take the register file; rows unpadded, 16-B chunks
+// XOR-swizzled at the source address for conflict-free fragment reads) through a double-buffered stage.  V arrives TRANSPOSED ([C][N],
+// what the value projection GEMM writes with bias_per_row); the S^T accumulator's key order {0-3, 8-11} + 4 (l >> 5) is met by reading
+// the V^T fragment as two 8-byte pieces of the row.  The O
+// rescale (128 multiplies per lane) is skipped while no lane's running maximum moved.  fp32 statistics, P rounded to bf16 for the PV
+// product, fp32 accumulate -- the arithmetic of the three-launch form (its PV GEMM rounded the fp32 probabilities while staging).
+typedef __attribute__((address_space(3))) void ab_lds_void;
+__device__ __forceinline__ void ab_glds16(const void* gsrc, unsigned lds_dst) {     // LDS-DMA: 64 lanes x 16 B -> LDS [lds_dst, +1 KB); M0 saved / restored
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int DH>
+__global__ __launch_bounds__(512, 1) void attnblock16_kernel(AP<bf16_t> p) {
+  static_assert(DH == 256, "the AttnBlock width of this path");
+  // 8 waves: wave pair (2 g, 2 g + 1) shares the 32 queries of group g and splits the d axis (4 of the 8 O^T tiles each); both compute
+  // S^T (16 of a wave's 24 MFMAs per tile: the matrix pipe is far from the bound here) -- with all eight tiles in one wave the kernel
+  // spilled, and every scratch reload's vmcnt(0) also waited for the tile prefetch in flight
+  constexpr int TK = 32, KROW = DH * 2, VROW = TK * 2, DT = DH / 64, KK = DH / 16;
+  constexpr int KTILE = TK * KROW, VTILE = DH * VROW;                     // 16 KB + 16 KB per stage, rows unpadded (the DMA writes 1 KB runs)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;                                               // [2][TK][KROW]: 16-B chunk c of key row r at position c ^ (r & 15)
+  unsigned char* Vt = smem + 2 * KTILE;                                   // [2][DH][VROW]: chunk c of row d at position c ^ ((d >> 2) & 3)
+  const unsigned lds0 = (unsigned)(uintptr_t)((ab_lds_void*)smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + (wave >> 1) * 32 + (lane & 31);
+  const int hh = lane >> 5, dbase = (wave & 1) * (DH / 2);
+  const bf16_t* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq;
+  const bf16_t* K = p.k + b * p.k_bs;
+  const bf16_t* VT = p.v + b * p.v_bs;                                    // [DH][ldv >= S]
+  const float c = p.scale * 1.44269504088896340736f;
+
+  bf16x8 qf[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Q + kk * 16 + hh * 8));
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  // staging by LDS-DMA (no registers in flight): per tile 16 + 16 instructions of 1 KB, four of each per wave
+  // two K and two V^T instructions per wave: slot (wave * 2 + i) * 64 + lane: K row = 4 wave + 2 i + (lane >> 5), position lane & 31;
+  // V^T row = 32 wave + 16 i + (lane >> 2), position lane & 3
+  auto issue = [&](int key0, int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kr = 4 * wave + 2 * i + hh;
+      ab_glds16(K + (long long)(key0 + kr) * p.ldk + (((lane & 31) ^ (kr & 15)) << 3), lds0 + (unsigned)(buf * KTILE + (wave * 2 + i) * 1024));
+      const int vr = 32 * wave + 16 * i + (lane >> 2);
+      ab_glds16(VT + (long long)vr * p.ldv + key0 + (((lane & 3) ^ ((vr >> 2) & 3)) << 3), lds0 + (unsigned)(2 * KTILE + buf * VTILE + (wave * 2 + i) * 1024));
+    }
+  };
+  const int krow = lane & 31, ksw = krow & 15;
+  const int vsw = (krow >> 2) & 3;                                         // rows 32 d + (l & 31): (row >> 2) & 3 does not depend on the d tile
+
+  const int ntiles = p.S / TK;
+  issue(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) issue((t + 1) * TK, buf ^ 1);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const unsigned char* kp = Ks + buf * KTILE + krow * KROW;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kp + (((2 * kk + hh) ^ ksw) << 4))), qf[kk], s, 0, 0, 0);
+    float tmax = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax * c);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float psum = 0.f, e[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { e[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -m_new)); psum += e[r]; }
+    // accumulator regs 0-7 = keys {0-3, 8-11} + 4 hh of the first 16, regs 8-15 = the same of the second 16
+    bf16x8 pf[2];
+    pf[0] = __builtin_bit_cast(bf16x8, make_uint4(pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])));
+    pf[1] = __builtin_bit_cast(bf16x8, make_uint4(pack2(e[8], e[9]), pack2(e[10], e[11]), pack2(e[12], e[13]), pack2(e[14], e[15])));
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum;
+    if (__any(m_new != m)) {                                               // wave-uniform: some lane's maximum moved
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+    m = m_new;
+    // O^T += V^T P^T: A = V^T row d, the SAME 8 keys this lane's P fragment holds: two 8-byte pieces of the row (keys 16 g + 4 hh + 0..3 and + 8)
+    const unsigned char* vp = Vt + buf * VTILE + (dbase + krow) * VROW + hh * 8;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp + d * 32 * VROW + (((2 * g) ^ vsw) << 4));
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + d * 32 * VROW + (((2 * g + 1) ^ vsw) << 4));
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)), pf[g], oacc[d], 0, 0, 0);
+      }
+  }
+  bf16_t* O = p.o + b * p.o_bs + (long long)qrow * p.ldo;
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      St<bf16_t>::st4(O + dbase + 32 * d + 8 * g + 4 * hh, make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv));
+}
+
 // d_head = 4: one query per lane, 64 queries per block; the block's 4 waves split the S keys
 // (wave w owns keys [w*S/4, (w+1)*S/4)), K/V broadcast from LDS, 8 keys per online-softmax step,
 // and the four partial (m, l, acc) states are merged through LDS at the end.
@@ -590,4 +708,18 @@ extern "C" int smx_attention_bf16(const void* q, int ldq, int64_t q_bs, const vo
                                   const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream) {
   return attention_launch<bf16_t>((const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs, (const bf16_t*)v, ldv, v_bs, (bf16_t*)o, ldo, o_bs,
                                   key_mask, B, H, L, S, dh, scale, stream);
+}
+
+/* The AttnBlock core fused (attnblock16_kernel): o[b][q][:] = softmax_k(q.k * scale) v, ONE head of d = 256, V given TRANSPOSED. */
+extern "C" int smx_attnblock_bf16(const void* q, int ldq, int64_t q_bs, const void* k, int ldk, int64_t k_bs, const void* vt, int ldvt, int64_t vt_bs,
+                                  void* o, int ldo, int64_t o_bs, int B, int L, int S, int d, float scale, void* stream) {
+  if (!q || !k || !vt || !o || B <= 0 || B > 65535 || d != 256 || L <= 0 || L % 128 || S <= 0 || S % 32) return SMX_EINVAL;
+  if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldq < d || ldk < d || ldvt < S || ldo < d || q_bs % 8 || k_bs % 8 || vt_bs % 8 || o_bs % 4) return SMX_EINVAL;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)o & 7)) return SMX_EINVAL;
+  AP<bf16_t> p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, nullptr, q_bs, k_bs, vt_bs, o_bs, ldq, ldk, ldvt, ldo, 1, L, S, scale};
+  constexpr int LDS = 2 * (32 * 256 * 2 + 256 * 32 * 2);     // 65,536 B
+  static bool attr = false;
+  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)attnblock16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  SMX_LAUNCH(attnblock16_kernel<256>, dim3(L / 128, B), dim3(512), LDS, (hipStream_t)stream, p);
+  return smx_launch_status();
 }

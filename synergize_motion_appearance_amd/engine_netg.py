@@ -16,12 +16,16 @@ MI355X-first choices:
   * the redundant third warp per scale (`deform_feat_list`, :615/:714) is not recomputed.
 """
 import math
+import os
 
 import torch
 
+from . import lib as L
 from . import ops
 from .manifest import encoder_plan, generator_plan, CHANNELS
 from .ops import Conv, ACT_RELU, ACT_LRELU02, ACT_GELU
+
+ATTNBLOCK_FUSED16 = int(os.environ.get("SMX_ATTNBLOCK_FUSED16", "1"))     # bf16 AttnBlock core as one kernel (0 = QK^T GEMM, softmax_rows, PV GEMM)
 
 _SCALE_K = {32: 1, 64: 2, 128: 3, 256: 4}
 
@@ -66,6 +70,13 @@ class _Attn:
         vt = torch.empty((B, Cc, N), device=x.device, dtype=x.dtype)          # V^T = Wv . hn^T + bv
         ops.gemm_nt(self.wv, hn, vt, M=Cc, N=N, K=Cc, lda=Cc, ldb=Cc, ldc=N, nb0=B, bt_bs=(N * Cc, 0),
                     c_bs=(Cc * N, 0), bias=self.bv, bias_per_row=True)
+        if x.dtype == torch.bfloat16 and ATTNBLOCK_FUSED16 and Cc == 256 and N % 128 == 0:
+            # configs[2]: the core as ONE kernel (csrc/attention.hip attnblock16_kernel): no [B,N,N] score tensor, fp32 statistics
+            h = torch.empty((B, H, W, Cc), device=x.device, dtype=x.dtype)
+            L.check(ops._timed("attnblock", {"flops": 4.0 * B * N * N * Cc, "bf16": 1} if ops._PROFILE is not None else None, L.load().smx_attnblock_bf16,
+                               qk.data_ptr(), 2 * Cc, N * 2 * Cc, qk.data_ptr() + 2 * Cc, 2 * Cc, N * 2 * Cc, vt.data_ptr(), N, Cc * N,
+                               h.data_ptr(), Cc, N * Cc, B, N, N, Cc, float(int(Cc) ** (-0.5)), ops._stream()), "smx_attnblock_bf16")
+            return ops.conv(h, self.proj, res=x)
         # logits and probabilities stay fp32 in both storage modes (bf16 path: c_f32 store, fp32 softmax, a_f32 operand converted
         # while staging): raw q.k sums over C = 256 lose too much in 8 mantissa bits before the softmax
         s = torch.empty((B, N, N), device=x.device, dtype=torch.float32)

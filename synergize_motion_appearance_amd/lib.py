@@ -108,6 +108,9 @@ SIGNATURES = {
     "smx_to_uint8_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
     "smx_conv3x3_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     "smx_conv3x3_sft_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_gemm_rp_f32_ok": (_i, [_i64, _i, _i]),
+    "smx_gemm_rp_f32_pack": (_i, [_p, _i, _p, _i, _i, _p]),
+    "smx_gemm_rp_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
     "smx_gemm_rp_bf16_ok": (_i, [_i64, _i, _i]),
     "smx_gemm_rp_bf16_pack": (_i, [_p, _i, _p, _i, _i, _p]),
     "smx_gemm_rp_bf16": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
@@ -117,6 +120,7 @@ SIGNATURES = {
     "smx_groupnorm_apply_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smx_layernorm_pos_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "smx_attention_bf16": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "smx_attnblock_bf16": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _f, _p]),
     "smx_softmax_rows_bf16": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
     "smx_warp_nhwc_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "smx_resize_bilinear_ac_nhwc_bf16": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

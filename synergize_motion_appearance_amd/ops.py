@@ -113,7 +113,7 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -122,6 +122,16 @@ class Conv:
         self._u43 = None
         self._w16t = None
         self._w16rp = None
+        self._wrp = None
+
+    @property
+    def w_rp(self):
+        """fragment-ordered fp32 pack of a 1x1 layer for the fp32 row-panel kernel (smx_gemm_rp_f32_pack), built once per layer."""
+        if self._wrp is None:
+            wp = torch.empty((self.cout // 32) * (self.cin // 8) * 256, device=self.w.device, dtype=torch.float32)
+            L.check(L.load().smx_gemm_rp_f32_pack(self.w.data_ptr(), self.w.shape[1], wp.data_ptr(), self.cout, self.cin, _stream()), "smx_gemm_rp_f32_pack")
+            self._wrp = wp
+        return self._wrp
 
     @property
     def w16_rp(self):
@@ -228,6 +238,7 @@ CONV16_TILE_H = int(_os.environ.get("SMX_CONV16_TILE_H", "0"))      # 0 = auto, 
 CONV16_F32_REGION = int(_os.environ.get("SMX_CONV16_F32_REGION", "1"))   # fp32-storage form of the region kernel (bf16-compute training); 0 = implicit GEMM
 
 
+GEMM_RP = int(_os.environ.get("SMX_GEMM_RP", "1"))                   # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
 GEMM16_RP = int(_os.environ.get("SMX_GEMM16_RP", "1"))               # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
 GEMM16_RP_MIN_ROWS = 16384                                           # below: too few 32-row tiles to fill the persistent blocks (tests lower it)
 
@@ -445,6 +456,14 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
         x = groupnorm_apply(x, in_ss, in_swish)
         a_ptr, lda = _pix(x, "conv input")
     M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
+    if (GEMM_RP and not direct and tile == 0 and cv.kh == 1 and cv.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not up2 and not d2s
+            and (Ho, Wo) == (H, W) and M >= GEMM16_RP_MIN_ROWS and L.load().smx_gemm_rp_f32_ok(M, cv.cout, K) and lda % 4 == 0 and ldc % 4 == 0
+            and a_ptr % 16 == 0 and c_ptr % 16 == 0 and (res is None or (ldr % 4 == 0 and r_ptr % 16 == 0))):
+        # short-K token Linears: persistent row-panel kernel (weights in registers, rows by LDS-DMA)
+        meta = {"flops": 2.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "rp": 1} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_f32, a_ptr, lda, cv.w_rp.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       r_ptr, ldr, c_ptr, ldc, M, cv.cout, K, act, _stream()), "smx_gemm_rp_f32")
+        return out
     ksplit, ws = 1, None
     if not d2s and K >= 1024:
         # weight-streaming layers (deep hourglass): few output tiles, long K -> split K over blocks

@@ -479,6 +479,38 @@ def test_row_panel_gemm_bf16(ops, B, K, N, act, with_res, sliced):
         ops.GEMM16_RP_MIN_ROWS = rows
 
 
+def test_attnblock_fused_bf16(ops):
+    """engine_netg._Attn on bf16 storage: the core as ONE kernel (smx_attnblock_bf16) against (i) the three-launch form it replaces (QK^T GEMM with
+    fp32 scores, softmax_rows, PV GEMM that rounds the probabilities while staging -- the same arithmetic up to summation order) and (ii) the
+    fp32 module evaluated on the bf16-rounded input: within twice the three-launch form's own distance from it."""
+    from synergize_motion_appearance_amd import engine_netg as E
+    C_, B = 256, 3
+    P = {"a.norm.weight": 1 + 0.1 * rnd("ab_g", (C_,)), "a.norm.bias": 0.1 * rnd("ab_b", (C_,))}
+    for n in ("q", "k", "v", "proj_out"):
+        P[f"a.{n}.weight"] = rnd("ab_w" + n, (C_, C_, 1, 1), 1.5 / math.sqrt(C_))
+        P[f"a.{n}.bias"] = rnd("ab_bias" + n, (C_,), 0.1)
+    P = {k: v.cuda() for k, v in P.items()}
+    blk = E._Attn(P, "a")
+    x = r16(rnd("ab_x", (B, 32, 32, C_))).cuda()
+    ref32 = blk(x)
+    with ops.profile() as rec:
+        fused = blk(x.to(BF))
+    assert "attnblock" in [r[0] for r in rec.rows] and "softmax" not in [r[0] for r in rec.rows]
+    E.ATTNBLOCK_FUSED16 = 0
+    try:
+        with ops.profile() as rec3:
+            three = blk(x.to(BF))
+    finally:
+        E.ATTNBLOCK_FUSED16 = 1
+    assert "attnblock" not in [r[0] for r in rec3.rows]
+    d3 = float((three.float() - ref32).abs().max())
+    df = float((fused.float() - ref32).abs().max())
+    d = float((fused.float() - three.float()).abs().max())
+    scale = float(ref32.abs().max())
+    assert df <= 2.0 * d3 + 2.0 ** -8 * scale and d <= 2.0 * d3 + 2.0 ** -7 * scale, (df, d3, d, scale)
+    assert float((fused.float() - ref32).abs().mean()) <= 1.5 * float((three.float() - ref32).abs().mean()) + 1e-4
+
+
 def test_conv3x3_small_n_bf16_input(ops):
     B, Cin, Co, H = 2, 64, 3, 32
     x = r16(rnd("sn16x", (B, Cin, H, H)))

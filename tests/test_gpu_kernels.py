@@ -271,6 +271,43 @@ def test_patch_embed_and_unpatchify(ops):
         assert maxabs(nchw(y2), ref2) < 3e-5, s
 
 
+@pytest.mark.parametrize("B,K,N,act,with_res,sliced", [(8, 256, 256, 0, True, False), (4, 256, 512, 4, False, True), (8, 128, 128, 0, False, False),
+                                                      (4, 128, 256, 1, True, True), (5, 256, 128, 0, True, False)])
+def test_row_panel_gemm_f32(ops, B, K, N, act, with_res, sliced):
+    """csrc/gemm_rp_f32.hip (persistent row-panel kernel for the K = 128 / 256 1x1 layers, fp32 MFMA) against the fp64 product; bias /
+    activation / residual; channel-slice views (ld > C); == the implicit GEMM to summation order; and it is the kernel that ran."""
+    H = W = 64
+    rows = ops.GEMM16_RP_MIN_ROWS
+    ops.GEMM16_RP_MIN_ROWS = 1024
+    try:
+        xw = rnd(f"rfx{K}{N}", (B, H, W, K + (24 if sliced else 0))).cuda()
+        x = xw[..., 8:8 + K] if sliced else xw
+        w = rnd(f"rfw{K}{N}", (N, K), 1.0 / math.sqrt(K))
+        b = rnd(f"rfb{K}{N}", (N,), 0.2)
+        rw = rnd(f"rfr{K}{N}", (B, H, W, N + (16 if sliced else 0))).cuda()
+        res = (rw[..., 16:] if sliced else rw) if with_res else None
+        cv = ops.Conv(w.cuda().contiguous(), b.cuda(), 1, 1, K, N)
+        with ops.profile() as rec:
+            y = ops.conv(x, cv, act=act, res=res)
+        assert [r[1].get("rp") for r in rec.rows] == [1], rec.rows
+        ref = x.cpu().reshape(-1, K).double() @ w.double().T + b.double()
+        if act == 1:
+            ref = torch.relu(ref)
+        elif act == 4:
+            ref = F.gelu(ref)
+        if res is not None:
+            ref = ref + res.cpu().reshape(-1, N).double()
+        assert maxabs(y.cpu().reshape(-1, N), ref.float()) < 2e-5 * max(1.0, float(ref.abs().max()))
+        ops.GEMM_RP = 0
+        try:
+            y0 = ops.conv(x, cv, act=act, res=res)
+        finally:
+            ops.GEMM_RP = 1
+        assert maxabs(y0, y) < 2e-5 * max(1.0, float(ref.abs().max()))
+    finally:
+        ops.GEMM16_RP_MIN_ROWS = rows
+
+
 def test_gemm_nt_batched_heads(ops):
     """attention-shaped batched NT GEMMs incl. d_head = 4 (generic path) and per-row bias."""
     for dh, E in ((32, 256), (4, 32)):
