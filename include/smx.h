@@ -122,6 +122,16 @@ int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream);
  * while every wave keeps its weight fragments in registers; `wp` = the [N/32][K/16][64 lanes][8] fragment-ordered pack built once per
  * layer by smx_gemm_rp_bf16_pack from the [N][ldw >= K] bf16 layout smx_gemm_conv_bf16 takes ((N/32)*(K/16)*512 elements).
  * Replaces smx_gemm_conv_bf16 at the token Linears of the transformer layers (archs/appmotioncodebook_arch.py:69-70,101-115). */
+/* 7x7 / stride 1 heads of the motion estimator on fp32 storage in "bf16x3" arithmetic (csrc/conv7_bf16x3.hip; configs[2] only): every
+ * fp32 operand is split hi + lo (bf16 each) and a product is three bf16 MFMAs (hi hi + hi lo + lo hi), fp32 accumulate: ~2^-17 relative
+ * per product, so keypoints / jacobians / masks keep fp32-grade accuracy at 3/16 of the fp32 pipe's time; region-direct (the input is
+ * staged once per 16-channel slice, not once per tap).  w [N][7][7][Cin] fp32 -> wp by smx_conv7_bf16x3_pack
+ * (smx_conv7_bf16x3_pack_elems bf16 elements); pad 0 (valid: archs/keypoint_detector_arch.py:60-86) or 3 (archs/dense_motion_arch.py:
+ * 118-161); Cin % 4 == 0, N <= 96; y [B][H+2pad-6][W+2pad-6][ldc] fp32. */
+long long smx_conv7_bf16x3_pack_elems(int Cin, int N);
+int smx_conv7_bf16x3_pack(const float* w, void* wp, int Cin, int N, void* stream);
+int smx_conv7_bf16x3_f32(const float* x, int lda, const void* wp, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
+                         int N, int pad, int act, void* stream);
 int smx_gemm_rp_f32_ok(long long M, int N, int K);      /* the fp32 form (csrc/gemm_rp_f32.hip): fp32 MFMA, weights [N/32][K/8][64 lanes][4] */
 int smx_gemm_rp_f32_pack(const float* w, int ldw, float* wp, int N, int K, void* stream);
 int smx_gemm_rp_f32(const float* a, int lda, const float* wp, const float* bias, const float* res, int ldres, float* c, int ldc,

@@ -298,8 +298,10 @@ __global__ __launch_bounds__(512, 1) void attnblock16_kernel(AP<bf16_t> p) {
   constexpr int TK = 32, KROW = DH * 2, VROW = TK * 2, DT = DH / 64, KK = DH / 16;
   constexpr int KTILE = TK * KROW, VTILE = DH * VROW;                     // 16 KB + 16 KB per stage, rows unpadded (the DMA writes 1 KB runs)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ks = smem;                                               // [2][TK][KROW]: 16-B chunk c of key row r at position c ^ (r & 15)
-  unsigned char* Vt = smem + 2 * KTILE;                                   // [2][DH][VROW]: chunk c of row d at position c ^ ((d >> 2) & 3)
+  constexpr int NST = 4;                                                  // stages: tiles t+1 .. t+3 in flight while tile t is multiplied (one block per CU:
+                                                                          // nothing else covers the L2 / HBM round trip of a tile, ~3 tile times)
+  unsigned char* Ks = smem;                                               // [NST][TK][KROW]: 16-B chunk c of key row r at position c ^ (r & 15)
+  unsigned char* Vt = smem + NST * KTILE;                                 // [NST][DH][VROW]: chunk c of row d at position c ^ ((d >> 2) & 3)
   const unsigned lds0 = (unsigned)(uintptr_t)((ab_lds_void*)smem);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -329,19 +331,22 @@ __global__ __launch_bounds__(512, 1) void attnblock16_kernel(AP<bf16_t> p) {
       const int kr = 4 * wave + 2 * i + hh;
       ab_glds16(K + (long long)(key0 + kr) * p.ldk + (((lane & 31) ^ (kr & 15)) << 3), lds0 + (unsigned)(buf * KTILE + (wave * 2 + i) * 1024));
       const int vr = 32 * wave + 16 * i + (lane >> 2);
-      ab_glds16(VT + (long long)vr * p.ldv + key0 + (((lane & 3) ^ ((vr >> 2) & 3)) << 3), lds0 + (unsigned)(2 * KTILE + buf * VTILE + (wave * 2 + i) * 1024));
+      ab_glds16(VT + (long long)vr * p.ldv + key0 + (((lane & 3) ^ ((vr >> 2) & 3)) << 3), lds0 + (unsigned)(NST * KTILE + buf * VTILE + (wave * 2 + i) * 1024));
     }
   };
   const int krow = lane & 31, ksw = krow & 15;
   const int vsw = (krow >> 2) & 3;                                         // rows 32 d + (l & 31): (row >> 2) & 3 does not depend on the d tile
 
   const int ntiles = p.S / TK;
-  issue(0, 0);
+  for (int t = 0; t < NST - 1 && t < ntiles; ++t) issue(t * TK, t);
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < ntiles) issue((t + 1) * TK, buf ^ 1);
+    const int buf = t & (NST - 1);
+    // four DMA instructions per wave and tile, nothing else in flight: tile t has landed once at most the younger tiles' remain
+    if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                       // everyone's part of tile t is there; everyone is past tile t - 1
+    if (t + NST - 1 < ntiles) issue((t + NST - 1) * TK, (t + NST - 1) & (NST - 1));
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -717,7 +722,7 @@ extern "C" int smx_attnblock_bf16(const void* q, int ldq, int64_t q_bs, const vo
   if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldq < d || ldk < d || ldvt < S || ldo < d || q_bs % 8 || k_bs % 8 || vt_bs % 8 || o_bs % 4) return SMX_EINVAL;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)o & 7)) return SMX_EINVAL;
   AP<bf16_t> p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, nullptr, q_bs, k_bs, vt_bs, o_bs, ldq, ldk, ldvt, ldo, 1, L, S, scale};
-  constexpr int LDS = 2 * (32 * 256 * 2 + 256 * 32 * 2);     // 65,536 B
+  constexpr int LDS = 4 * (32 * 256 * 2 + 256 * 32 * 2);     // 4 stages x 32 KB
   static bool attr = false;
   if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)attnblock16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
   SMX_LAUNCH(attnblock16_kernel<256>, dim3(L / 128, B), dim3(512), LDS, (hipStream_t)stream, p);

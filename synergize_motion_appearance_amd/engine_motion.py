@@ -12,11 +12,15 @@ Design points (MI355X-first, not a translation):
   * B driving frames run per launch (the reference loops B=1): the deep hourglass layers are
     weight-bandwidth bound at B=1 (207 MB of fp32 weights per frame).
 """
+import os
+
 import torch
 
 from . import ops
 from .manifest import hourglass_channels
 from .ops import Conv, ACT_RELU
+
+HEADS_X3 = int(os.environ.get("SMX_HEADS_X3", "1"))      # configs[2]: the 7x7 heads in bf16x3 arithmetic on the bf16 MFMA (0 = fp32 implicit GEMM)
 
 
 def _fold_bn(P, pre):
@@ -106,7 +110,8 @@ class KPEngine:
         buf, inp = self.hg.alloc_input(B, r, image_nchw.device)
         ops.antialias_down(image_nchw, self.down, out=inp)
         fm = self.hg.run(buf, B, r)                           # [B,64,64,35 (+1 zero pad)]
-        heads = ops.conv(fm, self.head_conv, pad=(0, 0))      # 7x7 valid -> [B,58,58,76] = [jac 60 | kp 15 | 0]
+        # 7x7 valid -> [B,58,58,76] = [jac 60 | kp 15 | 0]; configs[2]: bf16x3 on the bf16 MFMA (fp32-grade products, region-direct)
+        heads = ops.conv7_x3(fm, self.head_conv, pad=0) if (self.hg.m16 and HEADS_X3) else ops.conv(fm, self.head_conv, pad=(0, 0))
         value, jac = ops.kp_head(heads[..., self.n_jac:self.n_jac + self.num_kp], heads[..., :self.n_jac],
                                  self.num_kp, self.temperature)
         return {"value": value, "jacobian": jac}
@@ -137,7 +142,8 @@ class DenseEngine:
                                          kp_source["value"], kp_source["jacobian"].reshape(kp_source["value"].shape[0], -1, 4),
                                          inp, B, self.num_kp, self.kp_variance)
         pred = self.hg.run(buf, B, r)                         # [B,64,64,128]
-        mlog = ops.conv(pred, self.mo_conv)                   # 7x7 pad 3 -> [B,64,64,17] = [mask 16 | occlusion logit]
+        # 7x7 pad 3 -> [B,64,64,17] = [mask 16 | occlusion logit]
+        mlog = ops.conv7_x3(pred, self.mo_conv, pad=3) if (self.hg.m16 and HEADS_X3) else ops.conv(pred, self.mo_conv)
         deformation, mask, occ = ops.mask_deformation(mlog, sparse, want_mask=want_aux, K1=self.num_kp + 1, fused_occ=True)
         out = {"deformation": deformation, "occlusion_nhwc": occ, "heat_nhwc": heat, "sparse_motion": sparse}
         if want_aux:

@@ -113,7 +113,7 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -123,6 +123,19 @@ class Conv:
         self._w16t = None
         self._w16rp = None
         self._wrp = None
+        self._w7x3 = None
+
+    @property
+    def w7_x3(self):
+        """hi / lo bf16 split of a 7x7 layer in the fragment order of csrc/conv7_bf16x3.hip, built once per layer."""
+        if self._w7x3 is None:
+            n = int(L.load().smx_conv7_bf16x3_pack_elems(self.cin, self.cout))
+            if n <= 0 or self.kh != 7 or self.kw != 7:
+                raise L.SmxError(f"w7_x3: not a 7x7 layer with N <= 96 ({self.kh}x{self.kw}, N {self.cout})")
+            wp = torch.empty(n, device=self.w.device, dtype=BF16)
+            L.check(L.load().smx_conv7_bf16x3_pack(self.w.data_ptr(), wp.data_ptr(), self.cin, self.cout, _stream()), "smx_conv7_bf16x3_pack")
+            self._w7x3 = wp
+        return self._w7x3
 
     @property
     def w_rp(self):
@@ -478,6 +491,19 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
              kh=cv.kh, kw=cv.kw, stride=stride, pad_t=pt, pad_l=pl, up2=int(up2), act=act, alpha=1.0,
              d2s_p=d2s[0] if d2s else 0, d2s_c=d2s[1] if d2s else 0, tile=tile, ksplit=ksplit,
              ws=None if ws is None else ws.data_ptr())
+    return out
+
+
+def conv7_x3(x, cv, pad=3, act=ACT_NONE):
+    """7x7 / stride 1 head on fp32 storage in bf16x3 arithmetic (csrc/conv7_bf16x3.hip): x [B,H,W,Cin] fp32 -> [B,H+2pad-6,W+2pad-6,N] fp32."""
+    B, H, W, Cin = x.shape
+    a_ptr, lda = _pix(x, "conv7 input")
+    out = torch.empty((B, H + 2 * pad - 6, W + 2 * pad - 6, cv.cout), device=x.device, dtype=torch.float32)
+    M = B * out.shape[1] * out.shape[2]
+    meta = {"flops": 2.0 * M * cv.cout * 49 * Cin, "mfma_flops": 6.0 * M * 32 * ((cv.cout + 31) // 32) * 49 * 16 * ((Cin + 15) // 16),
+            "M": M, "N": cv.cout, "K": 49 * Cin, "nb": 1, "k": 7, "bf16": 1} if _PROFILE is not None else None
+    L.check(_timed("conv7_x3", meta, L.load().smx_conv7_bf16x3_f32, a_ptr, lda, cv.w7_x3.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                   out.data_ptr(), cv.cout, B, H, W, Cin, cv.cout, pad, act, _stream()), "smx_conv7_bf16x3_f32")
     return out
 
 

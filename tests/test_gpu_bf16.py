@@ -479,6 +479,27 @@ def test_row_panel_gemm_bf16(ops, B, K, N, act, with_res, sliced):
         ops.GEMM16_RP_MIN_ROWS = rows
 
 
+@pytest.mark.parametrize("B,H,W,Cin,N,pad", [(2, 64, 64, 128, 17, 3), (2, 64, 64, 36, 76, 0), (1, 24, 40, 20, 33, 3), (3, 16, 16, 4, 96, 0)])
+def test_conv7_bf16x3_heads(ops, B, H, W, Cin, N, pad):
+    """csrc/conv7_bf16x3.hip: the 7x7 heads in hi + lo bf16 arithmetic (three bf16 MFMAs per product) against the fp64 convolution --
+    fp32-grade: 2e-5 of the largest output (plain bf16 operands would sit at ~4e-3), and against the fp32 implicit GEMM it replaces."""
+    x = rnd(f"c7x{Cin}{N}", (B, Cin, H, W))
+    w = rnd(f"c7w{Cin}{N}", (N, Cin, 7, 7), 1.0 / math.sqrt(49 * Cin))
+    b = rnd(f"c7b{Cin}{N}", (N,), 0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=pad).float()
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    with ops.profile() as rec:
+        y = ops.conv7_x3(xin, cv, pad=pad)
+    assert [r[0] for r in rec.rows] == ["conv7_x3"] and y.dtype == torch.float32
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxabs(nchw32(y), ref) < 2e-5 * scale, maxabs(nchw32(y), ref)
+    y32 = ops.conv(xin, cv, pad=(pad, pad))
+    assert maxabs(y, y32) < 3e-5 * scale
+    plain = F.conv2d(r16(x).double(), r16(w).double(), b.double(), padding=pad).float()       # what bf16 operands would give
+    assert maxabs(plain, ref) > 20 * maxabs(nchw32(y), ref)
+
+
 def test_attnblock_fused_bf16(ops):
     """engine_netg._Attn on bf16 storage: the core as ONE kernel (smx_attnblock_bf16) against (i) the three-launch form it replaces (QK^T GEMM with
     fp32 scores, softmax_rows, PV GEMM that rounds the probabilities while staging -- the same arithmetic up to summation order) and (ii) the
