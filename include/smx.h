@@ -140,6 +140,10 @@ int smx_gemm_rp_bf16_ok(long long M, int N, int K);
 int smx_gemm_rp_bf16_pack(const void* w, int ldw, void* wp, int N, int K, void* stream);
 int smx_gemm_rp_bf16(const void* a, int lda, const void* wp, const float* bias, const void* res, int ldres, void* c, int ldc,
                      long long M, int N, int K, int act, void* stream);
+/* with the un-patchify (depth-to-space) store of the patch Linears (n = (p1 p + p2) d2s_c + ch -> pixel (oy p + p1, ox p + p2), channel ch;
+ * c is [B][Ho p][Wo p][ldc >= d2s_c], M = B Ho Wo tokens, d2s_c % 16 == 0): smx_gemm_conv_bf16's d2s_p / d2s_c on the row-panel kernel */
+int smx_gemm_rp_d2s_bf16(const void* a, int lda, const void* wp, const float* bias, void* c, int ldc, long long M, int N, int K, int act,
+                         int d2s_p, int d2s_c, int Ho, int Wo, void* stream);
 
 /* Fused Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 convolutions (same call sites as above for
  * the eligible layers: ResBlock / Upsample / SFT / FFN / RefineFlow 3x3 convs): 2.25x fewer MFMA

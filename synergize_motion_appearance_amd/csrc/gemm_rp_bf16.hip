@@ -33,6 +33,7 @@ constexpr int EX_F = 32 * EXP;                 // floats per wave
 struct RP {
   const bf16_t* a; const bf16_t* wp; const float* bias; const bf16_t* res; bf16_t* c;
   int lda, ldres, ldc, M, N, K, act, tiles;
+  int d2s_p, d2s_c, Ho, Wo;                    // un-patchify (depth-to-space) store: n = (p1 * p + p2) * d2s_c + c -> pixel (oy p + p1, ox p + p2), channel c
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -55,7 +56,8 @@ __device__ __forceinline__ float rp_act(float v, int act) {
 }
 
 // KS = K / 16 (8 | 16), NT = 32-column tiles per wave (1 | 2)
-template <int KS, int NT>
+// D2S: the un-patchify store (its own instantiation: the plain form sits at the 256-VGPR edge)
+template <int KS, int NT, bool D2S = false>
 __global__ __launch_bounds__(256, 2) void gemm_rp_bf16_kernel(RP p) {
   constexpr int CPR = KS * 2;                  // 16-B chunks per A row
   constexpr int ROWB = CPR * 16;               // bytes per A row in LDS
@@ -101,6 +103,16 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_bf16_kernel(RP p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[j][e] = p.bias ? p.bias[n0 + 32 * j + 16 * eh + e] : 0.f;
 
+  // un-patchify store: this lane's 16-column runs never straddle a sub-pixel (d2s_c % 16 == 0): resolve (p1, p2, c) once
+  int d_p1[NT], d_p2[NT], d_oc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    d_p1[j] = d_p2[j] = d_oc[j] = 0;
+    if (D2S) {
+      const int nc = n0 + 32 * j + 16 * eh, dq = nc / p.d2s_c;
+      d_oc[j] = nc - dq * p.d2s_c; d_p1[j] = dq / p.d2s_p; d_p2[j] = dq - d_p1[j] * p.d2s_p;
+    }
+  }
   int t = blockIdx.x, it = 0;
   if (t < p.tiles) issue(t, 0);
   for (; t < p.tiles; t += gridDim.x, ++it) {
@@ -124,6 +136,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_bf16_kernel(RP p) {
     }
     // ---- epilogue: per 32 x 32 tile through the wave's own exchange buffer ---------------------------------------------------------
     const long long grow = (long long)t * TM + erow;
+    int d_img = 0, d_oy = 0, d_ox = 0;
+    if (D2S) {
+      const int hw = p.Ho * p.Wo;
+      d_img = (int)(grow / hw); const int rem = (int)(grow - (long long)d_img * hw);
+      d_oy = rem / p.Wo; d_ox = rem - d_oy * p.Wo;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int nc = n0 + 32 * j + 16 * eh;
@@ -154,6 +172,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_bf16_kernel(RP p) {
       }
       const float lo[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}, hi[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
       bf16_t* cp = p.c + grow * p.ldc + nc;
+      if (D2S) {
+        const long long opix = ((long long)d_img * (p.Ho * p.d2s_p) + d_oy * p.d2s_p + d_p1[j]) * (p.Wo * p.d2s_p) + d_ox * p.d2s_p + d_p2[j];
+        cp = p.c + opix * p.ldc + d_oc[j];
+      }
       *reinterpret_cast<uint4*>(cp) = pack8(lo);
       *reinterpret_cast<uint4*>(cp + 8) = pack8(hi);
     }
@@ -173,14 +195,14 @@ __global__ __launch_bounds__(256) void gemm_rp_pack_kernel(const bf16_t* __restr
   }
 }
 
-template <int KS, int NT>
+template <int KS, int NT, bool D2S = false>
 int rp_launch(const RP& p, hipStream_t st) {
   constexpr int LDS = 2 * TM * KS * 32 + 4 * EX_F * 4;
   static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)gemm_rp_bf16_kernel<KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)gemm_rp_bf16_kernel<KS, NT, D2S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
   const int ny = p.N / (128 * NT);
   int gx = 512 / ny; if (gx < 1) gx = 1; if (gx > p.tiles) gx = p.tiles;
-  SMX_LAUNCH((gemm_rp_bf16_kernel<KS, NT>), dim3(gx, ny), dim3(256), LDS, st, p);
+  SMX_LAUNCH((gemm_rp_bf16_kernel<KS, NT, D2S>), dim3(gx, ny), dim3(256), LDS, st, p);
   return smx_launch_status();
 }
 
@@ -198,17 +220,37 @@ extern "C" int smx_gemm_rp_bf16_pack(const void* w, int ldw, void* wp, int N, in
   return smx_launch_status();
 }
 
-extern "C" int smx_gemm_rp_bf16(const void* a, int lda, const void* wp, const float* bias, const void* res, int ldres, void* c, int ldc,
-                                long long M, int N, int K, int act, void* stream) {
+static int rp_bf16_launch(const void* a, int lda, const void* wp, const float* bias, const void* res, int ldres, void* c, int ldc,
+                          long long M, int N, int K, int act, int d2s_p, int d2s_c, int Ho, int Wo, void* stream) {
   if (!a || !wp || !c || !smx_gemm_rp_bf16_ok(M, N, K)) return SMX_EINVAL;
-  if (lda < K || lda % 8 || ldc < N || ldc % 8 || (res && (ldres < N || ldres % 8))) return SMX_EINVAL;
+  if (d2s_p) {
+    if (d2s_p < 1 || d2s_c <= 0 || d2s_c % 16 || N != d2s_p * d2s_p * d2s_c || ldc < d2s_c || ldc % 8 || res || Ho <= 0 || Wo <= 0 || M % ((long long)Ho * Wo)) return SMX_EINVAL;
+  } else if (ldc < N) return SMX_EINVAL;
+  if (lda < K || lda % 8 || ldc % 8 || (res && (ldres < N || ldres % 8))) return SMX_EINVAL;
   if (((uintptr_t)a | (uintptr_t)wp | (uintptr_t)c | (uintptr_t)res) & 15) return SMX_EINVAL;
   if ((long long)TM * lda > 2147483647LL) return SMX_EINVAL;
   RP p;
   p.a = (const bf16_t*)a; p.wp = (const bf16_t*)wp; p.bias = bias; p.res = (const bf16_t*)res; p.c = (bf16_t*)c;
   p.lda = lda; p.ldres = res ? ldres : 0; p.ldc = ldc; p.M = (int)M; p.N = N; p.K = K; p.act = act; p.tiles = (int)(M / TM);
+  p.d2s_p = d2s_p; p.d2s_c = d2s_c; p.Ho = Ho; p.Wo = Wo;
   hipStream_t st = (hipStream_t)stream;
   const bool two = N % 256 == 0;
+  if (d2s_p) {                                 // one 32-column tile per wave: room for the store's coordinates
+    if (K == 256) return rp_launch<16, 1, true>(p, st);
+    return rp_launch<8, 1, true>(p, st);
+  }
   if (K == 256) return two ? rp_launch<16, 2>(p, st) : rp_launch<16, 1>(p, st);
   return two ? rp_launch<8, 2>(p, st) : rp_launch<8, 1>(p, st);
+}
+
+extern "C" int smx_gemm_rp_bf16(const void* a, int lda, const void* wp, const float* bias, const void* res, int ldres, void* c, int ldc,
+                                long long M, int N, int K, int act, void* stream) {
+  return rp_bf16_launch(a, lda, wp, bias, res, ldres, c, ldc, M, N, K, act, 0, 0, 0, 0, stream);
+}
+
+/* the same with the un-patchify (depth-to-space) store of the patch Linears: c is [B][Ho p][Wo p][ldc >= d2s_c], M = B * Ho * Wo tokens */
+extern "C" int smx_gemm_rp_d2s_bf16(const void* a, int lda, const void* wp, const float* bias, void* c, int ldc, long long M, int N, int K, int act,
+                                    int d2s_p, int d2s_c, int Ho, int Wo, void* stream) {
+  if (d2s_p < 1) return SMX_EINVAL;
+  return rp_bf16_launch(a, lda, wp, bias, nullptr, 0, c, ldc, M, N, K, act, d2s_p, d2s_c, Ho, Wo, stream);
 }

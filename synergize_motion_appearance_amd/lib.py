@@ -116,6 +116,7 @@ SIGNATURES = {
     "smx_gemm_rp_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
     "smx_gemm_rp_bf16_ok": (_i, [_i64, _i, _i]),
     "smx_gemm_rp_bf16_pack": (_i, [_p, _i, _p, _i, _i, _p]),
+    "smx_gemm_rp_d2s_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_gemm_rp_bf16": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
     "smx_conv3x3_mfma16_f32": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i] + [_i] * 8 + [_p]),
     "smx_groupnorm_swish_nhwc_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),

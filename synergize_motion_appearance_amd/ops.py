@@ -358,6 +358,13 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
         L.check(_timed("gemm_bf16", meta, L.load().smx_gemm_rp_bf16, a_ptr, lda, cv.w16_rp.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
                        r_ptr, ldr, c_ptr, ldc, M, cv.cout, K, act, _stream()), "smx_gemm_rp_bf16")
         return out
+    if (GEMM16_RP and d2s and tile == 0 and x.dtype == BF16 and out.dtype == BF16 and cv.kh == 1 and cv.kw == 1 and stride == 1 and (pt, pl) == (0, 0)
+            and not up2 and in_ss is None and res is None and (Ho, Wo) == (H, W) and M >= GEMM16_RP_MIN_ROWS and d2s[1] % 16 == 0
+            and L.load().smx_gemm_rp_bf16_ok(M, cv.cout, K) and lda % 8 == 0 and ldc % 8 == 0 and a_ptr % 16 == 0 and c_ptr % 16 == 0):
+        meta = {"flops": 2.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "bf16": 1, "rp": 1} if _PROFILE is not None else None
+        L.check(_timed("gemm_bf16", meta, L.load().smx_gemm_rp_d2s_bf16, a_ptr, lda, cv.w16_rp.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       c_ptr, ldc, M, cv.cout, K, act, d2s[0], d2s[1], Ho, Wo, _stream()), "smx_gemm_rp_d2s_bf16")
+        return out
     ksplit, ws = 1, None
     if not d2s and K >= 2048:
         blocks = ((M + 63) // 64) * ((cv.cout + 63) // 64)

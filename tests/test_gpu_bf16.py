@@ -479,6 +479,30 @@ def test_row_panel_gemm_bf16(ops, B, K, N, act, with_res, sliced):
         ops.GEMM16_RP_MIN_ROWS = rows
 
 
+def test_row_panel_gemm_bf16_unpatchify_store(ops):
+    """the row-panel kernel with the un-patchify (depth-to-space) store of the patch Linears == the implicit GEMM's d2s store, bit for bit
+    up to summation order (same operands, same single rounding)."""
+    rows = ops.GEMM16_RP_MIN_ROWS
+    ops.GEMM16_RP_MIN_ROWS = 1024
+    try:
+        for (p_, C_, B) in ((8, 64, 3), (4, 128, 2), (2, 64, 5)):
+            N, K = p_ * p_ * C_, 256
+            x = r16(rnd(f"d2x{p_}", (B, 32, 32, K))).cuda().to(BF)
+            cv = ops.Conv(rnd(f"d2w{p_}", (N, K), 1.0 / math.sqrt(K)).cuda().contiguous(), rnd(f"d2b{p_}", (N,), 0.2).cuda(), 1, 1, K, N)
+            with ops.profile() as rec:
+                y = ops.conv(x, cv, d2s=(p_, C_))
+            assert [r[1].get("rp") for r in rec.rows] == [1] and tuple(y.shape) == (B, 32 * p_, 32 * p_, C_)
+            ops.GEMM16_RP = 0
+            try:
+                y0 = ops.conv(x, cv, d2s=(p_, C_))
+            finally:
+                ops.GEMM16_RP = 1
+            assert float((y0.float() - y.float()).abs().max()) <= 2.0 ** -7 * float(y0.float().abs().max())
+            assert float((y0.float() - y.float()).abs().mean()) < 1e-3 * float(y0.float().abs().mean())
+    finally:
+        ops.GEMM16_RP_MIN_ROWS = rows
+
+
 @pytest.mark.parametrize("B,H,W,Cin,N,pad", [(2, 64, 64, 128, 17, 3), (2, 64, 64, 36, 76, 0), (1, 24, 40, 20, 33, 3), (3, 16, 16, 4, 96, 0)])
 def test_conv7_bf16x3_heads(ops, B, H, W, Cin, N, pad):
     """csrc/conv7_bf16x3.hip: the 7x7 heads in hi + lo bf16 arithmetic (three bf16 MFMAs per product) against the fp64 convolution --
