@@ -251,9 +251,30 @@ CONV16_TILE_H = int(_os.environ.get("SMX_CONV16_TILE_H", "0"))      # 0 = auto, 
 CONV16_F32_REGION = int(_os.environ.get("SMX_CONV16_F32_REGION", "1"))   # fp32-storage form of the region kernel (bf16-compute training); 0 = implicit GEMM
 
 
-GEMM_RP = int(_os.environ.get("SMX_GEMM_RP", "1"))                   # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
-GEMM16_RP = int(_os.environ.get("SMX_GEMM16_RP", "1"))               # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
+# SMX_SHARED_DEVICE=1: this process shares its GPU with another process of the job (the two-ranks-on-one-device test harness; never a
+# deployment: one process per GPU).  The persistent row-panel kernels are switched off there: with two torch.distributed ranks on ONE
+# MI355X the bf16 pipeline produced rare wrong frames in its first pass (bit-exact again when re-run in the same process; never seen
+# with one process per GPU, in 3000-iteration two-process stress runs of the kernel alone, or with the kernel's DMA fully serialised) --
+# unexplained, DESIGN section 6 "open issue".
+_SHARED_DEVICE = bool(int(_os.environ.get("SMX_SHARED_DEVICE", "0")))
+GEMM_RP = int(_os.environ.get("SMX_GEMM_RP", "1")) and not _SHARED_DEVICE      # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
+GEMM16_RP = int(_os.environ.get("SMX_GEMM16_RP", "1")) and not _SHARED_DEVICE  # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
 GEMM16_RP_MIN_ROWS = 16384                                           # below: too few 32-row tiles to fill the persistent blocks (tests lower it)
+
+
+_RP_DEBUG = int(_os.environ.get("SMX_RP_DEBUG", "0"))
+
+
+def _rp_debug_ok(x, out, res, lda, ldc, K, N):
+    if _RP_DEBUG & 1 and (lda != K or ldc != N):
+        return False
+    if _RP_DEBUG & 2 and res is not None:
+        return False
+    if _RP_DEBUG & 4 and x.shape[0] == 1:
+        return False
+    if _RP_DEBUG & 8 and x.shape[0] != 1:
+        return False
+    return True
 
 
 def _rows_dense(t):
@@ -352,7 +373,7 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
             and not up2 and not d2s and in_ss is None and (Ho, Wo) == (H, W) and (res is None or res.dtype == BF16) and M >= GEMM16_RP_MIN_ROWS
             and cv.w is not None and L.load().smx_gemm_rp_bf16_ok(M, cv.cout, K) and lda % 8 == 0 and ldc % 8 == 0 and a_ptr % 16 == 0
             and c_ptr % 16 == 0 and (res is None or (ldr % 8 == 0 and r_ptr % 16 == 0)) and _rows_dense(x) and _rows_dense(out)
-            and (res is None or _rows_dense(res))):
+            and (res is None or _rows_dense(res)) and _rp_debug_ok(x, out, res, lda, ldc, K, cv.cout)):
         # short-K token Linears: persistent row-panel kernel (weights in registers, rows by LDS-DMA)
         meta = {"flops": 2.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "bf16": 1, "rp": 1} if _PROFILE is not None else None
         L.check(_timed("gemm_bf16", meta, L.load().smx_gemm_rp_bf16, a_ptr, lda, cv.w16_rp.data_ptr(), None if cv.b is None else cv.b.data_ptr(),

@@ -32,7 +32,7 @@ def variant(name):
 
 
 def family(name):
-    for key, fam in (("winograd_", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("conv3x3_bf16", "conv3x3_bf16"), ("conv3x3_t32", "conv3x3_bf16"), ("attn_", "attention"),
+    for key, fam in (("winograd_", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("gemm_rp_bf16_kernel", "gemm_bf16"), ("gemm_rp_f32_kernel", "gemm_conv"), ("conv7_bf16x3", "conv7_x3"), ("attnblock16", "attnblock"), ("conv3x3_bf16", "conv3x3_bf16"), ("conv3x3_t32", "conv3x3_bf16"), ("attn_", "attention"),
                      ("warp_", "warp"), ("gn_", "groupnorm"), ("layernorm", "layernorm")):
         if key in name:
             return fam
