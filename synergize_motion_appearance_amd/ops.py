@@ -252,10 +252,11 @@ CONV16_F32_REGION = int(_os.environ.get("SMX_CONV16_F32_REGION", "1"))   # fp32-
 
 
 # SMX_SHARED_DEVICE=1: this process shares its GPU with another process of the job (the two-ranks-on-one-device test harness; never a
-# deployment: one process per GPU).  The persistent row-panel kernels are switched off there: with two torch.distributed ranks on ONE
-# MI355X the bf16 pipeline produced rare wrong frames in its first pass (bit-exact again when re-run in the same process; never seen
-# with one process per GPU, in 3000-iteration two-process stress runs of the kernel alone, or with the kernel's DMA fully serialised) --
-# unexplained, DESIGN section 6 "open issue".
+# deployment: one process per GPU).  The inference kernels that stage through LDS-DMA (row-panel GEMMs, bf16x3 7x7 heads, fused
+# AttnBlock, 16x32-tile 3x3) are switched off there: with two torch.distributed ranks on ONE MI355X the bf16 pipeline produced wrong
+# frames in ~30 % of first passes (bit-exact again when re-run in the same process; never seen with one process per GPU, in
+# 3000-iteration two-process stress runs of a kernel alone, or with the kernel's DMA fully serialised) -- unexplained, DESIGN
+# section 6 "open issue".
 _SHARED_DEVICE = bool(int(_os.environ.get("SMX_SHARED_DEVICE", "0")))
 GEMM_RP = int(_os.environ.get("SMX_GEMM_RP", "1")) and not _SHARED_DEVICE      # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
 GEMM16_RP = int(_os.environ.get("SMX_GEMM16_RP", "1")) and not _SHARED_DEVICE  # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
@@ -288,7 +289,7 @@ def _rows_dense(t):
     return True
 
 
-CONV16_T32 = int(_os.environ.get("SMX_CONV16_T32", "1"))           # 16x32-tile kernel (csrc/conv3x3_bf16_t32.hip) for the big launches; 0 = off
+CONV16_T32 = int(_os.environ.get("SMX_CONV16_T32", "1")) and not _SHARED_DEVICE           # 16x32-tile kernel (csrc/conv3x3_bf16_t32.hip) for the big launches; 0 = off
 CONV16_T32_MIN_BLOCKS = 1024                                         # two resident rounds of the chip's 512 block slots; tests lower it
 
 
