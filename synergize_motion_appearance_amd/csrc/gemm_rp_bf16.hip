@@ -34,7 +34,6 @@ constexpr int EX_F = 32 * EXP;                 // floats per wave
 struct RP {
   const bf16_t* a; const bf16_t* wp; const float* bias; const bf16_t* res; bf16_t* c;
   int lda, ldres, ldc, M, N, K, act, tiles;
-  int dbg;                                     // debug bits (SMX_RP_KDEBUG): 1 = no prefetch overlap, 2 = barrier at the end of a tile
   int d2s_p, d2s_c, Ho, Wo;                    // un-patchify (depth-to-space) store: n = (p1 * p + p2) * d2s_c + c -> pixel (oy p + p1, ox p + p2), channel c
 };
 
@@ -121,9 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_bf16_kernel(RP p) {
     const int buf = it & 1;
     mem_drain();                               // this wave's part of tile t has landed (and its stores of the previous tile are out)
     __syncthreads();                           // everyone's has; everyone is past its reads of the other buffer
-    if (p.dbg & 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }
-    if (!(p.dbg & 1) && t + (int)gridDim.x < p.tiles) issue(t + gridDim.x, buf ^ 1);
-    if (p.dbg & 8) { __builtin_amdgcn_s_sleep(20); __syncthreads(); }
+    if (t + (int)gridDim.x < p.tiles) issue(t + gridDim.x, buf ^ 1);
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -183,8 +180,6 @@ __global__ __launch_bounds__(256, 2) void gemm_rp_bf16_kernel(RP p) {
       *reinterpret_cast<uint4*>(cp) = pack8(lo);
       *reinterpret_cast<uint4*>(cp + 8) = pack8(hi);
     }
-    if (p.dbg & 2) __syncthreads();
-    if ((p.dbg & 1) && t + (int)gridDim.x < p.tiles) { __syncthreads(); issue(t + gridDim.x, buf ^ 1); }
   }
 }
 
@@ -239,7 +234,6 @@ static int rp_bf16_launch(const void* a, int lda, const void* wp, const float* b
   p.a = (const bf16_t*)a; p.wp = (const bf16_t*)wp; p.bias = bias; p.res = (const bf16_t*)res; p.c = (bf16_t*)c;
   p.lda = lda; p.ldres = res ? ldres : 0; p.ldc = ldc; p.M = (int)M; p.N = N; p.K = K; p.act = act; p.tiles = (int)(M / TM);
   p.d2s_p = d2s_p; p.d2s_c = d2s_c; p.Ho = Ho; p.Wo = Wo;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SMX_RP_KDEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   hipStream_t st = (hipStream_t)stream;
   const bool two = N % 256 == 0;
   if (d2s_p) {                                 // one 32-column tile per wave: room for the store's coordinates

@@ -477,6 +477,45 @@ __global__ __launch_bounds__(256) void pack_winograd_u_kernel(const float* __res
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) pack_winograd_u_elem(w, u, i, Cout, Cin, mode);
 }
 
+// The same values by (n, c) GROUP: one thread loads the nine weights once and forms one frequency ROW (4 of the 16 outputs) from them, with the
+// per-element function's own expression and order of additions (bit-identical).  The per-element form re-read the nine weights for each
+// of the 16 outputs: 250 M elements x 9 strided loads per fp32 training step.  Block b of an item covers groups [64 b, 64 b + 64); the
+// block behind the last group writes the 1024 zeros of the prefetch pad.
+__device__ __forceinline__ void pack_winograd_u_group(const float* __restrict__ w, float* __restrict__ u, long long g, int fi, int Cout, int Cin, int mode) {
+  const int N = mode ? Cin : Cout, Cc = mode ? Cout : Cin;
+  const int n32 = (N + 31) / 32, c8 = Cc / 8;
+  const long long plane = (long long)n32 * 32 * Cc;
+  if (g >= plane) {                                       // pad: 64 groups x 16 zeros
+    const long long o = 16 * plane + (g - plane) * 16 + 4 * fi;
+    if (g - plane < 64) { u[o] = 0.f; u[o + 1] = 0.f; u[o + 2] = 0.f; u[o + 3] = 0.f; }
+    return;
+  }
+  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  long long t = g;
+  const int e = (int)(t & 3); t >>= 2; const int r = (int)(t & 31); t >>= 5; const int hh = (int)(t & 1); t >>= 1;
+  const int s = (int)(t % c8); const int nt = (int)(t / c8);
+  const int n = nt * 32 + r, c = 8 * s + 4 * hh + e;
+  float gw[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      gw[a][b] = (n < N) ? (mode ? w[((long long)c * Cin + n) * 9 + (2 - a) * 3 + (2 - b)] : w[((long long)n * Cin + c) * 9 + a * 3 + b]) : 0.f;
+#pragma unroll
+  for (int fj = 0; fj < 4; ++fj) {
+    float out = 0.f;
+    if (n < N) {
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc += G[fi][a] * (double)gw[a][b] * G[fj][b];
+      out = (float)acc;
+    }
+    u[(long long)(4 * fi + fj) * plane + g] = out;
+  }
+}
+
 // every packing of a step in ONE launch: a table of items (sorted by first_block), block b works on the item whose block range holds it,
 // 1024 output elements per block.  The per-layer launches were ~660 per training step at 6-11 us each, most of it launch latency.
 __global__ __launch_bounds__(256) void pack_batch_kernel(const smx_pack_item* __restrict__ items, int n) {
@@ -484,6 +523,10 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const smx_pack_item* __
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
   const smx_pack_item it = items[lo];
   const long long base = (long long)((int)blockIdx.x - it.first_block) * 1024;
+  if (it.kind == SMX_PACK_WINOGRAD_U) {                   // 1024 outputs per block = 64 (n, c) groups x 16 frequencies: 4 threads per group
+    pack_winograd_u_group(it.w, (float*)it.out, (base >> 4) + (threadIdx.x >> 2), threadIdx.x & 3, it.cout, it.cin, it.mode);
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const long long i = base + e * 256 + threadIdx.x;

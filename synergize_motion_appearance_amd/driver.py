@@ -172,14 +172,8 @@ def broadcast_source_states(net_g, motion_estimator, owned, owners, adapt_moveme
     img = _img_size(net_g)
     pending = [(j,) + broadcast_flat(flats.get(j), device, owner, group, adt, async_op=True, img_size=img) for j, owner in sorted(owners.items())]
     out = {}
-    import os
-    dbg = int(os.environ.get("SMX_STATE_DEBUG", "0"))
     for j, buf, work in pending:
         work.wait()
-        if dbg & 2:
-            torch.cuda.synchronize()
-        if dbg & 1:
-            buf = buf.clone()
         out[j] = unpack_source_state(buf, adt, img)
     return out
 

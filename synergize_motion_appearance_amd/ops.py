@@ -257,25 +257,10 @@ CONV16_F32_REGION = int(_os.environ.get("SMX_CONV16_F32_REGION", "1"))   # fp32-
 # frames in ~30 % of first passes (bit-exact again when re-run in the same process; never seen with one process per GPU, in
 # 3000-iteration two-process stress runs of a kernel alone, or with the kernel's DMA fully serialised) -- unexplained, DESIGN
 # section 6 "open issue".
-_SHARED_DEVICE = bool(int(_os.environ.get("SMX_SHARED_DEVICE", "0")))
+_SHARED_DEVICE = bool(int(_os.environ.get("SMX_SHARED_DEVICE", "0"))) and not int(_os.environ.get("SMX_FORCE_LDSDMA", "0"))   # FORCE: tools/bisect_cons.sh
 GEMM_RP = int(_os.environ.get("SMX_GEMM_RP", "1")) and not _SHARED_DEVICE      # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
 GEMM16_RP = int(_os.environ.get("SMX_GEMM16_RP", "1")) and not _SHARED_DEVICE  # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
 GEMM16_RP_MIN_ROWS = 16384                                           # below: too few 32-row tiles to fill the persistent blocks (tests lower it)
-
-
-_RP_DEBUG = int(_os.environ.get("SMX_RP_DEBUG", "0"))
-
-
-def _rp_debug_ok(x, out, res, lda, ldc, K, N):
-    if _RP_DEBUG & 1 and (lda != K or ldc != N):
-        return False
-    if _RP_DEBUG & 2 and res is not None:
-        return False
-    if _RP_DEBUG & 4 and x.shape[0] == 1:
-        return False
-    if _RP_DEBUG & 8 and x.shape[0] != 1:
-        return False
-    return True
 
 
 def _rows_dense(t):
@@ -374,7 +359,7 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
             and not up2 and not d2s and in_ss is None and (Ho, Wo) == (H, W) and (res is None or res.dtype == BF16) and M >= GEMM16_RP_MIN_ROWS
             and cv.w is not None and L.load().smx_gemm_rp_bf16_ok(M, cv.cout, K) and lda % 8 == 0 and ldc % 8 == 0 and a_ptr % 16 == 0
             and c_ptr % 16 == 0 and (res is None or (ldr % 8 == 0 and r_ptr % 16 == 0)) and _rows_dense(x) and _rows_dense(out)
-            and (res is None or _rows_dense(res)) and _rp_debug_ok(x, out, res, lda, ldc, K, cv.cout)):
+            and (res is None or _rows_dense(res))):
         # short-K token Linears: persistent row-panel kernel (weights in registers, rows by LDS-DMA)
         meta = {"flops": 2.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "bf16": 1, "rp": 1} if _PROFILE is not None else None
         L.check(_timed("gemm_bf16", meta, L.load().smx_gemm_rp_bf16, a_ptr, lda, cv.w16_rp.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
