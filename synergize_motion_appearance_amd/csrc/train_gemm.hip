@@ -477,6 +477,30 @@ __global__ __launch_bounds__(256) void pack_winograd_u_kernel(const float* __res
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) pack_winograd_u_elem(w, u, i, Cout, Cin, mode);
 }
 
+// 3x3 weights by (row, column) PAIR of the OIHW parameter: one thread reads the pair's nine taps (36 contiguous bytes; a wave reads one
+// contiguous run in mode 0) and writes nine outputs, each coalesced across the wave -- the per-element form issued nine strided 4-byte
+// loads per pair.  Same values, same destinations as pack_weight_elem.
+template <typename TO>
+__device__ __forceinline__ void pack_weight_pair9(const float* __restrict__ w, TO* __restrict__ o, long long g, int Cout, int Cin, int mode) {
+  // mode 0: g = co * Cin + ci (output [co][tap][ci]);  mode 1: g = ci * Cout + co (output [ci][flipped tap][co])
+  int co, ci;
+  if (mode == 0) { co = (int)(g / Cin); ci = (int)(g - (long long)co * Cin); }
+  else { ci = (int)(g / Cout); co = (int)(g - (long long)ci * Cout); }
+  const float* src = w + ((long long)co * Cin + ci) * 9;
+  float v[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) v[t] = src[t];
+  if (mode == 0) {
+    TO* dst = o + (long long)co * 9 * Cin + ci;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) St<TO>::st(dst + (long long)t * Cin, v[t]);
+  } else {
+    TO* dst = o + (long long)ci * 9 * Cout + co;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) St<TO>::st(dst + (long long)t * Cout, v[8 - t]);     // tap t reads (ky, kx) = (2 - t / 3, 2 - t % 3) = source tap 8 - t
+  }
+}
+
 // The same values by (n, c) GROUP: one thread loads the nine weights once and forms one frequency ROW (4 of the 16 outputs) from them, with the
 // per-element function's own expression and order of additions (bit-identical).  The per-element form re-read the nine weights for each
 // of the 16 outputs: 250 M elements x 9 strided loads per fp32 training step.  Block b of an item covers groups [64 b, 64 b + 64); the
@@ -523,6 +547,14 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const smx_pack_item* __
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
   const smx_pack_item it = items[lo];
   const long long base = (long long)((int)blockIdx.x - it.first_block) * 1024;
+  if (it.kind != SMX_PACK_WINOGRAD_U && it.kh == 3 && it.kw == 3) {     // 3x3: one thread per (co, ci) pair; the item's first total / 9 threads work
+    const long long g = (base >> 2) + threadIdx.x;        // block b of the item = threads [256 b, 256 b + 256)
+    if (g < it.total / 9) {
+      if (it.kind == SMX_PACK_F32) pack_weight_pair9<float>(it.w, (float*)it.out, g, it.cout, it.cin, it.mode);
+      else pack_weight_pair9<bf16_t>(it.w, (bf16_t*)it.out, g, it.cout, it.cin, it.mode);
+    }
+    return;
+  }
   if (it.kind == SMX_PACK_WINOGRAD_U) {                   // 1024 outputs per block = 64 (n, c) groups x 16 frequencies: 4 threads per group
     pack_winograd_u_group(it.w, (float*)it.out, (base >> 4) + (threadIdx.x >> 2), threadIdx.x & 3, it.cout, it.cin, it.mode);
     return;
