@@ -475,3 +475,62 @@ def test_t32_kernel_isa_keeps_its_hands_off_registers_with_requests_in_flight():
     assert kernels == 1 and loops == 2, (kernels, loops)            # one shipped instantiation; one register-staged K loop per GroupNorm loader mode (GN / GN + swish;
     assert requests == claims and requests >= 30, (requests, claims)   # without a loader the region goes by LDS-DMA and no register is ever in flight)
     assert not bad, bad[:5]
+
+
+def test_wgrad_split_and_reduce_items_host_side():
+    """the host halves of the training step's weight-gradient plumbing run without a GPU: smx_wgrad_conv_ws_floats picks the region kernel's
+    pixel split for 3x3 / s1 / p1 layers with 64-multiple channels and 32-multiple widths (and the generic split otherwise), and
+    smx_wgrad_reduce_describe fills the smx_reduce_item the deferred batch launch consumes (train_ops.ReducePlan.ITEM mirrors the C struct)."""
+    import ctypes as C
+    import numpy as np
+    from synergize_motion_appearance_amd import lib as L
+    from synergize_motion_appearance_amd.train_ops import ReducePlan
+    so = ctypes.CDLL(L.LIB_PATH)
+    for name in ("smx_wgrad_conv_ws_floats", "smx_wgrad_ws_floats", "smx_wgrad_reduce_describe"):
+        fn = getattr(so, name)
+        fn.restype, fn.argtypes = L.SIGNATURES[name]
+    ms_r, ms_g = C.c_int(0), C.c_int(0)
+    M = 4 * 256 * 256
+    n_r = so.smx_wgrad_conv_ws_floats(1, M, 64, 64, 256, 256, 256, 256, 3, 3, 1, 1, 1, 0, C.byref(ms_r))
+    n_g = so.smx_wgrad_ws_floats(1, M, 64, 9 * 64, C.byref(ms_g))
+    assert ms_r.value == 256 and ms_g.value == 113                      # one block per CU for the region form; 1024 / 9 tiles for the GEMM form
+    assert n_r == ms_r.value * (64 * 576 + 64) and n_g == ms_g.value * (64 * 576 + 64)
+    ms2 = C.c_int(0)                                                    # 7x7, odd channels, stride 2: the generic split
+    assert so.smx_wgrad_conv_ws_floats(1, 2 * 64 * 64, 76, 36, 64, 64, 58, 58, 7, 7, 1, 0, 0, 0, C.byref(ms2)) == \
+        so.smx_wgrad_ws_floats(1, 2 * 64 * 64, 76, 49 * 36, C.byref(ms_g)) and ms2.value == ms_g.value
+    assert ReducePlan.ITEM.itemsize == 80
+    rec = np.zeros(1, dtype=ReducePlan.ITEM)
+    ws, out, bias = 0x7f0000000000, 0x7f1000000000, 0x7f2000000000      # 16-byte-aligned fake device addresses: nothing is dereferenced
+    assert so.smx_wgrad_reduce_describe(ws, 256, out, 64, 64, 3, 3, 0, 0, 1, 0.5, bias, rec.ctypes.data) == 0
+    r = rec[0]
+    assert (int(r["ws"]), int(r["out"]), int(r["bias_out"])) == (ws, out, bias) and int(r["bias_ws"]) == ws + 4 * 256 * 64 * 576
+    assert (int(r["msplit"]), int(r["Cout"]), int(r["K"]), int(r["Cin"]), int(r["khw"]), int(r["accumulate"])) == (256, 64, 576, 64, 9, 1)
+    assert int(r["kind"]) == 2 and int(r["nblocks"]) == 64 * 576 * 8 // 256 and abs(float(r["alpha"]) - 0.5) < 1e-7    # many splits, small layer: 32 split groups
+    assert so.smx_wgrad_reduce_describe(ws, 4, out, 512, 512, 3, 3, 0, 0, 1, 1.0, None, rec.ctypes.data) == 0
+    assert int(rec[0]["kind"]) == 1 and int(rec[0]["bias_ws"]) == 0
+    assert so.smx_wgrad_reduce_describe(0, 4, out, 512, 512, 3, 3, 0, 0, 1, 1.0, None, rec.ctypes.data) != 0           # null workspace
+
+
+def test_round4_kernel_eligibility_rules_host_side():
+    """shape rules the Python dispatch relies on, straight from the library (no GPU): the row-panel GEMMs take K = 128 / 256, N % 128 == 0,
+    M % 32 == 0; the bf16x3 7x7 pack size; the shared-device switch of ops.py turns every LDS-DMA inference kernel off."""
+    import subprocess
+    import sys
+    from synergize_motion_appearance_amd import lib as L
+    so = ctypes.CDLL(L.LIB_PATH)
+    for name in ("smx_gemm_rp_bf16_ok", "smx_gemm_rp_f32_ok", "smx_conv7_bf16x3_pack_elems"):
+        fn = getattr(so, name)
+        fn.restype, fn.argtypes = L.SIGNATURES[name]
+    for ok in (so.smx_gemm_rp_bf16_ok, so.smx_gemm_rp_f32_ok):
+        assert ok(307200, 256, 256) == 1 and ok(307200, 512, 128) == 1 and ok(19660800, 128, 128) == 1
+        assert ok(307200, 192, 256) == 0 and ok(307200, 256, 64) == 0 and ok(307200, 256, 192) == 0 and ok(1000, 256, 256) == 0 and ok(0, 256, 256) == 0
+    assert so.smx_conv7_bf16x3_pack_elems(128, 17) == 8 * 49 * 1 * 2 * 512 and so.smx_conv7_bf16x3_pack_elems(36, 76) == 3 * 49 * 3 * 2 * 512
+    assert so.smx_conv7_bf16x3_pack_elems(128, 97) == -1
+    code = ("import os; os.environ['SMX_SHARED_DEVICE'] = '1'\n"
+            "from synergize_motion_appearance_amd import ops, engine_motion, engine_netg\n"
+            "assert not (ops.GEMM16_RP or ops.GEMM_RP or ops.CONV16_T32 or engine_motion.HEADS_X3 or engine_netg.ATTNBLOCK_FUSED16)\n"
+            "print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    from synergize_motion_appearance_amd import ops
+    assert ops.GEMM16_RP and ops.GEMM_RP and ops.CONV16_T32                 # the default path keeps them
