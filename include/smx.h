@@ -405,7 +405,14 @@ int smx_resize_bilinear_ac_nhwc_bf16(const void* x, int ldx, void* y, int ldy, i
 int smx_resize_taps_gather_bf16(const void* x, int ldx, void* taps, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream);
 int smx_resize_taps_combine_bf16(const void* taps, void* y, int ldy, int B, int Hin, int Win, int Hout, int Wout, int C, void* stream);
 int smx_conv3x3_smalln_bf16(const void* x, int lda, const float* w, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
-                            int Cout, int act, const float* in_ss, int in_swish, void* stream);   /* fp32 weights / bias / output */
+                            int Cout, int act, const float* in_ss, int in_swish, void* stream);
+/* the same layers (C_out <= 4, 3x3 / s1 / p1, bf16 input, fp32 output, fused GroupNorm(+swish) loader) on the bf16 MFMA with one 32-wide N
+ * tile (csrc/conv3x3_smalln_mfma16.hip): region-direct, weights bf16 in the fragment-ordered pack of smx_conv3x3_smalln_mfma_pack
+ * (w [N][3][3][Cin] fp32 -> smx_conv3x3_smalln_mfma_pack_elems bf16 elements).  Cin % 64 == 0, H % 8 == 0, W % 32 == 0. */
+long long smx_conv3x3_smalln_mfma_pack_elems(int Cin, int N);
+int smx_conv3x3_smalln_mfma_pack(const float* w, void* wp, int Cin, int N, void* stream);
+int smx_conv3x3_smalln_mfma_bf16(const void* x, int lda, const void* wp, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
+                                 int Cout, int act, const float* in_ss, int in_swish, void* stream);   /* fp32 weights / bias / output */
 int smx_sft_combine_bf16(const void* dec, int ld_dec, const void* scale, const void* shift, void* out, float w, int64_t P, int C, void* stream);
 int smx_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* copy / convert a channel slice between storage types (dtype codes: 0 = fp32, 1 = bf16) */

@@ -108,6 +108,9 @@ SIGNATURES = {
     "smx_to_uint8_f32": (_i, [_p, _p, _i64, _f, _f, _p]),
     "smx_conv3x3_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     "smx_conv3x3_sft_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_conv3x3_smalln_mfma_pack_elems": (_i64, [_i, _i]),
+    "smx_conv3x3_smalln_mfma_pack": (_i, [_p, _p, _i, _i, _p]),
+    "smx_conv3x3_smalln_mfma_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "smx_conv7_bf16x3_pack_elems": (_i64, [_i, _i]),
     "smx_conv7_bf16x3_pack": (_i, [_p, _p, _i, _i, _p]),
     "smx_conv7_bf16x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -107,13 +107,15 @@ def set_tuning(name, value):
 
 
 SMALLN = not _os.environ.get("SMX_NO_SMALLN")
+SMALLN_MFMA_MIN_BLOCKS = 512                                          # 8 x 32-pixel tiles; below: the VALU kernel (tests lower it)
+SMALLN_MFMA = int(_os.environ.get("SMX_SMALLN_MFMA", "1"))           # bf16 storage: C_out <= 4 3x3 layers on the bf16 MFMA (csrc/conv3x3_smalln_mfma16.hip); 0 = the VALU kernel
 
 WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -124,6 +126,19 @@ class Conv:
         self._w16rp = None
         self._wrp = None
         self._w7x3 = None
+        self._wsn16 = None
+
+    @property
+    def w_sn16(self):
+        """bf16 fragment-ordered pack of a C_out <= 4 3x3 layer for csrc/conv3x3_smalln_mfma16.hip, built once per layer."""
+        if self._wsn16 is None:
+            n = int(L.load().smx_conv3x3_smalln_mfma_pack_elems(self.cin, self.cout))
+            if n <= 0 or self.kh != 3 or self.kw != 3:
+                raise L.SmxError(f"w_sn16: not a 3x3 layer with Cin % 64 == 0 and C_out <= 4 (Cin {self.cin}, C_out {self.cout})")
+            wp = torch.empty(n, device=self.w.device, dtype=BF16)
+            L.check(L.load().smx_conv3x3_smalln_mfma_pack(_dev(self.w).data_ptr(), wp.data_ptr(), self.cin, self.cout, _stream()), "smx_conv3x3_smalln_mfma_pack")
+            self._wsn16 = wp
+        return self._wsn16
 
     @property
     def w7_x3(self):
@@ -258,6 +273,7 @@ CONV16_F32_REGION = int(_os.environ.get("SMX_CONV16_F32_REGION", "1"))   # fp32-
 # 3000-iteration two-process stress runs of a kernel alone, or with the kernel's DMA fully serialised) -- unexplained, DESIGN
 # section 6 "open issue".
 _SHARED_DEVICE = bool(int(_os.environ.get("SMX_SHARED_DEVICE", "0"))) and not int(_os.environ.get("SMX_FORCE_LDSDMA", "0"))   # FORCE: tools/bisect_cons.sh
+SMALLN_MFMA = SMALLN_MFMA and not _SHARED_DEVICE
 GEMM_RP = int(_os.environ.get("SMX_GEMM_RP", "1")) and not _SHARED_DEVICE      # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
 GEMM16_RP = int(_os.environ.get("SMX_GEMM16_RP", "1")) and not _SHARED_DEVICE  # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
 GEMM16_RP_MIN_ROWS = 16384                                           # below: too few 32-row tiles to fill the persistent blocks (tests lower it)
@@ -302,6 +318,17 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
     a_ptr, lda = _pix(x, "conv input")
     c_ptr, ldc = _pix(out, "conv output")
     r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
+    if (SMALLN and SMALLN_MFMA and tile == 0 and x.dtype == BF16 and out.dtype == torch.float32 and cv.kh == 3 and cv.kw == 3 and stride == 1
+            and (pt, pl) == (1, 1) and not d2s and not up2 and res is None and cv.cout <= 4 and Cin % 64 == 0 and (Ho, Wo) == (H, W)
+            and H % 8 == 0 and W % 32 == 0 and lda % 8 == 0 and a_ptr % 16 == 0 and B * (H // 8) * (W // 32) >= SMALLN_MFMA_MIN_BLOCKS
+            and act in (ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SIGMOID)):
+        # the same layers on the bf16 MFMA (one 32-wide N tile, region-direct): the image head at 256^2 was 2.85 ms on the vector ALUs
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * Ho * Wo * 32 * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin,
+                "nb": 1, "k": 3, "bf16": 1, "bytes": B * Ho * Wo * (2.0 * Cin + 4.0 * cv.cout)} if _PROFILE is not None else None
+        L.check(_timed("conv_small_n", meta, L.load().smx_conv3x3_smalln_mfma_bf16, a_ptr, lda, cv.w_sn16.data_ptr(),
+                       None if cv.b is None else cv.b.data_ptr(), c_ptr, ldc, B, H, W, Cin, cv.cout, act,
+                       None if in_ss is None else in_ss.data_ptr(), int(in_swish), _stream()), "smx_conv3x3_smalln_mfma_bf16")
+        return out
     if (SMALLN and tile == 0 and x.dtype == BF16 and out.dtype == torch.float32 and cv.kh == 3 and cv.kw == 3 and stride == 1
             and (pt, pl) == (1, 1) and not d2s and not up2 and res is None and cv.cout <= 4 and Cin in (64, 128, 256)
             and (Ho, Wo) == (H, W) and W % 4 == 0 and lda % 4 == 0 and a_ptr % 8 == 0):

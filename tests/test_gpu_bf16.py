@@ -556,6 +556,40 @@ def test_attnblock_fused_bf16(ops):
     assert float((fused.float() - ref32).abs().mean()) <= 1.5 * float((three.float() - ref32).abs().mean()) + 1e-4
 
 
+@pytest.mark.parametrize("B,Cin,Co,H,W,act,gn", [(2, 64, 3, 64, 64, 0, True), (1, 128, 2, 32, 96, 1, False), (3, 256, 4, 16, 32, 0, True)])
+def test_conv3x3_small_n_mfma(ops, B, Cin, Co, H, W, act, gn):
+    """csrc/conv3x3_smalln_mfma16.hip (C_out <= 4 on the bf16 MFMA, one 32-wide N tile, fused GroupNorm + swish loader) against the fp64
+    convolution of the bf16-rounded operands (weights are bf16 in this kernel, like every other layer of the configuration), and against
+    the VALU kernel it replaces (fp32 weights: differs by the weight rounding only)."""
+    x = r16(rnd(f"snm_x{Cin}", (B, Cin, H, W)))
+    w = rnd(f"snm_w{Cin}", (Co, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd(f"snm_b{Cin}", (Co,), 0.1)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    ss = None
+    xin = x
+    if gn:
+        ss = torch.stack([1.0 + 0.2 * rnd(f"snm_s{Cin}", (B, Cin)), 0.1 * rnd(f"snm_t{Cin}", (B, Cin))], -1).contiguous()
+        xin = O.swish(x * ss[..., 0][:, :, None, None] + ss[..., 1][:, :, None, None])
+    old = ops.SMALLN_MFMA_MIN_BLOCKS
+    ops.SMALLN_MFMA_MIN_BLOCKS = 1
+    try:
+        with ops.profile() as rec:
+            y = ops.conv(nhwc16(x), cv, act=act, out_dtype=torch.float32, in_ss=None if ss is None else ss.cuda(), in_swish=gn)
+        assert [r[0] for r in rec.rows] == ["conv_small_n"] and rec.rows[0][1].get("mfma_flops", 0) > 0 and y.dtype == torch.float32
+        ops.SMALLN_MFMA = 0
+        try:
+            yv = ops.conv(nhwc16(x), cv, act=act, out_dtype=torch.float32, in_ss=None if ss is None else ss.cuda(), in_swish=gn)
+        finally:
+            ops.SMALLN_MFMA = 1
+    finally:
+        ops.SMALLN_MFMA_MIN_BLOCKS = old
+    ref = F.conv2d(r16(xin).double(), r16(w).double(), b.double(), padding=1)
+    ref = (F.relu(ref) if act == 1 else ref).float()
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxabs(nchw32(y), ref) < (3e-3 if gn else 2e-5) * scale          # gn: the normalised input is rounded to bf16 once more inside the loader
+    assert maxabs(y, yv) < 1.2e-2 * scale                                    # VALU kernel: fp32 weights, unrounded normalised input
+
+
 def test_conv3x3_small_n_bf16_input(ops):
     B, Cin, Co, H = 2, 64, 3, 32
     x = r16(rnd("sn16x", (B, Cin, H, H)))
