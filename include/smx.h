@@ -128,6 +128,11 @@ int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream);
  * staged once per 16-channel slice, not once per tap).  w [N][7][7][Cin] fp32 -> wp by smx_conv7_bf16x3_pack
  * (smx_conv7_bf16x3_pack_elems bf16 elements); pad 0 (valid: archs/keypoint_detector_arch.py:60-86) or 3 (archs/dense_motion_arch.py:
  * 118-161); Cin % 4 == 0, N <= 96; y [B][H+2pad-6][W+2pad-6][ldc] fp32. */
+/* BasicMotionEncoder.convf1 in the bf16 configuration (csrc/conv7_c2_bf16.hip): 7x7 / pad 3 convolution of a 2-channel fp32 map (dense,
+ * [B][H][W][2]) to N % 128 == 0 bf16 channels; wp = [N/32][7][64 lanes][8] bf16 from smx_conv7_c2_bf16_pack (w [N][7][7][2] fp32, K padded
+ * 98 -> 112); H % 8 == 0, W % 32 == 0. */
+int smx_conv7_c2_bf16_pack(const float* w, void* wp, int N, void* stream);
+int smx_conv7_c2_bf16(const float* x, const void* wp, const float* bias, void* y, int ldc, int B, int H, int W, int N, int act, void* stream);
 long long smx_conv7_bf16x3_pack_elems(int Cin, int N);
 int smx_conv7_bf16x3_pack(const float* w, void* wp, int Cin, int N, void* stream);
 int smx_conv7_bf16x3_f32(const float* x, int lda, const void* wp, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,

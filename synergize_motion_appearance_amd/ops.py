@@ -107,6 +107,7 @@ def set_tuning(name, value):
 
 
 SMALLN = not _os.environ.get("SMX_NO_SMALLN")
+CONV7_C2 = int(_os.environ.get("SMX_CONV7_C2", "1"))                 # bf16 configuration: BasicMotionEncoder.convf1 on csrc/conv7_c2_bf16.hip (0 = implicit GEMM)
 SMALLN_MFMA_MIN_BLOCKS = 512                                          # 8 x 32-pixel tiles; below: the VALU kernel (tests lower it)
 SMALLN_MFMA = int(_os.environ.get("SMX_SMALLN_MFMA", "1"))           # bf16 storage: C_out <= 4 3x3 layers on the bf16 MFMA (csrc/conv3x3_smalln_mfma16.hip); 0 = the VALU kernel
 
@@ -115,7 +116,7 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -127,6 +128,16 @@ class Conv:
         self._wrp = None
         self._w7x3 = None
         self._wsn16 = None
+        self._w7c2 = None
+
+    @property
+    def w7_c2(self):
+        """bf16 fragment-ordered pack of a 7x7, C_in = 2 layer for csrc/conv7_c2_bf16.hip, built once per layer."""
+        if self._w7c2 is None:
+            wp = torch.empty((self.cout // 32) * 7 * 512, device=self.w.device, dtype=BF16)
+            L.check(L.load().smx_conv7_c2_bf16_pack(_dev(self.w).data_ptr(), wp.data_ptr(), self.cout, _stream()), "smx_conv7_c2_bf16_pack")
+            self._w7c2 = wp
+        return self._w7c2
 
     @property
     def w_sn16(self):
@@ -318,6 +329,15 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
     a_ptr, lda = _pix(x, "conv input")
     c_ptr, ldc = _pix(out, "conv output")
     r_ptr, ldr = (None, 0) if res is None else _pix(res, "conv residual")
+    if (CONV7_C2 and tile == 0 and x.dtype == torch.float32 and out.dtype == BF16 and cv.kh == 7 and cv.kw == 7 and Cin == 2 and stride == 1
+            and (pt, pl) == (3, 3) and not d2s and not up2 and res is None and in_ss is None and cv.w is not None and cv.cout % 128 == 0
+            and (Ho, Wo) == (H, W) and H % 8 == 0 and W % 32 == 0 and lda == 2 and ldc % 8 == 0 and a_ptr % 8 == 0 and c_ptr % 16 == 0
+            and act in (ACT_NONE, ACT_RELU, ACT_LRELU02) and B * (H // 8) * (W // 32) >= 256):
+        # BasicMotionEncoder.convf1: the lane builds its MFMA operand from the 2-channel region in LDS instead of a scalar implicit-GEMM gather
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 98, "M": B * Ho * Wo, "N": cv.cout, "K": 98, "nb": 1, "k": 7, "bf16": 1} if _PROFILE is not None else None
+        L.check(_timed("gemm_bf16", meta, L.load().smx_conv7_c2_bf16, a_ptr, cv.w7_c2.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       c_ptr, ldc, B, H, W, cv.cout, act, _stream()), "smx_conv7_c2_bf16")
+        return out
     if (SMALLN and SMALLN_MFMA and tile == 0 and x.dtype == BF16 and out.dtype == torch.float32 and cv.kh == 3 and cv.kw == 3 and stride == 1
             and (pt, pl) == (1, 1) and not d2s and not up2 and res is None and cv.cout <= 4 and Cin % 64 == 0 and (Ho, Wo) == (H, W)
             and H % 8 == 0 and W % 32 == 0 and lda % 8 == 0 and a_ptr % 16 == 0 and B * (H // 8) * (W // 32) >= SMALLN_MFMA_MIN_BLOCKS

@@ -556,6 +556,29 @@ def test_attnblock_fused_bf16(ops):
     assert float((fused.float() - ref32).abs().mean()) <= 1.5 * float((three.float() - ref32).abs().mean()) + 1e-4
 
 
+def test_conv7x7_two_channel_flow_encoder(ops):
+    """csrc/conv7_c2_bf16.hip (BasicMotionEncoder.convf1: 7x7 pad 3, 2 fp32 channels -> 128 bf16, ReLU): the stored value is the correctly
+    rounded fp32 result of the bf16-rounded operands; == the implicit GEMM it replaces up to the last bf16 bit."""
+    B, H, W, N = 9, 64, 64, 128
+    x = rnd("c72x", (B, 2, H, W)) * 3.0
+    w = rnd("c72w", (N, 2, 7, 7), 1.0 / math.sqrt(98))
+    b = rnd("c72b", (N,), 0.1)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    with ops.profile() as rec:
+        y = ops.conv(xin, cv, act=1, mfma16=True)
+    assert y.dtype == BF and rec.rows[0][1]["K"] == 98 and rec.rows[0][1].get("k") == 7
+    ref = F.relu(F.conv2d(r16(x).double(), r16(w).double(), b.double(), padding=3)).float()
+    ok, worst = close16(nchw32(y), ref, ulps=1.0)
+    assert ok, worst
+    ops.CONV7_C2 = 0
+    try:
+        y0 = ops.conv(xin, cv, act=1, mfma16=True)
+    finally:
+        ops.CONV7_C2 = 1
+    assert float((y0.float() - y.float()).abs().max()) <= 2.0 ** -7 * float(y0.float().abs().max())
+
+
 @pytest.mark.parametrize("B,Cin,Co,H,W,act,gn", [(2, 64, 3, 64, 64, 0, True), (1, 128, 2, 32, 96, 1, False), (3, 256, 4, 16, 32, 0, True)])
 def test_conv3x3_small_n_mfma(ops, B, Cin, Co, H, W, act, gn):
     """csrc/conv3x3_smalln_mfma16.hip (C_out <= 4 on the bf16 MFMA, one 32-wide N tile, fused GroupNorm + swish loader) against the fp64
