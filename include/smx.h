@@ -133,10 +133,18 @@ int smx_gemm_conv_bf16(const smx_gemm16_desc* d, void* stream);
  * 98 -> 112); H % 8 == 0, W % 32 == 0. */
 int smx_conv7_c2_bf16_pack(const float* w, void* wp, int N, void* stream);
 int smx_conv7_c2_bf16(const float* x, const void* wp, const float* bias, void* y, int ldc, int B, int H, int W, int N, int act, void* stream);
+/* the fp32 configuration's form (v_mfma_f32_32x32x2_f32: the MFMA's k pair is the channel pair; wp = [N/32][49][64 lanes] floats), fp32 output */
+int smx_conv7_c2_f32_pack(const float* w, float* wp, int N, void* stream);
+int smx_conv7_c2_f32(const float* x, const float* wp, const float* bias, float* y, int ldc, int B, int H, int W, int N, int act, void* stream);
 long long smx_conv7_bf16x3_pack_elems(int Cin, int N);
 int smx_conv7_bf16x3_pack(const float* w, void* wp, int Cin, int N, void* stream);
 int smx_conv7_bf16x3_f32(const float* x, int lda, const void* wp, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
                          int N, int pad, int act, void* stream);
+/* the fp32 configuration's form of the same two heads: exact fp32 products (v_mfma_f32_32x32x2_f32), the same region-direct staging;
+ * wp from smx_conv7_f32_pack (smx_conv7_bf16x3_pack_elems(Cin, N) / 2 floats) */
+int smx_conv7_f32_pack(const float* w, float* wp, int Cin, int N, void* stream);
+int smx_conv7_f32(const float* x, int lda, const float* wp, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
+                  int N, int pad, int act, void* stream);
 int smx_gemm_rp_f32_ok(long long M, int N, int K);      /* the fp32 form (csrc/gemm_rp_f32.hip): fp32 MFMA, weights [N/32][K/8][64 lanes][4] */
 int smx_gemm_rp_f32_pack(const float* w, int ldw, float* wp, int N, int K, void* stream);
 int smx_gemm_rp_f32(const float* a, int lda, const float* wp, const float* bias, const float* res, int ldres, float* c, int ldc,

@@ -177,6 +177,144 @@ __global__ __launch_bounds__(256, 2) void conv7_bf16x3_kernel(C7 p) {
   }
 }
 
+// ---- the fp32 configuration's form: the same region-direct scheme on v_mfma_f32_32x32x2_f32 (exact fp32 products) --------------------------
+// The implicit GEMM stages every input pixel 49 times (L2 -> LDS bound: 6.0 + 4.1 ms per step for the two heads against 3.1 + 2.2 ms of
+// matrix time); here the region of a 16-channel slice is staged once as [pixel][16 floats] (the 16-B chunk XOR-swizzled by (column >> 2) & 3:
+// conflict-free ds_read_b128 over 16 consecutive pixels) and one ds_read_b128 feeds four MFMAs through the free k pairing (lanes 0-31
+// hold channels 8 q + t, lanes 32-63 channels 8 q + 4 + t of step t); weights: one ky row per step by LDS-DMA, [kx][nt][q][64 lanes][4].
+constexpr int PLANE_F_B = RPX * 64;                                       // 34,048 B: [pixel][16 floats]
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv7_f32_kernel(C7 p) {
+  constexpr int WROW_B = 7 * NT * 2 * 1024;
+  constexpr int NCH = (RPX * 4 + 255) / 256;                              // float4 chunks of the region per thread: 9
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Rg = smem;
+  unsigned char* Ws = smem + PLANE_F_B;
+  const unsigned lds_w = (unsigned)(uintptr_t)((lds_void*)Ws);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int bx = bid % p.tiles_x; bid /= p.tiles_x;
+  const int by = bid % p.tiles_y; const int img = bid / p.tiles_y;
+  const float* __restrict__ X = p.x + (long long)img * p.H * p.W * p.lda;
+  const int iy0 = by * TH - p.pad, ix0 = bx * TW - p.pad;
+  float4 rr[NCH];
+  auto load_region = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int item = tid + 256 * k;
+      const int px = item >> 2, ch = item & 3;
+      const int ry = px / RW, rx = px - ry * RW;
+      const int iy = iy0 + ry, ix = ix0 + rx;
+      const int c = c0 + 4 * ch;
+      const bool ok = item < RPX * 4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c + 3 < p.Cin;
+      rr[k] = ok ? *reinterpret_cast<const float4*>(X + ((long long)iy * p.W + ix) * p.lda + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_region = [&]() {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int item = tid + 256 * k;
+      if (item < RPX * 4) {
+        const int px = item >> 2, ch = item & 3, rx = px % RW;
+        *reinterpret_cast<float4*>(Rg + px * 64 + ((ch ^ ((rx >> 2) & 3)) << 4)) = rr[k];
+      }
+    }
+  };
+  auto issue_w = [&](int step, int buf) {
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.wp) + (long long)step * WROW_B + lane * 16;
+#pragma unroll
+    for (int q = 0; q < (7 * NT * 2 + 3) / 4; ++q) {
+      const int i = wave + 4 * q;
+      if (i < 7 * NT * 2) glds16(src + i * 1024, lds_w + (unsigned)(buf * WROW_B + i * 1024));
+    }
+  };
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][j][q] = 0.f;
+  const int pc = lane & 31, hh = lane >> 5;
+  const int nsteps = p.nslices * 7;
+  load_region(0);
+  issue_w(0, 0);
+  for (int step = 0; step < nsteps; ++step) {
+    const int s = step / 7, ky = step - s * 7, buf = step & 1;
+    if (ky == 0) store_region();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (step + 1 < nsteps) issue_w(step + 1, buf ^ 1);
+    if (ky == 4 && s + 1 < p.nslices) load_region((s + 1) * 16);
+    const unsigned char* wb = Ws + buf * WROW_B + lane * 16;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float4 xv[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int col = pc + kx;
+          xv[r] = *reinterpret_cast<const float4*>(Rg + ((2 * wave + r + ky) * RW + col) * 64 + (((2 * q + hh) ^ ((col >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float4 wv = *reinterpret_cast<const float4*>(wb + ((kx * NT + j) * 2 + q) * 1024);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv[r].x, acc[r][j], 0, 0, 0);
+            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv[r].y, acc[r][j], 0, 0, 0);
+            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv[r].z, acc[r][j], 0, 0, 0);
+            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv[r].w, acc[r][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (ky == 6) __syncthreads();
+  }
+  float* __restrict__ Y = p.y + (long long)img * p.Ho * p.Wo * p.ldc;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int oy = by * TH + 2 * wave + r, ox = bx * TW + pc;
+    if (oy < p.Ho && ox < p.Wo) {
+      float* yp = Y + ((long long)oy * p.Wo + ox) * p.ldc;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int n = 32 * j + (q & 3) + 8 * (q >> 2) + 4 * hh;
+          if (n < p.N) yp[n] = c7_act(acc[r][j][q] + (p.bias ? p.bias[n] : 0.f), p.act);
+        }
+    }
+  }
+}
+
+// w [N][7][7][Cin] fp32 -> [slice][ky][kx][nt][q][64 lanes][4] fp32: lane l holds row 32 nt + (l & 31), channels 16 s + 8 q + 4 (l >> 5) + 0..3
+__global__ __launch_bounds__(256) void conv7_f32_pack_kernel(const float* __restrict__ w, float4* __restrict__ wp, int N, int Cin, int NT, int nslices) {
+  const long long total = (long long)nslices * 49 * NT * 2 * 64;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    long long f = i >> 6;
+    const int q = (int)(f & 1); f >>= 1;
+    const int nt = (int)(f % NT); f /= NT;
+    const int tap = (int)(f % 49); const int s = (int)(f / 49);
+    const int n = 32 * nt + (lane & 31), c0 = 16 * s + 8 * q + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (n < N && c0 + e < Cin) ? w[((long long)n * 49 + tap) * Cin + c0 + e] : 0.f;
+    wp[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <int NT>
+int c7f_launch(const C7& p, hipStream_t st) {
+  constexpr int LDS = PLANE_F_B + 2 * 7 * NT * 2 * 1024;
+  static bool attr = false;
+  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv7_f32_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  SMX_LAUNCH(conv7_f32_kernel<NT>, dim3((unsigned)((long long)p.B * p.tiles_y * p.tiles_x)), dim3(256), LDS, st, p);
+  return smx_launch_status();
+}
+
 // w [N][7][7][Cin] fp32 (k contiguous: the forward layout of ops.Conv) -> [slice][ky][kx][nt][hi | lo][64 lanes][8] bf16
 __global__ __launch_bounds__(256) void conv7_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int N, int Cin, int NT, int nslices) {
   const long long total = (long long)nslices * 49 * NT * 64;             // one thread per (slice, tap, nt, lane): writes hi and lo
@@ -234,4 +372,31 @@ extern "C" int smx_conv7_bf16x3_f32(const float* x, int lda, const void* wp, con
   hipStream_t st = (hipStream_t)stream;
   const int NT = (N + 31) / 32;
   return NT == 1 ? c7_launch<1>(p, st) : NT == 2 ? c7_launch<2>(p, st) : c7_launch<3>(p, st);
+}
+
+/* the fp32 configuration's form of the same heads: exact fp32 products on v_mfma_f32_32x32x2_f32, region-direct; wp from smx_conv7_f32_pack
+ * (smx_conv7_bf16x3_pack_elems(Cin, N) / 2 floats: the two packs have the same byte size) */
+extern "C" int smx_conv7_f32_pack(const float* w, float* wp, int Cin, int N, void* stream) {
+  if (!w || !wp || smx_conv7_bf16x3_pack_elems(Cin, N) < 0 || ((uintptr_t)wp & 15)) return SMX_EINVAL;
+  const int NT = (N + 31) / 32, ns = (Cin + 15) / 16;
+  const long long total = (long long)ns * 49 * NT * 2 * 64;
+  int g = smx_cdiv(total, 256); if (g > 4096) g = 4096;
+  SMX_LAUNCH(conv7_f32_pack_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (float4*)wp, N, Cin, NT, ns);
+  return smx_launch_status();
+}
+
+extern "C" int smx_conv7_f32(const float* x, int lda, const float* wp, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
+                             int N, int pad, int act, void* stream) {
+  if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 4 || N <= 0 || N > 96 || (pad != 0 && pad != 3)) return SMX_EINVAL;
+  if (lda < Cin || lda % 4 || ldc < N || ((uintptr_t)x & 15) || ((uintptr_t)wp & 15)) return SMX_EINVAL;
+  if (act != SMX_ACT_NONE && act != SMX_ACT_RELU && act != SMX_ACT_LRELU02 && act != SMX_ACT_SIGMOID) return SMX_EINVAL;
+  C7 p;
+  p.x = x; p.wp = (const bf16_t*)wp; p.bias = bias; p.y = y; p.lda = lda; p.ldc = ldc; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
+  p.pad = pad; p.act = act; p.Ho = H + 2 * pad - 6; p.Wo = W + 2 * pad - 6;
+  if (p.Ho <= 0 || p.Wo <= 0) return SMX_EINVAL;
+  p.tiles_y = smx_cdiv(p.Ho, TH); p.tiles_x = smx_cdiv(p.Wo, TW); p.nslices = (Cin + 15) / 16;
+  if ((long long)B * p.tiles_y * p.tiles_x > 2147483647LL || (long long)H * W * lda > 2147483647LL) return SMX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int NT = (N + 31) / 32;
+  return NT == 1 ? c7f_launch<1>(p, st) : NT == 2 ? c7f_launch<2>(p, st) : c7f_launch<3>(p, st);
 }

@@ -97,6 +97,71 @@ __global__ __launch_bounds__(256, 2) void conv7_c2_kernel(C2 p) {
   }
 }
 
+// The fp32 configuration's form: v_mfma_f32_32x32x2_f32, one MFMA per tap -- the MFMA's k pair IS the channel pair (lanes 0-31 supply
+// channel 0 of tap t at their pixel, lanes 32-63 channel 1), so the pixel operand is one 4-byte LDS read and the wave's 49 weight
+// values per lane stay in registers.  fp32 output, 4 x 16-B stores per lane.
+__global__ __launch_bounds__(256, 2) void conv7_c2_f32_kernel(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int ldc, int H, int W, int act, int tiles_y, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) float Rf[RPX * 2];
+  __shared__ __attribute__((aligned(16))) float Ex[4 * EX_F];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int bx = bid % tiles_x; bid /= tiles_x;
+  const int by = bid % tiles_y; const int img = bid / tiles_y;
+  const float2* __restrict__ X = reinterpret_cast<const float2*>(x) + (long long)img * H * W;
+  for (int i = tid; i < RPX; i += 256) {
+    const int ry = i / RW, rx = i - ry * RW;
+    const int iy = by * TH - 3 + ry, ix = bx * TW - 3 + rx;
+    const float2 v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? X[(long long)iy * W + ix] : make_float2(0.f, 0.f);
+    Rf[2 * i] = v.x; Rf[2 * i + 1] = v.y;
+  }
+  const int n0 = (blockIdx.y * 4 + wave) * 32;
+  float wf[49];                                                           // W[n0 + (l & 31)][tap][c = l >> 5]
+  {
+    const float* wp = wpk + (long long)(n0 / 32) * 49 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 49; ++t) wf[t] = wp[t * 64];
+  }
+  const int pc = lane & 31, hh = lane >> 5;
+  __syncthreads();
+  float* ex = Ex + wave * EX_F;
+  const int erow = lane >> 1, eh = lane & 1;
+  float bv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bv[e] = bias ? bias[n0 + 16 * eh + e] : 0.f;
+  float* __restrict__ Y = y + (long long)img * H * W * ldc;
+  for (int r = 0; r < TH; ++r) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const float* rp = Rf + 2 * (r * RW + pc) + hh;
+#pragma unroll
+    for (int t = 0; t < 49; ++t)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t], rp[2 * ((t / 7) * RW + (t % 7))], acc, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(ex + pc * EXP + 8 * g + 4 * hh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    float* yp = Y + ((long long)(by * TH + r) * W + bx * TW + erow) * ldc + n0 + 16 * eh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 t = *reinterpret_cast<const float4*>(ex + erow * EXP + 16 * eh + 4 * q);
+      t.x += bv[4 * q]; t.y += bv[4 * q + 1]; t.z += bv[4 * q + 2]; t.w += bv[4 * q + 3];
+      if (act == SMX_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      else if (act == SMX_ACT_LRELU02) { t.x = t.x > 0.f ? t.x : 0.2f * t.x; t.y = t.y > 0.f ? t.y : 0.2f * t.y; t.z = t.z > 0.f ? t.z : 0.2f * t.z; t.w = t.w > 0.f ? t.w : 0.2f * t.w; }
+      *reinterpret_cast<float4*>(yp + 4 * q) = t;
+    }
+  }
+}
+
+// w [N][98] fp32 -> [N/32][49 taps][64 lanes]: lane l holds W[32 nt + (l & 31)][tap][l >> 5]
+__global__ __launch_bounds__(256) void conv7_c2_f32_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int N) {
+  const int total = (N / 32) * 49 * 64;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int lane = i & 63, f = i >> 6, t = f % 49, nt = f / 49;
+    wp[i] = w[(32 * nt + (lane & 31)) * 98 + 2 * t + (lane >> 5)];
+  }
+}
+
 // w [N][7][7][2] fp32 (= [N][98], k = tap * 2 + c) -> [N/32][7 k-steps][64 lanes][8] bf16, K padded to 112 with zeros
 __global__ __launch_bounds__(256) void conv7_c2_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int N) {
   const int total = (N / 32) * 7 * 64;
@@ -128,5 +193,21 @@ extern "C" int smx_conv7_c2_bf16(const float* x, const void* wp, const float* bi
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL) return SMX_EINVAL;
   SMX_LAUNCH(conv7_c2_kernel, dim3((unsigned)blocks, N / 128), dim3(256), 0, (hipStream_t)stream, p);
+  return smx_launch_status();
+}
+
+extern "C" int smx_conv7_c2_f32_pack(const float* w, float* wp, int N, void* stream) {
+  if (!w || !wp || N <= 0 || N % 128) return SMX_EINVAL;
+  SMX_LAUNCH(conv7_c2_f32_pack_kernel, dim3(smx_cdiv((N / 32) * 49 * 64, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, N);
+  return smx_launch_status();
+}
+
+extern "C" int smx_conv7_c2_f32(const float* x, const float* wp, const float* bias, float* y, int ldc, int B, int H, int W, int N, int act, void* stream) {
+  if (!x || !wp || !y || B <= 0 || H <= 0 || W <= 0 || H % TH || W % TW || N <= 0 || N % 128 || ldc < N || ldc % 4) return SMX_EINVAL;
+  if (((uintptr_t)x & 7) || ((uintptr_t)y & 15)) return SMX_EINVAL;
+  if (act != SMX_ACT_NONE && act != SMX_ACT_RELU && act != SMX_ACT_LRELU02) return SMX_EINVAL;
+  const long long blocks = (long long)B * (H / TH) * (W / TW);
+  if (blocks > 2147483647LL) return SMX_EINVAL;
+  SMX_LAUNCH(conv7_c2_f32_kernel, dim3((unsigned)blocks, N / 128), dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, ldc, H, W, act, H / TH, W / TW);
   return smx_launch_status();
 }

@@ -111,8 +111,12 @@ SIGNATURES = {
     "smx_conv3x3_smalln_mfma_pack_elems": (_i64, [_i, _i]),
     "smx_conv3x3_smalln_mfma_pack": (_i, [_p, _p, _i, _i, _p]),
     "smx_conv3x3_smalln_mfma_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "smx_conv7_c2_f32_pack": (_i, [_p, _p, _i, _p]),
+    "smx_conv7_c2_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "smx_conv7_c2_bf16_pack": (_i, [_p, _p, _i, _p]),
     "smx_conv7_c2_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "smx_conv7_f32_pack": (_i, [_p, _p, _i, _i, _p]),
+    "smx_conv7_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_conv7_bf16x3_pack_elems": (_i64, [_i, _i]),
     "smx_conv7_bf16x3_pack": (_i, [_p, _p, _i, _i, _p]),
     "smx_conv7_bf16x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -116,7 +116,7 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -129,6 +129,16 @@ class Conv:
         self._w7x3 = None
         self._wsn16 = None
         self._w7c2 = None
+        self._w7c2f = None
+
+    @property
+    def w7_c2f(self):
+        """fp32 fragment-ordered pack of a 7x7, C_in = 2 layer for conv7_c2_f32_kernel, built once per layer."""
+        if self._w7c2f is None:
+            wp = torch.empty((self.cout // 32) * 49 * 64, device=self.w.device, dtype=torch.float32)
+            L.check(L.load().smx_conv7_c2_f32_pack(_dev(self.w).data_ptr(), wp.data_ptr(), self.cout, _stream()), "smx_conv7_c2_f32_pack")
+            self._w7c2f = wp
+        return self._w7c2f
 
     @property
     def w7_c2(self):
@@ -525,6 +535,14 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
                 "smx_winograd_conv3x3_f32")
         if part is not None:
             out._gn_part = part
+        return out
+    if (CONV7_C2 and not direct and tile == 0 and cv.kh == 7 and cv.kw == 7 and Cin == 2 and stride == 1 and (pt, pl) == (3, 3) and not d2s and not up2
+            and res is None and in_ss is None and cv.cout % 128 == 0 and (Ho, Wo) == (H, W) and H % 8 == 0 and W % 32 == 0 and lda == 2
+            and ldc % 4 == 0 and a_ptr % 8 == 0 and c_ptr % 16 == 0 and act in (ACT_NONE, ACT_RELU, ACT_LRELU02) and B * (H // 8) * (W // 32) >= 256):
+        # BasicMotionEncoder.convf1 (7x7, 2 channels): one MFMA per tap, the k pair = the channel pair, operands straight from a 4 KB LDS region
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 98, "M": B * Ho * Wo, "N": cv.cout, "K": 98, "nb": 1, "k": 7} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_conv7_c2_f32, a_ptr, cv.w7_c2f.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       c_ptr, ldc, B, H, W, cv.cout, act, _stream()), "smx_conv7_c2_f32")
         return out
     if in_ss is not None:      # layer not eligible for the fused loader: normalise in its own pass, then convolve
         x = groupnorm_apply(x, in_ss, in_swish)

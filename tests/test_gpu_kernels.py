@@ -308,6 +308,28 @@ def test_row_panel_gemm_f32(ops, B, K, N, act, with_res, sliced):
         ops.GEMM16_RP_MIN_ROWS = rows
 
 
+def test_conv7x7_two_channel_flow_encoder_f32(ops):
+    """conv7_c2_f32_kernel (BasicMotionEncoder.convf1 in the fp32 configuration: one fp32 MFMA per tap, k pair = channel pair) against the
+    fp64 convolution and against the implicit GEMM it replaces."""
+    B, H, W, N = 9, 64, 64, 128
+    x = rnd("c72fx", (B, 2, H, W)) * 3.0
+    w = rnd("c72fw", (N, 2, 7, 7), 1.0 / math.sqrt(98))
+    b = rnd("c72fb", (N,), 0.1)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    with ops.profile() as rec:
+        y = ops.conv(xin, cv, act=1)
+    assert y.dtype == torch.float32 and rec.rows[0][1]["K"] == 98
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=3)).float()
+    assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    ops.CONV7_C2 = 0
+    try:
+        y0 = ops.conv(xin, cv, act=1)
+    finally:
+        ops.CONV7_C2 = 1
+    assert maxabs(y0, y) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_gemm_nt_batched_heads(ops):
     """attention-shaped batched NT GEMMs incl. d_head = 4 (generic path) and per-row bias."""
     for dh, E in ((32, 256), (4, 32)):
