@@ -107,6 +107,7 @@ def set_tuning(name, value):
 
 
 SMALLN = not _os.environ.get("SMX_NO_SMALLN")
+CONV7_F32 = int(_os.environ.get("SMX_CONV7_F32", "1"))               # fp32 configuration: the 7x7 heads on conv7_f32_kernel (0 = implicit GEMM)
 CONV7_C2 = int(_os.environ.get("SMX_CONV7_C2", "1"))                 # bf16 configuration: BasicMotionEncoder.convf1 on csrc/conv7_c2_bf16.hip (0 = implicit GEMM)
 SMALLN_MFMA_MIN_BLOCKS = 512                                          # 8 x 32-pixel tiles; below: the VALU kernel (tests lower it)
 SMALLN_MFMA = int(_os.environ.get("SMX_SMALLN_MFMA", "1"))           # bf16 storage: C_out <= 4 3x3 layers on the bf16 MFMA (csrc/conv3x3_smalln_mfma16.hip); 0 = the VALU kernel
@@ -116,7 +117,7 @@ WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -130,6 +131,19 @@ class Conv:
         self._wsn16 = None
         self._w7c2 = None
         self._w7c2f = None
+        self._w7f = None
+
+    @property
+    def w7_f32(self):
+        """fp32 fragment-ordered pack of a 7x7 head for conv7_f32_kernel (csrc/conv7_bf16x3.hip), built once per layer."""
+        if self._w7f is None:
+            n = int(L.load().smx_conv7_bf16x3_pack_elems(self.cin, self.cout))
+            if n <= 0 or self.kh != 7 or self.kw != 7:
+                raise L.SmxError(f"w7_f32: not a 7x7 layer with N <= 96 ({self.kh}x{self.kw}, N {self.cout})")
+            wp = torch.empty(n // 2, device=self.w.device, dtype=torch.float32)
+            L.check(L.load().smx_conv7_f32_pack(_dev(self.w).data_ptr(), wp.data_ptr(), self.cin, self.cout, _stream()), "smx_conv7_f32_pack")
+            self._w7f = wp
+        return self._w7f
 
     @property
     def w7_c2f(self):
@@ -535,6 +549,17 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
                 "smx_winograd_conv3x3_f32")
         if part is not None:
             out._gn_part = part
+        return out
+    if (CONV7_F32 and not direct and tile == 0 and cv.kh == 7 and cv.kw == 7 and stride == 1 and (pt, pl) in ((3, 3), (0, 0)) and not d2s and not up2
+            and res is None and in_ss is None and Cin % 16 == 0 and cv.cout <= 96 and (Ho, Wo) == (H + 2 * pt - 6, W + 2 * pl - 6)
+            and lda % 4 == 0 and a_ptr % 16 == 0 and ldc == cv.cout and act in (ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SIGMOID)
+            and B * ((Ho + 7) // 8) * ((Wo + 31) // 32) >= 256 and not _SHARED_DEVICE):
+        # the mask / occlusion head (128 -> 17): region-direct on the fp32 MFMA (the implicit GEMM staged every input pixel 49 times): 6.0 -> 3.5 ms.
+        # C_in % 16 == 0 only: the keypoint head's 36 channels pad to 48 here and lose to the implicit GEMM (4.4 against 4.1 ms)
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 49 * Cin, "mfma_flops": 2.0 * B * Ho * Wo * 32 * ((cv.cout + 31) // 32) * 49 * 16 * ((Cin + 15) // 16),
+                "M": B * Ho * Wo, "N": cv.cout, "K": 49 * Cin, "nb": 1, "k": 7} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_conv7_f32, a_ptr, lda, cv.w7_f32.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       c_ptr, ldc, B, H, W, Cin, cv.cout, pt, act, _stream()), "smx_conv7_f32")
         return out
     if (CONV7_C2 and not direct and tile == 0 and cv.kh == 7 and cv.kw == 7 and Cin == 2 and stride == 1 and (pt, pl) == (3, 3) and not d2s and not up2
             and res is None and in_ss is None and cv.cout % 128 == 0 and (Ho, Wo) == (H, W) and H % 8 == 0 and W % 32 == 0 and lda == 2

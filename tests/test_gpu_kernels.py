@@ -308,6 +308,35 @@ def test_row_panel_gemm_f32(ops, B, K, N, act, with_res, sliced):
         ops.GEMM16_RP_MIN_ROWS = rows
 
 
+@pytest.mark.parametrize("B,H,W,Cin,N,pad", [(17, 64, 64, 128, 17, 3), (17, 64, 64, 36, 76, 0), (48, 24, 40, 20, 33, 3)])
+def test_conv7x7_heads_region_kernel_f32(ops, B, H, W, Cin, N, pad):
+    """conv7_f32_kernel (the motion estimator's 7x7 heads in the fp32 configuration: region-direct, exact fp32 products on the fp32 MFMA)
+    against the fp64 convolution and the implicit GEMM it replaces; and it is the kernel that ran."""
+    x = rnd(f"c7fx{Cin}{N}", (B, Cin, H, W))
+    w = rnd(f"c7fw{Cin}{N}", (N, Cin, 7, 7), 1.0 / math.sqrt(49 * Cin))
+    b = rnd(f"c7fb{Cin}{N}", (N,), 0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=pad).float()
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    with ops.profile() as rec:
+        y = ops.conv(xin, cv, pad=(pad, pad))
+    assert (rec.rows[0][1].get("mfma_flops", 0) > 0) == (Cin % 16 == 0)  # only the region kernel reports its padded executed flops; C_in % 16 != 0 stays on the implicit GEMM
+    if Cin % 16:
+        from synergize_motion_appearance_amd import lib as L                # the kernel itself handles ragged channel counts: call it directly
+        yk = torch.empty_like(y)
+        L.check(L.load().smx_conv7_f32(xin.data_ptr(), Cin, cv.w7_f32.data_ptr(), cv.b.data_ptr(), yk.data_ptr(), N, B, H, W, Cin, N, pad, 0,
+                                       torch.cuda.current_stream().cuda_stream), "smx_conv7_f32")
+        assert maxabs(yk, y) < 2e-5 * max(1.0, float(ref.abs().max()))
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) < 2e-5 * scale
+    ops.CONV7_F32 = 0
+    try:
+        y0 = ops.conv(xin, cv, pad=(pad, pad))
+    finally:
+        ops.CONV7_F32 = 1
+    assert maxabs(y0, y) < 2e-5 * scale
+
+
 def test_conv7x7_two_channel_flow_encoder_f32(ops):
     """conv7_c2_f32_kernel (BasicMotionEncoder.convf1 in the fp32 configuration: one fp32 MFMA per tap, k pair = channel pair) against the
     fp64 convolution and against the implicit GEMM it replaces."""
