@@ -149,6 +149,8 @@ int smx_gemm_rp_f32_ok(long long M, int N, int K);      /* the fp32 form (csrc/g
 int smx_gemm_rp_f32_pack(const float* w, int ldw, float* wp, int N, int K, void* stream);
 int smx_gemm_rp_f32(const float* a, int lda, const float* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
                     long long M, int N, int K, int act, void* stream);
+int smx_gemm_rp_d2s_f32(const float* a, int lda, const float* wp, const float* bias, float* c, int ldc, long long M, int N, int K, int act,
+                        int d2s_p, int d2s_c, int Ho, int Wo, void* stream);      /* the un-patchify store, as smx_gemm_rp_d2s_bf16; N % 256 == 0 */
 int smx_gemm_rp_bf16_ok(long long M, int N, int K);
 int smx_gemm_rp_bf16_pack(const void* w, int ldw, void* wp, int N, int K, void* stream);
 int smx_gemm_rp_bf16(const void* a, int lda, const void* wp, const float* bias, const void* res, int ldres, void* c, int ldc,

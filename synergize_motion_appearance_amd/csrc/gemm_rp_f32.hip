@@ -27,6 +27,7 @@ constexpr int EX_F = 32 * EXP;
 struct RPF {
   const float* a; const float* wp; const float* bias; const float* res; float* c;
   int lda, ldres, ldc, M, N, K, act, tiles;
+  int d2s_p, d2s_c, Ho, Wo;                    // un-patchify (depth-to-space) store: n = (p1 * p + p2) * d2s_c + c -> pixel (oy p + p1, ox p + p2), channel c
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -49,7 +50,7 @@ __device__ __forceinline__ float rpf_act(float v, int act) {
 }
 
 // KG = K / 8 (16 | 32): 8-deep groups; NW = waves per block (4 | 8) = 32-column tiles per block
-template <int KG, int NW>
+template <int KG, int NW, bool D2S = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_rp_f32_kernel(RPF p) {
   constexpr int CPR = KG * 2;                  // 16-B chunks per A row
   constexpr int ROWB = CPR * 16;
@@ -88,6 +89,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_rp_f32_kernel(R
 #pragma unroll
   for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[n0 + 16 * eh + e] : 0.f;
 
+  int d_p1 = 0, d_p2 = 0, d_oc = 0;            // un-patchify: this lane's 16-column run never straddles a sub-pixel (d2s_c % 16 == 0)
+  if (D2S) {
+    const int nc = n0 + 16 * eh, dq = nc / p.d2s_c;
+    d_oc = nc - dq * p.d2s_c; d_p1 = dq / p.d2s_p; d_p2 = dq - d_p1 * p.d2s_p;
+  }
   int t = blockIdx.x, it = 0;
   if (t < p.tiles) issue(t, 0);
   for (; t < p.tiles; t += gridDim.x, ++it) {
@@ -120,6 +126,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_rp_f32_kernel(R
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4*>(ex + arow * EXP + 8 * g + 4 * ahalf) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
     float* cp = p.c + grow * p.ldc + nc;
+    if (D2S) {
+      const int hw = p.Ho * p.Wo;
+      const int img = (int)(grow / hw), rem = (int)(grow - (long long)img * hw);
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const long long opix = ((long long)img * (p.Ho * p.d2s_p) + oy * p.d2s_p + d_p1) * (p.Wo * p.d2s_p) + ox * p.d2s_p + d_p2;
+      cp = p.c + opix * p.ldc + d_oc;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 x = *reinterpret_cast<const float4*>(ex + erow * EXP + 16 * eh + 4 * q);
@@ -144,14 +157,14 @@ __global__ __launch_bounds__(256) void gemm_rp_f32_pack_kernel(const float* __re
   }
 }
 
-template <int KG, int NW>
+template <int KG, int NW, bool D2S = false>
 int rpf_launch(const RPF& p, hipStream_t st) {
   constexpr int LDS = 2 * TM * KG * 32 + NW * EX_F * 4;
   static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)gemm_rp_f32_kernel<KG, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)gemm_rp_f32_kernel<KG, NW, D2S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
   const int ny = p.N / (32 * NW);
   int gx = (NW == 8 ? 256 : 512) / ny; if (gx < 1) gx = 1; if (gx > p.tiles) gx = p.tiles;
-  SMX_LAUNCH((gemm_rp_f32_kernel<KG, NW>), dim3(gx, ny), dim3(64 * NW), LDS, st, p);
+  SMX_LAUNCH((gemm_rp_f32_kernel<KG, NW, D2S>), dim3(gx, ny), dim3(64 * NW), LDS, st, p);
   return smx_launch_status();
 }
 
@@ -169,17 +182,34 @@ extern "C" int smx_gemm_rp_f32_pack(const float* w, int ldw, float* wp, int N, i
   return smx_launch_status();
 }
 
-extern "C" int smx_gemm_rp_f32(const float* a, int lda, const float* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
-                               long long M, int N, int K, int act, void* stream) {
+static int rp_f32_launch(const float* a, int lda, const float* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
+                         long long M, int N, int K, int act, int d2s_p, int d2s_c, int Ho, int Wo, void* stream) {
   if (!a || !wp || !c || !smx_gemm_rp_f32_ok(M, N, K)) return SMX_EINVAL;
-  if (lda < K || lda % 4 || ldc < N || ldc % 4 || (res && (ldres < N || ldres % 4))) return SMX_EINVAL;
+  if (d2s_p) {
+    if (d2s_p < 1 || d2s_c <= 0 || d2s_c % 16 || N != d2s_p * d2s_p * d2s_c || N % 256 || ldc < d2s_c || res || Ho <= 0 || Wo <= 0 || M % ((long long)Ho * Wo)) return SMX_EINVAL;
+  } else if (ldc < N) return SMX_EINVAL;
+  if (lda < K || lda % 4 || ldc % 4 || (res && (ldres < N || ldres % 4))) return SMX_EINVAL;
   if (((uintptr_t)a | (uintptr_t)wp | (uintptr_t)c | (uintptr_t)res) & 15) return SMX_EINVAL;
   if ((long long)TM * lda > 2147483647LL) return SMX_EINVAL;
   RPF p;
   p.a = a; p.wp = wp; p.bias = bias; p.res = res; p.c = c;
   p.lda = lda; p.ldres = res ? ldres : 0; p.ldc = ldc; p.M = (int)M; p.N = N; p.K = K; p.act = act; p.tiles = (int)(M / TM);
+  p.d2s_p = d2s_p; p.d2s_c = d2s_c; p.Ho = Ho; p.Wo = Wo;
   hipStream_t st = (hipStream_t)stream;
+  if (d2s_p) return K == 256 ? rpf_launch<32, 8, true>(p, st) : rpf_launch<16, 8, true>(p, st);
   const bool wide = N % 256 == 0;
   if (K == 256) return wide ? rpf_launch<32, 8>(p, st) : rpf_launch<32, 4>(p, st);
   return wide ? rpf_launch<16, 8>(p, st) : rpf_launch<16, 4>(p, st);
+}
+
+extern "C" int smx_gemm_rp_f32(const float* a, int lda, const float* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
+                               long long M, int N, int K, int act, void* stream) {
+  return rp_f32_launch(a, lda, wp, bias, res, ldres, c, ldc, M, N, K, act, 0, 0, 0, 0, stream);
+}
+
+/* with the un-patchify (depth-to-space) store of the patch Linears: c is [B][Ho p][Wo p][ldc >= d2s_c], M = B * Ho * Wo tokens, N % 256 == 0 */
+extern "C" int smx_gemm_rp_d2s_f32(const float* a, int lda, const float* wp, const float* bias, float* c, int ldc, long long M, int N, int K, int act,
+                                   int d2s_p, int d2s_c, int Ho, int Wo, void* stream) {
+  if (d2s_p < 1) return SMX_EINVAL;
+  return rp_f32_launch(a, lda, wp, bias, nullptr, 0, c, ldc, M, N, K, act, d2s_p, d2s_c, Ho, Wo, stream);
 }

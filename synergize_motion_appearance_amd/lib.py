@@ -122,6 +122,7 @@ SIGNATURES = {
     "smx_conv7_bf16x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_gemm_rp_f32_ok": (_i, [_i64, _i, _i]),
     "smx_gemm_rp_f32_pack": (_i, [_p, _i, _p, _i, _i, _p]),
+    "smx_gemm_rp_d2s_f32": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_gemm_rp_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
     "smx_gemm_rp_bf16_ok": (_i, [_i64, _i, _i]),
     "smx_gemm_rp_bf16_pack": (_i, [_p, _i, _p, _i, _i, _p]),

@@ -581,6 +581,13 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
         L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_f32, a_ptr, lda, cv.w_rp.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
                        r_ptr, ldr, c_ptr, ldc, M, cv.cout, K, act, _stream()), "smx_gemm_rp_f32")
         return out
+    if (GEMM_RP and d2s and not direct and tile == 0 and cv.kh == 1 and cv.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not up2 and res is None
+            and (Ho, Wo) == (H, W) and M >= GEMM16_RP_MIN_ROWS and d2s[1] % 16 == 0 and cv.cout % 256 == 0 and L.load().smx_gemm_rp_f32_ok(M, cv.cout, K)
+            and lda % 4 == 0 and ldc % 4 == 0 and a_ptr % 16 == 0 and c_ptr % 16 == 0):
+        meta = {"flops": 2.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "rp": 1} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_d2s_f32, a_ptr, lda, cv.w_rp.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       c_ptr, ldc, M, cv.cout, K, act, d2s[0], d2s[1], Ho, Wo, _stream()), "smx_gemm_rp_d2s_f32")
+        return out
     ksplit, ws = 1, None
     if not d2s and K >= 1024:
         # weight-streaming layers (deep hourglass): few output tiles, long K -> split K over blocks

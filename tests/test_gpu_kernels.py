@@ -308,6 +308,28 @@ def test_row_panel_gemm_f32(ops, B, K, N, act, with_res, sliced):
         ops.GEMM16_RP_MIN_ROWS = rows
 
 
+def test_row_panel_gemm_f32_unpatchify_store(ops):
+    """the fp32 row-panel kernel with the un-patchify (depth-to-space) store == the implicit GEMM's d2s store (summation order only)."""
+    rows = ops.GEMM16_RP_MIN_ROWS
+    ops.GEMM16_RP_MIN_ROWS = 1024
+    try:
+        for (p_, C_, B) in ((8, 64, 3), (4, 128, 2), (2, 64, 5)):
+            N, K = p_ * p_ * C_, 256
+            x = rnd(f"fd2x{p_}", (B, 32, 32, K)).cuda()
+            cv = ops.Conv(rnd(f"fd2w{p_}", (N, K), 1.0 / math.sqrt(K)).cuda().contiguous(), rnd(f"fd2b{p_}", (N,), 0.2).cuda(), 1, 1, K, N)
+            with ops.profile() as rec:
+                y = ops.conv(x, cv, d2s=(p_, C_))
+            assert [r[1].get("rp") for r in rec.rows] == [1] and tuple(y.shape) == (B, 32 * p_, 32 * p_, C_)
+            ops.GEMM_RP = 0
+            try:
+                y0 = ops.conv(x, cv, d2s=(p_, C_))
+            finally:
+                ops.GEMM_RP = 1
+            assert maxabs(y0, y) < 2e-5 * max(1.0, float(y0.abs().max()))
+    finally:
+        ops.GEMM16_RP_MIN_ROWS = rows
+
+
 @pytest.mark.parametrize("B,H,W,Cin,N,pad", [(17, 64, 64, 128, 17, 3), (17, 64, 64, 36, 76, 0), (48, 24, 40, 20, 33, 3)])
 def test_conv7x7_heads_region_kernel_f32(ops, B, H, W, Cin, N, pad):
     """conv7_f32_kernel (the motion estimator's 7x7 heads in the fp32 configuration: region-direct, exact fp32 products on the fp32 MFMA)
