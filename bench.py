@@ -284,6 +284,7 @@ def train_bench(args, world, rank, dev, dist, collective):
     topt["perceptual_opt"] = dict(topt["perceptual_opt"], synthetic_vgg19=True)
     topt["compute_dtype"] = cdt
     topt["overlap_allreduce"] = not args.no_overlap
+    TrainStep.COLLECTIVES_AT_WORLD_1 = dist is not None and world == 1      # `--gpus 1` under torch.distributed.run: the collectives still run (RCCL, one rank)
     step = TrainStep(net_g, me, topt, use_graph=not args.eager, net_d=net_d)
     W += (step.GRAPH_WARMUP + 1) if not args.eager else 0
     _, clip = synth_clip(2 * B, seed=321 + rank)             # every rank its own pairs (a DistributedSampler shard)
@@ -331,8 +332,8 @@ def train_bench(args, world, rank, dev, dist, collective):
                                    + (" + hinge GAN branch" if args.gan else ""), "pairs_per_gpu": B, "global_batch": world * B,
                        "parallelism": (f"dp{world}: gradient all-reduce of two flat fp32 buffers ({grad_mb:.0f} MB) over {collective} in 64 MB buckets; net_g's issued at the end "
                                        f"of its backward and {'overlapped with' if not args.no_overlap else 'NOT overlapped with (--no-overlap)'} the motion estimator's backward; "
-                                       "parameters / Adam state / BatchNorm buffers broadcast from rank 0 at construction") if world > 1 else "1 GPU",
-                       "launch": "eager launches" if args.eager else ("two hipGraphs cut where net_g's gradients are final" if world > 1 and not args.no_overlap else "one hipGraph per step")},
+                                       "parameters / Adam state / BatchNorm buffers broadcast from rank 0 at construction") if dist is not None else "1 GPU",
+                       "launch": "eager launches" if args.eager else ("two hipGraphs cut where net_g's gradients are final" if dist is not None and not args.no_overlap else "one hipGraph per step")},
             "rank_times_s": {"per_rank": [round(float(r[3]), 4) for r in rows]},
             "replicas_bit_identical": identical, "l_g_total_last": round(total, 5),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
@@ -437,7 +438,7 @@ def render_leg(args, dtype, world, rank, dev, dist, collective, net_g, me, drv, 
         """frame-invariant work of the job: every source is encoded once, by its owner.  N>1: each rank encodes the sources it
         owns FIRST, then all broadcasts are issued asynchronously and waited for together (driver.broadcast_source_states) -- no
         host synchronisation between sources, the hull ratio stays on the device."""
-        if world > 1:
+        if dist is not None:
             owners = {j: j % world for j in range(n_src)}
             owned = {j: (my_sources[j], drv[0:1]) for j in my_sources}
             states.update(driver.broadcast_source_states(net_g, me, owned, owners, True, device=dev))
@@ -733,7 +734,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist, collective = (None, None) if world == 1 else init_distributed(rank, world, dev)
+    # a rank started by torch.distributed.run joins the process group even when it is the only one: `--gpus 1` under the launcher runs the
+    # N>1 code path (RCCL communicator, source-state broadcast inside the timed region) on one GPU; plain `python bench.py` stays collective-free
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    dist, collective = (None, None) if (world == 1 and not launched) else init_distributed(rank, world, dev)
 
     if args.train:
         res = train_bench(args, world, rank, dev, dist, collective)
@@ -777,7 +781,7 @@ def main():
                                    f"; one {collective} broadcast per source of its packed frame-invariant state "
                                    f"({4 * driver.cache_numel(net_g.engine().adt, px) / 1e6:.1f} MB) from the owner rank, inside the timed region: every rank "
                                    "encodes the sources it owns first, then all broadcasts are issued async and waited together")
-                   if world > 1 else "1 GPU",
+                   if dist is not None else "1 GPU",
                    "relative": True, "adapt_movement_scale": True, "output": "uint8 HWC frames in HBM"},
         "rank_times_s": {"max": round(max(rt), 4), "min": round(min(rt), 4), "per_rank": [round(x, 4) for x in rt],
                          "what": "each rank's own wall time for the timed region (prologue + K steps, device-synchronised) before the closing barrier"},

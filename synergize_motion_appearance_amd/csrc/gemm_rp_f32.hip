@@ -171,7 +171,7 @@ int rpf_launch(const RPF& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int smx_gemm_rp_f32_ok(long long M, int N, int K) {
-  return (M > 0 && M % TM == 0 && M / TM <= 2147483647LL && (K == 128 || K == 256) && N > 0 && N % 128 == 0) ? 1 : 0;
+  return (M > 0 && M % TM == 0 && M <= 2147483647LL && (K == 128 || K == 256) && N > 0 && N % 128 == 0) ? 1 : 0;
 }
 
 extern "C" int smx_gemm_rp_f32_pack(const float* w, int ldw, float* wp, int N, int K, void* stream) {

@@ -329,8 +329,10 @@ CONV16_T32 = int(_os.environ.get("SMX_CONV16_T32", "1")) and not _SHARED_DEVICE 
 CONV16_T32_MIN_BLOCKS = 1024                                         # two resident rounds of the chip's 512 block slots; tests lower it
 
 
-def _conv16_t32_ok(B, Ho, Wo, Cin, cout):
-    return (CONV16_T32 and Ho % 16 == 0 and Wo % 32 == 0 and Cin % 16 == 0 and
+def _conv16_t32_ok(B, Ho, Wo, Cin, cout, in_ss=None):
+    """the 16x32-tile kernel's own limits: its fused GroupNorm loader keeps the per-channel (scale, shift) table in 4 KB of LDS (Cin <= 512);
+    a GroupNorm-fed layer above that falls through to the 16x16 region kernel / the implicit GEMM."""
+    return (CONV16_T32 and Ho % 16 == 0 and Wo % 32 == 0 and Cin % 16 == 0 and (in_ss is None or Cin <= 512) and
             B * (Ho // 16) * (Wo // 32) * ((cout + 63) // 64) >= CONV16_T32_MIN_BLOCKS)
 
 
@@ -386,7 +388,7 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
         out._gn_part = None
     if (REGION3X3 and tile == 0 and x.dtype == BF16 and out.dtype == BF16 and cv.kh == 3 and cv.kw == 3 and stride == 1 and (pt, pl) == (1, 1)
             and not d2s and (Ho, Wo) == ((2 * H, 2 * W) if up2 else (H, W)) and lda % 8 == 0 and a_ptr % 16 == 0
-            and _conv16_t32_ok(B, Ho, Wo, Cin, cv.cout)):
+            and _conv16_t32_ok(B, Ho, Wo, Cin, cv.cout, in_ss)):
         # the big launches: 16x32-pixel tiles, 16-channel slices through a double-buffered stage, weights by LDS-DMA from the fragment-ordered pack
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 9 * Cin, "M": B * Ho * Wo, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "bf16": 1, "t32": 1,
                 "bytes": 2.0 * B * Ho * Wo * (Cin / (4.0 if up2 else 1.0) + cv.cout * (2 if res is not None else 1))} if _PROFILE is not None else None

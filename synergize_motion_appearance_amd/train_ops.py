@@ -127,7 +127,9 @@ class ReducePlan:
         if self._owner != id(tp.G):
             self._owner, self.segs, self.cur, self.replay = id(tp.G), [], [], False
         else:
-            self.replay = bool(self.segs) and not self.cur
+            if self.cur:                                 # a recording step died half-way (an exception): record again from scratch
+                self.segs, self.cur = [], []
+            self.replay = bool(self.segs)
         self.seg_i = self.item_i = 0
 
     def request(self, tp, sig, n_floats, device):

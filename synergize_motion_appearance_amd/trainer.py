@@ -328,6 +328,7 @@ class TrainStep:
         compute_dtype = compute_dtype or str(dict(train_opt).get("compute_dtype", "f32"))
         self.use_graph = bool(dict(train_opt).get("use_hip_graph", False)) if use_graph is None else bool(use_graph)
         self._graph, self._graph2, self._static, self._eager_steps = None, None, None, 0
+        self._variant = None                     # (gan, overlap cut) of the last step: a change drops the captured graphs (step())
         self.g = NetGTrainStep(net_g, train_opt, compute_dtype)
         self.me = motion_estimator
         self.flat_m = FlatParams(motion_estimator)
@@ -386,10 +387,12 @@ class TrainStep:
         self._pending = []
         self.sync_replicas()
 
-    @staticmethod
-    def _dist():
+    COLLECTIVES_AT_WORLD_1 = False     # tests/test_gpu_rccl.py: run every collective call site over a 1-rank RCCL group (identities, real communicator)
+
+    @classmethod
+    def _dist(cls):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or cls.COLLECTIVES_AT_WORLD_1):
             return dist
         return None
 
@@ -615,9 +618,7 @@ class TrainStep:
         and `on_cut()` (the generator's gradient all-reduce) is issued between their replays."""
         st = self._static
         key = (tuple(source.shape), tuple(driving.shape), float(w), bool(gan), on_cut is not None)
-        if st is not None and st["key"][:3] == key[:3] and st["key"] != key:       # the GAN branch switched on (net_d_start_iter): capture anew
-            self._graph, self._graph2, self._static, st = None, None, None, None
-        if st is not None and st["key"] != key:
+        if st is not None and st["key"] != key:                # (a GAN / overlap switch never gets here: step() drops the graphs and warms up eagerly first)
             raise L.SmxError(f"TrainStep(use_graph): the captured step is for {st['key']}, got {key}; build another TrainStep for another shape")
         tf_new = transform if transform is not None else self._draw_transform(driving.shape[0], driving.device)
         if st is None:
@@ -660,6 +661,17 @@ class TrainStep:
         def start_g():                                         # net_g's gradients are final: their all-reduce runs under the estimator's backward
             pending.extend(self.g.flat.all_reduce_start(dist))
         on_cut = start_g if (dist is not None and self.overlap_allreduce) else None
+        variant = (bool(gan), on_cut is not None)
+        if variant != self._variant:
+            # another step variant (the GAN branch switching on at net_d_start_iter, the overlap cut): its weight-gradient ReducePlan
+            # has to RECORD first, and recording cannot happen inside a stream capture -- drop the captured graphs and run
+            # GRAPH_WARMUP eager steps of the new variant before capturing again.  Plans of a variant that cannot come back
+            # (gan=False once the branch is on) are released with their persistent workspaces.
+            self._graph, self._graph2, self._static, self._eager_steps = None, None, None, 0
+            if self._reduce_plans is not None and variant[0]:
+                for k in [k for k in self._reduce_plans if isinstance(k, tuple) and not k[0]]:
+                    del self._reduce_plans[k]
+            self._variant = variant
         if self.use_graph and self._eager_steps >= self.GRAPH_WARMUP:
             losses, out = self._graph_step(source, driving, w, transform, gan, on_cut)
         else:

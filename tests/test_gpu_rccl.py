@@ -1,0 +1,163 @@
+"""RCCL on the one GPU of the test box (round-4 review: "RCCL itself has never carried a byte").  A process group of world_size 1 over
+the `nccl` backend (= RCCL on ROCm) runs every collective call site of the multi-GPU path -- the communicator is real, the kernels
+are RCCL's, the stream semantics (`async_op` work handles joined with `wait()`, collectives ordered behind the launch stream) are
+the ones an 8-GPU job uses; only the peer is missing:
+
+  * `driver.broadcast_source_states` (async broadcasts of the packed source state, waited together) and `animate_sharded(gather=True)`
+    through the DEVICE gather branch (`driver.py`: the host staging is gloo-only), against `animate_batched`;
+  * `TrainStep` with its collectives forced on at world 1: construction-time broadcast of parameters / Adam state / BatchNorm buffers,
+    the flat-gradient all-reduce issued from inside the backward (`overlap_allreduce`), eager and through the two-hipGraph form, against
+    a TrainStep that never touches torch.distributed (bit-identical parameters after the steps);
+  * `bench.py --gpus 1` under `torch.distributed.run` (no SMX_BENCH_BACKEND): RCCL initialised, the source state broadcast inside the
+    timed region, `config.parallelism` says so.
+Reference: `/root/reference/basicsr/utils/dist_util.py:10-57` (init), `/root/reference/basicsr/models/base_model.py:71-74` (DDP)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _render_worker(port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import yaml
+        from basicsr.archs import build_network
+        from synergize_motion_appearance_amd import driver
+        from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
+        cfg = yaml.safe_load(open(os.path.join(REPO, "options/test.yml")))
+        net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+        net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
+        me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
+        net_g, me = net_g.cuda().eval(), me.cuda().eval()
+        src, drv = synth_clip(9, seed=31)
+        src, drv = src.cuda(), drv.cuda()
+        res = {"backend": dist.get_backend()}
+        for dt in ("f32", "bf16"):
+            net_g.set_compute_dtype(dt)
+            me.set_compute_dtype(dt)
+            with torch.no_grad():
+                one = driver.animate_batched(src, drv, net_g, me, True, True, batch=4, anchor_idx=2)
+                out = driver.animate_sharded(src, drv, net_g, me, relative=True, adapt_movement_scale=True, batch=4, root=0, anchor_idx=2, gather=True)
+                # several sources: every owner encodes first, then all broadcasts in flight at once, waited together
+                src2 = synth_clip(1, seed=77)[0].cuda()
+                states = driver.broadcast_source_states(net_g, me, {0: (src.unsqueeze(0), drv[2:3]), 1: (src2.unsqueeze(0), drv[2:3])}, {0: 0, 1: 0}, True)
+                again = driver.render_frames(states[0], drv, net_g, me, True, True, batch=4)
+                other = driver.render_frames(states[1], drv, net_g, me, True, True, batch=4)
+            torch.cuda.synchronize()
+            res[dt] = {"gather_vs_single": int((out.int() - one.int()).abs().max()), "bcast_vs_single": int((again.int() - one.int()).abs().max()),
+                       "other_source_differs": int((other.int() - one.int()).abs().max()), "shape": tuple(out.shape), "is_cuda": bool(out.is_cuda)}
+        q.put(res)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(target, timeout=900):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=target, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=timeout)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    return res
+
+
+def test_rccl_world1_broadcast_and_device_gather_equal_the_single_process_frames():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    res = _run(_render_worker)
+    assert res["backend"] == "nccl"
+    for dt in ("f32", "bf16"):
+        r = res[dt]
+        assert r["shape"] == (9, 256, 256, 3) and r["is_cuda"]
+        # same batching on both sides: the broadcast state is a bit copy of the encoded one, so the frames are identical
+        assert r["gather_vs_single"] == 0 and r["bcast_vs_single"] == 0, (dt, r)
+        assert r["other_source_differs"] > 8, (dt, r)
+
+
+def _train_worker(port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    import yaml
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
+    from synergize_motion_appearance_amd.trainer import TrainStep, EquivarianceTransform
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    topt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "gan_opt", "kp_distance_opt")}
+    _, clip = synth_clip(8, seed=321)
+    src, drv = clip[[0, 5]].contiguous().cuda(), clip[[3, 7]].contiguous().cuda()
+
+    def run(use_graph, collectives):
+        net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
+        net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
+        me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
+        TrainStep.COLLECTIVES_AT_WORLD_1 = collectives
+        step = TrainStep(net_g.cuda(), me.cuda(), topt, use_graph=use_graph)
+        gen = torch.Generator().manual_seed(11)
+        for _ in range(4):                                     # graph form: 2 eager steps, capture + replay, replay
+            tf = EquivarianceTransform(2, sigma_affine=0.05, sigma_tps=0.005, points_tps=5, generator=gen)
+            losses, _ = step.step(src, drv, transform=tf)
+        torch.cuda.synchronize()
+        return step.g.flat.value.clone(), step.flat_m.value.clone(), float(losses["l_g_total"]), (step._graph2 is not None)
+    base = run(False, False)                                   # never touches torch.distributed
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eager = run(False, True)
+        graph = run(True, True)
+        base_graph = None
+        TrainStep.COLLECTIVES_AT_WORLD_1 = False
+        q.put({"eager_g": float((eager[0] - base[0]).abs().max()), "eager_m": float((eager[1] - base[1]).abs().max()),
+               "graph_g": float((graph[0] - base[0]).abs().max()), "graph_m": float((graph[1] - base[1]).abs().max()),
+               "scale_g": float(base[0].abs().max()), "two_graphs": graph[3], "loss": (base[2], eager[2], graph[2]), "base_graph": base_graph})
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_training_step_collectives():
+    """the flat-gradient all-reduce (issued at the cut of the backward, joined before Adam) and the construction-time broadcast over RCCL:
+    at world 1 both are identities, so the parameters after four steps equal those of a step that never called a collective -- bit for bit
+    in the eager form (same launches), to the warp-backward atomics' noise through the two-graph form."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    r = _run(_train_worker, timeout=1500)
+    assert r["two_graphs"] is True                            # the overlapped form: [.. backward of net_g] | all-reduce | [backward of the estimator]
+    assert r["eager_g"] <= 2e-6 * r["scale_g"] and r["eager_m"] <= 1e-5, r
+    assert r["graph_g"] <= 1e-4 * r["scale_g"] and r["graph_m"] <= 1e-3, r
+    assert all(abs(l - r["loss"][0]) <= 1e-3 * abs(r["loss"][0]) for l in r["loss"]), r
+
+
+def test_bench_one_rank_under_torchrun_uses_rccl():
+    """`bench.py --gpus 1` launched like the N>1 runs (torch.distributed.run, no backend override): the process group is RCCL, the packed
+    source state is broadcast inside the timed region, and the line says so."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("SMX_BENCH_BACKEND", "SMX_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "12", "--no-cpu-baseline", "--no-roofline", "--no-bf16-leg", "--no-train-leg", "--no-d2h"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["batch_consistency"]["max_lsb_vs_b1"] <= 1
+    assert "RCCL" in j["config"]["parallelism"] and "gloo" not in j["config"]["parallelism"]

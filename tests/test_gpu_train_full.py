@@ -397,6 +397,64 @@ def test_full_step_with_the_gan_branch_vs_reference():
     assert float((step.flat_d.value - before).abs().max()) > 1e-6 and torch.isfinite(step.flat_d.value).all() and torch.isfinite(step.g.flat.value).all()
 
 
+def test_hip_graph_step_survives_the_gan_switch():
+    """train.use_hip_graph across net_d_start_iter: graph-replayed steps without the GAN branch, then gan=True.  The new variant's
+    weight-gradient ReducePlan has to record before anything is captured (recording inside a capture raised and left a corrupt plan:
+    round-4 advisor finding), so step() drops the graphs, runs GRAPH_WARMUP eager steps of the GAN variant, captures again -- and the
+    replayed GAN step is the same computation as eager launches at identical parameters.  The gan=False plans are released."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from basicsr.archs import build_network
+    from synergize_motion_appearance_amd.synth import synth_clip, synth_state_dict
+    from synergize_motion_appearance_amd.trainer import TrainStep, EquivarianceTransform
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/train.yml")))
+    net_g, me, net_d = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"]), build_network(cfg["network_d"])
+    net_g.load_state_dict(weights("network_g"), strict=True)
+    me.load_state_dict(weights("network_motion_estimator"), strict=True)
+    net_d.load_state_dict(synth_state_dict([(k, tuple(v.shape)) for k, v in net_d.state_dict().items()]), strict=True)
+    train_opt = {k: v for k, v in cfg["train"].items() if k not in ("perceptual_opt", "kp_distance_opt")}
+    _, clip = synth_clip(8, seed=99)
+    src, drv = clip[[0, 1]].contiguous().cuda(), clip[[2, 3]].contiguous().cuda()
+    tf = EquivarianceTransform(2, sigma_affine=0.05, sigma_tps=0.005, points_tps=5, generator=torch.Generator().manual_seed(5))
+    step = TrainStep(net_g.cuda(), me.cuda(), train_opt, use_graph=True, net_d=net_d.cuda())
+    for _ in range(step.GRAPH_WARMUP + 2):                                  # eager, eager, capture + replay, replay
+        step.step(src, drv, transform=tf)
+    assert step._graph is not None and step._static["key"][3] is False
+    assert (False, False) in step._reduce_plans
+    for i in range(step.GRAPH_WARMUP):                                      # the switch: eager steps of the new variant first
+        losses, _ = step.step(src, drv, transform=tf, gan=True)
+        assert step._graph is None, i
+    assert (False, False) not in step._reduce_plans and (True, False) in step._reduce_plans
+    for _ in range(2):                                                      # capture + replay, replay
+        losses, _ = step.step(src, drv, transform=tf, gan=True)
+    torch.cuda.synchronize()
+    assert step._graph is not None and step._static["key"][3] is True
+    assert all(torch.isfinite(v).all() for v in losses.values() if torch.is_tensor(v))
+    assert torch.isfinite(step.g.flat.value).all() and torch.isfinite(step.flat_d.value).all()
+    # the replayed GAN step == eager launches at the same parameters
+    bn = {k: v.clone() for k, v in step.bufs.items()}
+    bnd = {k: v.clone() for k, v in step.net_d.state_dict().items() if "running" in k or "num_batches" in k}
+
+    def rewind():
+        for k, v in step.bufs.items():
+            v.copy_(bn[k])
+        sd = step.net_d.state_dict()
+        for k, v in bnd.items():
+            sd[k].copy_(v)
+    rewind()
+    step.g.flat.zero_grad()
+    step.flat_m.zero_grad()
+    le, _ = step.forward_backward(src, drv, transform=tf, gan=True)
+    torch.cuda.synchronize()
+    le, ge, me_ = {k: float(v) for k, v in le.items()}, step.g.flat.grad.clone(), step.flat_m.grad.clone()
+    rewind()
+    lg, _ = step._graph_step(src, drv, 1.0, tf, gan=True)
+    torch.cuda.synchronize()
+    for k in le:
+        assert abs(le[k] - float(lg[k])) <= 2e-5 * max(1.0, abs(le[k])), (k, le[k], float(lg[k]))
+    for a, b, what in ((ge, step.g.flat.grad, "net_g"), (me_, step.flat_m.grad, "motion estimator")):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()), (what, float((a - b).abs().max()), float(a.abs().max()))
+
+
 def test_gan_branch_with_the_adaptive_weight_strictly_inside_its_clamp():
     """round-3 review: train_step_gan.npz pins d_weight only at its clamp (41.5 / 0.118 -> clamp -> 0.8).  Here the discriminator's last
     convolution is scaled by 880 on both sides (tests/golden/train_step_gan_unsat.npz, make_golden_r3.py train_step_gan_unsat), so
