@@ -119,13 +119,14 @@ def _idle_cpus(allowed, want, dt=0.3):
     return sorted(allowed)[:want]
 
 
-def cpu_baseline(Pg, Pm, src, drv, frames=20, warmup=2, threads=None, budget_s=15.0):
+def cpu_baseline(Pg, Pm, src, drv, frames=20, warmup=2, threads=None, budget_s=150.0, cached_frames=5, cached_budget_s=20.0):
     """SURVEY 8(d) protocol: the oracle port of demo.make_animation (B=1, sequential), warm-up 2 frames, MEDIAN of
     >= 20 per-frame times (p10 / p90 beside it); once as the reference runs it (source re-encoded every
     frame, demo.py:130) and once with the source encoder cached; host core count and thread count printed.  The process is
     confined to `cores` CPUs for the duration (one thread per CPU; the least busy ones of a /proc/stat window): on a shared 256-CPU host
-    the unpinned pool migrated between sockets and the figure moved 0.77-1.25 fps between runs.  Bounded: each of the two variants stops
-    after `budget_s` seconds of timed work once it has >= 5 frames (a contended host otherwise turned the 20 frames into minutes)."""
+    the unpinned pool migrated between sockets and the figure moved 0.77-1.25 fps between runs.  The stated variant (source re-encoded per
+    frame, as demo.py does) always gets its `frames` = 20 timed frames unless `budget_s` = 150 s of timed work runs out
+    first -- then `protocol_met` is false and the line says how many frames it has; the cached-encoder side figure is 5 frames / 20 s."""
     from oracle import reenact_oracle as O
     host = os.cpu_count() or 1
     allowed = sorted(os.sched_getaffinity(0))
@@ -146,18 +147,18 @@ def cpu_baseline(Pg, Pm, src, drv, frames=20, warmup=2, threads=None, budget_s=1
                 dm = O.dense_motion(Pm, s, kp_n, kp_s)
                 return O.tensor2img(O.netg_forward(Pg, s, dm, enc=enc if cached else None)["out"])
 
-            def run(cached):
+            def run(cached, n, budget):
                 for t in range(warmup):
                     one(t, cached)
                 ts = []
-                for t in range(frames):
+                for t in range(n):
                     t0 = time.perf_counter()
                     one((warmup + t) % drv.shape[0], cached)
                     ts.append(time.perf_counter() - t0)
-                    if len(ts) >= 5 and sum(ts) > budget_s:
+                    if len(ts) >= 5 and sum(ts) > budget:
                         break
                 return ts
-            t_ref, t_cached = run(False), run(True)
+            t_ref, t_cached = run(False, frames, budget_s), run(True, cached_frames, cached_budget_s)
     finally:
         for tid, mask in prev.items():
             try:
@@ -167,6 +168,7 @@ def cpu_baseline(Pg, Pm, src, drv, frames=20, warmup=2, threads=None, budget_s=1
     a, c = summarise_cpu_times(t_ref), summarise_cpu_times(t_cached)
     return {"value": round(1.0 / a["median_s"], 4), "unit": "frames/s", "cores": cores, "host_cpu_count": host, "kind": "port",
             "value_p10_p90": [round(1.0 / a["p90_s"], 4), round(1.0 / a["p10_s"], 4)],
+            "frames_timed": len(t_ref), "protocol_met": len(t_ref) >= frames,
             "value_cached_encoder": round(1.0 / c["median_s"], 4),
             "value_cached_encoder_p10_p90": [round(1.0 / c["p90_s"], 4), round(1.0 / c["p10_s"], 4)],
             "pinned_cpus": f"{min(cpus)}-{max(cpus)}" if max(cpus) - min(cpus) + 1 == len(cpus) else ",".join(str(c) for c in sorted(cpus)),
@@ -391,6 +393,21 @@ def load_profile_json(name):
     return json.load(open(p)) if os.path.exists(p) else None
 
 
+# kernel family -> the objects of libsmx.so that hold its kernels: a committed counter summary is quoted for a family only while those
+# objects are the ones the counters were taken on (profiles/*_pmc.json "library_build" == lib/build_stamp.json)
+FAMILY_OBJECTS = {"winograd": ("winograd.o",), "winograd_wide": ("winograd.o",), "winograd_nw1": ("winograd.o",), "warp": ("warp_resize.o",),
+                  "gemm_conv": ("gemm_conv.o", "gemm_rp_f32.o", "conv7_bf16x3.o"), "gemm_bf16": ("gemm_bf16.o", "gemm_rp_bf16.o"),
+                  "conv3x3_bf16": ("conv3x3_bf16.o", "conv3x3_bf16_t32.o"), "attention": ("attention.o",), "vq": ("vq.o",)}
+
+
+def pmc_is_current(summary, family):
+    """True when `summary` (a profiles/*_pmc.json) was taken on the library build this process runs, as far as `family`'s kernels go."""
+    from synergize_motion_appearance_amd.build import read_stamp
+    then, now = (summary or {}).get("library_build"), (read_stamp() or {}).get("objects")
+    objs = FAMILY_OBJECTS.get(family)
+    return bool(then and now and objs) and all(then.get(o) is not None and then.get(o) == now.get(o) for o in objs)
+
+
 def summarise_cpu_times(ts):
     ts = sorted(ts)
     q = lambda f: ts[min(len(ts) - 1, max(0, int(round(f * (len(ts) - 1)))))]   # noqa: E731
@@ -577,6 +594,13 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     traffic = load_profile_json(f"{PROFILE_TAG}_traffic_pmc{sfx}.json")
     tfam = (traffic or {}).get("families", {}) if B == DEFAULT_BATCH else {}
     mfma_pmc = load_profile_json(f"{PROFILE_TAG}_mfma_pmc{sfx}.json") if B == DEFAULT_BATCH else None
+    # counters of a kernel that was rebuilt since the PMC pass are not quoted (traffic: null, "pmc_stale" lists what was dropped)
+    stale = sorted(k for k in tfam if not pmc_is_current(traffic, "attention" if k.startswith("attention") else k))
+    tfam = {k: v for k, v in tfam.items() if k not in stale}
+    if mfma_pmc:
+        stale_m = sorted(k for k in mfma_pmc.get("kernels", {}) if not pmc_is_current(mfma_pmc, "attention" if k.startswith("attention") else k))
+        mfma_pmc = dict(mfma_pmc, kernels={k: v for k, v in mfma_pmc["kernels"].items() if k not in stale_m})
+        stale = sorted(set(stale) | set(stale_m))
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     dom = max((k for k in fam if fam[k]["mfma_flops"] > 0 and k not in ("winograd_wide", "winograd_nw1")), key=lambda k: fam[k]["ms"])
     g = fam[dom]
@@ -606,6 +630,9 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
         "launches_per_step": g["calls"] // nprof, "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
         "share_of_step_time": round(g["ms"] / nprof / step_ms, 3),
         "method": f"HIP events around every launch on the launch stream, {nprof} instrumented steps after the timed region"}
+    if stale:
+        roof["pmc_stale"] = {"families": stale, "why": f"profiles/{PROFILE_TAG}_*_pmc{sfx}.json were taken on another build of these kernels (library_build digests differ "
+                                                       "from lib/build_stamp.json): not quoted; re-run tools/gpu_round.sh <tag> tests pmc"}
     if tkey in tfam:
         tl = fam[tkey]
         roof["traffic_launches"] = tkey
@@ -630,7 +657,8 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
         avg_s = f["ms"] * 1e-3 / f["calls"]
         if f["bytes"]:
             e["algorithmic_GBps"] = round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)
-            e["hbm_frac_algorithmic"] = round(e["algorithmic_GBps"] / PEAK_HBM_GBS, 4)
+            # SURVEY 8(d) bytes per second over the HBM peak: NOT a utilisation (operands that stay in L2 / MALL make it exceed 1); `hbm_frac` below is
+            e["algorithmic_GBps_over_hbm_peak"] = round(e["algorithmic_GBps"] / PEAK_HBM_GBS, 4)
         if f["flops"]:
             e["TFLOPs_algorithmic"] = round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2)
         if f["mfma_flops"] and f["mfma_flops"] != f["flops"]:
@@ -641,7 +669,7 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
             # source-encoder launches are separated by block shape / grid size in tools/pmc_traffic.py)
             e["pmc_hbm_bytes_per_launch"] = round(tfam[pf]["hbm_bytes_per_launch"])
             e["pmc_hbm_GBps"] = round(tfam[pf]["hbm_bytes_per_launch"] / avg_s / 1e9, 1)
-            e["hbm_frac_pmc"] = round(e["pmc_hbm_GBps"] / PEAK_HBM_GBS, 4)
+            e["hbm_frac"] = round(e["pmc_hbm_GBps"] / PEAK_HBM_GBS, 4)       # the roofline figure: counter bytes / event time / 8 TB/s
         kern[name] = e
     if "warp" in kern:
         kern["warp"]["note"] = ("algorithmic = SURVEY 8(d) bytes (every frame charged a source read + output write + flow + occlusion); pmc = "

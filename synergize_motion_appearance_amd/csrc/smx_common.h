@@ -16,7 +16,11 @@
 // must not be reported as our launch failing): clear it right before the launch, read it after.
 static inline void smx_clear_stale_error() {
   const hipError_t e = hipGetLastError();
+#ifdef SMX_TOOLS
   if (e != hipSuccess && getenv("SMX_DEBUG_STALE")) fprintf(stderr, "[libsmx] cleared stale caller error: %s\n", hipGetErrorString(e));
+#else
+  (void)e;
+#endif
 }
 
 #define SMX_LAUNCH(...)               \

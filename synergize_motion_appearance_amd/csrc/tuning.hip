@@ -1,6 +1,7 @@
-// Library-wide tuning / test knobs: one table, initialised ONCE from the environment (so the tools that set
-// SMX_* variables keep working), changed at run time through smx_set_tuning -- the launch paths read plain
-// ints, never getenv.  -1 = "auto" (the launcher's own device-tuned choice).
+// Library-wide tuning / test knobs: one table of plain ints the launch paths read; changed at run time through smx_set_tuning (an explicit call:
+// tests, tools).  The SHIPPED library never reads the environment -- a product run's kernel selection cannot be changed by a stray variable;
+// a -DSMX_TOOLS build (tools/*.py, tools/*.sh: A/B timing, ablations) also initialises the table ONCE from SMX_* variables.
+// -1 = "auto" (the launcher's own device-tuned choice).
 #include <string.h>
 #include <stdlib.h>
 #include "smx.h"
@@ -30,14 +31,12 @@ bool g_init = false;
 void init_once() {
   if (g_init) return;
   g_init = true;
+#ifdef SMX_TOOLS
   for (int i = 0; i < SMX_TUNE_COUNT; ++i) {
     const char* e = getenv(g_knobs[i].env);
     if (e && *e) g_knobs[i].value = atoi(e);
   }
-  // round-1 spellings of the negative switches
-  if (getenv("SMX_NO_XCD_SWIZZLE")) g_knobs[SMX_TUNE_GEMM_XCD_SWIZZLE].value = 0;
-  if (getenv("SMX_WARP_OLD")) g_knobs[SMX_TUNE_WARP_ROWS].value = 0;
-  if (getenv("SMX_WARP_NO_REORDER")) g_knobs[SMX_TUNE_WARP_REORDER].value = 0;
+#endif
 }
 }  // namespace
 

@@ -80,6 +80,13 @@ def _same(name, *ts):
             raise L.SmxError(f"{name}: operands must share one storage type ({d} vs {t.dtype})")
 
 
+def _live(*ts):
+    """dense versions of the operands, to be kept in a local until the launch that reads them has been queued.  `t.contiguous().data_ptr()`
+    inside a call expression frees a dense COPY the moment its address has been taken; with two such operands in one call the second
+    copy can be handed the block the first one just gave back -- and the kernel reads the second operand through the first pointer."""
+    return [t if t.is_contiguous() else t.contiguous() for t in ts]
+
+
 def _pix(t, name="tensor"):
     """(ptr, ld) of an NHWC tensor or channel-slice view (fp32 or bf16): last stride 1, dense pixels."""
     _dev(t, name, _ANY)
@@ -106,13 +113,20 @@ def set_tuning(name, value):
     return old.value
 
 
-SMALLN = not _os.environ.get("SMX_NO_SMALLN")
-CONV7_F32 = int(_os.environ.get("SMX_CONV7_F32", "1"))               # fp32 configuration: the 7x7 heads on conv7_f32_kernel (0 = implicit GEMM)
-CONV7_C2 = int(_os.environ.get("SMX_CONV7_C2", "1"))                 # bf16 configuration: BasicMotionEncoder.convf1 on csrc/conv7_c2_bf16.hip (0 = implicit GEMM)
-SMALLN_MFMA_MIN_BLOCKS = 512                                          # 8 x 32-pixel tiles; below: the VALU kernel (tests lower it)
-SMALLN_MFMA = int(_os.environ.get("SMX_SMALLN_MFMA", "1"))           # bf16 storage: C_out <= 4 3x3 layers on the bf16 MFMA (csrc/conv3x3_smalln_mfma16.hip); 0 = the VALU kernel
+def _knob(name, default):
+    """kernel-selection switches are a TOOLS facility (bisection, A/B timing): they are read from the environment only when SMX_TOOLS is set
+    (tools/*.sh export it).  A product run never consults them -- which kernel renders a frame does not depend on a stray variable;
+    tests change the module attributes below (or `set_tuning`) explicitly."""
+    return int(_os.environ.get(name, default)) if _os.environ.get("SMX_TOOLS") else int(default)
 
-WINOGRAD = not _os.environ.get("SMX_NO_WINOGRAD")
+
+SMALLN = bool(_knob("SMX_SMALLN", 1))
+CONV7_F32 = _knob("SMX_CONV7_F32", 1)               # fp32 configuration: the 7x7 heads on conv7_f32_kernel (0 = implicit GEMM)
+CONV7_C2 = _knob("SMX_CONV7_C2", 1)                 # bf16 configuration: BasicMotionEncoder.convf1 on csrc/conv7_c2_bf16.hip (0 = implicit GEMM)
+SMALLN_MFMA_MIN_BLOCKS = 512                                          # 8 x 32-pixel tiles; below: the VALU kernel (tests lower it)
+SMALLN_MFMA = _knob("SMX_SMALLN_MFMA", 1)           # bf16 storage: C_out <= 4 3x3 layers on the bf16 MFMA (csrc/conv3x3_smalln_mfma16.hip); 0 = the VALU kernel
+
+WINOGRAD = bool(_knob("SMX_WINOGRAD", 1))
 
 
 class Conv:
@@ -294,11 +308,11 @@ def gemm16_raw(**kw):
     L.check(_timed("gemm_bf16", meta, L.load().smx_gemm_conv_bf16, C.byref(d), _stream()), "smx_gemm_conv_bf16")
 
 
-REGION3X3 = not _os.environ.get("SMX_NO_REGION3X3")
-CONV16_TILE_H = int(_os.environ.get("SMX_CONV16_TILE_H", "0"))      # 0 = auto, 8 | 16 = forced (tools / tests)
+REGION3X3 = bool(_knob("SMX_REGION3X3", 1))
+CONV16_TILE_H = _knob("SMX_CONV16_TILE_H", 0)      # 0 = auto, 8 | 16 = forced (tools / tests)
 
 
-CONV16_F32_REGION = int(_os.environ.get("SMX_CONV16_F32_REGION", "1"))   # fp32-storage form of the region kernel (bf16-compute training); 0 = implicit GEMM
+CONV16_F32_REGION = _knob("SMX_CONV16_F32_REGION", 1)   # fp32-storage form of the region kernel (bf16-compute training); 0 = implicit GEMM
 
 
 # SMX_SHARED_DEVICE=1: this process shares its GPU with another process of the job (the two-ranks-on-one-device test harness; never a
@@ -464,7 +478,7 @@ def _conv16(x, cv, out, stride, pt, pl, up2, act, res, Ho, Wo, d2s, tile, in_ss,
 
 # F(4x4,3x3) (csrc/winograd43.hip): parity-tested, selectable, OFF by default -- measured 0.81-0.93x the speed of the F(2x2,3x3) wide
 # kernel on the B=60 shapes (executed-MFMA fraction 0.23-0.29 vs 0.45-0.61; profiles/r03_wino43_*.txt, DESIGN section 4 "Round 3")
-WINO43 = int(_os.environ.get("SMX_WINO43", "0"))
+WINO43 = _knob("SMX_WINO43", 0)
 WINO43_MIN_BLOCKS = 512                                 # tests force the kernel on small inputs by lowering this
 
 
@@ -663,6 +677,9 @@ def groupnorm(x, gamma, beta, swish=True, out=None, groups=32, eps=1e-6):
     return out
 
 
+EPILOGUE_STATS = True      # groupnorm_stats consumes the Welford partials a producing convolution left on its output (False: always the two-pass kernel; tests)
+
+
 def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
     """per-(b,c) {scale, shift} of GroupNorm for x [B,H,W,C] (fp32 or bf16 storage) -> ss [B,C,2] fp32 (consumed by conv(in_ss=...))."""
     B, H, W, Cc = x.shape
@@ -670,7 +687,7 @@ def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
     lib = L.load()
     ss = torch.empty((B, Cc, 2), device=x.device, dtype=torch.float32)
     part = getattr(x, "_gn_part", None)
-    if part is not None and part.shape[0] == B and part.shape[2] == Cc and not _os.environ.get("SMX_NO_EPILOGUE_STATS"):
+    if part is not None and part.shape[0] == B and part.shape[2] == Cc and EPILOGUE_STATS:
         # the producing conv already reduced its output per block: finalize only (reads B*nch*C*8 bytes)
         L.check(_timed("groupnorm", {"bytes": 8.0 * part.numel() / 2}, lib.smx_groupnorm_finalize_f32, part.data_ptr(),
                        _dev(gamma).data_ptr(), _dev(beta).data_ptr(), ss.data_ptr(), B, H * W, Cc, groups, part.shape[1], eps,
@@ -787,8 +804,8 @@ def antialias_down(img_nchw, w, out=None, step=4):
     if out is None:
         out = torch.empty((B, (H + step - 1) // step, (W + step - 1) // step, Cc), device=img_nchw.device, dtype=torch.float32)
     yp, ldy = _pix(out, "antialias output")
-    L.check(L.load().smx_antialias_down_f32(img_nchw.contiguous().data_ptr(), _dev(w).contiguous().data_ptr(), yp, ldy, B, Cc,
-                                            H, W, K, step, _stream()), "antialias_down")
+    xc, wc = img_nchw.contiguous(), _dev(w).contiguous()     # dense copies (if any) stay referenced until the launch is queued: see _live
+    L.check(L.load().smx_antialias_down_f32(xc.data_ptr(), wc.data_ptr(), yp, ldy, B, Cc, H, W, K, step, _stream()), "antialias_down")
     return out
 
 
@@ -809,7 +826,13 @@ def normalize_kp(kp_d, kp_0, kp_s, scale, rel_move, rel_jac):
     v, j = _dev(kp_d["value"]).contiguous(), _dev(kp_d["jacobian"]).contiguous()
     B, K = v.shape[0], v.shape[1]
     ov, oj = torch.empty_like(v), torch.empty_like(j)
-    ptr = lambda d, k: None if d is None else _dev(d[k]).contiguous().data_ptr()
+    live = []                                                # see _live
+
+    def ptr(d, k):
+        if d is None:
+            return None
+        live.append(_dev(d[k]).contiguous())
+        return live[-1].data_ptr()
     if torch.is_tensor(scale):
         _dev(scale, "normalize_kp scale")
         L.check(L.load().smx_normalize_kp_dscale_f32(v.data_ptr(), j.data_ptr(), ptr(kp_0, "value"), ptr(kp_0, "jacobian"), ptr(kp_s, "value"),
@@ -830,9 +853,9 @@ def sparse_motion(src64, kpd_value, kpd_jac, kps_value, kps_jac, hg_in, B, K=15,
     heat = torch.empty((B, H, W, K), device=src64.device, dtype=torch.float32)
     for t in (kpd_value, kpd_jac, kps_value, kps_jac):
         _dev(t)
-    L.check(L.load().smx_sparse_motion_f32(_dev(src64).contiguous().data_ptr(), Bs, kpd_value.contiguous().data_ptr(),
-                                           kpd_jac.contiguous().data_ptr(), kps_value.contiguous().data_ptr(),
-                                           kps_jac.contiguous().data_ptr(), kps_value.shape[0], hp, ldh, sparse.data_ptr(),
+    live = _live(_dev(src64), kpd_value, kpd_jac, kps_value, kps_jac)
+    L.check(L.load().smx_sparse_motion_f32(live[0].data_ptr(), Bs, live[1].data_ptr(), live[2].data_ptr(), live[3].data_ptr(),
+                                           live[4].data_ptr(), kps_value.shape[0], hp, ldh, sparse.data_ptr(),
                                            heat.data_ptr(), B, H, W, K, var, _stream()), "sparse_motion")
     return sparse, heat
 
@@ -1006,7 +1029,8 @@ def vq_nearest(z_tokens, codebook, Ks, want_zq=True):
     sq = torch.empty((1,), device=z_tokens.device, dtype=torch.float32)
     ws = torch.empty((int(L.load().smx_vq_ws_floats(N)),), device=z_tokens.device, dtype=torch.float32)   # code norms + per-block loss partials (no atomics)
     meta = {"bytes": 8.0 * N * D + 4.0 * Ks * D + 8.0 * N, "flops": 2.0 * N * Ks * D}
-    L.check(_timed("vq", meta, L.load().smx_vq_nearest_f32, z_tokens.contiguous().data_ptr(), codebook.contiguous().data_ptr(),
+    live = _live(z_tokens, codebook)
+    L.check(_timed("vq", meta, L.load().smx_vq_nearest_f32, live[0].data_ptr(), live[1].data_ptr(),
                    idx.data_ptr(), None if zq is None else zq.data_ptr(), dmin.data_ptr(), sq.data_ptr(), ws.data_ptr(), N, D, Ks,
                    _stream()), "vq_nearest")
     return idx, zq, dmin, sq

@@ -899,8 +899,9 @@ def sparse_motion(tp, src64, kpd_value, kpd_jac, kps_value, kps_jac, K=15, var=0
         gs = gs if gs is None or gs.is_contiguous() else gs.contiguous()
         gd = gd if gd is None or gd.is_contiguous() else _dense(lib, gd)
         d = [_empty((B, K, 2), src64), _empty((B, K, 4), src64), _empty((B, K, 2), src64), _empty((B, K, 4), src64)]
-        L.check(lib.smx_sparse_motion_bwd_f32(src64.data_ptr(), kpd_value.contiguous().data_ptr(), dj.contiguous().data_ptr(),
-                                              kps_value.contiguous().data_ptr(), sj.contiguous().data_ptr(), gh.data_ptr(), 4 * (K + 1),
+        live = [t if t.is_contiguous() else t.contiguous() for t in (kpd_value, dj, kps_value, sj)]       # referenced until the launch is queued (ops._live)
+        L.check(lib.smx_sparse_motion_bwd_f32(src64.data_ptr(), live[0].data_ptr(), live[1].data_ptr(),
+                                              live[2].data_ptr(), live[3].data_ptr(), gh.data_ptr(), 4 * (K + 1),
                                               None if gs is None else gs.data_ptr(), None if gd is None else gd.data_ptr(),
                                               d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), B, 64, 64, K, float(var), _stream()),
                 "sparse_motion_bwd")

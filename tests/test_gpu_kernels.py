@@ -193,9 +193,9 @@ def test_winograd_epilogue_emits_groupnorm_partials(ops, B, C, Co, H, W, act, re
     if Co & (Co - 1) == 0:                                    # the two-pass kernel takes power-of-two C
         g, bt = rnd(f"wsg{Co}", (Co,)) * 0.2 + 1.0, rnd(f"wsbt{Co}", (Co,), 0.1)
         ss_fused = ops.groupnorm_stats(y, g.cuda(), bt.cuda())
-        monkeypatch.setenv("SMX_NO_EPILOGUE_STATS", "1")
+        monkeypatch.setattr(ops, "EPILOGUE_STATS", False)
         ss_two_pass = ops.groupnorm_stats(y, g.cuda(), bt.cuda())
-        monkeypatch.delenv("SMX_NO_EPILOGUE_STATS")
+        monkeypatch.setattr(ops, "EPILOGUE_STATS", True)
         assert maxabs(ss_fused.cpu(), ss_two_pass.cpu()) < 2e-5
         ref = F.group_norm(nchw(y), 32, g, bt, 1e-6)
         assert maxabs(nchw(ops.groupnorm_apply(y, ss_fused, swish=False)), ref) < 5e-5
@@ -551,9 +551,11 @@ def test_warp_row_chunk_kernel_equals_per_lane_kernel_and_oracle(ops, C, s, B, f
     fd, od, xs = flow.cuda().contiguous(), occ.view(B, fs, fs).cuda().contiguous(), nhwc(feat)
     xb = nhwc(feat.repeat(B, 1, 1, 1) * torch.linspace(0.5, 1.5, B).view(B, 1, 1, 1))
     new = [ops.warp(xs, fd, od), ops.warp(xs, fd), ops.warp(xb, fd, od)]
-    monkeypatch.setenv("SMX_WARP_OLD", "1")
-    old = [ops.warp(xs, fd, od), ops.warp(xs, fd), ops.warp(xb, fd, od)]
-    monkeypatch.delenv("SMX_WARP_OLD")
+    prev = ops.set_tuning("warp_rows", 0)                      # the per-lane-coordinates kernel
+    try:
+        old = [ops.warp(xs, fd, od), ops.warp(xs, fd), ops.warp(xb, fd, od)]
+    finally:
+        ops.set_tuning("warp_rows", prev)
     for a, b in zip(new, old):
         a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
         # two correct fp32 flow resizes differ by an ulp of the flow, amplified by (s-1)/2 x feature gradient

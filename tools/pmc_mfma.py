@@ -41,6 +41,17 @@ def variants(name):
     return out
 
 
+def _library_build():
+    """{object: sha256 of (flags + source + headers)} of the libsmx.so these counters were taken on (lib/build_stamp.json): bench.py quotes a
+    family's counters only while the objects that hold its kernels still have these digests."""
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "synergize_motion_appearance_amd", "lib", "build_stamp.json")
+    try:
+        return json.load(open(p))["objects"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main(pmc_dir, out, command=""):
     per = collections.defaultdict(lambda: collections.defaultdict(float))   # family -> counter -> sum
     disp = collections.defaultdict(dict)                                   # family -> dispatch id -> duration ns
@@ -76,7 +87,7 @@ def main(pmc_dir, out, command=""):
                 e[k + "_per_launch"] = round(c[k] / n)
         res[fam] = e
     json.dump({"source": "rocprofv3 --pmc (one pass) -- " + command, "definitions": __doc__.split("Derived per family:")[1].strip(),
-               "kernels": res}, open(out, "w"), indent=1)
+               "kernels": res, "library_build": _library_build()}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 

@@ -39,6 +39,17 @@ def family(name):
     return None
 
 
+def _library_build():
+    """{object: sha256 of (flags + source + headers)} of the libsmx.so these counters were taken on (lib/build_stamp.json): bench.py quotes a
+    family's counters only while the objects that hold its kernels still have these digests."""
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "synergize_motion_appearance_amd", "lib", "build_stamp.json")
+    try:
+        return json.load(open(p))["objects"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main(fetch_dir, write_dir, out):
     fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     fams = collections.defaultdict(lambda: {"launches": 0, "fetch_kb_raw": 0.0, "write_kb": 0.0, "wlaunches": 0})
@@ -67,7 +78,7 @@ def main(fetch_dir, write_dir, out):
                          "--profile-only` (timed steps only: no B=1 re-render check, so every warp / attention / layernorm launch is a full-batch (B = 300 by default) "
                          "launch; the B=1 source-encoder convolutions are separated by block shape: winograd_wide = the full-batch (B = 300 by default) launches); "
                          "FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B)",
-               "families": res}, open(out, "w"), indent=1)
+               "families": res, "library_build": _library_build()}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 

@@ -30,6 +30,8 @@ ap.add_argument("--reencode", action="store_true", help="re-encode the source st
 ap.add_argument("--poison", type=int, default=0, help="bit 1: fill every CU's LDS with NaN before every C-ABI call, bit 2: every SIMD's VGPRs/AGPRs "
                                                       "(tools/poison.hip -> /tmp/libpoison.so); the first two passes stay clean (the reference)")
 ap.add_argument("--poison-pattern", default="0xFFFFFFFF")
+ap.add_argument("--keep", type=int, default=0, help="keep full copies of the first K fingerprinted tensors of every pass; a mismatching pass is compared with the "
+                                                    "reference pass element by element (a sum fingerprint cannot see a permutation)")
 args = ap.parse_args()
 
 cfg = yaml.safe_load(open(os.path.join(REPO, "options/test.yml")))
@@ -43,6 +45,7 @@ src, drv = synth_clip(args.batch + 1, seed=31)
 src, drv = src.cuda(), drv.cuda()
 
 RECORDS = None          # list of (label, device int64 scalar) of the current pass
+KEPT = []               # --keep: clones of the first K fingerprinted tensors of the current pass
 POISON = [0]            # what the C-ABI proxy poisons before each call (0 = nothing)
 if args.poison:
     import ctypes as C
@@ -98,6 +101,8 @@ def _record(name, phase, obj):
         if b is None:
             continue
         RECORDS.append((f"{name}:{phase}{label} {tuple(t.shape)} {str(t.dtype)[6:]}", torch.sum(b, dtype=torch.int64)))
+        if len(KEPT) < args.keep:
+            KEPT.append(t.clone())
 
 
 def _wrap(name, fn):
@@ -124,17 +129,37 @@ def one_pass(state):
     if args.reencode:
         state = driver.encode_source_state(net_g, me, src, drv[0:1], True)
     RECORDS = [] if args.trace else None
+    del KEPT[:]
     out = driver.render_frames(state, drv[1:1 + args.batch], net_g, me, True, True, batch=args.batch)
     rec, RECORDS = RECORDS, None
     if rec is not None:
         labels = [l for l, _ in rec]
         vals = torch.stack([v for _, v in rec]).cpu()
-        return out, (labels, vals)
+        return out, (labels, vals, list(KEPT))
     return out, None
 
 
+def compare_kept(rec, ref_rec, limit=10):
+    """element-wise comparison of the kept tensors of a pass with the reference pass: which records differ, where, and by what."""
+    lines = []
+    for i, (a, b) in enumerate(zip(rec[2], ref_rec[2])):
+        if a.shape != b.shape or a.dtype != b.dtype:
+            lines.append(f"    #{i} {rec[0][i]}: shape / dtype differs")
+            continue
+        ne = (_bits(a) != _bits(b))
+        n = int(ne.sum())
+        if n:
+            idx = ne.nonzero()[:4].tolist()
+            lead = sorted(set(ix[0] for ix in ne.nonzero()[:, :1].tolist())) if ne.dim() > 1 else []
+            vals = [(tuple(ix), float(a[tuple(ix)].float()), float(b[tuple(ix)].float())) for ix in idx]
+            lines.append(f"    #{i} {rec[0][i]}: {n} of {a.numel()} elements differ; leading indices {lead[:8]}; first (index, got, reference): {vals}")
+            if len(lines) >= limit:
+                break
+    return "\n".join(lines) if lines else "    (all kept tensors equal the reference pass element by element)"
+
+
 def explain(rec, ref_rec, stable):
-    labels, vals = rec
+    labels, vals = rec[0], rec[1]
     if labels != ref_rec[0]:
         return " | launch sequence differs from the first pass"
     diff = [i for i in (vals != ref_rec[1]).nonzero().flatten().tolist() if stable[i]]
@@ -162,6 +187,8 @@ with torch.no_grad():
             if bad <= 12:
                 print(f"[{args.tag}] MISMATCH pass {p} t={time.time() - t0:.1f}s: per-frame max LSB {per_frame}, bytes differing {int((d > 0).sum())}"
                       + (explain(rec, ref_rec, stable) if rec is not None else ""), flush=True)
+                if rec is not None and args.keep:
+                    print(compare_kept(rec, ref_rec), flush=True)
         elif rec is not None and quiet < 3:
             diff = [i for i in (rec[1] != ref_rec[1]).nonzero().flatten().tolist() if stable[i]]
             if diff:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """time the A7 warp kernel at the four scales (B frames, source features broadcast) -> algorithmic GB/s
-usage: warp_bench.py [B] [noise|smooth]   (SMX_WARP_OLD=1: the per-lane-coordinates kernel for comparison)"""
+usage: warp_bench.py [B] [noise|smooth]   (SMX_TOOLS build + SMX_WARP_ROWS=0: the per-lane-coordinates kernel for comparison)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
