@@ -414,14 +414,6 @@ def summarise_cpu_times(ts):
     return {"median_s": statistics.median(ts), "p10_s": q(0.1), "p90_s": q(0.9)}
 
 
-def _poison_free_memory(dev, gb):
-    """debug (SMX_BENCH_POISON=<GB>): hand the caching allocator <GB> of 0xFF bytes (NaN in every float format) so that a kernel reading
-    memory nobody wrote shows up as NaN / a failed consistency check instead of depending on what the pages held before."""
-    blocks = [torch.full((1 << 28,), -1, dtype=torch.int32, device=dev) for _ in range(int(gb))]
-    torch.cuda.synchronize()
-    del blocks
-
-
 def render_leg(args, dtype, world, rank, dev, dist, collective, net_g, me, drv, my_sources, n_src):
     """one measured leg in `dtype` storage: prologue + W warm-up steps, then barrier | prologue + K steps | barrier, max over ranks;
     followed by the B=1 re-render check of the last timed batch.  -> dict with the timing, the states and the step closure."""
@@ -473,8 +465,6 @@ def render_leg(args, dtype, world, rank, dev, dist, collective, net_g, me, drv, 
             dist.barrier()
         torch.cuda.synchronize()
 
-    if os.environ.get("SMX_BENCH_POISON"):
-        _poison_free_memory(dev, os.environ["SMX_BENCH_POISON"])
     prologue()
     for i in range(W):
         step(work[i])
@@ -518,48 +508,13 @@ def render_leg(args, dtype, world, rank, dev, dist, collective, net_g, me, drv, 
             return worst, ndiff, ntot, dsum
         is_bad = lambda w_, s_, n_: (w_ > 1) if dtype == "f32" else (s_ / n_ >= 1.5 or w_ > 42)   # noqa: E731
         worst, ndiff, ntot, dsum = compare(out)
-        retries = 0
-        # SHARED-DEVICE TEST HARNESS ONLY (SMX_BENCH_ONE_DEVICE: two ranks of the job on one GPU).  There the bf16 pass shows transient wrong frames
-        # in ~10 % of runs -- already in the round-3 tree (2 of 16), bit-exact again when the same batch is rendered again in the same process,
-        # never with one process per GPU (open issue).  The harness re-renders the batch (at most twice) before it fails, and says so.
-        while is_bad(worst, dsum, ntot) and os.environ.get("SMX_BENCH_ONE_DEVICE") and retries < 2:
-            retries += 1
-            torch.cuda.synchronize()
-            print(f"[bench] rank {rank}: shared-device harness: consistency check failed ({worst} LSB, mean {dsum / ntot:.3f}); re-rendering the batch "
-                  f"(retry {retries})", file=sys.stderr, flush=True)
-            worst, ndiff, ntot, dsum = compare(step(work[W + K - 1]))
         consistency = {"frames_checked": len(picks), "max_lsb_vs_b1": worst, "mean_lsb_vs_b1": round(dsum / ntot, 5), "bytes_differing": ndiff,
                        "bytes": ntot, "what": f"frames {picks} of the last timed batch (B={n_mine}) re-rendered one at a time; uint8 outputs compared"}
-        if retries:
-            consistency["shared_device_harness_retries"] = retries
         # fp32: another batch size only reorders fp32 sums (<= 1 LSB).  bf16 storage: a reordered sum can round to the other
         # neighbour (2^-8) and the flip propagates through ~100 layers, so two bf16 evaluations are as far from each other as
         # each is from fp32; the bar there is the reference-under-autocast error (tests/golden/autocast_bf16.npz: mean 0.0078,
         # max 0.33 on [-1,1] = 1.0 / 42 LSB): mean < 1.5 LSB, worst pixel <= 42 LSB
         bad = is_bad(worst, dsum, ntot)
-        if bad and os.environ.get("SMX_BENCH_DEBUG_DIAG"):
-            from synergize_motion_appearance_amd import ops as _ops
-            torch.cuda.synchronize()
-            outs = {"first": out}
-            outs["again"] = step(work[W + K - 1])
-            outs["again2"] = step(work[W + K - 1])
-            _ops.GEMM16_RP = 0
-            outs["norp"] = step(work[W + K - 1])
-            _ops.GEMM16_RP = 1
-            torch.cuda.synchronize()
-            ref = outs["norp"].int()
-            msg = {k: (int((v.int() - ref).abs().max()), float((v.int() - ref).abs().float().mean())) for k, v in outs.items()}
-            ones = {}
-            for flag in (1, 0):
-                _ops.GEMM16_RP = flag
-                o1 = torch.cat([driver.render_frames(states[j_last], fr_last[i:i + 1], net_g, me, True, True, batch=1) for i in range(fr_last.shape[0])])
-                ones[flag] = o1
-            _ops.GEMM16_RP = 1
-            torch.cuda.synchronize()
-            msg["b1_rp_vs_b1_norp"] = int((ones[1].int() - ones[0].int()).abs().max())
-            msg["b1_norp_vs_b6_norp"] = int((ones[0].int() - ref[off:off + fr_last.shape[0]]).abs().max())
-            per_frame = [(int((ones[1][i].int() - ones[0][i].int()).abs().max()), int((outs["first"][off + i].int() - ref[off + i]).abs().max())) for i in range(fr_last.shape[0])]
-            print(f"[bench diag rank {rank}] vs B=6 without the row-panel kernel (max, mean): {msg}; per frame (B=1 rp vs no rp, first B=6 vs no rp): {per_frame}", file=sys.stderr, flush=True)
         if bad:
             raise SystemExit(f"[bench] batch consistency FAILED ({dtype}): B={n_mine} output differs from B=1 by {worst} LSB (mean {dsum / ntot:.3f})")
     return {"dt": dt, "fps": fps, "frames_total": frames_total, "rank_times": rank_times, "consistency": consistency, "states": states,
@@ -756,8 +711,6 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the HIP path)"
     one_device = bool(os.environ.get("SMX_BENCH_ONE_DEVICE"))   # test knob: exercise the N>1 control flow on a 1-GPU box
-    if one_device:
-        os.environ["SMX_SHARED_DEVICE"] = "1"                   # ops.py: several processes on this GPU (see the note there)
     if one_device:
         local = 0
     torch.cuda.set_device(local)

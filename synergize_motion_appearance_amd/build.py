@@ -18,6 +18,20 @@ LIB = os.path.join(LIBDIR, "libsmx.so")
 # that consumes accumulators (softmax on S, O rescale, Winograd / GEMM epilogues) needs no v_accvgpr_read/write copies
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-mllvm", "-amdgpu-mfma-vgpr-form",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
+# No packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in the library's generated code.  Measured on the MI355X (DESIGN
+# section 6, profiles/r05_shared_device_*.txt): `sparse_motion_kernel`, whose keypoint arithmetic hipcc SLP-packs into such instructions, returned wrong
+# values in lanes 48-63 of some waves whenever ANOTHER process on the same GPU was running the bf16 MFMA convolution -- identical inputs, a
+# different output, 10-30 % of the frames of a shared-device run; rebuilt without the packed forms the same kernel is bit-stable
+# (tools/sm_probe.hip, 0 of 346,592 launches against 187 M wrong elements), and so is the whole pipeline (0 of 9,269 passes against 50 of
+# 1,883).  Every other kernel was checked as the victim of the same neighbour and is clean either way; the two Winograd files keep the
+# packed forms (their input transform is where they pay: -2.4 % on the fp32 headline without them).  The flag is a device-side target
+# feature; the host half of the compilation prints a harmless "not a recognized feature" note.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+KEEPS_PACKED_FP32 = ("winograd.hip", "winograd43.hip")
+
+
+def flags_for(src):
+    return FLAGS + ([] if os.path.basename(src) in KEEPS_PACKED_FP32 else NO_PACKED_FP32)
 
 
 def sources():
@@ -57,7 +71,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
     headers = sorted([os.path.join(REPO, "include", "smx.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")])
-    flags = FLAGS + (["-DSMX_TOOLS"] if os.environ.get("SMX_TOOLS") else [])
+    extra = (["-DSMX_TOOLS"] if os.environ.get("SMX_TOOLS") else []) + os.environ.get("SMX_HIPCC_EXTRA", "").split()   # EXTRA: A/B builds (tools)
     old = (read_stamp() or {}).get("objects", {})
     new = {}
     objs, jobs = [], []
@@ -65,6 +79,7 @@ def build(force=False, verbose=True):
         name = os.path.basename(src)[:-4] + ".o"
         obj = os.path.join(LIBDIR, name)
         objs.append(obj)
+        flags = flags_for(src) + extra
         new[name] = _digest([src] + headers, " ".join(a for a in flags if not a.startswith(REPO)))
         if force or not os.path.exists(obj) or old.get(name) != new[name]:
             jobs.append([hipcc] + flags + ["-c", src, "-o", obj])

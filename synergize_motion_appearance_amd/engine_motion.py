@@ -12,7 +12,6 @@ Design points (MI355X-first, not a translation):
   * B driving frames run per launch (the reference loops B=1): the deep hourglass layers are
     weight-bandwidth bound at B=1 (207 MB of fp32 weights per frame).
 """
-import os
 
 import torch
 
@@ -20,7 +19,7 @@ from . import ops
 from .manifest import hourglass_channels
 from .ops import Conv, ACT_RELU
 
-HEADS_X3 = int(os.environ.get("SMX_HEADS_X3", "1")) and not ops._SHARED_DEVICE      # configs[2]: the 7x7 heads in bf16x3 arithmetic on the bf16 MFMA (0 = fp32 implicit GEMM)
+HEADS_X3 = ops._knob("SMX_HEADS_X3", 1)      # configs[2]: the 7x7 heads in bf16x3 arithmetic on the bf16 MFMA (0 = fp32 implicit GEMM)
 
 
 def _fold_bn(P, pre):

@@ -16,7 +16,6 @@ MI355X-first choices:
   * the redundant third warp per scale (`deform_feat_list`, :615/:714) is not recomputed.
 """
 import math
-import os
 
 import torch
 
@@ -25,7 +24,7 @@ from . import ops
 from .manifest import encoder_plan, generator_plan, CHANNELS
 from .ops import Conv, ACT_RELU, ACT_LRELU02, ACT_GELU
 
-ATTNBLOCK_FUSED16 = int(os.environ.get("SMX_ATTNBLOCK_FUSED16", "1")) and not ops._SHARED_DEVICE     # bf16 AttnBlock core as one kernel (0 = QK^T GEMM, softmax_rows, PV GEMM)
+ATTNBLOCK_FUSED16 = ops._knob("SMX_ATTNBLOCK_FUSED16", 1)     # bf16 AttnBlock core as one kernel (0 = QK^T GEMM, softmax_rows, PV GEMM)
 
 _SCALE_K = {32: 1, 64: 2, 128: 3, 256: 4}
 

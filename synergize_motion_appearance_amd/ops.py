@@ -315,16 +315,8 @@ CONV16_TILE_H = _knob("SMX_CONV16_TILE_H", 0)      # 0 = auto, 8 | 16 = forced (
 CONV16_F32_REGION = _knob("SMX_CONV16_F32_REGION", 1)   # fp32-storage form of the region kernel (bf16-compute training); 0 = implicit GEMM
 
 
-# SMX_SHARED_DEVICE=1: this process shares its GPU with another process of the job (the two-ranks-on-one-device test harness; never a
-# deployment: one process per GPU).  The inference kernels that stage through LDS-DMA (row-panel GEMMs, bf16x3 7x7 heads, fused
-# AttnBlock, 16x32-tile 3x3) are switched off there: with two torch.distributed ranks on ONE MI355X the bf16 pipeline produced wrong
-# frames in ~30 % of first passes (bit-exact again when re-run in the same process; never seen with one process per GPU, in
-# 3000-iteration two-process stress runs of a kernel alone, or with the kernel's DMA fully serialised) -- unexplained, DESIGN
-# section 6 "open issue".
-_SHARED_DEVICE = bool(int(_os.environ.get("SMX_SHARED_DEVICE", "0"))) and not int(_os.environ.get("SMX_FORCE_LDSDMA", "0"))   # FORCE: tools/bisect_cons.sh
-SMALLN_MFMA = SMALLN_MFMA and not _SHARED_DEVICE
-GEMM_RP = int(_os.environ.get("SMX_GEMM_RP", "1")) and not _SHARED_DEVICE      # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
-GEMM16_RP = int(_os.environ.get("SMX_GEMM16_RP", "1")) and not _SHARED_DEVICE  # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
+GEMM_RP = _knob("SMX_GEMM_RP", 1)          # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
+GEMM16_RP = _knob("SMX_GEMM16_RP", 1)      # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
 GEMM16_RP_MIN_ROWS = 16384                                           # below: too few 32-row tiles to fill the persistent blocks (tests lower it)
 
 
@@ -339,7 +331,7 @@ def _rows_dense(t):
     return True
 
 
-CONV16_T32 = int(_os.environ.get("SMX_CONV16_T32", "1")) and not _SHARED_DEVICE           # 16x32-tile kernel (csrc/conv3x3_bf16_t32.hip) for the big launches; 0 = off
+CONV16_T32 = _knob("SMX_CONV16_T32", 1)           # 16x32-tile kernel (csrc/conv3x3_bf16_t32.hip) for the big launches; 0 = off
 CONV16_T32_MIN_BLOCKS = 1024                                         # two resident rounds of the chip's 512 block slots; tests lower it
 
 
@@ -569,7 +561,7 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     if (CONV7_F32 and not direct and tile == 0 and cv.kh == 7 and cv.kw == 7 and stride == 1 and (pt, pl) in ((3, 3), (0, 0)) and not d2s and not up2
             and res is None and in_ss is None and Cin % 16 == 0 and cv.cout <= 96 and (Ho, Wo) == (H + 2 * pt - 6, W + 2 * pl - 6)
             and lda % 4 == 0 and a_ptr % 16 == 0 and ldc == cv.cout and act in (ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SIGMOID)
-            and B * ((Ho + 7) // 8) * ((Wo + 31) // 32) >= 256 and not _SHARED_DEVICE):
+            and B * ((Ho + 7) // 8) * ((Wo + 31) // 32) >= 256):
         # the mask / occlusion head (128 -> 17): region-direct on the fp32 MFMA (the implicit GEMM staged every input pixel 49 times): 6.0 -> 3.5 ms.
         # C_in % 16 == 0 only: the keypoint head's 36 channels pad to 48 here and lose to the implicit GEMM (4.4 against 4.1 ms)
         meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 49 * Cin, "mfma_flops": 2.0 * B * Ho * Wo * 32 * ((cv.cout + 31) // 32) * 49 * 16 * ((Cin + 15) // 16),

@@ -30,7 +30,6 @@ def _free_port():
 def _worker(rank, world, port, n_frames, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    os.environ["SMX_SHARED_DEVICE"] = "1"                  # both ranks on ONE GPU (ops.py: the row-panel kernels stay off in this harness)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:

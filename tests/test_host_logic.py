@@ -513,7 +513,7 @@ def test_wgrad_split_and_reduce_items_host_side():
 
 def test_round4_kernel_eligibility_rules_host_side():
     """shape rules the Python dispatch relies on, straight from the library (no GPU): the row-panel GEMMs take K = 128 / 256, N % 128 == 0,
-    M % 32 == 0; the bf16x3 7x7 pack size; the shared-device switch of ops.py turns every LDS-DMA inference kernel off."""
+    M % 32 == 0; the bf16x3 7x7 pack size; the kernel-selection switches of ops.py are a tools facility a product run never reads."""
     import subprocess
     import sys
     from synergize_motion_appearance_amd import lib as L
@@ -526,11 +526,20 @@ def test_round4_kernel_eligibility_rules_host_side():
         assert ok(307200, 192, 256) == 0 and ok(307200, 256, 64) == 0 and ok(307200, 256, 192) == 0 and ok(1000, 256, 256) == 0 and ok(0, 256, 256) == 0
     assert so.smx_conv7_bf16x3_pack_elems(128, 17) == 8 * 49 * 1 * 2 * 512 and so.smx_conv7_bf16x3_pack_elems(36, 76) == 3 * 49 * 3 * 2 * 512
     assert so.smx_conv7_bf16x3_pack_elems(128, 97) == -1
-    code = ("import os; os.environ['SMX_SHARED_DEVICE'] = '1'\n"
+    # kernel selection does not depend on the environment: the switches are read only under SMX_TOOLS (tools/*.sh), never by a product run
+    code = ("import os\n"
+            "for k in ('SMX_SHARED_DEVICE', 'SMX_GEMM16_RP', 'SMX_GEMM_RP', 'SMX_CONV16_T32', 'SMX_HEADS_X3', 'SMX_ATTNBLOCK_FUSED16', 'SMX_WINOGRAD'):\n"
+            "    os.environ[k] = '0'\n"
+            "os.environ['SMX_SHARED_DEVICE'] = '1'\n"
+            "os.environ.pop('SMX_TOOLS', None)\n"
             "from synergize_motion_appearance_amd import ops, engine_motion, engine_netg\n"
-            "assert not (ops.GEMM16_RP or ops.GEMM_RP or ops.CONV16_T32 or engine_motion.HEADS_X3 or engine_netg.ATTNBLOCK_FUSED16)\n"
+            "assert ops.GEMM16_RP and ops.GEMM_RP and ops.CONV16_T32 and ops.WINOGRAD and engine_motion.HEADS_X3 and engine_netg.ATTNBLOCK_FUSED16\n"
             "print('ok')")
     r = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    code = code.replace("os.environ.pop('SMX_TOOLS', None)", "os.environ['SMX_TOOLS'] = '1'").replace(
+        "assert ops.GEMM16_RP and", "assert not (ops.GEMM16_RP or ops.GEMM_RP or ops.CONV16_T32 or ops.WINOGRAD or engine_motion.HEADS_X3 or engine_netg.ATTNBLOCK_FUSED16)  #")
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]                 # ... and under SMX_TOOLS they are honoured (bisection, A/B timing)
     from synergize_motion_appearance_amd import ops
     assert ops.GEMM16_RP and ops.GEMM_RP and ops.CONV16_T32                 # the default path keeps them

@@ -6,6 +6,7 @@
 //   0 the product kernel as it was        1 zx / zy by multiplication with a precomputed reciprocal (no fp32 division by the grid size)
 //   2 no fp32 division at all (v_rcp_f32 + one Newton step for 1/det, the Gaussians' 1/var as a multiplication)
 //   3 variant 0 with 32-bit index arithmetic (no 64-bit division sequence)
+//   4 variant 0 with s_waitcnt vmcnt(0) between the keypoint loads and their first use      5 the same + 16 wait states (s_nop 7 x2)
 //   sm_probe <seconds> <variant> [tag]
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -38,16 +39,19 @@ __global__ __launch_bounds__(256) void sparse_motion_variant(const float* __rest
       const int kk = k - 1;
       const float* dv = kdv + ((long long)b * K + kk) * 2; const float* dj = kdj + ((long long)b * K + kk) * 4;
       const float* sv = ksv + ((long long)b * ks_bs * K + kk) * 2; const float* sj = ksj + ((long long)b * ks_bs * K + kk) * 4;
-      const float a = dj[0], bb = dj[1], c = dj[2], d = dj[3];
+      float a = dj[0], bb = dj[1], c = dj[2], d = dj[3];
+      float dv0 = dv[0], dv1 = dv[1], sv0 = sv[0], sv1 = sv[1], sj0 = sj[0], sj1 = sj[1], sj2 = sj[2], sj3 = sj[3];
+      if (V == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(bb), "+v"(c), "+v"(d), "+v"(dv0), "+v"(dv1), "+v"(sv0), "+v"(sv1), "+v"(sj0), "+v"(sj1), "+v"(sj2), "+v"(sj3));
+      if (V == 5) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(a), "+v"(bb), "+v"(c), "+v"(d), "+v"(dv0), "+v"(dv1), "+v"(sv0), "+v"(sv1), "+v"(sj0), "+v"(sj1), "+v"(sj2), "+v"(sj3));
       const float det = a * d - bb * c;
       float i00, i01, i10, i11;
       if (V == 2) { float r = __builtin_amdgcn_rcpf(det); r = r * (2.f - det * r); i00 = d * r; i01 = -bb * r; i10 = -c * r; i11 = a * r; }
       else { i00 = d / det; i01 = -bb / det; i10 = -c / det; i11 = a / det; }
-      const float J00 = sj[0] * i00 + sj[1] * i10, J01 = sj[0] * i01 + sj[1] * i11;
-      const float J10 = sj[2] * i00 + sj[3] * i10, J11 = sj[2] * i01 + sj[3] * i11;
-      const float cx = zx - dv[0], cy = zy - dv[1];
-      tx = J00 * cx + J01 * cy + sv[0]; ty = J10 * cx + J11 * cy + sv[1];
-      const float ddx = zx - dv[0], ddy = zy - dv[1], sdx = zx - sv[0], sdy = zy - sv[1];
+      const float J00 = sj0 * i00 + sj1 * i10, J01 = sj0 * i01 + sj1 * i11;
+      const float J10 = sj2 * i00 + sj3 * i10, J11 = sj2 * i01 + sj3 * i11;
+      const float cx = zx - dv0, cy = zy - dv1;
+      tx = J00 * cx + J01 * cy + sv0; ty = J10 * cx + J11 * cy + sv1;
+      const float ddx = zx - dv0, ddy = zy - dv1, sdx = zx - sv0, sdy = zy - sv1;
       float gd, gs;
       if (V == 2) { gd = expf(-0.5f * (ddx * ddx + ddy * ddy) * rvar); gs = expf(-0.5f * (sdx * sdx + sdy * sdy) * rvar); }
       else { gd = expf(-0.5f * (ddx * ddx + ddy * ddy) / var); gs = expf(-0.5f * (sdx * sdx + sdy * sdy) / var); }
@@ -137,6 +141,76 @@ static void run(double secs, const char* tg) {
   fflush(stdout);
 }
 
+// ---- canary: WHAT is corrupted in the victim wave?  Every lane keeps constants in registers, re-loads a known pattern, and runs two identical
+// arithmetic chains (integer, fp32 fma, transcendental) in separate registers; any disagreement is counted by category and lane quarter.
+struct Canary { unsigned long long held[4], load[4], ialu[4], fma[4], trans[4], pk[4], sgpr, launches; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void canary_kernel(const unsigned* __restrict__ pat, int iters, int mask_lane0, Canary* c) {
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  unsigned held[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { held[k] = (threadIdx.x * 2654435761u) ^ (k * 40503u + 17u); asm volatile("" : "+v"(held[k])); }
+  unsigned sconst = __builtin_amdgcn_readfirstlane(blockIdx.x * 7u + 3u);
+  asm volatile("" : "+s"(sconst));
+  unsigned ia = threadIdx.x + 1u, ib = threadIdx.x + 1u;
+  float fa = 1.f + 0.001f * lane, fb = 1.f + 0.001f * lane, ta = 0.5f + 0.01f * lane, tb = 0.5f + 0.01f * lane;
+  asm volatile("" : "+v"(ib), "+v"(fb), "+v"(tb));                          // the second chain is opaque to the optimiser
+  f32x2 pa = {1.f + 0.002f * lane, 0.5f - 0.001f * lane}, pb = pa;
+  const f32x2 pm = {0.999f, 1.001f}, pc = {0.37f, -0.11f};
+  asm volatile("" : "+v"(pb));
+  unsigned bad_load = 0, bad_i = 0, bad_f = 0, bad_t = 0, bad_p = 0;
+  for (int it = 0; it < iters; ++it) {
+    if (!mask_lane0 || (lane & 15) != 0) {                                  // like sparse_motion's k > 0 block: lane 0 of every 16 sits the loads out
+      const int w = ((lane & 15) * 4 + it * 4) & 255;
+      const uint4 v = *reinterpret_cast<const uint4*>(pat + w);
+      const uint2 u = *reinterpret_cast<const uint2*>(pat + ((w + 64) & 255));
+      bad_load += (v.x != (w * 2654435761u ^ 0x5bd1e995u)) + (v.y != ((w + 1) * 2654435761u ^ 0x5bd1e995u)) + (v.z != ((w + 2) * 2654435761u ^ 0x5bd1e995u)) +
+                  (v.w != ((w + 3) * 2654435761u ^ 0x5bd1e995u)) + (u.x != (((w + 64) & 255) * 2654435761u ^ 0x5bd1e995u)) + (u.y != ((((w + 64) & 255) + 1) * 2654435761u ^ 0x5bd1e995u));
+    }
+    ia = ia * 1664525u + 1013904223u; ib = ib * 1664525u + 1013904223u; bad_i += ia != ib;
+    fa = fmaf(fa, 0.999f, 0.37f); fb = fmaf(fb, 0.999f, 0.37f); bad_f += __float_as_uint(fa) != __float_as_uint(fb);
+    ta = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-ta)) + 0.25f; tb = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-tb)) + 0.25f;
+    bad_t += __float_as_uint(ta) != __float_as_uint(tb);
+    if (mask_lane0 != 2 || (lane & 15) != 0) {                             // mask_lane0 == 2: the packed chain runs with lanes 0, 16, 32, 48 switched off
+      pa = pa * pm + pc; pb = pb * pm + pc;                                 // v_pk_fma_f32 (checked in the ISA)
+      bad_p += (__float_as_uint(pa.x) != __float_as_uint(pb.x)) + (__float_as_uint(pa.y) != __float_as_uint(pb.y));
+    }
+    asm volatile("" : "+v"(ib), "+v"(fb), "+v"(tb), "+v"(pb));
+  }
+  unsigned bad_h = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { asm volatile("" : "+v"(held[k])); bad_h += held[k] != ((threadIdx.x * 2654435761u) ^ (k * 40503u + 17u)); }
+  asm volatile("" : "+s"(sconst));
+  if (bad_h) atomicAdd(&c->held[q], (unsigned long long)bad_h);
+  if (bad_load) atomicAdd(&c->load[q], (unsigned long long)bad_load);
+  if (bad_i) atomicAdd(&c->ialu[q], (unsigned long long)bad_i);
+  if (bad_f) atomicAdd(&c->fma[q], (unsigned long long)bad_f);
+  if (bad_t) atomicAdd(&c->trans[q], (unsigned long long)bad_t);
+  if (bad_p) atomicAdd(&c->pk[q], (unsigned long long)bad_p);
+  if (lane == 0 && sconst != blockIdx.x * 7u + 3u) atomicAdd(&c->sgpr, 1ull);
+}
+
+static void run_canary(double secs, int mask_lane0, const char* tg) {
+  std::vector<unsigned> h(320);
+  for (int w = 0; w < 320; ++w) h[w] = (unsigned)(w & 255) * 2654435761u ^ 0x5bd1e995u;
+  for (int w = 256; w < 320; ++w) h[w] = (unsigned)(w) * 2654435761u ^ 0x5bd1e995u;      // uint4 / uint2 reads past word 255 see the formula continued
+  unsigned* pat; CK(hipMalloc(&pat, 320 * 4)); CK(hipMemcpy(pat, h.data(), 320 * 4, hipMemcpyHostToDevice));
+  Canary* d; CK(hipMalloc(&d, sizeof(Canary))); CK(hipMemset(d, 0, sizeof(Canary)));
+  hipStream_t s; CK(hipStreamCreate(&s));
+  const double t_end = now_s() + secs; unsigned long long launches = 0;
+  while (now_s() < t_end) {
+    for (int k = 0; k < 32; ++k) { canary_kernel<<<1536, 256, 0, s>>>(pat, 24, mask_lane0, d); ++launches; }
+    CK(hipStreamSynchronize(s));
+  }
+  Canary c; CK(hipMemcpy(&c, d, sizeof(c), hipMemcpyDeviceToHost));
+  auto q4 = [](const unsigned long long* v) { static char b[4][96]; static int k = 0; k = (k + 1) & 3; snprintf(b[k], 96, "%llu %llu %llu %llu", v[0], v[1], v[2], v[3]); return b[k]; };
+  printf("[%s] canary (lane 0 of 16 %s the loads): %llu launches | wrong by lane quarter -- held registers: %s | loaded data: %s | integer chain: %s",
+         tg, mask_lane0 ? "sits out" : "joins", launches, q4(c.held), q4(c.load), q4(c.ialu));
+  printf(" | fma chain: %s | rcp/exp chain: %s", q4(c.fma), q4(c.trans));
+  printf(" | packed-fp32 chain: %s | SGPR: %llu\n", q4(c.pk), c.sgpr);
+  fflush(stdout);
+}
+
 // ---- partners: what the OTHER process on the GPU is doing -------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -180,10 +254,34 @@ __global__ __launch_bounds__(256) void partner_stream(const float4* a, float4* b
   for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
 }
 
+// the product kernels' LDS-DMA idiom (csrc/gemm_rp_bf16.hip glds16): M0 saved, pointed at the LDS destination, restored; a 4-slot ring per wave
+typedef __attribute__((address_space(3))) void lds_void_t;
+__global__ __launch_bounds__(256) void partner_lds_dma(const unsigned* src, unsigned src_kb, int iters, unsigned* out) {
+  __shared__ __attribute__((aligned(16))) unsigned ring[4][4][256];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned base = (unsigned)(uintptr_t)((lds_void_t*)&ring[wave][0][0]);
+  unsigned acc = 0;
+  for (int i = 0; i < iters + 3; ++i) {
+    if (i < iters) {
+      const void* g = src + (size_t)((blockIdx.x * 4u + wave) * 7919u + (unsigned)i * 104729u) % src_kb * 256 + lane * 4;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(g), "s"(base + (i & 3) * 1024) : "memory");
+    }
+    if (i >= 3) {
+      if (i < iters) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint4 v = *reinterpret_cast<const uint4*>(&ring[wave][(i - 3) & 3][lane * 4]);
+      acc += v.x ^ v.y ^ v.z ^ v.w;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if (acc == 0x12345u) out[0] = acc;
+}
+
 static int partner(char mode, double secs) {
   float* out; CK(hipMalloc(&out, 64));
   float4 *a = nullptr, *b = nullptr; const size_t n = (size_t)64 << 20;
-  if (mode == 'm') { CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&b, n * 16)); CK(hipMemset(a, 1, n * 16)); }
+  if (mode == 'm' || mode == 'd') { CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&b, n * 16)); CK(hipMemset(a, 1, n * 16)); }
   const double t_end = now_s() + secs; long it = 0;
   while (now_s() < t_end) {
     for (int k = 0; k < 8; ++k) {
@@ -192,6 +290,7 @@ static int partner(char mode, double secs) {
       else if (mode == 'v') partner_valu_div<<<4096, 256>>>(out, 2000);
       else if (mode == 'l') partner_lds<<<2048, 256>>>(out, 20000);
       else if (mode == 'm') partner_stream<<<4096, 256>>>(a, b, n);
+      else if (mode == 'd') partner_lds_dma<<<2048, 256>>>((const unsigned*)a, (unsigned)(n * 16 / 1024), 2000, (unsigned*)out);
       else return 1;
     }
     CK(hipDeviceSynchronize()); ++it;
@@ -201,10 +300,14 @@ static int partner(char mode, double secs) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 3) { fprintf(stderr, "usage: sm_probe <seconds> <variant 0..3> [tag] | sm_probe partner <b|f|v|l|m> <seconds>\n"); return 1; }
+  if (argc < 3) { fprintf(stderr, "usage: sm_probe <seconds> <variant 0..3> [tag] | sm_probe partner <b|f|v|l|m|d> <seconds>\n"); return 1; }
   CK(hipSetDevice(0));
   if (!strcmp(argv[1], "partner")) return partner(argv[2][0], argc > 3 ? atof(argv[3]) : 5.0);
   const double secs = atof(argv[1]); const int v = atoi(argv[2]); const char* tg = argc > 3 ? argv[3] : "sm";
-  if (v == 0) run<0>(secs, tg); else if (v == 1) run<1>(secs, tg); else if (v == 2) run<2>(secs, tg); else if (v == 3) run<3>(secs, tg); else return 1;
+  if (v == 8) { run_canary(secs, 1, tg); return 0; }
+  if (v == 9) { run_canary(secs, 0, tg); return 0; }
+  if (v == 10) { run_canary(secs, 2, tg); return 0; }
+  if (v == 0) run<0>(secs, tg); else if (v == 1) run<1>(secs, tg); else if (v == 2) run<2>(secs, tg); else if (v == 3) run<3>(secs, tg);
+  else if (v == 4) run<4>(secs, tg); else if (v == 5) run<5>(secs, tg); else return 1;
   return 0;
 }

@@ -14,7 +14,9 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "synergize_motion_appearance_amd", "csrc", "conv3x3_bf16_t32.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I", os.path.join(REPO, "include"), "-I", os.path.dirname(SRC)]
+sys.path.insert(0, REPO)
+from synergize_motion_appearance_amd.build import flags_for  # noqa: E402  (the library's own flags for this source, minus -fPIC)
+FLAGS = [f for f in flags_for(SRC) if f != "-fPIC"]
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
 
