@@ -413,6 +413,11 @@ int smx_attention_bf16(const void* q, int ldq, int64_t q_bs, const void* k, int 
  * [B][L][S] score tensor of the three-launch form (QK^T GEMM, softmax_rows, PV GEMM) never exists.  L % 128 == 0, S % 32 == 0. */
 int smx_attnblock_bf16(const void* q, int ldq, int64_t q_bs, const void* k, int ldk, int64_t k_bs, const void* vt, int ldvt, int64_t vt_bs,
                        void* o, int ldo, int64_t o_bs, int B, int L, int S, int d, float scale, void* stream);
+/* The same AttnBlock core in the fp32 configuration (archs/vqgan_arch.py:229-253 in the reference's own arithmetic): fp32 storage, exact fp32
+ * products, one kernel -- replaces the QK^T GEMM + softmax_rows + PV GEMM launches and their [B][L][S] fp32 score tensor.  Same contract as
+ * the bf16 entry (d = 256, `vt` = V transposed, L % 128 == 0, S % 32 == 0), rows 16-B aligned. */
+int smx_attnblock_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs, const float* vt, int ldvt, int64_t vt_bs,
+                      float* o, int ldo, int64_t o_bs, int B, int L, int S, int d, float scale, void* stream);
 int smx_softmax_rows_bf16(void* s, int ld, int R, int S, float scale, const uint8_t* mask, int rows_per_mask, void* stream);
 int smx_warp_nhwc_bf16(const void* feat, int feat_batch, const float* flow, const float* occ, void* out, int B, int H, int W, int C,
                        int Hf, int Wf, void* stream);

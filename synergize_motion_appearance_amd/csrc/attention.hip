@@ -396,6 +396,118 @@ __global__ __launch_bounds__(512, 1) void attnblock16_kernel(AP<bf16_t> p) {
       St<bf16_t>::st4(O + dbase + 32 * d + 8 * g + 4 * hh, make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv));
 }
 
+// The same AttnBlock core in the fp32 configuration (configs[1], the reference's own arithmetic): ONE kernel on v_mfma_f32_32x32x2_f32,
+// no [B, N, N] score tensor, no softmax_rows pass.  The contraction is matrix-bound here (322 GFLOP per call at B = 300 against ~1 GB of
+// traffic), so the shape is the opposite of the bf16 kernel's: ONE wave per SIMD (4 waves, 128 queries per block, one block per CU) that owns 32
+// queries AND all eight O^T tiles -- Q^T fragments (128 VGPRs, pre-scaled by scale * log2 e) + O^T accumulators (128 VGPRs) at the 512-register
+// budget -- and issues 256 MFMAs per 32-key tile (128 for S^T = K Q^T, 128 for O^T += V^T P^T) against 64 ds_read_b128: nothing but the matrix
+// pipe is near a limit.  K tiles [32 keys][256] and V^T tiles [256][32 keys] stream global -> LDS by LDS-DMA into a double-buffered stage
+// (64 KB each), 16-B chunks XOR-swizzled at the source address (K: chunk c of key row r at position c ^ (r & 15); V^T: chunk c of row d at
+// position c ^ (d & 7)) so that the fragment reads of 8 consecutive lanes hit 8 distinct 16-B bank slots.  One lane's ds_read_b128 feeds
+// FOUR MFMAs through the free k pairing (A and B only have to agree): S^T step kk multiplies d = 8 kk + 4 hh + t, PV group g multiplies keys
+// 8 g + 4 hh + t -- exactly the keys the S^T accumulator's registers 4 g + t hold, so P feeds the second product straight from registers.
+// Softmax statistics fp32, lane-local + one wavefront shuffle; the O rescale is skipped while no lane's running maximum moved.
+template <int DH>
+__global__ __launch_bounds__(256, 1) void attnblock32_kernel(AP<float> p) {
+  static_assert(DH == 256, "the AttnBlock width of this path");
+  constexpr int TK = 32, KROW = DH * 4, VROW = TK * 4, DT = DH / 32, KK = DH / 8;
+  constexpr int KTILE = TK * KROW, VTILE = DH * VROW;                     // 32 KB + 32 KB per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;                                               // [2][TK][KROW]
+  unsigned char* Vt = smem + 2 * KTILE;                                   // [2][DH][VROW]
+  const unsigned lds0 = (unsigned)(uintptr_t)((ab_lds_void*)smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int hh = lane >> 5;
+  const float* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq;
+  const float* K = p.k + b * p.k_bs;
+  const float* VT = p.v + b * p.v_bs;                                     // [DH][ldv >= S]
+  const float sc = p.scale * 1.44269504088896340736f;                     // scores in log2 units: softmax via v_exp_f32
+
+  float4 qf[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const float4 t = *reinterpret_cast<const float4*>(Q + kk * 8 + hh * 4);
+    qf[kk] = make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc);
+  }
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  // per tile 32 + 32 DMA instructions of 1 KB (8 + 8 per wave): a K instruction is one key row (64 chunks), a V^T instruction is 8 d rows x 8 chunks
+  auto issue = [&](int key0, int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kr = wave * 8 + i;
+      ab_glds16(K + (long long)(key0 + kr) * p.ldk + ((lane ^ (kr & 15)) << 2), lds0 + (unsigned)(buf * KTILE + kr * KROW));
+      const int vr = (wave * 8 + i) * 8 + (lane >> 3);
+      ab_glds16(VT + (long long)vr * p.ldv + key0 + (((lane & 7) ^ (vr & 7)) << 2), lds0 + (unsigned)(2 * KTILE + buf * VTILE + (wave * 8 + i) * 1024));
+    }
+  };
+  const int krow = lane & 31, ksw = krow & 15, vsw = krow & 7;            // V^T rows 32 dt + krow: (row & 7) does not depend on the d tile
+  const int ntiles = p.S / TK;
+  issue(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's 16 pieces of tile t (requested a whole tile ago)
+    __syncthreads();                                                       // everyone's pieces are there; everyone is past tile t - 1
+    if (t + 1 < ntiles) issue((t + 1) * TK, buf ^ 1);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const unsigned char* kp = Ks + buf * KTILE + krow * KROW;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const float4 kf = *reinterpret_cast<const float4*>(kp + (((2 * kk + hh) ^ ksw) << 4));
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk].w, s, 0, 0, 0);
+    }
+    float tmax = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum;
+    if (__any(m_new != m)) {                                               // wave-uniform: some lane's maximum moved
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+    m = m_new;
+    // O^T += V^T P^T: A = V^T row d, keys 8 g + 4 hh + (0..3) = one 16-B chunk; B = the S^T registers 4 g + (0..3) of the same keys
+    const unsigned char* vp = Vt + buf * VTILE + krow * VROW;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 vf = *reinterpret_cast<const float4*>(vp + d * 32 * VROW + (((2 * g + hh) ^ vsw) << 4));
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, s[4 * g + 0], oacc[d], 0, 0, 0);
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, s[4 * g + 1], oacc[d], 0, 0, 0);
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, s[4 * g + 2], oacc[d], 0, 0, 0);
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, s[4 * g + 3], oacc[d], 0, 0, 0);
+      }
+  }
+  float* O = p.o + b * p.o_bs + (long long)qrow * p.ldo;
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(O + 32 * d + 8 * g + 4 * hh) = make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+}
+
 // d_head = 4: one query per lane, 64 queries per block; the block's 4 waves split the S keys
 // (wave w owns keys [w*S/4, (w+1)*S/4)), K/V broadcast from LDS, 8 keys per online-softmax step,
 // and the four partial (m, l, acc) states are merged through LDS at the end.
@@ -726,5 +838,19 @@ extern "C" int smx_attnblock_bf16(const void* q, int ldq, int64_t q_bs, const vo
   static bool attr = false;
   if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)attnblock16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
   SMX_LAUNCH(attnblock16_kernel<256>, dim3(L / 128, B), dim3(512), LDS, (hipStream_t)stream, p);
+  return smx_launch_status();
+}
+
+/* The same core in the fp32 configuration (attnblock32_kernel): fp32 storage, exact fp32 products on v_mfma_f32_32x32x2_f32. */
+extern "C" int smx_attnblock_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs, const float* vt, int ldvt, int64_t vt_bs,
+                                 float* o, int ldo, int64_t o_bs, int B, int L, int S, int d, float scale, void* stream) {
+  if (!q || !k || !vt || !o || B <= 0 || B > 65535 || d != 256 || L <= 0 || L % 128 || S <= 0 || S % 32) return SMX_EINVAL;
+  if (ldq % 4 || ldk % 4 || ldvt % 4 || ldo % 4 || ldq < d || ldk < d || ldvt < S || ldo < d || q_bs % 4 || k_bs % 4 || vt_bs % 4 || o_bs % 4) return SMX_EINVAL;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o) & 15) return SMX_EINVAL;
+  AP<float> p{q, k, vt, o, nullptr, q_bs, k_bs, vt_bs, o_bs, ldq, ldk, ldvt, ldo, 1, L, S, scale};
+  constexpr int LDS = 2 * (32 * 256 * 4 + 256 * 32 * 4);     // 2 stages x 64 KB
+  static bool attr = false;
+  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)attnblock32_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  SMX_LAUNCH(attnblock32_kernel<256>, dim3(L / 128, B), dim3(256), LDS, (hipStream_t)stream, p);
   return smx_launch_status();
 }

@@ -26,6 +26,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"warp_nt", "SMX_WARP_NT", 1},                // warp row-chunk kernels: non-temporal output stores (write-once stream: 6.5 -> 8.3 TB/s algorithmic at B = 300; 0 = plain stores)
   {"wgrad_region", "SMX_WGRAD_REGION", 1},      // training: 3x3 / s1 / p1 weight gradients with 64-multiple channels on the region kernel (0 = the generic TN GEMM)
   {"wgrad_slots", "SMX_WGRAD_SLOTS", 256},      // region weight gradient: blocks the pixel split aims at (device sweep profiles/r04_wgrad_region.txt: 256 = one block per CU beats 512 -- half the partials to write and reduce, twice the rows per run -- and 128)
+  {"wino_stagger", "SMX_WINO_STAGGER", 0},      // wide Winograd: shader cycles the second resident round of a launch's first blocks waits (phase stagger of the two blocks of a CU); 0 = off
 };
 bool g_init = false;
 void init_once() {

@@ -55,6 +55,7 @@ struct WP {
   int tiles_y, tiles_x;          // blocks per image along y / x
   int n32;                       // ceil(Cout/32) (U is packed for n32*32 rows)
   int nt;                        // wide kernel: non-temporal residual loads / output stores
+  int stagger;                   // wide kernel: shader cycles the SECOND resident round of the launch's first blocks waits before it starts (0 = off)
   const float* mul; int ldmul; float sft_w;   // SFT epilogue (Fuse_sft_block, appmotioncodebook_arch.py:49-51): y = res + sft_w * (res * mul + conv)
 };
 
@@ -404,6 +405,17 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   }
   auto mark = [&](int k) __attribute__((always_inline)) { if (ABL & 32) stamp[k] = (unsigned)__builtin_readcyclecounter(); };
   mark(0);
+  // Phase stagger.  Two blocks share a CU (one wave of each per SIMD) and every block lives equally long, so two blocks that start together stay
+  // in lockstep for the whole launch: both in their prologue (matrix pipe idle), both in the slice loop (contending), both in the epilogue (idle
+  // again).  The launch's first 256 x 2 blocks are the ones that start together -- the second 256 of them (the second block of every CU) wait
+  // `stagger` cycles once, and from then on each CU's two blocks run half a lifetime apart: one multiplies while the other stages / stores.
+  if (p.stagger > 0) {
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin >= 256u && lin < 512u) {
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   const int hh = lane >> 5, t = lane & 31;
   const int tr = t >> 3, tc = t & 7;
   int bid = blockIdx.x;
@@ -802,6 +814,7 @@ static int winograd_launch(const float* x, int lda, const float* u_packed, const
   p.in_ss = in_ss; p.in_swish = in_swish; p.stats = stats_part; p.mul = mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
   p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32; p.nt = smx_tune(SMX_TUNE_WINO_NT);
+  p.stagger = smx_tune(SMX_TUNE_WINO_STAGGER);
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
   if ((long long)H * W * ldc > 2147483647LL || (long long)H * W * (res ? ldres : 0) > 2147483647LL || (long long)H * W * (mul ? ldmul : 0) > 2147483647LL) return SMX_EINVAL;

@@ -365,7 +365,7 @@ class FramePipeline:
             self._render_eager(gstate, gin)                          # warm-up outside the capture (one-time attribute calls, allocator pools)
             torch.cuda.synchronize(self.dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread may query events meanwhile (trainer.CAPTURE_MODE)
                 gout = self._render_eager(gstate, gin)
             self._graph, self._graph_src = (g, gin, gout, flat, gstate, adt), state
         g, gin, gout, flat, gstate, _ = self._graph

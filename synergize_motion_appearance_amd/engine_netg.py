@@ -24,7 +24,8 @@ from . import ops
 from .manifest import encoder_plan, generator_plan, CHANNELS
 from .ops import Conv, ACT_RELU, ACT_LRELU02, ACT_GELU
 
-ATTNBLOCK_FUSED16 = ops._knob("SMX_ATTNBLOCK_FUSED16", 1)     # bf16 AttnBlock core as one kernel (0 = QK^T GEMM, softmax_rows, PV GEMM)
+ATTNBLOCK_FUSED16 = ops._knob("SMX_ATTNBLOCK_FUSED16", 1)
+ATTNBLOCK_FUSED32 = ops._knob("SMX_ATTNBLOCK_FUSED32", 1)     # fp32 AttnBlock core as one kernel (0 = QK^T GEMM, softmax_rows, PV GEMM)     # bf16 AttnBlock core as one kernel (0 = QK^T GEMM, softmax_rows, PV GEMM)
 
 _SCALE_K = {32: 1, 64: 2, 128: 3, 256: 4}
 
@@ -75,6 +76,13 @@ class _Attn:
             L.check(ops._timed("attnblock", {"flops": 4.0 * B * N * N * Cc, "bf16": 1} if ops._PROFILE is not None else None, L.load().smx_attnblock_bf16,
                                qk.data_ptr(), 2 * Cc, N * 2 * Cc, qk.data_ptr() + 2 * Cc, 2 * Cc, N * 2 * Cc, vt.data_ptr(), N, Cc * N,
                                h.data_ptr(), Cc, N * Cc, B, N, N, Cc, float(int(Cc) ** (-0.5)), ops._stream()), "smx_attnblock_bf16")
+            return ops.conv(h, self.proj, res=x)
+        if x.dtype == torch.float32 and ATTNBLOCK_FUSED32 and Cc == 256 and N % 128 == 0:
+            # configs[1]: the same fusion in the reference's own arithmetic (attnblock32_kernel: exact fp32 products on the fp32 MFMA)
+            h = torch.empty((B, H, W, Cc), device=x.device, dtype=x.dtype)
+            L.check(ops._timed("attnblock", {"flops": 4.0 * B * N * N * Cc} if ops._PROFILE is not None else None, L.load().smx_attnblock_f32,
+                               qk.data_ptr(), 2 * Cc, N * 2 * Cc, qk.data_ptr() + 4 * Cc, 2 * Cc, N * 2 * Cc, vt.data_ptr(), N, Cc * N,
+                               h.data_ptr(), Cc, N * Cc, B, N, N, Cc, float(int(Cc) ** (-0.5)), ops._stream()), "smx_attnblock_f32")
             return ops.conv(h, self.proj, res=x)
         # logits and probabilities stay fp32 in both storage modes (bf16 path: c_f32 store, fp32 softmax, a_f32 operand converted
         # while staging): raw q.k sums over C = 256 lose too much in 8 mantissa bits before the softmax

@@ -135,6 +135,7 @@ SIGNATURES = {
     "smx_layernorm_pos_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "smx_attention_bf16": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _f, _p]),
     "smx_attnblock_bf16": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _f, _p]),
+    "smx_attnblock_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _i, _i, _i, _i, _f, _p]),
     "smx_softmax_rows_bf16": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
     "smx_warp_nhwc_bf16": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "smx_resize_bilinear_ac_nhwc_bf16": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

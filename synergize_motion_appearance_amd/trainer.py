@@ -314,6 +314,12 @@ def kp_distance_value(kp_driving_value, kp_source_value, weight=1.0):
     return (one(kp_source_value) + one(kp_driving_value)) * weight
 
 
+# hipGraph captures run in THREAD-LOCAL error mode: with a process group alive, RCCL's watchdog thread polls the events of earlier collectives
+# (hipEventQuery) while this thread captures; under the default global mode that call is "not permitted while a stream is capturing", the
+# watchdog raises and takes the process down (found by tests/test_gpu_rccl.py on one GPU -- every multi-GPU training run would have hit it).
+CAPTURE_MODE = "thread_local"
+
+
 class TrainStep:
     """The generator + motion-estimator half of `optimize_parameters` (models/appmotioncomp_model.py:294-420) on the HIP path:
     motion_estimator(gt, source) in training mode -> net_g(source, dense_motion, w=1, gt=gt) -> losses -> ONE backward through both
@@ -624,11 +630,11 @@ class TrainStep:
         if st is None:
             st = {"key": key, "src": source.float().contiguous().clone(), "drv": driving.float().contiguous().clone(), "tf": tf_new}
             g, g2 = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if on_cut is not None else None)
-            cap = {"ctx": torch.cuda.graph(g)}
+            cap = {"ctx": torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE)}
 
             def cut_capture():                                 # end graph 1 here, continue recording into graph 2 (same pool, replayed in order)
                 cap["ctx"].__exit__(None, None, None)
-                cap["ctx"] = torch.cuda.graph(g2, pool=g.pool())
+                cap["ctx"] = torch.cuda.graph(g2, pool=g.pool(), capture_error_mode=CAPTURE_MODE)
                 cap["ctx"].__enter__()
             cap["ctx"].__enter__()
             try:

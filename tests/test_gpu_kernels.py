@@ -402,6 +402,60 @@ def test_gemm_nt_batched_heads(ops):
     assert maxabs(c.cpu(), ref) < 2e-5
 
 
+def test_attnblock_fused_f32(ops):
+    """engine_netg._Attn in the fp32 configuration: the core as ONE kernel (smx_attnblock_f32: exact fp32 products on the fp32 MFMA, online softmax,
+    no [B, N, N] score tensor) against (i) the AttnBlock of the reference restated in fp64 (archs/vqgan_arch.py:229-253: GroupNorm, q / k / v 1x1
+    convolutions, softmax(q k^T / sqrt(C)) v, proj_out, residual) and (ii) the three-launch form it replaces (QK^T GEMM, softmax_rows, PV GEMM);
+    large, badly centred logits included (the running maximum has to move)."""
+    from synergize_motion_appearance_amd import engine_netg as E
+    C_, B = 256, 3
+    P = {"a.norm.weight": 1 + 0.1 * rnd("af_g", (C_,)), "a.norm.bias": 0.1 * rnd("af_b", (C_,))}
+    for n in ("q", "k", "v", "proj_out"):
+        P[f"a.{n}.weight"] = rnd("af_w" + n, (C_, C_, 1, 1), (3.0 if n in ("q", "k") else 1.5) / math.sqrt(C_))
+        P[f"a.{n}.bias"] = rnd("af_bias" + n, (C_,), 0.1)
+    x = rnd("af_x", (B, 32, 32, C_))
+    # fp64 restatement
+    xd = x.permute(0, 3, 1, 2).double()
+    hn = F.group_norm(xd, 32, P["a.norm.weight"].double(), P["a.norm.bias"].double(), eps=1e-6)
+    q, k, v = (F.conv2d(hn, P[f"a.{n}.weight"].double(), P[f"a.{n}.bias"].double()).reshape(B, C_, -1) for n in ("q", "k", "v"))
+    w_ = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * (int(C_) ** (-0.5)), dim=2)
+    h_ = torch.bmm(v, w_.permute(0, 2, 1)).reshape(B, C_, 32, 32)
+    ref = (xd + F.conv2d(h_, P["a.proj_out.weight"].double(), P["a.proj_out.bias"].double())).permute(0, 2, 3, 1).float()
+    blk = E._Attn({k_: v_.cuda() for k_, v_ in P.items()}, "a")
+    with ops.profile() as rec:
+        fused = blk(x.cuda())
+    names = [r[0] for r in rec.rows]
+    assert "attnblock" in names and "softmax" not in names, names
+    E.ATTNBLOCK_FUSED32 = 0
+    try:
+        with ops.profile() as rec3:
+            three = blk(x.cuda())
+    finally:
+        E.ATTNBLOCK_FUSED32 = 1
+    assert "attnblock" not in [r[0] for r in rec3.rows] and "softmax" in [r[0] for r in rec3.rows]
+    scale = float(ref.abs().max())
+    assert maxabs(fused.cpu(), ref) < 2e-5 * scale, (maxabs(fused.cpu(), ref), scale)
+    assert maxabs(fused.cpu(), three.cpu()) < 2e-5 * scale
+    # the kernel alone on hostile scores: one query's logits span +-60 (exp2 range) and the maximum arrives in the LAST tile
+    N = 1024
+    qk = torch.zeros((2, N, 2 * C_))
+    qk[..., :C_] = rnd("af_q2", (2, N, C_), 1.0)
+    qk[..., C_:] = rnd("af_k2", (2, N, C_), 1.0)
+    qk[:, -1, C_:] *= 6.0                                                    # the last key dominates many rows
+    vt = rnd("af_v2", (2, C_, N), 1.0)
+    sc = 0.25
+    qd, kd = qk[..., :C_].double(), qk[..., C_:].double()
+    o_ref = torch.bmm(torch.softmax(torch.bmm(qd, kd.transpose(1, 2)) * sc, dim=2), vt.double().transpose(1, 2)).float()
+    from synergize_motion_appearance_amd import lib as L_
+    qkc, vtc = qk.cuda().contiguous(), vt.cuda().contiguous()
+    o = torch.empty((2, N, C_), device="cuda")
+    L_.check(L_.load().smx_attnblock_f32(qkc.data_ptr(), 2 * C_, N * 2 * C_, qkc.data_ptr() + 4 * C_, 2 * C_, N * 2 * C_, vtc.data_ptr(), N, C_ * N,
+                                         o.data_ptr(), C_, N * C_, 2, N, N, C_, sc, ops._stream()), "smx_attnblock_f32")
+    assert maxabs(o.cpu(), o_ref) < 3e-5 * float(o_ref.abs().max()), maxabs(o.cpu(), o_ref)
+    assert L_.load().smx_attnblock_f32(qkc.data_ptr(), 2 * C_, N * 2 * C_, qkc.data_ptr() + 4 * C_, 2 * C_, N * 2 * C_, vtc.data_ptr(), N, C_ * N,
+                                       o.data_ptr(), C_, N * C_, 2, N - 32, N, C_, sc, ops._stream()) != 0     # L % 128 != 0 is refused
+
+
 @pytest.mark.parametrize("dh,E,S,shared,masked", [(32, 256, 1024, False, True), (32, 256, 256, True, False), (32, 256, 768, True, False),
                                                    (4, 32, 1024, False, False), (4, 32, 512, True, False), (4, 32, 1024, False, True)])
 def test_fused_attention(ops, dh, E, S, shared, masked):

@@ -76,7 +76,15 @@ def _run(target, timeout=900):
     q = ctx.Queue()
     p = ctx.Process(target=target, args=(_free_port(), q))
     p.start()
-    res = q.get(timeout=timeout)
+    import queue
+    import time
+    t0, res = time.time(), None
+    while res is None:
+        try:
+            res = q.get(timeout=5)
+        except queue.Empty:
+            assert p.is_alive() or not q.empty(), f"the worker died (exit code {p.exitcode}) before it reported"
+            assert time.time() - t0 < timeout, "the worker did not report in time"
     p.join(timeout=120)
     assert p.exitcode == 0
     return res
