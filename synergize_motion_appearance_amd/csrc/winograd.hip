@@ -105,10 +105,11 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   for (int k = 0; k < NIT; ++k) {
     const int item = tid + NTHR * k;
     lok[k] = item < RH * RW * 8;
-    const int px = item >> 3, c4 = item & 7;
+    const int px = min(item >> 3, RH * RW - 1), c4 = item & 7;
     const int ry = px / RW, rx = px - ry * RW;
     int iy = by * 8 - 1 + ry, ix = bx * 16 - 1 + rx;
     gok[k] = lok[k] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1);   // always a legal address: the loads are unconditional, the padding is a select at store time
     if (p.up2) { iy >>= 1; ix >>= 1; }
     goff[k] = (iy * Ws + ix) * p.lda + c4 * 4;
     loff[k] = (ry * RP + rx) * RLD + c4 * 4;
@@ -126,11 +127,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
       ssa = *reinterpret_cast<const float4*>(sp); ssb = *reinterpret_cast<const float4*>(sp + 4);
     }
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gok[k]) v = *reinterpret_cast<const float4*>(X + goff[k] + c0);
-      stage[k] = v;
-    }
+    for (int k = 0; k < NIT; ++k) stage[k] = *reinterpret_cast<const float4*>(X + goff[k] + c0);
   };
   auto store_items = [&](float* rb, auto mode) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode)::value;
@@ -149,8 +146,8 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
           v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
           v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
         }
-        v.x = gok[k] ? v.x : 0.f; v.y = gok[k] ? v.y : 0.f; v.z = gok[k] ? v.z : 0.f; v.w = gok[k] ? v.w : 0.f;
       }
+      v.x = gok[k] ? v.x : 0.f; v.y = gok[k] ? v.y : 0.f; v.z = gok[k] ? v.z : 0.f; v.w = gok[k] ? v.w : 0.f;
       if (lok[k]) *reinterpret_cast<float4*>(rb + loff[k]) = v;
     }
   };
@@ -427,13 +424,17 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
 
   constexpr int NIT = (RH * RW * 8 + NTHR - 1) / NTHR;                 // 6
   float4 stage[NIT];
+  // the global offset is ALWAYS a legal one (coordinates clamped into the frame, a thread without a sixth item re-reads the region's last pixel):
+  // the loads below are issued unconditionally, back to back -- with `if (in frame) load` hipcc wrapped each of the six in its own pair of
+  // branches (~45 instructions between two requests of a slice) -- and the padding is zeroed by a select when the value goes to LDS
   auto item_geo = [&](int k, int& g, int& l, bool& gok, bool& lok) {
     const int item = tid + NTHR * k;
     lok = item < RH * RW * 8;
-    const int px = item >> 3, c4 = item & 7;
+    const int px = min(item >> 3, RH * RW - 1), c4 = item & 7;
     const int ry = px / RW, rx = px - ry * RW;
     int iy = by * 8 - 1 + ry, ix = bx * 16 - 1 + rx;
     gok = lok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1);
     if (p.up2) { iy >>= 1; ix >>= 1; }
     g = (iy * Ws + ix) * p.lda + c4 * 4;
     l = (ry * RP + rx) * RLD + c4 * 4;
@@ -452,9 +453,7 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       int g, l; bool gok, lok; item_geo(k, g, l, gok, lok);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gok) v = *reinterpret_cast<const float4*>(X + g + c0);
-      stage[k] = v;
+      stage[k] = *reinterpret_cast<const float4*>(X + g + c0);
     }
   };
   auto store_items = [&](float* rb, auto mode) __attribute__((always_inline)) {
@@ -472,8 +471,8 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
           v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
           v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
         }
-        v.x = gok ? v.x : 0.f; v.y = gok ? v.y : 0.f; v.z = gok ? v.z : 0.f; v.w = gok ? v.w : 0.f;   // the conv's zero padding
       }
+      v.x = gok ? v.x : 0.f; v.y = gok ? v.y : 0.f; v.z = gok ? v.z : 0.f; v.w = gok ? v.w : 0.f;     // the conv's zero padding
       if (lok) *reinterpret_cast<float4*>(rb + l) = v;
     }
   };
@@ -560,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
         float4 v[4];
         if (ABL & 1) { v[0] = vconst[0]; v[1] = vconst[1]; v[2] = vconst[2]; v[3] = vconst[3]; }
         else transform(rb, sub, v);
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);                  // round 5 re-measured the alternatives (none / inverted / staging above the MFMA groups): -1.5 ... -3.5 %, profiles/r05_wino_stagger.txt
         mfma32(v, (s * 4 + sub) * 4);
         __builtin_amdgcn_s_setprio(0);
         if ((ABL & 32) && s == 1) { if (sub == 0) mark(15); else if (sub == 1) mark(16); else if (sub == 2) mark(17); }

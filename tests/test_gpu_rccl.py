@@ -115,43 +115,66 @@ def _train_worker(port, q):
     _, clip = synth_clip(8, seed=321)
     src, drv = clip[[0, 5]].contiguous().cuda(), clip[[3, 7]].contiguous().cuda()
 
-    def run(use_graph, collectives):
+    def fresh(use_graph, collectives):
         net_g, me = build_network(cfg["network_g"]), build_network(cfg["network_motion_estimator"])
         net_g.load_state_dict(synth_state_dict([(k, v.shape) for k, v in net_g.state_dict().items()]), strict=True)
         me.load_state_dict(synth_state_dict([(k, v.shape) for k, v in me.state_dict().items()]), strict=True)
         TrainStep.COLLECTIVES_AT_WORLD_1 = collectives
-        step = TrainStep(net_g.cuda(), me.cuda(), topt, use_graph=use_graph)
+        return TrainStep(net_g.cuda(), me.cuda(), topt, use_graph=use_graph)
+
+    def run(use_graph, collectives):
+        step = fresh(use_graph, collectives)
+        init = step.g.flat.value.clone()
         gen = torch.Generator().manual_seed(11)
         for _ in range(4):                                     # graph form: 2 eager steps, capture + replay, replay
             tf = EquivarianceTransform(2, sigma_affine=0.05, sigma_tps=0.005, points_tps=5, generator=gen)
             losses, _ = step.step(src, drv, transform=tf)
         torch.cuda.synchronize()
-        return step.g.flat.value.clone(), step.flat_m.value.clone(), float(losses["l_g_total"]), (step._graph2 is not None)
+        return step.g.flat.value.clone(), init, float(losses["l_g_total"]), (step._graph2 is not None)
     base = run(False, False)                                   # never touches torch.distributed
+    base2 = run(False, False)                                  # ... twice: the run-to-run noise of the warp-backward atomics under Adam's g / sqrt(v)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        # (i) the collectives themselves are identities at world 1, bit for bit, through RCCL
+        step = fresh(False, True)
+        before = [f.value.clone() for f in (step.g.flat, step.flat_m)]
+        synced = step.sync_replicas()
+        same_params = all(bool(torch.equal(b, f.value)) for b, f in zip(before, (step.g.flat, step.flat_m)))
+        tf = EquivarianceTransform(2, sigma_affine=0.05, sigma_tps=0.005, points_tps=5, generator=torch.Generator().manual_seed(11))
+        step.g.flat.zero_grad(), step.flat_m.zero_grad()
+        step.forward_backward(src, drv, transform=tf)
+        g0, m0 = step.g.flat.grad.clone(), step.flat_m.grad.clone()
+        pend = step.g.flat.all_reduce_start(dist) + step.flat_m.all_reduce_start(dist)
+        n_async = len(pend)
+        step.g.flat.all_reduce_wait(pend)
+        torch.cuda.synchronize()
+        same_grads = bool(torch.equal(g0, step.g.flat.grad)) and bool(torch.equal(m0, step.flat_m.grad))
+        # (ii) whole steps with the collectives in them: eager, and replayed from the two hipGraphs with the all-reduce between them
         eager = run(False, True)
         graph = run(True, True)
-        base_graph = None
         TrainStep.COLLECTIVES_AT_WORLD_1 = False
-        q.put({"eager_g": float((eager[0] - base[0]).abs().max()), "eager_m": float((eager[1] - base[1]).abs().max()),
-               "graph_g": float((graph[0] - base[0]).abs().max()), "graph_m": float((graph[1] - base[1]).abs().max()),
-               "scale_g": float(base[0].abs().max()), "two_graphs": graph[3], "loss": (base[2], eager[2], graph[2]), "base_graph": base_graph})
+        move = float((base[0] - base[1]).abs().mean())
+        q.put({"synced": bool(synced), "same_params": same_params, "same_grads": same_grads, "async_works": n_async,
+               "noise": float((base2[0] - base[0]).abs().mean()) / move, "eager": float((eager[0] - base[0]).abs().mean()) / move,
+               "graph": float((graph[0] - base[0]).abs().mean()) / move, "two_graphs": graph[3], "loss": (base[2], base2[2], eager[2], graph[2]),
+               "finite": bool(torch.isfinite(eager[0]).all() and torch.isfinite(graph[0]).all())})
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def test_rccl_world1_training_step_collectives():
-    """the flat-gradient all-reduce (issued at the cut of the backward, joined before Adam) and the construction-time broadcast over RCCL:
-    at world 1 both are identities, so the parameters after four steps equal those of a step that never called a collective -- bit for bit
-    in the eager form (same launches), to the warp-backward atomics' noise through the two-graph form."""
+    """the construction-time broadcast and the flat-gradient all-reduce over RCCL: at world 1 both are identities -- checked bit for bit on the
+    buffers themselves -- and whole steps with the collectives inside (eager; and replayed from TWO hipGraphs with net_g's all-reduce issued
+    between them) land where steps without any collective land, to the run-to-run noise two collective-free runs show among themselves (the
+    warp-backward atomics, amplified by Adam's g / sqrt(v) in the first steps)."""
     assert torch.cuda.is_available(), "needs an MI355X"
     r = _run(_train_worker, timeout=1500)
+    assert r["synced"] and r["same_params"] and r["same_grads"] and r["async_works"] >= 2 and r["finite"], r
     assert r["two_graphs"] is True                            # the overlapped form: [.. backward of net_g] | all-reduce | [backward of the estimator]
-    assert r["eager_g"] <= 2e-6 * r["scale_g"] and r["eager_m"] <= 1e-5, r
-    assert r["graph_g"] <= 1e-4 * r["scale_g"] and r["graph_m"] <= 1e-3, r
-    assert all(abs(l - r["loss"][0]) <= 1e-3 * abs(r["loss"][0]) for l in r["loss"]), r
+    assert r["eager"] <= 2.0 * r["noise"] + 0.02 and r["graph"] <= 2.0 * r["noise"] + 0.02, r
+    spread = abs(r["loss"][1] - r["loss"][0])                   # two collective-free runs: what the noise does to the fourth step's loss
+    assert all(abs(l - r["loss"][0]) <= 3.0 * spread + 2e-2 * abs(r["loss"][0]) for l in r["loss"]), r
 
 
 def test_bench_one_rank_under_torchrun_uses_rccl():
