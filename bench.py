@@ -46,7 +46,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: v_mfma_f32_32x32x16_bf16 dense pe
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
 CLIP = 300                       # frames of the driving clip (BASELINE.json configs[1])
 DEFAULT_BATCH = 300              # frames per step: the whole clip in flight (HBM holds it many times over); 60 until round 3 (545 -> 565 frames/s)
-PROFILE_TAG = "r04"              # profiles/<tag>_{traffic,mfma}_pmc[_bf16].json: the committed counter summaries this run quotes
+PROFILE_TAG = "r05"              # profiles/<tag>_{traffic,mfma}_pmc[_bf16].json: the committed counter summaries this run quotes
 
 
 def build_nets(device, img_size=256):

@@ -2,7 +2,7 @@
 # One gpurun call: GPU tests, bench (+shape table), rocprofv3 kernel stats, PMC passes (MFMA + traffic).
 # usage: tools/gpu_round.sh <tag> [tests|notests] [pmc|nopmc] [extra bench args...]
 TAG=${1:-r02a}; TESTS=${2:-tests}; PMC=${3:-pmc}; shift 3 || true
-OUT=$PWD/gpurun_out; mkdir -p $OUT
+OUT=$PWD/gpurun_out; mkdir -p $OUT; R0=$PWD
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 if [ "$TESTS" = "tests" ]; then
   timeout 3000 python -m pytest tests -m gpu -x -q > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_$TAG.log
@@ -29,6 +29,9 @@ if [ "$PMC" = "pmc" ]; then
   # drop the multi-hundred-MB raw traces, keep the counter csv
   find $OUT/pmc_mfma_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG -name "*kernel_trace.csv" -delete 2>/dev/null
   du -sh $OUT/pmc_mfma_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG 2>/dev/null
+  # summarised HERE, on the library these counters were taken on (the JSON carries its per-object build digests; bench.py refuses a mismatch)
+  python $R0/tools/pmc_traffic.py $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG $OUT/traffic_pmc_$TAG.json > /dev/null 2>&1; echo "traffic summary rc=$?"
+  python $R0/tools/pmc_mfma.py $OUT/pmc_mfma_$TAG $OUT/mfma_pmc_$TAG.json "$BENCH" > /dev/null 2>&1; echo "mfma summary rc=$?"
 fi
 find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} head -12 {} | cut -c1-160
 du -sh $OUT/prof_$TAG
