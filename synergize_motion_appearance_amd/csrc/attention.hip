@@ -38,7 +38,9 @@ struct AP {
   int H, L, S; float scale;
 };
 
-template <typename T, int DH>
+// MASK: a key-padding mask exists (the appearance cross-attention); without one (every self-attention call) the per-score compare / select
+// against the staged mask bytes -- 49 of the ~180 non-MFMA instructions of a 32-key tile -- and the mask staging are compiled out
+template <typename T, int DH, bool MASK = true>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(AP<T> p) {
   constexpr int TK = 32, KLD = DH + 4, KS = DH / 8, DT = DH / 32;
   __shared__ __attribute__((aligned(16))) float Ks[2][TK * KLD];
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP<T> p) {
   const T* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq + h * DH;
   const T* K = p.k + b * p.k_bs + h * DH;
   const T* V = p.v + b * p.v_bs + h * DH;
-  const uint8_t* M = p.mask ? p.mask + (long long)b * p.S : nullptr;
+  const uint8_t* M = (MASK && p.mask) ? p.mask + (long long)b * p.S : nullptr;
 
   float4 qf[KS];
 #pragma unroll
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP<T> p) {
         vreg[i] = St<T>::ld4(V + (long long)(key0 + r) * p.ldv + c4 * 4);
       }
     }
-    if (M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
+    if (MASK && M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP<T> p) {
         *reinterpret_cast<float4*>(&Vs[buf][r * DH + c4 * 4]) = vreg[i];
       }
     }
-    if (threadIdx.x < TK) Ms[buf][threadIdx.x] = M ? mreg : 0;
+    if (MASK && threadIdx.x < TK) Ms[buf][threadIdx.x] = M ? mreg : 0;
   };
 
   const int ntiles = p.S / TK;
@@ -118,12 +120,12 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AP<T> p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (Ms[buf][key]) s[r] = -INFINITY;
+      if (MASK && Ms[buf][key]) s[r] = -INFINITY;
       tmax = fmaxf(tmax, s[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m, tmax);
-    const bool dead = (m_new == -INFINITY);                 // every key so far masked
+    const bool dead = MASK && (m_new == -INFINITY);         // every key so far masked
     const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
     float psum = 0.f;
 #pragma unroll
@@ -806,6 +808,7 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
         SMX_LAUNCH(attn_mfma16_kernel<32>, dim3(L / 128, B * H), dim3(256), 0, st, p);
       }
     }
+    else if (dh == 32 && !key_mask) SMX_LAUNCH((attn_mfma_kernel<T, 32, false>), dim3(L / 128, B * H), dim3(256), 0, st, p);
     else if (dh == 32) SMX_LAUNCH((attn_mfma_kernel<T, 32>), dim3(L / 128, B * H), dim3(256), 0, st, p);
     else SMX_LAUNCH((attn_mfma_kernel<T, 64>), dim3(L / 128, B * H), dim3(256), 0, st, p);
   } else {

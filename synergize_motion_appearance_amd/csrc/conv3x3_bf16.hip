@@ -104,11 +104,15 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
   float4 ssv[4];
   const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
   auto chunk_ok = [&](int k, int& g) __attribute__((always_inline)) -> bool {   // in-image offsets fit 32 bits (launcher check)
+    // `g` is ALWAYS a legal offset (coordinates clamped into the frame, a thread past the region's last chunk re-reads that chunk): the loads
+    // are issued unconditionally, back to back (hipcc wraps every `if (ok) load` in its own pair of branches -- csrc/winograd.hip, round 5:
+    // +2.5 % from this alone); the padding is zeroed when the chunk goes to LDS
     const int item = tid + NT * k;
-    const int px = item >> CPPL, c8 = item & (CPP - 1);
+    const int px = min(item >> CPPL, RPX - 1), c8 = item & (CPP - 1);
     const int ry = px / RW, rx = px - ry * RW;
     int iy = by * TH - 1 + ry, ix = bx * TW - 1 + rx;
     const bool ok = item < RPX * CPP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1);
     if (p.up2) { iy >>= 1; ix >>= 1; }
     g = (iy * Ws_ + ix) * p.lda + c8 * 8;
     return ok;
@@ -121,15 +125,13 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
     }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      int g; const bool ok = chunk_ok(k, g);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      int g; (void)chunk_ok(k, g);
+      uint4 v;
       if (F32) {
-        if (ok) {
-          const float4 a = *reinterpret_cast<const float4*>(Xf + g + c0), b = *reinterpret_cast<const float4*>(Xf + g + c0 + 4);
-          const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-          v = pack8(f);
-        }
-      } else if (ok) v = *reinterpret_cast<const uint4*>(X + g + c0);
+        const float4 a = *reinterpret_cast<const float4*>(Xf + g + c0), b = *reinterpret_cast<const float4*>(Xf + g + c0 + 4);
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        v = pack8(f);
+      } else v = *reinterpret_cast<const uint4*>(X + g + c0);
       rreg[k] = v;
     }
   };
@@ -139,8 +141,8 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
     for (int k = 0; k < NCH; ++k) {
       const int item = tid + NT * k;
       uint4 v = rreg[k];
+      int g; const bool ok = chunk_ok(k, g);
       if (MODE >= 1) {
-        int g; const bool ok = chunk_ok(k, g);
         float f[8]; unpack8(v, f);
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
@@ -153,8 +155,8 @@ __global__ __launch_bounds__(NT, TH == 16 ? 2 : 3) void conv3x3_bf16_kernel(CP p
           for (int e = 0; e < 8; ++e) f[e] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * f[e]));
         }
         v = pack8(f);
-        if (!ok) v = make_uint4(0u, 0u, 0u, 0u);                          // the conv's zero padding stays exactly 0
       }
+      if (!ok) v = make_uint4(0u, 0u, 0u, 0u);                            // the conv's zero padding stays exactly 0
       if (item < RPX * CPP) *reinterpret_cast<uint4*>(Rg + (item >> CPPL) * PB + (item & (CPP - 1)) * 16) = v;
     }
   };
