@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     goff[k] = (iy * Ws + ix) * p.lda + c4 * 4;
     loff[k] = (ry * RP + rx) * RLD + c4 * 4;
   }
-  float4 stage[NIT];
+  f32x4 stage[NIT];
   // load_region only ISSUES the global loads (consumed a whole slice of MFMAs later) -- the region AND the GroupNorm
   // scale/shift pair of this thread's channel quad (item & 7 == tid & 7 for every item); store_region applies the fused
   // GroupNorm(+swish) branch-free and writes LDS.  (A per-item `if (in frame) { load ss; ...}` serialised one L2 round
@@ -156,35 +156,44 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
       ssa = *reinterpret_cast<const float4*>(sp); ssb = *reinterpret_cast<const float4*>(sp + 4);
     }
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) stage[k] = *reinterpret_cast<const float4*>(X + goff[k] + c0);
+    for (int k = 0; k < NIT; ++k) stage[k] = *reinterpret_cast<const f32x4*>(X + goff[k] + c0);
   };
-  auto store_items = [&](float* rb, auto mode) __attribute__((always_inline)) {
+  // packed forms + no padding select inside the frame: see winograd_wide_kernel (an fp32 MFMA never runs under a VALU instruction on gfx950)
+  const bool interior = by * 8 >= 1 && by * 8 + RH - 1 <= p.H && bx * 16 >= 1 && bx * 16 + RW - 1 <= p.W;
+  auto store_items = [&](float* rb, auto mode, auto inside) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode)::value;
+    constexpr bool INSIDE = decltype(inside)::value;
+    const f32x4 sc = {ssa.x, ssa.z, ssb.x, ssb.z}, sh = {ssa.y, ssa.w, ssb.y, ssb.w};
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      float4 v = stage[k];
+      f32x4 v = stage[k];
       if (MODE >= 1) {
         // GroupNorm(+swish) of the producer folded into the loader: each input element is normalised
         // once per staged region instead of in a separate read+write pass; padding stays exactly 0
-        v = make_float4(fmaf(v.x, ssa.x, ssa.y), fmaf(v.y, ssa.z, ssa.w), fmaf(v.z, ssb.x, ssb.y), fmaf(v.w, ssb.z, ssb.w));
+        v = __builtin_elementwise_fma(v, sc, sh);
         if (MODE == 2) {
           // swish = v * rcp(1 + 2^(-v*log2e)): v_exp_f32 + v_rcp_f32 (1 ulp each) keep the loader light
           constexpr float L2E = 1.44269504088896340736f;
-          v.x *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.x));
-          v.y *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.y));
-          v.z *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.z));
-          v.w *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-L2E * v.w));
+          f32x4 e = v * (-L2E);
+          e = f32x4{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y), __builtin_amdgcn_exp2f(e.z), __builtin_amdgcn_exp2f(e.w)} + 1.f;
+          v *= f32x4{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y), __builtin_amdgcn_rcpf(e.z), __builtin_amdgcn_rcpf(e.w)};
         }
       }
-      v.x = gok[k] ? v.x : 0.f; v.y = gok[k] ? v.y : 0.f; v.z = gok[k] ? v.z : 0.f; v.w = gok[k] ? v.w : 0.f;
-      if (lok[k]) *reinterpret_cast<float4*>(rb + loff[k]) = v;
+      if (!INSIDE) { v.x = gok[k] ? v.x : 0.f; v.y = gok[k] ? v.y : 0.f; v.z = gok[k] ? v.z : 0.f; v.w = gok[k] ? v.w : 0.f; }
+      if (k + 1 < NIT || lok[k]) *reinterpret_cast<f32x4*>(rb + loff[k]) = v;
     }
   };
   auto store_region = [&](int buf) __attribute__((always_inline)) {
     float* rb = smem + buf * RPIX * RLD;
-    if (loader == 2) store_items(rb, std::integral_constant<int, 2>{});
-    else if (loader == 1) store_items(rb, std::integral_constant<int, 1>{});
-    else store_items(rb, std::integral_constant<int, 0>{});
+    if (interior) {
+      if (loader == 2) store_items(rb, std::integral_constant<int, 2>{}, std::true_type{});
+      else if (loader == 1) store_items(rb, std::integral_constant<int, 1>{}, std::true_type{});
+      else store_items(rb, std::integral_constant<int, 0>{}, std::true_type{});
+    } else {
+      if (loader == 2) store_items(rb, std::integral_constant<int, 2>{}, std::false_type{});
+      else if (loader == 1) store_items(rb, std::integral_constant<int, 1>{}, std::false_type{});
+      else store_items(rb, std::integral_constant<int, 0>{}, std::false_type{});
+    }
   };
 
   // which two patch rows frequency row fi needs: B^T rows (0:[d0-d2] 1:[d1+d2] 2:[d2-d1] 3:[d1-d3])
@@ -213,28 +222,29 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   load_region(0); store_region(0);
   // U ring: slot j holds the fragment of the unit with frequency j; prefetch distance = 2 units
   // (= 8 MFMAs of this wave, ~4x that in wall time with 4 waves per SIMD) hides the L2 latency.
-  float4 ur[4];
-  auto uload = [&](int unit) -> float4 {
-    return *reinterpret_cast<const float4*>(U + ((unit & 3) * ufs + (unit >> 2) * 256) + lane4);
-  };
+  f32x4 ur[4];
+  const __amdgpu_buffer_rsrc_t RU = u_resource(U);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto uload = [&](int unit) -> f32x4 { return u_fetch(RU, lane16, (unsigned)((unit & 3) * ufs + (unit >> 2) * 256) * 4u); };
   ur[0] = uload(0); ur[1] = uload(1);
   __syncthreads();
   // input transform of 8-channel step `sub` for frequency row fi, this lane's (tile, 4 channels):
   // t_b = d[ra][b] +- d[rb][b];  V[i][0..3] = t0-t2, t1+t2, t2-t1, t1-t3
-  auto transform = [&](const float* rb, int sub, float4 (&v)[4]) {
-    float4 tt[4];
+  auto transform = [&](const float* rb, int sub, f32x4 (&v)[4]) {
+    f32x4 tt[4];
+    const f32x4 s4 = {sgn, sgn, sgn, sgn};
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int ch = (2 * sub + hh) * 4;
-      const float4 da = *reinterpret_cast<const float4*>(rb + pa + b * RLD + ch);
-      const float4 db = *reinterpret_cast<const float4*>(rb + pb + b * RLD + ch);
-      tt[b] = make_float4(fmaf(sgn, db.x, da.x), fmaf(sgn, db.y, da.y), fmaf(sgn, db.z, da.z), fmaf(sgn, db.w, da.w));
+      const f32x4 da = *reinterpret_cast<const f32x4*>(rb + pa + b * RLD + ch);
+      const f32x4 db = *reinterpret_cast<const f32x4*>(rb + pb + b * RLD + ch);
+      tt[b] = __builtin_elementwise_fma(s4, db, da);
     }
-    v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+    v[0] = pk_sub(tt[0], tt[2]); v[1] = tt[1] + tt[2]; v[2] = pk_sub(tt[2], tt[1]); v[3] = pk_sub(tt[1], tt[3]);
   };
   // A = U, B = V: the accumulator tile is [n][tile] -- a lane holds 4 consecutive channels per register quad, which the
   // epilogue moves through LDS as ds_write_b128
-  auto mfma16 = [&](const float4 (&v)[4], int unit0) {
+  auto mfma16 = [&](const f32x4 (&v)[4], int unit0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (!(ABL & 2)) ur[(j + 2) & 3] = uload(unit0 + j + 2);
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
     //  MFMAs of step sub measured 15-20% SLOWER under hipcc's scheduling -- kept simple.)
 #pragma unroll 1
     for (int sub = 0; sub < 4; ++sub) {
-      float4 v[4];
+      f32x4 v[4];
       transform(rb, sub, v);
       __builtin_amdgcn_s_setprio(1);
       mfma16(v, (s * 4 + sub) * 4);
@@ -837,10 +847,14 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
 }
 
 
+#ifdef SMX_TOOLS
 // ---------------------------------------------------------------------------------------------------------------------------------------------
-// Producer / consumer split of the wide kernel (round 5; DESIGN section 4 "Round 5").  What limits `winograd_wide_kernel` is not latency inside
-// its MFMA groups but the instructions a wave executes OUTSIDE them (block prologue, per-slice staging + address arithmetic, epilogue: 68 % of a
-// wave's life), during which its SIMD's matrix pipe is only fed by the other resident wave.  Here the two waves of a SIMD get different JOBS:
+// Producer / consumer split of the wide kernel -- a round-5 EXPERIMENT, compiled into the tools build only (tuning knob `wino_ws`; results
+// bit-identical to the wide kernel's, tools/wino_ws_check.py).  The idea: what limits `winograd_wide_kernel` are the instructions a wave executes
+// OUTSIDE its MFMA groups (block prologue, per-slice staging + address arithmetic, epilogue), so give the two waves of a SIMD different JOBS.
+// Why it does not win (profiles/r05_winograd_valu_vs_mfma.txt): on gfx950 an fp32 MFMA and a VALU instruction never execute side by side on a SIMD --
+// the partner wave of a wave that issues fp32 MFMAs back to back gets no issue slots at all, and a wave's own VALU instruction costs the pipe its
+// full 4+ cycles -- so the helper waves only run while the MFMA waves wait, and the sum MFMA + VALU is the same as in the symmetric kernel.
 //   * waves 0-3 (one per SIMD, frequency row = wave): transform + MFMA only.  They never leave the slice loop: a block is persistent and walks
 //     tile after tile; between two tiles an MFMA wave only moves its accumulators into the exchange buffer and clears them;
 //   * waves 4-7 (one per SIMD): everything else -- region staging (global -> GroupNorm + swish -> LDS) into a 3-buffer ring, always ahead of the
@@ -1242,6 +1256,7 @@ __global__ __launch_bounds__(512, 2) void winograd_ws_kernel(WP p, int nblk_coun
     for (int k = 0; k < 8; ++k) o[k] = (unsigned)hk[k];
   }
 }
+#endif  // SMX_TOOLS
 
 }  // namespace
 
@@ -1278,29 +1293,23 @@ static int winograd_launch(const float* x, int lda, const float* u_packed, const
   hipStream_t st = (hipStream_t)stream;
   const int wide = smx_tune(SMX_TUNE_WINO_WIDE);
   const int abl = smx_tune(SMX_TUNE_WINO_ABLATE);
+#ifdef SMX_TOOLS
   const bool ws_ok = nw == 2 && wide > 0 && smx_tune(SMX_TUNE_WINO_WS) && blocks % 8 == 0 && Cout % 64 == 0 && ldc % 4 == 0 && !((uintptr_t)y & 15) &&
                      (!res || (ldres % 4 == 0 && !((uintptr_t)res & 15))) && (!mul || (ldmul % 4 == 0 && !((uintptr_t)mul & 15))) &&
                      (!bias || !((uintptr_t)bias & 15)) && blocks * (Cout / 64) <= 2147483647LL;
   if (ws_ok) {
     // the producer / consumer split: one persistent 8-wave block per CU
-    static std::once_flag ws_once;
-    static hipError_t ws_err = hipSuccess;
-    std::call_once(ws_once, [] { ws_err = hipFuncSetAttribute((const void*)winograd_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS); });
-    if (ws_err != hipSuccess) return SMX_ELAUNCH;
     const int total = (int)(blocks * (Cout / 64));
     const int grid_ws = total < 256 ? total : 256;
-#ifdef SMX_TOOLS
 #define SMX_WSD(D) do { SMX_HIP(hipFuncSetAttribute((const void*)winograd_ws_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS)); \
                         SMX_LAUNCH(winograd_ws_kernel<D>, dim3(grid_ws), dim3(512), WS_LDS, st, p, Cout / 64, total); } while (0)
     switch (smx_tune(SMX_TUNE_WINO_ABLATE)) { case 1: SMX_WSD(1); break; case 2: SMX_WSD(2); break; case 3: SMX_WSD(3); break; case 4: SMX_WSD(4); break; case 7: SMX_WSD(7); break;
                                               case 8: SMX_WSD(8); break; case 15: SMX_WSD(15); break; case 20: SMX_WSD(20); break; case 21: SMX_WSD(21); break; case 22: SMX_WSD(22); break; case 23: SMX_WSD(23); break;
                                               case 31: SMX_WSD(31); break; case 32: SMX_WSD(32); break; default: SMX_WSD(0); break; }
 #undef SMX_WSD
-#else
-    SMX_LAUNCH(winograd_ws_kernel<0>, dim3(grid_ws), dim3(512), WS_LDS, st, p, Cout / 64, total);
-#endif
     return smx_launch_status();
   }
+#endif
 #ifndef SMX_TOOLS
   // the timing-only ablation / trace instantiations (they skip loads or barriers, or overwrite the GroupNorm partials with
   // cycle stamps: WRONG results by design) exist only in the tools build (-DSMX_TOOLS, tools/wino_bench.py / wino_trace.py)

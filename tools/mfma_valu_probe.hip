@@ -7,8 +7,10 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { P_NONE, P_FMA, P_PKFMA, P_EXP, P_MOV, P_SALU, P_DSREAD, P_SLEEP, P_FMA_PRIO, P_COUNT };
+static const char* MFNAME[] = {"32x32x2 f32", "16x16x4 f32", "32x32x16 bf16", "16x16x32 bf16"};
 static const char* PNAME[] = {"nothing", "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_mov_b32", "s_add_u32", "ds_read_b128", "s_sleep 1", "v_fma_f32 @prio3"};
 
 template <int MF, int PK, int OWN>   // OWN: the MFMA wave itself issues OWN v_fma per MFMA (no partner needed)
@@ -26,6 +28,9 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, int iters,
     float x[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { x[c] = a + c; for (int r = 0; r < 16; ++r) acc[c][r] = 0.f; for (int r = 0; r < 4; ++r) acq[c][r] = 0.f; }
+    bf16x8 ha, hb;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { ha[r] = (__bf16)(a + r); hb[r] = (__bf16)(b * r); }
     float2 y2[4] = {{a, b}, {b, a}, {a, a}, {b, b}};
     f32x4 dd[4] = {{a, b, a, b}, {b, a, b, a}, {a, a, b, b}, {b, b, a, a}};
     unsigned sacc2 = 0;
@@ -39,7 +44,9 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, int iters,
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           if (MF == 0) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
-          else acq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acq[c], 0, 0, 0);
+          else if (MF == 1) acq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acq[c], 0, 0, 0);
+          else if (MF == 2) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, hb, acc[c], 0, 0, 0);
+          else acq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb, acq[c], 0, 0, 0);
 #pragma unroll
           for (int k = 0; k < OWN; ++k) {
             if (PK == P_NONE || PK == P_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[(c + k) & 7]) : "v"(a), "v"(b));
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, int iters,
 
 template <int MF, int PK, int OWN>
 double run(unsigned long long* dout, double alone) {
-  const int nblk = 256, iters = MF == 0 ? 2000 : 4000;
+  const int nblk = 256, iters = (MF == 0 || MF == 2) ? 2000 : 4000;
   for (int r = 0; r < 2; ++r) probe<MF, PK, OWN><<<nblk, 512>>>(dout, iters, 1.f, 1e-6f);
   hipDeviceSynchronize();
   static unsigned long long h[256 * 8 * 2];
@@ -112,11 +119,11 @@ double run(unsigned long long* dout, double alone) {
   double mc = 0, mn = 0, pc = 0, pn = 0;
   for (int b = 0; b < nblk; ++b) for (int w = 0; w < 8; ++w) { (w < 4 ? mc : pc) += h[(b * 8 + w) * 2]; (w < 4 ? mn : pn) += h[(b * 8 + w) * 2 + 1]; }
   const double cpm = mc / mn;
-  if (OWN) printf("  %-12s + %d own %-20s per MFMA : %6.1f cycles per MFMA  -> %5.1f pipe cycles per own instruction\n", MF == 0 ? "32x32x2 f32" : "16x16x4 f32", OWN,
+  if (OWN) printf("  %-12s + %d own %-20s per MFMA : %6.1f cycles per MFMA  -> %5.1f pipe cycles per own instruction\n", MFNAME[MF], OWN,
                   PK == P_NONE ? "v_fma_f32" : PK == P_SLEEP ? "global_load_dwordx4" : PNAME[PK], cpm, (cpm - alone) / OWN);
-  else if (PK == P_NONE) printf("  %-12s alone                 : %6.1f cycles per MFMA\n", MF == 0 ? "32x32x2 f32" : "16x16x4 f32", cpm);
+  else if (PK == P_NONE) printf("  %-12s alone                 : %6.1f cycles per MFMA\n", MFNAME[MF], cpm);
   else printf("  %-12s next to %-13s: %6.1f cycles per MFMA, partner %6.1f instr / 1000 cycles -> %5.1f pipe cycles per partner instruction\n",
-              MF == 0 ? "32x32x2 f32" : "16x16x4 f32", PNAME[PK], cpm, 1000.0 * pn / pc, pn > 0 ? (cpm - alone) * (mn / mc) * pc / pn : 0.0);
+              MFNAME[MF], PNAME[PK], cpm, 1000.0 * pn / pc, pn > 0 ? (cpm - alone) * (mn / mc) * pc / pn : 0.0);
   return cpm;
 }
 
@@ -134,5 +141,11 @@ int main() {
   run<1, P_FMA, 0>(dout, a1); run<1, P_PKFMA, 0>(dout, a1); run<1, P_EXP, 0>(dout, a1); run<1, P_MOV, 0>(dout, a1);
   run<1, P_SALU, 0>(dout, a1); run<1, P_DSREAD, 0>(dout, a1);
   run<1, P_NONE, 1>(dout, a1); run<1, P_NONE, 2>(dout, a1); run<1, P_NONE, 4>(dout, a1);
+  const double a2 = run<2, P_NONE, 0>(dout, 0);
+  run<2, P_FMA, 0>(dout, a2); run<2, P_NONE, 1>(dout, a2); run<2, P_NONE, 2>(dout, a2); run<2, P_NONE, 4>(dout, a2); run<2, P_NONE, 8>(dout, a2);
+  run<2, P_PKFMA, 4>(dout, a2); run<2, P_SALU, 4>(dout, a2); run<2, P_DSREAD, 1>(dout, a2); run<2, P_DSREAD, 2>(dout, a2); run<2, P_SLEEP, 1>(dout, a2);
+  const double a3 = run<3, P_NONE, 0>(dout, 0);
+  run<3, P_FMA, 0>(dout, a3); run<3, P_NONE, 1>(dout, a3); run<3, P_NONE, 2>(dout, a3); run<3, P_NONE, 4>(dout, a3);
+  run<3, P_DSREAD, 1>(dout, a3); run<3, P_SLEEP, 1>(dout, a3);
   return 0;
 }
