@@ -95,8 +95,8 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
 // U fragments through buffer loads: the resource (wave-uniform base) and the unit's byte offset live in SGPRs, the lane's 16 B slot in ONE VGPR --
 // no 64-bit vector add per request (global_load took a v_lshl_add_u64 each: eight VALU instructions per 32 MFMAs that the matrix pipe waits out)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t u_resource(const float* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t u_resource(const float* base, long long bytes) {   // bytes: to the end of the packed U (a read past it returns 0)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(bytes < 0x7fffffffLL ? bytes : 0x7fffffffLL), 0x00020000);
 }
 __device__ __forceinline__ f32x4 u_fetch(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned unit_bytes) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, unit_bytes, 0));
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256 * NW, NW == 1 ? 3 : 4) void winograd_kernel(WP 
   // U ring: slot j holds the fragment of the unit with frequency j; prefetch distance = 2 units
   // (= 8 MFMAs of this wave, ~4x that in wall time with 4 waves per SIMD) hides the L2 latency.
   f32x4 ur[4];
-  const __amdgpu_buffer_rsrc_t RU = u_resource(U);
+  const long long u_bytes = (16LL * p.n32 * cs8 * 256 + 1024) * 4;     // smx_winograd_u_floats
+  const __amdgpu_buffer_rsrc_t RU = u_resource(U, u_bytes - (U - p.u) * 4);
   const unsigned lane16 = (unsigned)lane * 16u;
   auto uload = [&](int unit) -> f32x4 { return u_fetch(RU, lane16, (unsigned)((unit & 3) * ufs + (unit >> 2) * 256) * 4u); };
   ur[0] = uload(0); ur[1] = uload(1);
@@ -551,7 +552,8 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   f32x4 ur[NI][4];
   // wave-uniform base (SGPR pair) + the lane's 32-bit byte offset: the saddr form of global_load, no 64-bit vector add per request
   const unsigned lane16 = (unsigned)lane * 16u;
-  const __amdgpu_buffer_rsrc_t R0 = u_resource(U0), R1 = u_resource(U1);
+  const long long u_bytes = (16LL * p.n32 * cs8 * 256 + 1024) * 4;     // smx_winograd_u_floats
+  const __amdgpu_buffer_rsrc_t R0 = u_resource(U0, u_bytes - (U0 - p.u) * 4), R1 = u_resource(U1, u_bytes - (U1 - p.u) * 4);
   auto uload = [&](const __amdgpu_buffer_rsrc_t& R, int unit) -> f32x4 { return u_fetch(R, lane16, (unsigned)((unit & 3) * ufs + (unit >> 2) * 256) * 4u); };
   auto transform = [&](const float* rb, int sub, f32x4 (&v)[4]) {
     f32x4 tt[4];
