@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(ABP p) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
 
-__global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(ABP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_mfma_kernel(ABP p) {
   constexpr int DH = 32, TK = 32, KLD = DH + 4, KS = DH / 8;
   __shared__ __attribute__((aligned(16))) float Ks[2][TK * KLD];
   __shared__ __attribute__((aligned(16))) float Vs[2][TK * KLD];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(ABP p) {
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(ABP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_mfma_kernel(ABP p) {
   constexpr int DH = 32, TQ = 32, KLD = DH + 4, KS = DH / 8;
   __shared__ __attribute__((aligned(16))) float Qs[2][TQ * KLD];
   __shared__ __attribute__((aligned(16))) float Gs[2][TQ * KLD];

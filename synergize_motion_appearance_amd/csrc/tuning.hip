@@ -27,7 +27,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"wgrad_region", "SMX_WGRAD_REGION", 1},      // training: 3x3 / s1 / p1 weight gradients with 64-multiple channels on the region kernel (0 = the generic TN GEMM)
   {"wgrad_slots", "SMX_WGRAD_SLOTS", 256},      // region weight gradient: blocks the pixel split aims at (device sweep profiles/r04_wgrad_region.txt: 256 = one block per CU beats 512 -- half the partials to write and reduce, twice the rows per run -- and 128)
   {"wino_stagger", "SMX_WINO_STAGGER", 0},      // wide Winograd: shader cycles the second resident round of a launch's first blocks waits (phase stagger of the two blocks of a CU); 0 = off
-  {"wino_ws", "SMX_WINO_WS", 0},                // wide Winograd launches on the producer / consumer-split kernel (winograd_ws_kernel: persistent 8-wave blocks, MFMA waves + helper waves)
+  {"wino_ws", "SMX_WINO_WS", 0},                // TOOLS BUILD ONLY: wide Winograd launches on the producer / consumer-split kernel (winograd_ws_kernel: persistent 8-wave blocks, MFMA waves + helper waves); ignored by the shipped library
 };
 bool g_init = false;
 void init_once() {

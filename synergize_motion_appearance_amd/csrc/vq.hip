@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void vq_code_norms_kernel(const float* __restr
 }
 
 template <int D, bool PROF, bool SPLIT>
-__global__ __launch_bounds__(256) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb, const float* __restrict__ norms,
+__global__ __launch_bounds__(256, 2) void vq_kernel(const float* __restrict__ z, const float* __restrict__ cb, const float* __restrict__ norms,
                                                  int64_t* __restrict__ idx_out, float* __restrict__ zq,
                                                  float* __restrict__ dmin_out, float* __restrict__ sq_part, int N, int Ks,
                                                  int tiles_per_split, float* __restrict__ pd, int* __restrict__ pi) {
