@@ -20,6 +20,7 @@
 #include "smx_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -38,7 +39,25 @@ struct GP {
   int tiles_n; int is1x1;
   int xcd_swizzle; int variant;
   int ksplit; float* ws;            // split-K: blockIdx.z owns a K range, raw partials -> ws[z][M][N]
+  int fast;                         // the buffer-load loader applies (host-checked: vector layout, Cin % 32 == 0, no upsampling, tile-relative offsets < 2^31)
 };
+
+// MODE 2 loader (round 5).  On gfx950 a VALU instruction costs an fp32 MFMA kernel its full issue time (profiles/r05_winograd_valu_vs_mfma.txt), and the
+// gather below spent ~114 of them per 16-32 MFMAs on 64-bit addresses, zero-fills and predicates.  Here every operand quad is ONE buffer load: the
+// resource (tile base) and the slice's offset (k0, or the filter tap's pixel offset + channel) are wave-uniform SGPR values, the thread's row offset is
+// computed once per block, and a row that must read zero (M / N tail, padding) presents an offset past the buffer instead of taking a branch:
+// 0 VALU per quad for a 1x1 layer / the weights, 5 for a k x k layer (the tap's bit of the row's validity masks -> v_cndmask of the offset).
+constexpr unsigned GC_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gc_resource(const float* base) {
+  // (the base IS wave-uniform; saying so keeps hipcc from wrapping every load of the bigger tiles in a waterfall loop)
+  const unsigned long long u = (unsigned long long)(uintptr_t)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 gc_fetch(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));   // (bit_cast of the builtin's own vector type: an implicit
+  return make_float4(v.x, v.y, v.z, v.w);                                                                // conversion to an ext_vector made hipcc load ONE dword)
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -51,8 +70,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool VEC>
+template <int BM, int BN, int WGM, int WGN, int LMODE>     // LMODE 0: any layout (scalar gather), 1: float4 gather, 2: float4 buffer loads (p.fast)
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
+  constexpr bool VEC = LMODE >= 1, FAST = LMODE == 2;
   constexpr int NT = 64 * WGM * WGN, RPP = NT / 8;   // threads; staging rows per pass (8 float4 per 32-k row)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -103,6 +123,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
     b_ok[i] = n < p.N && (!GB || r0 + RPP * i < BN); b_base[i] = (long long)n * p.ldb;
   }
   const int Hlim = p.up2 ? 2 * p.Hin : p.Hin, Wlim = p.up2 ? 2 * p.Win : p.Win;
+  // MODE 2: tile-relative byte offsets, validity masks (bit ky of f_my: input row iy0 + ky is inside the frame; bit kx of f_mx likewise)
+  unsigned f_av[RA], f_my[RA], f_mx[RA], f_bv[RB];
+  const int f_img0 = FAST && !p.is1x1 ? (tile_m * BM) / HoWo : 0;
+  const long long f_abias = FAST && !p.is1x1 ? ((long long)p.pad_t * p.Win + p.pad_l) * p.lda : 0;          // floats: keeps a padded row's offset non-negative
+  const __amdgpu_buffer_rsrc_t f_ra = gc_resource(p.is1x1 ? A + (long long)tile_m * BM * p.lda : A + (long long)f_img0 * p.Hin * p.Win * p.lda - f_abias);
+  const __amdgpu_buffer_rsrc_t f_rb = gc_resource(Bt + (long long)tile_n * BN * p.ldb);
+  if (FAST) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int row = r0 + RPP * i, m = tile_m * BM + row;
+      const bool ok = m < p.M && (!GA || row < BM);
+      if (p.is1x1) {
+        f_av[i] = ok ? (unsigned)(row * p.lda + c4 * 4) * 4u : GC_OOB; f_my[i] = 1u; f_mx[i] = 1u;
+      } else {
+        const int img = m / HoWo, rem = m - img * HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+        f_av[i] = (unsigned)(((long long)(img - f_img0) * p.Hin + iy0) * p.Win + ix0) * (unsigned)p.lda * 4u + (unsigned)(f_abias + c4 * 4) * 4u;
+        unsigned my = 0u, mx = 0u;
+        for (int k = 0; k < p.kh; ++k) my |= (unsigned)(iy0 + k >= 0 && iy0 + k < p.Hin) << k;
+        for (int k = 0; k < p.kw; ++k) mx |= (unsigned)(ix0 + k >= 0 && ix0 + k < p.Win) << k;
+        f_my[i] = ok ? my : 0u; f_mx[i] = mx;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = r0 + RPP * i, n = tile_n * BN + row;
+      f_bv[i] = (n < p.N && (!GB || row < BN)) ? (unsigned)(row * p.ldb + c4 * 4) * 4u : GC_OOB;
+    }
+  }
 
   float4 areg[RA], breg[RB];
   const int nslices_all = (p.K + BK - 1) / BK;
@@ -118,7 +167,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_conv_kernel(GP p) {
   }
 
   auto load_slice = [&](int k0) {
-    if (VEC) {
+    if (FAST) {
+      const unsigned sa = p.is1x1 ? (unsigned)k0 * 4u : (unsigned)((tap_ky * p.Win + tap_kx) * p.lda + tap_c0) * 4u;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        unsigned vo = f_av[i];
+        if (!p.is1x1) vo = ((f_my[i] >> tap_ky) & (f_mx[i] >> tap_kx) & 1u) ? vo : GC_OOB;
+        areg[i] = gc_fetch(f_ra, vo, sa);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) breg[i] = gc_fetch(f_rb, f_bv[i], (unsigned)k0 * 4u);
+      tap_c0 += BK;
+      if (tap_c0 >= p.Cin) { tap_c0 = 0; if (++tap_kx == p.kw) { tap_kx = 0; ++tap_ky; } }
+    } else if (VEC) {
       // Cin % 32 == 0: the slice lies inside one tap (running counters).  Cin % 4 == 0 only (e.g. the
       // 36-channel keypoint head): this lane's float4 column has its own (tap, channel) -- two integer
       // divisions per slice per lane, shared by all its rows; K % 32 != 0 needs the k < K guard.
@@ -385,12 +446,19 @@ int launch_cfg(const GP& p, int nb, bool vec, hipStream_t st) {
   GP q = p; q.tiles_n = tiles_n;
   dim3 grid(tiles_m * tiles_n, nb, p.ksplit > 1 ? p.ksplit : 1), block(64 * WGM * WGN);
   size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-  if (vec) {
-    auto k = gemm_conv_kernel<BM, BN, WGM, WGN, true>;
+  // MODE 2's offsets are 32-bit and relative to the tile: a tile's rows span at most BM / (Ho Wo) + 2 images of the input
+  const long long span = ((long long)BM / ((long long)p.Ho * p.Wo) + 2) * p.Hin * p.Win * p.lda * 4 + ((long long)p.pad_t * p.Win + p.pad_l + 8) * p.lda * 4;
+  q.fast = (vec && p.fast && (p.is1x1 || span < 0x7fffffffLL) && (long long)BM * p.lda * 4 < 0x7fffffffLL && (long long)BN * p.ldb * 4 + (long long)p.K * 4 < 0x7fffffffLL) ? 1 : 0;
+  if (q.fast) {
+    auto k = gemm_conv_kernel<BM, BN, WGM, WGN, 2>;
+    if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMX_LAUNCH(k, grid, block, lds, st, q);
+  } else if (vec) {
+    auto k = gemm_conv_kernel<BM, BN, WGM, WGN, 1>;
     if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SMX_LAUNCH(k, grid, block, lds, st, q);
   } else {
-    auto k = gemm_conv_kernel<BM, BN, WGM, WGN, false>;
+    auto k = gemm_conv_kernel<BM, BN, WGM, WGN, 0>;
     if (lds > 64 * 1024) SMX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SMX_LAUNCH(k, grid, block, lds, st, q);
   }
@@ -429,6 +497,7 @@ extern "C" int smx_gemm_conv_f32(const smx_gemm_desc* d, void* stream) {
   p.is1x1 = (d->kh == 1 && d->kw == 1 && d->stride == 1 && !d->up2 && d->pad_t == 0 && d->pad_l == 0 &&
              d->Hin == d->Ho && d->Win == d->Wo) ? 1 : 0;
   p.cin_bk = d->Cin % BK == 0 ? 1 : 0;
+  p.fast = (p.cin_bk && !d->up2 && d->kh <= 32 && d->kw <= 32 && smx_tune(SMX_TUNE_GEMM_LOADER) != 0) ? 1 : 0;
   const bool vec = (d->Cin % 4 == 0) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) &&
                    (((uintptr_t)d->a & 15) == 0) && (((uintptr_t)d->bt & 15) == 0) &&
                    (d->a_bs0 % 4 == 0) && (d->a_bs1 % 4 == 0) && (d->bt_bs0 % 4 == 0) && (d->bt_bs1 % 4 == 0);
