@@ -24,8 +24,22 @@
 #include "bf16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// operand quads by buffer loads (see gemm_conv.hip, "MODE 2 loader"): SGPR resource + SGPR slice offset + a 32-bit per-thread offset; a quad that must
+// read zero (row past the split, padding, column past K) presents an offset past the buffer -- no branch, no 64-bit vector address
+constexpr unsigned WG_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_resource(const float* base) {
+  const unsigned long long u = (unsigned long long)(uintptr_t)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 wg_fetch(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 inline int grid_for(long long total) { int g = smx_cdiv(total, 256); return g > 16384 ? 16384 : (g < 1 ? 1 : g); }
 
@@ -36,6 +50,7 @@ struct WG {
   int Hin, Win, Cin, Ho, Wo, kh, kw, stride, pad_t, pad_l, up2;
   int is1x1, vec_x, vec_y;
   int msplit, mper, tiles_k;
+  int fast;                                                       // host-checked: vector layouts, Cout % 4 == 0, 32-bit byte offsets -> the buffer-load loader
   int adv_y, adv_x;                                              // 32 pixels further along the row-major (oy, ox) walk: 32 / Wo rows and 32 % Wo columns
 };
 
@@ -48,7 +63,7 @@ struct WG {
 // BF16: the same tiles, staged in fp32 as they are read, but contracted on v_mfma_f32_32x32x16_bf16 -- each lane rounds its 8 pixels of a
 // column to bf16 (RNE) on the way from LDS to the MFMA, fp32 accumulate: what torch.autocast(bfloat16) does to this GEMM (the bias
 // gradient keeps summing the unrounded dy).  2 MFMAs per 32-pixel slice and accumulator instead of 16.
-template <bool BF16, int TC, int TKT>
+template <bool BF16, int TC, int TKT, bool FAST = false>
 __global__ __launch_bounds__(256, 4) void wgrad_kernel(WG p) {
   constexpr int PA = TC + 4, PB = TKT + 4;                 // LDS pitches
   constexpr int CA4 = TC / 4, CB4 = TKT / 4;               // float4 columns per staged row
@@ -95,7 +110,54 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(WG p) {
   float4 areg0[NA], breg0[NB], areg1[NA], breg1[NB];
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);            // bias gradient: this thread's 4 dy columns summed over its rows (tile_k == 0 blocks)
   const bool do_bias = p.bias_ws != nullptr && tile_k == 0;
+  // FAST: resources at the split's first row (dy; x of a 1x1 layer) or at the group's first image (x of a k x k layer); per-thread offsets once
+  const __amdgpu_buffer_rsrc_t f_ry = wg_resource(DY + (long long)m_begin * p.ldy);
+  const __amdgpu_buffer_rsrc_t f_rx = wg_resource(p.is1x1 ? X + (long long)m_begin * p.ldx : X);
+  unsigned f_ya[NA], f_xb[NB]; int f_img[NB];
+  if (FAST) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) f_ya[i] = (co0 + ca4 * 4 + 3 < p.Cout) ? (unsigned)((ra0 + RA * i) * p.ldy + co0 + ca4 * 4) * 4u : WG_OOB;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      f_xb[i] = (k0 + cb4 * 4 + 3 < p.K) ? (unsigned)((rb0 + RB * i) * p.ldx + k0 + cb4 * 4) * 4u : WG_OOB;
+      f_img[i] = (m_begin + rb0 + RB * i) / HoWo;
+    }
+  }
   auto load_slice = [&](int m0, float4 (&areg)[NA], float4 (&breg)[NB]) {
+    if (FAST) {
+      const bool tail = m0 + 32 > m_end;                           // wave-uniform: only a split's last slice has rows to blank
+      const unsigned sy = (unsigned)(m0 - m_begin) * (unsigned)p.ldy * 4u;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        unsigned vo = f_ya[i];
+        if (tail && m0 + ra0 + RA * i >= m_end) vo = WG_OOB;
+        const float4 a = wg_fetch(f_ry, vo, sy);
+        areg[i] = a;
+        if (do_bias) { bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w; }
+      }
+      if (p.is1x1) {
+        const unsigned sx = (unsigned)(m0 - m_begin) * (unsigned)p.ldx * 4u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          unsigned vo = f_xb[i];
+          if (tail && m0 + rb0 + RB * i >= m_end) vo = WG_OOB;
+          breg[i] = wg_fetch(f_rx, vo, sx);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          int iy = cy[i] * p.stride - p.pad_t + b_ky[0], ix = cx[i] * p.stride - p.pad_l + b_kx[0];
+          const bool ok = b_in[3] && iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim && !(tail && m0 + rb0 + RB * i >= m_end);
+          if (p.up2) { iy >>= 1; ix >>= 1; }
+          const unsigned off = (unsigned)(((f_img[i] * p.Hin + iy) * p.Win + ix) * p.ldx + b_cc[0]) * 4u;
+          breg[i] = wg_fetch(f_rx, ok ? off : WG_OOB, 0u);
+          cx[i] += p.adv_x; cy[i] += p.adv_y;
+          if (cx[i] >= p.Wo) { cx[i] -= p.Wo; ++cy[i]; }
+          while (cy[i] >= p.Ho) { cy[i] -= p.Ho; ++f_img[i]; }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int m = m0 + ra0 + RA * i;
@@ -698,8 +760,14 @@ static int wgrad_launch(bool bf16, const float* dy, int ldy, int64_t dy_bs, cons
   if (region) {
     const int rc = smx_wgrad_region_launch(bf16, dy, ldy, x, ldx, M, Cout, Hin, Win, Cin, Ho, Wo, up2, ws, p.bias_ws, msplit, stream);
     if (rc != SMX_OK) return rc;
-  } else if (bf16) SMX_LAUNCH((wgrad_kernel<true, 64, 64>), grid, dim3(256), 0, st, p);
-  else SMX_LAUNCH((wgrad_kernel<false, 64, 64>), grid, dim3(256), 0, st, p);
+  } else {
+    // the buffer-load loader: whole quads only (vector layouts, Cout and the taps' channel count multiples of 4) and 32-bit byte offsets
+    p.fast = (p.vec_x && p.vec_y && Cout % 4 == 0 && Cin % 4 == 0 && smx_tune(SMX_TUNE_GEMM_LOADER) != 0 &&
+              (long long)(p.mper + 64) * ldy * 4 < 0x7fffffffLL && (long long)(p.mper + 64) * ldx * 4 < 0x7fffffffLL &&
+              (p.is1x1 || ((long long)(M / (Ho * Wo)) + 1) * Hin * Win * ldx * 4 < 0x7fffffffLL)) ? 1 : 0;
+    if (bf16) { if (p.fast) SMX_LAUNCH((wgrad_kernel<true, 64, 64, true>), grid, dim3(256), 0, st, p); else SMX_LAUNCH((wgrad_kernel<true, 64, 64>), grid, dim3(256), 0, st, p); }
+    else { if (p.fast) SMX_LAUNCH((wgrad_kernel<false, 64, 64, true>), grid, dim3(256), 0, st, p); else SMX_LAUNCH((wgrad_kernel<false, 64, 64>), grid, dim3(256), 0, st, p); }
+  }
   if (accumulate & 2) return nb == 1 ? smx_launch_status() : SMX_EINVAL;      // deferred: the partials stay in ws for smx_wgrad_reduce_batch
   const long long per_g = (long long)Cout * p.K;
   int nblk = 0;

@@ -22,7 +22,13 @@ def main():
     ap.add_argument("--gan", action="store_true", help="the form past net_d_start_iter: discriminator term with the adaptive weight + the discriminator's own step")
     ap.add_argument("--graph", action="store_true", help="train.use_hip_graph: replay the captured step")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: convolution / Linear contractions on the bf16 MFMA (train.compute_dtype)")
+    ap.add_argument("--tune", action="append", default=[], help="name=value for smx_set_tuning before anything is launched or captured (A/B runs)")
     a = ap.parse_args()
+    if a.tune:
+        from synergize_motion_appearance_amd import ops as _ops
+        for kv in a.tune:
+            k, v = kv.split("=")
+            _ops.set_tuning(k, int(v))
     from basicsr.archs import build_network
     from synergize_motion_appearance_amd.synth import synth_state_dict, synth_clip
     from synergize_motion_appearance_amd.trainer import TrainStep
