@@ -395,9 +395,13 @@ def load_profile_json(name):
 
 # kernel family -> the objects of libsmx.so that hold its kernels: a committed counter summary is quoted for a family only while those
 # objects are the ones the counters were taken on (profiles/*_pmc.json "library_build" == lib/build_stamp.json)
+_GEMM_OBJS = ("gemm_conv.o", "gemm_rp_f32.o", "conv7_bf16x3.o", "conv_small.o")
 FAMILY_OBJECTS = {"winograd": ("winograd.o",), "winograd_wide": ("winograd.o",), "winograd_nw1": ("winograd.o",), "warp": ("warp_resize.o",),
-                  "gemm_conv": ("gemm_conv.o", "gemm_rp_f32.o", "conv7_bf16x3.o"), "gemm_bf16": ("gemm_bf16.o", "gemm_rp_bf16.o"),
-                  "conv3x3_bf16": ("conv3x3_bf16.o", "conv3x3_bf16_t32.o"), "attention": ("attention.o",), "vq": ("vq.o",)}
+                  "gemm_conv": _GEMM_OBJS, "gemm_bf16": ("gemm_bf16.o", "gemm_rp_bf16.o"),
+                  "conv_gemm_family": _GEMM_OBJS + ("winograd.o", "gemm_bf16.o", "gemm_rp_bf16.o", "conv3x3_bf16.o", "conv3x3_bf16_t32.o", "conv3x3_smalln_mfma16.o", "conv7_c2_bf16.o"),
+                  "conv3x3_bf16": ("conv3x3_bf16.o", "conv3x3_bf16_t32.o"), "conv7_x3": ("conv7_bf16x3.o",),
+                  "attention": ("attention.o",), "attention_mfma": ("attention.o",), "attention_mfma16": ("attention.o",), "attnblock": ("attention.o",),
+                  "groupnorm": ("norm_softmax.o",), "layernorm": ("norm_softmax.o",), "vq": ("vq.o",)}
 
 
 def pmc_is_current(summary, family):
