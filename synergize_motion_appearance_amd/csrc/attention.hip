@@ -40,6 +40,13 @@ struct AP {
 
 // MASK: a key-padding mask exists (the appearance cross-attention); without one (every self-attention call) the per-score compare / select
 // against the staged mask bytes -- 49 of the ~180 non-MFMA instructions of a 32-key tile -- and the mask staging are compiled out
+// lanes' bit set: `if_set`, otherwise `otherwise` (one v_cndmask with a wave-uniform lane mask in an SGPR pair)
+__device__ __forceinline__ float lane_select(unsigned long long lanes, float if_set, float otherwise) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(otherwise), "v"(if_set), "s"(lanes));
+  return r;
+}
+
 template <typename T, int DH, bool MASK = true>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AP<T> p) {
   constexpr int TK = 32, KLD = DH + 4, KS = DH / 8, DT = DH / 32;
@@ -98,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AP<T> p) {
   };
 
   const int ntiles = p.S / TK;
+  bool seen_live = !MASK;                                       // wave-uniform: some key of the tiles so far is not masked
   load_tile(0); store_tile(0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
@@ -116,34 +124,48 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AP<T> p) {
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk].z, s, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk].w, s, 0, 0, 0);
     }
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (MASK && Ms[buf][key]) s[r] = -INFINITY;
-      tmax = fmaxf(tmax, s[r]);
+    // A masked key is masked for EVERY query, so the tile's mask is one wave-uniform 32-bit word: the per-score select takes its lane mask from two
+    // scalar bit tests (keys k and k + 4 of the two half-waves) instead of an LDS byte, a compare and a select per score, a tile without masked keys
+    // pays nothing, and "every key so far masked" is a scalar flag, not a per-lane select on alpha and on each probability.
+    unsigned mb = 0u;
+    if (MASK) {
+      mb = (unsigned)__ballot(Ms[buf][lane & 31] != 0);
+      seen_live = seen_live || mb != 0xFFFFFFFFu;
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m, tmax);
-    const bool dead = MASK && (m_new == -INFINITY);         // every key so far masked
-    const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
-    float psum = 0.f;
+    if (!MASK || seen_live) {
+      if (MASK && mb != 0u) {
+        const float ninf = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = dead ? 0.f : __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
-    psum += __shfl_xor(psum, 32, 64);
-    l = l * alpha + psum; m = m_new;
+        for (int r = 0; r < 16; ++r) {
+          const int k0 = (r & 3) + 8 * (r >> 2);
+          const unsigned long long lanes = (unsigned long long)(0u - ((mb >> k0) & 1u)) | ((unsigned long long)(0u - ((mb >> (k0 + 4)) & 1u)) << 32);
+          s[r] = lane_select(lanes, ninf, s[r]);
+        }
+      }
+      float tmax = -INFINITY;
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m, tmax);                      // finite: this tile or an earlier one holds a live key
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-    // O^T += V^T P^T
-    const float* vp = &Vs[buf][(lane & 31)];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
+      psum += __shfl_xor(psum, 32, 64);
+      l = l * alpha + psum; m = m_new;
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[key * DH + d * 32], s[r], oacc[d], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      // O^T += V^T P^T
+      const float* vp = &Vs[buf][(lane & 31)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[key * DH + d * 32], s[r], oacc[d], 0, 0, 0);
+      }
     }
     if (t + 1 < ntiles) store_tile(buf ^ 1);
     __syncthreads();
