@@ -105,6 +105,34 @@ def test_conv(ops, case):
     assert maxabs(nchw(y), ref) < 2e-5, tag
 
 
+LOADER_CASES = [  # (B, Cin, Cout, H, W, k, stride, pad, tile, res, tag)
+    (2, 64, 128, 24, 40, 1, 1, (0, 0), 0, False, "1x1 ragged M"), (3, 256, 192, 17, 19, 1, 1, (0, 0), 12, True, "1x1 tile12 residual, N tail"),
+    (2, 32, 48, 33, 21, 3, 2, (1, 1), 5, False, "3x3 s2 pad1 odd grid"), (1, 128, 17, 30, 26, 7, 1, (3, 3), 3, False, "7x7 128->17 small N"),
+    (2, 96, 64, 9, 33, 5, 1, (2, 2), 8, True, "5x5 tile8 residual"), (5, 64, 64, 4, 4, 3, 1, (1, 1), 1, False, "4x4 maps: a tile spans several images"),
+    (1, 128, 128, 32, 32, 3, 1, (1, 1), 6, False, "tile6"), (1, 64, 64, 16, 48, 3, 1, (0, 2), 10, False, "asymmetric pad tile10"),
+]
+
+
+@pytest.mark.parametrize("case", LOADER_CASES, ids=[c[-1] for c in LOADER_CASES])
+def test_gemm_conv_buffer_loader_equals_the_gather(ops, case, tuning):
+    """gemm_conv's LMODE 2 loader (round 5: one buffer_load per operand quad, SGPR tile base + slice offset, padding / tails as out-of-range offsets;
+    knob `gemm_loader`) against the float4 gather it replaces: the same products in the same order -> bit-identical, and both equal F.conv2d."""
+    B, Cin, Cout, H, W, k, stride, pad, tile, res, tag = case
+    x = rnd("lx" + tag, (B, Cin, H, W))
+    w = rnd("lw" + tag, (Cout, Cin, k, k), 1.0 / math.sqrt(Cin * k * k))
+    b = rnd("lb" + tag, (Cout,), 0.1)
+    ref = F.leaky_relu(F.conv2d(x, w, b, stride=stride, padding=pad), 0.2)
+    r = rnd("lr" + tag, tuple(ref.shape)) if res else None
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    ys = []
+    for knob in (1, 0):
+        tuning("gemm_loader", knob)
+        ys.append(ops.conv(nhwc(x), cv, stride=stride, pad=pad, act=2, tile=tile, res=nhwc(r) if res else None, direct=True).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1]), tag
+    assert maxabs(nchw(ys[0]), ref + r if res else ref) < 2e-5, tag
+
+
 WINO_CASES = [(2, 64, 64, 32, False, 0, False), (1, 128, 128, 64, False, 3, True), (2, 256, 512, 32, False, 4, False),
               (1, 128, 64, 64, False, 0, True), (2, 64, 64, 16, True, 0, False), (1, 160, 126, 32, False, 1, False),
               (1, 128, 96, 32, False, 1, False), (3, 32, 32, 32, False, 2, True), (1, 64, 64, 256, False, 0, True)]

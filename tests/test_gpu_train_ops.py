@@ -643,3 +643,47 @@ def test_batched_weight_packing_equals_the_per_layer_launches():
     # a tape over a different parameter dict resets the plan instead of packing from stale pointers
     Tape(dict(P), G, plan=plan)
     assert not plan.items
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride,pad,up2,bf16", [(2, 64, 128, 24, 40, 1, 1, 0, 0, 0), (3, 32, 48, 17, 19, 3, 2, 1, 0, 0), (1, 128, 20, 30, 26, 7, 1, 3, 0, 0),
+                                                                  (2, 64, 64, 20, 24, 3, 1, 1, 1, 0), (2, 96, 64, 9, 33, 5, 1, 2, 0, 1), (4, 256, 256, 8, 8, 1, 1, 0, 0, 1)])
+def test_weight_gradient_buffer_loader_equals_the_gather(B, Cin, Cout, H, W, k, stride, pad, up2, bf16):
+    """wgrad_kernel's buffer-load loader (round 5: SGPR resource + slice offset, rows past the split / padded taps as out-of-range offsets; knob
+    `gemm_loader`) against the float4 gather on channel SLICES of wider buffers, odd grids, strides, nearest-x2 inputs and tail slices: the same
+    products in the same order -- bit-identical, bias gradient included."""
+    import ctypes as C
+    from synergize_motion_appearance_amd import lib as L
+    lib = L.load()
+    Hin, Win = (H, W)
+    He, We = (2 * H, 2 * W) if up2 else (H, W)
+    Ho, Wo = (He + 2 * pad - k) // stride + 1, (We + 2 * pad - k) // stride + 1
+    xw = rnd("bl_x", (B, Hin, Win, Cin + 8)).cuda()
+    dyw = rnd("bl_dy", (B, Ho, Wo, Cout + 12)).cuda()
+    x, dy = xw[..., 4:4 + Cin], dyw[..., 8:8 + Cout]
+    M = B * Ho * Wo
+    st = torch.cuda.current_stream().cuda_stream
+    fn = lib.smx_wgrad_mfma16_f32 if bf16 else lib.smx_wgrad_f32
+    outs = []
+    try:
+        L.check(lib.smx_set_tuning(b"wgrad_region", 0), "knob")
+        for knob in (1, 0):
+            L.check(lib.smx_set_tuning(b"gemm_loader", knob), "knob")
+            ms = C.c_int(0)
+            n = int(lib.smx_wgrad_conv_ws_floats(1, M, Cout, Cin, Hin, Win, Ho, Wo, k, k, stride, pad, pad, up2, C.byref(ms)))
+            ws = torch.empty(n, device="cuda")
+            out = torch.full((Cout, Cin, k, k), 0.25, device="cuda")
+            bias = torch.full((Cout,), -0.5, device="cuda")
+            L.check(fn(dy.data_ptr(), Cout + 12, 0, x.data_ptr(), Cin + 8, 0, 1, M, Cout, Hin, Win, Cin, Ho, Wo, k, k, stride, pad, pad, up2, ws.data_ptr(), ms.value,
+                       out.data_ptr(), 0, 0, 0, 1, 0.5, bias.data_ptr(), st), "wgrad")
+            torch.cuda.synchronize()
+            outs.append((out.cpu(), bias.cpu()))
+    finally:
+        L.check(lib.smx_set_tuning(b"gemm_loader", 1), "knob")
+        L.check(lib.smx_set_tuning(b"wgrad_region", 1), "knob")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    if not bf16:
+        xr = x.cpu().permute(0, 3, 1, 2)
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest") if up2 else xr
+        w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+        F.conv2d(xr, w, stride=stride, padding=pad).backward(dy.cpu().permute(0, 3, 1, 2))
+        assert rel(outs[0][0] - 0.25, 0.5 * w.grad) < 2e-4
