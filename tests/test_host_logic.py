@@ -543,3 +543,27 @@ def test_round4_kernel_eligibility_rules_host_side():
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]                 # ... and under SMX_TOOLS they are honoured (bisection, A/B timing)
     from synergize_motion_appearance_amd import ops
     assert ops.GEMM16_RP and ops.GEMM_RP and ops.CONV16_T32                 # the default path keeps them
+
+
+def test_round5_measurement_plumbing_host_side():
+    """(i) every kernel family named in the committed counter summaries maps to the object files whose rebuild makes the summary stale
+    (a family without a mapping used to be reported stale forever); (ii) the summaries carry the library's per-object digests;
+    (iii) the shipped tuning table has the round-5 knobs at their shipped values (no GPU needed: the table lives in host code)."""
+    import ctypes as C
+    import json
+    import bench
+    from synergize_motion_appearance_amd import lib as L
+    prof = os.path.join(REPO, "profiles")
+    for name in ("r05_traffic_pmc.json", "r05_traffic_pmc_bf16.json", "r05_mfma_pmc.json", "r05_mfma_pmc_bf16.json"):
+        j = json.load(open(os.path.join(prof, name)))
+        fams = j.get("families") or j.get("kernels")
+        assert fams and isinstance(j.get("library_build"), dict) and j["library_build"], name
+        for f in fams:
+            objs = bench.FAMILY_OBJECTS.get(f)
+            assert objs, (name, f)
+            assert all(o in j["library_build"] for o in objs), (name, f, objs)
+    lib = L.load()
+    for knob, want in (("gemm_loader", 1), ("wino_ws", 0), ("wino_stagger", 0), ("wino_wide", 1)):
+        v = C.c_int(-99)
+        assert lib.smx_get_tuning(knob.encode(), C.byref(v)) == 0 and v.value == want, (knob, v.value)
+    assert lib.smx_get_tuning(b"no_such_knob", C.byref(C.c_int(0))) != 0
