@@ -67,6 +67,7 @@ struct WP {
   int tiles_y, tiles_x;          // blocks per image along y / x
   int n32;                       // ceil(Cout/32) (U is packed for n32*32 rows)
   int nt;                        // wide kernel: non-temporal residual loads / output stores
+  int xcd_group;                 // wide kernel: output blocks of a spatial tile 8 block ids apart (same XCD, same time): gridDim.x % 8 == 0 && gridDim.y > 1
   int stagger;                   // wide kernel: shader cycles the SECOND resident round of the launch's first blocks waits before it starts (0 = off)
   const float* mul; int ldmul; float sft_w;   // SFT epilogue (Fuse_sft_block, appmotioncodebook_arch.py:49-51): y = res + sft_w * (res * mul + conv)
 };
@@ -455,10 +456,17 @@ __global__ __launch_bounds__(256, 2) void winograd_wide_kernel(WP p) {
   }
   const int hh = lane >> 5, t = lane & 31;
   const int tr = t >> 3, tc = t & 7;
-  int bid = blockIdx.x;
+  // Block -> (spatial tile, output block).  The dispatcher hands out linear block ids x-fastest and puts id L on XCD L % 8 (each XCD has its own L2).
+  // With the grid's natural meaning the C_out / 64 output blocks of one spatial tile are gridDim.x ids apart: different times, different XCDs -- the
+  // tile's input region comes from HBM once per output block.  Regrouped, ids L and L + 8 are the SAME spatial tile's next output block: same XCD,
+  // resident together, so the region is fetched from HBM once per XCD and the other blocks' loads are L2 hits.
+  int bid = blockIdx.x, nblk = blockIdx.y;
+  if (p.xcd_group) {
+    const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, per = 8u * gridDim.y, grp = L / per, r = L - grp * per;
+    bid = (int)(grp * 8u + (r & 7u)); nblk = (int)(r >> 3);
+  }
   const int bx = bid % p.tiles_x; bid /= p.tiles_x;
   const int by = bid % p.tiles_y; const int img = bid / p.tiles_y;
-  const int nblk = blockIdx.y;
   const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
   const float* __restrict__ X = p.x + (long long)img * Hs * Ws * p.lda;
 
@@ -1281,6 +1289,7 @@ static int winograd_launch(const float* x, int lda, const float* u_packed, const
   p.tiles_y = H / 8; p.tiles_x = W / 16; p.n32 = (Cout + 31) / 32; p.nt = smx_tune(SMX_TUNE_WINO_NT);
   p.stagger = smx_tune(SMX_TUNE_WINO_STAGGER);
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
+  p.xcd_group = (smx_tune(SMX_TUNE_WINO_XCD) != 0 && blocks % 8 == 0 && Cout > 64 && Cout % 64 == 0 && blocks * ((Cout + 63) / 64) <= 0x7fffffffLL) ? 1 : 0;
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
   if ((long long)H * W * ldc > 2147483647LL || (long long)H * W * (res ? ldres : 0) > 2147483647LL || (long long)H * W * (mul ? ldmul : 0) > 2147483647LL) return SMX_EINVAL;
   if (16LL * ((Cout + 31) / 32) * (Cin / 8) * 256 > 2147483647LL) return SMX_EINVAL;
