@@ -179,6 +179,22 @@ int smx_winograd_conv3x3_sft_f32(const float* x, int lda, const float* u_packed,
                                  const float* dec, int lddec, const float* scale, int ldscale, float w,
                                  float* y, int ldc, int B, int H, int W, int Cin, int Cout,
                                  float* stats_part, void* stream);
+/* The same two convolutions on the BF16 matrix pipe with fp32-grade arithmetic ("bf16x6", csrc/winograd_bf3.hip): every fp32 operand is
+ * split exactly into three bf16 values (U at pack time, the transformed input in registers) and a product is the six bf16 MFMA products
+ * down to 2^-24 -- same call sites (/root/reference/basicsr/archs/vqgan_arch.py:168-191, appmotioncodebook_arch.py:49-51), same
+ * arguments and epilogues as smx_winograd_conv3x3_f32 / _sft_f32.  u3 = smx_winograd_bf3_pack(u_packed of the fp32 kernel):
+ * [16][Cout/32][Cin/16][3 splits][64 lanes][8] bf16, smx_winograd_bf3_u_bytes bytes.  nprod: 6 (fp32-grade) or 3 (two-way split,
+ * ~2^-17, for comparison only).  Shapes: smx_winograd_bf3_shape_ok (H % 16 == 0, W % 16 == 0, Cin % 32 == 0, Cin <= 512,
+ * Cout % 64 == 0, every row stride % 4 == 0; all pointers 16 B-aligned); stats_part chunks are the fp32 kernel's (8 x 16 pixels). */
+int64_t smx_winograd_bf3_u_bytes(int Cout, int Cin);
+int smx_winograd_bf3_pack(const float* u_packed, void* u3, int Cout, int Cin, void* stream);
+int smx_winograd_bf3_shape_ok(int B, int H, int W, int Cin, int Cout, int lda, int ldc, int ldres, int ldmul);
+int smx_winograd_bf3_conv3x3_f32(const float* x, int lda, const void* u3, const float* bias, const float* res, int ldres, float* y, int ldc,
+                                 int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
+                                 float* stats_part, int nprod, void* stream);
+int smx_winograd_bf3_conv3x3_sft_f32(const float* x, int lda, const void* u3, const float* bias, const float* dec, int lddec,
+                                     const float* scale, int ldscale, float w, float* y, int ldc, int B, int H, int W, int Cin, int Cout,
+                                     float* stats_part, int nprod, void* stream);
 /* in_ss != NULL: the GroupNorm(+swish, if in_swish) that precedes the conv in ResBlock
  * (archs/vqgan_arch.py:183-188) is applied by the region loader: x*in_ss[b][c][0] + in_ss[b][c][1],
  * with in_ss from smx_groupnorm_stats_f32 -- the separate normalise read+write pass disappears.

@@ -1,0 +1,557 @@
+// Fused Winograd F(2x2,3x3) convolution with fp32 operands on the BF16 matrix pipe of gfx950 ("bf16x6": three-way split operands).
+//
+// Why: on gfx950 the fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VECTOR rate and shares its lanes with the VALU
+// (profiles/r05_winograd_valu_vs_mfma.txt); v_mfma_f32_32x32x16_bf16 is 16x faster per multiply and co-issues with VALU work.  An fp32
+// value splits EXACTLY into three bf16 values x = x1 + x2 + x3 (8 + 8 + 8 significand bits, round-to-nearest at every level), and
+//     u * v  =  u1 v1 + (u1 v2 + u2 v1) + (u1 v3 + u2 v2 + u3 v1)  +  O(2^-24 |u v|)
+// -- six bf16 products, each exact in the MFMA's fp32 accumulation -- carries the same 2^-24 relative error bound as one rounded fp32
+// product: 6 x 32 = 192 pipe cycles per 32x32x16 block of multiplies against 8 x 64 = 512 on the fp32 MFMA (tests/test_gpu_wino_bf3.py
+// measures both against fp64: the split form is not less accurate than the fp32-MFMA kernel).  NPROD = 3 keeps only the first three
+// products (two-way split, error ~2^-17: reported next to the six-product form, never selected for the fp32 configuration).
+//
+// The same reference call sites as smx_winograd_conv3x3_f32 (3x3 / s1 / p1 layers of /root/reference/basicsr/archs/vqgan_arch.py:168-191
+// and appmotioncodebook_arch.py's Fuse_sft_block), same epilogues (bias / activation / residual / SFT / GroupNorm partials), same fused
+// GroupNorm(+swish) loader; U = G g G^T is the fp32 kernel's, split at pack time.
+//
+// Shape of a block (one per CU: 8 waves, 256 registers each):
+//   * 16 x 16 output pixels (8 x 8 Winograd tiles = two MFMA M tiles) x 64 output channels x all 16 frequencies.  What fixes it:
+//     the accumulators (16 frequencies x M x N fp32) must fit the register file, U bytes per multiply fall with M (every CU streams U from
+//     L2 through its 64 B/clk vector-memory path: 2048 / M B/clk at full matrix rate -> M = 64 tiles = 32 B/clk), and the V split (VALU, per
+//     element of V) amortises over N -- so M = N = 64, and a wave owns BOTH M tiles and BOTH N tiles of two frequencies:
+//     wave w = (frequency row fi = w >> 1, column pair jh = w & 1), 2 x 2 x 2 accumulator tiles = 128 registers;
+//   * per 32-channel slice the raw 18 x 18-pixel region goes global -> LDS by LDS-DMA (no staging registers), is normalised (fused
+//     GroupNorm + swish) once per element on its way into the transform layout: [8 channel quads][18 rows][x parity][9] float4, so that the
+//     16 lanes of a ds_read_b128 group (tile columns 0-3 or 4-7 x four tile rows) hit 16 distinct bank groups;
+//   * a "phase" = one frequency x 16 channels: input transform of the lane's two tiles x 8 channels (its MFMA B fragment) in fp32,
+//     three-way split (v_cvt_pk_bf16_f32), then 24 MFMAs (6 products x 2 M tiles x 2 N tiles) on U fragments that came straight from L2 into
+//     registers one phase ahead (hand-counted vmcnt: the region DMA of the next slice is in flight under them);
+//   * two waves share a SIMD: one transforms / splits while the other multiplies;
+//   * epilogue per M tile: every wave writes its two partial column sums to the exchange buffer, one barrier, each thread finishes one
+//     2x2 output tile x 4 channels (bias / activation / residual or SFT, float4 stores, Welford partials in the fp32 kernel's chunk format).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <type_traits>
+#include <mutex>
+#include "smx.h"
+#include "smx_common.h"
+#include "bf16.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int B3_PLANE = 326;                          // float4 slots per channel-quad plane: 18 rows x 2 x-parities x 9 (+2: planes 6 bank groups apart)
+constexpr int B3_REGION_F = 8 * B3_PLANE * 4;          // floats per region buffer (32 channels)
+constexpr int B3_REGION_B = B3_REGION_F * 4;           // 41,728 B
+constexpr int B3_SS_B = 512 * 2 * 4;                   // GroupNorm scale / shift of the image (C_in <= 512)
+constexpr int B3_XCH_F = 2 * 8 * 32 * 68;              // exchange [2 q][8 waves][32 tiles][64 n, pitch 68]
+constexpr int B3_RED_F = 32 * 64 * 2;
+constexpr int B3_MAIN_B = 2 * B3_REGION_B + B3_SS_B;
+constexpr int B3_LDS = B3_XCH_F * 4 + B3_RED_F * 4;    // 155,648 B (the main loop's 87,552 B live inside the exchange's bytes)
+static_assert(B3_MAIN_B <= B3_XCH_F * 4, "main-loop LDS must fit under the exchange buffer");
+
+struct B3P {
+  const float* x; const unsigned char* u; const float* bias; const float* res; float* y; float* stats;
+  const float* in_ss; int in_swish;
+  int lda, ldc, ldres;
+  int B, H, W, Cin, Cout, up2, act;
+  int ty, tx;                       // 16 x 16-pixel blocks per image
+  int n32, nsteps;                  // Cout / 32, Cin / 16
+  int xcd_group;
+  const float* mul; int ldmul; float sft_w;
+  unsigned u_bytes;
+};
+
+__device__ __forceinline__ float b3_act(float v, int act) {
+  switch (act) {
+    case SMX_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SMX_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
+    case SMX_ACT_SWISH: return v / (1.f + expf(-v));
+    case SMX_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case SMX_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+// ---- vector memory: plain buffer loads the compiler sees (it counts vmcnt itself: every request of the loop is unconditional and in a fixed order,
+// so the wait in front of a phase's MFMAs is exactly "everything up to my fragments", with the two region items requested behind them still in
+// flight).  Two earlier forms were measured wrong on the device: region by LDS-DMA (its requests do not retire in order with register loads), and
+// hand-counted inline-asm requests with a conditional claim (hipcc copied the not-yet-landed registers in front of the wait on one branch).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 b3_load16(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned unit_bytes) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, unit_bytes, 0));
+}
+
+// x -> (hi, mid, lo) bf16, round-to-nearest-even at every level; eight values = one MFMA B fragment per level
+template <int NS>
+__device__ __forceinline__ void b3_split8(const float (&f)[8], uint4& hi, uint4& mid, uint4& lo) {
+  hi = pack8(f);
+  float h[8]; unpack8(hi, h);
+  float r[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = f[e] - h[e];
+  mid = pack8(r);
+  if (NS == 3) {
+    float m[8]; unpack8(mid, m);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = r[e] - m[e];
+    lo = pack8(s);
+  }
+}
+
+// the same split on four values, with the conversion opaque to the compiler (one v_cvt_pk_bf16_f32 per PAIR and level: left to itself hipcc converts
+// the even element a second time to form its fp32 image) -- 22 VALU instructions per four values
+__device__ __forceinline__ unsigned b3_cvt2(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int NS>
+__device__ __forceinline__ void b3_split4(const float (&v)[4], unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
+  float r[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    hi[q] = b3_cvt2(v[2 * q], v[2 * q + 1]);
+    r[2 * q] = v[2 * q] - __uint_as_float(hi[q] << 16);
+    r[2 * q + 1] = v[2 * q + 1] - __uint_as_float(hi[q] & 0xffff0000u);
+    mid[q] = b3_cvt2(r[2 * q], r[2 * q + 1]);
+    if (NS == 3) {
+      const float s0 = r[2 * q] - __uint_as_float(mid[q] << 16), s1 = r[2 * q + 1] - __uint_as_float(mid[q] & 0xffff0000u);
+      lo[q] = b3_cvt2(s0, s1);
+    } else lo[q] = 0u;
+  }
+}
+
+__device__ __forceinline__ bf16x8 b3_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 b3_frag(f32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// tile index (MFMA column 0..31 of an M tile) -> (tile row 0..3, tile column 0..7): columns 0-3 / 4-7 follow the lane groups a ds_read_b128 is
+// served in ({0-3,12-15,20-27} and {4-11,16-19,28-31}), so that every group reads four tile rows x four adjacent tile columns
+__device__ __forceinline__ int b3_tile_col(int t) { return 4 * (((t >> 2) ^ (t >> 3) ^ (t >> 4)) & 1) + (t & 3); }
+
+template <int NPROD>
+__global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
+  constexpr int NS = NPROD == 6 ? 3 : 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* smem_b = reinterpret_cast<unsigned char*>(smem);
+  float* ss_lds = reinterpret_cast<float*>(smem_b + 2 * B3_REGION_B);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = wave >> 1, jh = wave & 1;
+  const int hh = lane >> 5, t = lane & 31;
+  const int trl = t >> 3, tc = b3_tile_col(t);
+
+  // block -> (spatial block, output block); with xcd_group the output blocks of one spatial block are 8 block ids apart (same XCD, resident together)
+  int bid = blockIdx.x, nblk = blockIdx.y;
+  if (p.xcd_group) {
+    const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, per = 8u * gridDim.y, grp = L / per, r = L - grp * per;
+    bid = (int)(grp * 8u + (r & 7u)); nblk = (int)(r >> 3);
+  }
+  const int bx = bid % p.tx; bid /= p.tx;
+  const int by = bid % p.ty; const int img = bid / p.ty;
+  const int y0 = by * 16, x0 = bx * 16;
+  const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
+  const float* __restrict__ X = p.x + (long long)img * Hs * Ws * p.lda;
+  const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, Hs * Ws * p.lda * 4, 0x00020000);
+
+  // ---- staging: 432 threads = 3 region rows x 18 pixels x 8 channel quads; item k is the row 3k + r3 ----------------------------------
+  // The thread's staging geometry is RE-DERIVED from the lane id where it is used (once per slice, ~20 instructions): held in registers
+  // across the phases it would be spilled, and a scratch reload is a vector-memory request in the middle of the hand-counted ones.
+  const bool interior = y0 >= 1 && y0 + 17 <= p.H && x0 >= 1 && x0 + 17 <= p.W;
+  const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
+  auto stage_geo = [&](int& l, int& r3, int& srx, int& sc4) __attribute__((always_inline)) {
+    l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));                                                            // opaque: computed here, not carried
+    const int st = wave * 64 + l;
+    r3 = (st * 57) >> 13;                                                                   // st / 144 for st < 512; 3 = not a staging thread
+    const int rem = st - r3 * 144;
+    srx = rem >> 3; sc4 = rem & 7;
+  };
+  // two items per phase: rows 3k + r3 for k = 2 ph, 2 ph + 1 (ph = 0..2 covers the 18 rows)
+  f32x4 sreg[2];
+  auto issue_items = [&](f32x4 (&rg)[2], int ph, int c0) __attribute__((always_inline)) {
+    int l, r3, srx, sc4; stage_geo(l, r3, srx, sc4);
+    r3 = min(r3, 2);                                                                        // a non-staging lane of a staging wave requests a legal address and drops it
+    int sxc = min(max(x0 - 1 + srx, 0), p.W - 1);
+    if (p.up2) sxc >>= 1;
+    const int gcol = sxc * p.lda + sc4 * 4 + c0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int iy = min(max(y0 - 1 + 3 * (2 * ph + q) + r3, 0), p.H - 1);
+      if (p.up2) iy >>= 1;
+      rg[q] = b3_load16(RX, (unsigned)(iy * Ws * p.lda + gcol) * 4u, 0u);
+    }
+  };
+  auto store_items = [&](const f32x4 (&rg)[2], int ph, float* rb, int c0, auto mode, auto inside) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode)::value;
+    constexpr bool INSIDE = decltype(inside)::value;
+    int l, r3, srx, sc4; stage_geo(l, r3, srx, sc4);
+    if (r3 >= 3) return;
+    const int woff = (sc4 * B3_PLANE + (r3 * 2 + (srx & 1)) * 9 + (srx >> 1)) * 4;               // + k * 216 floats
+    const int six = x0 - 1 + srx;
+    const bool x_ok = six >= 0 && six < p.W;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE >= 1) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ss_lds + (c0 + sc4 * 4) * 2), b = *reinterpret_cast<const f32x4*>(ss_lds + (c0 + sc4 * 4) * 2 + 4);
+      sc = f32x4{a.x, a.z, b.x, b.z}; sh = f32x4{a.y, a.w, b.y, b.w};
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = 2 * ph + q;
+      f32x4 v = rg[q];
+      if (MODE >= 1) {
+        v = __builtin_elementwise_fma(v, sc, sh);
+        if (MODE == 2) {
+          constexpr float L2E = 1.44269504088896340736f;
+          f32x4 e = v * (-L2E);
+          e = f32x4{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y), __builtin_amdgcn_exp2f(e.z), __builtin_amdgcn_exp2f(e.w)} + 1.f;
+          v *= f32x4{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y), __builtin_amdgcn_rcpf(e.z), __builtin_amdgcn_rcpf(e.w)};
+        }
+      }
+      if (!INSIDE) {
+        const int iy = y0 - 1 + 3 * k + r3;
+        const bool ok = x_ok && iy >= 0 && iy < p.H;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;                // the convolution's zero padding
+      }
+      *reinterpret_cast<f32x4*>(rb + woff + k * 216) = v;
+    }
+  };
+  auto store_region = [&](const f32x4 (&rg)[2], int ph, int buf, int c0) __attribute__((always_inline)) {
+    float* rb = smem + buf * B3_REGION_F;
+    if (interior) {
+      if (loader == 2) store_items(rg, ph, rb, c0, std::integral_constant<int, 2>{}, std::true_type{});
+      else if (loader == 1) store_items(rg, ph, rb, c0, std::integral_constant<int, 1>{}, std::true_type{});
+      else store_items(rg, ph, rb, c0, std::integral_constant<int, 0>{}, std::true_type{});
+    } else {
+      if (loader == 2) store_items(rg, ph, rb, c0, std::integral_constant<int, 2>{}, std::false_type{});
+      else if (loader == 1) store_items(rg, ph, rb, c0, std::integral_constant<int, 1>{}, std::false_type{});
+      else store_items(rg, ph, rb, c0, std::integral_constant<int, 0>{}, std::false_type{});
+    }
+  };
+
+  // ---- transform geometry: frequency row fi needs patch rows (ra, rb) and sign sr; column j needs (ca, cb) and sign sc of the same table --
+  //   0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
+  const int ra = (fi == 0) ? 0 : ((fi == 2) ? 2 : 1);
+  const int rb_ = (fi == 0) ? 2 : ((fi == 1) ? 2 : ((fi == 2) ? 1 : 3));
+  const float sr = (fi == 1) ? 1.f : -1.f;
+  // lane part of a patch read (floats): channel quad 2 hh of the 16-channel step, tile row trl, tile column tc
+  const int lbase = (2 * hh * B3_PLANE + (2 * trl * 2) * 9 + tc) * 4;
+  auto col_off = [&](int r, int b) { return ((r * 2 + (b & 1)) * 9 + (b >> 1)) * 4; };     // patch pixel (row r, column b) relative to the tile's first pixel
+  int oa[2][2], ob[2][2];                                                                    // [frequency of the wave][row a | b]: WAVE-UNIFORM float offsets (SGPRs)
+  float scj[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int j = 2 * jh + f;
+    const int ca = (j == 0) ? 0 : ((j == 2) ? 2 : 1);
+    const int cb = (j == 0) ? 2 : ((j == 1) ? 2 : ((j == 2) ? 1 : 3));
+    scj[f] = (j == 1) ? 1.f : -1.f;
+    oa[f][0] = col_off(ra, ca); oa[f][1] = col_off(rb_, ca);
+    ob[f][0] = col_off(ra, cb); ob[f][1] = col_off(rb_, cb);
+  }
+
+  // ---- U: [16 f][n32][Cin/16][3 splits][64 lanes][8 bf16] ------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t RU = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.u), 0, (int)p.u_bytes, 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned ustep_b = 3u * 1024u;                                                       // bytes per (frequency, n tile, step)
+  unsigned ubase[2][2];                                                                      // [frequency of the wave][n tile]: byte offset of step 0
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      ubase[f][n] = (unsigned)(((fi * 4 + 2 * jh + f) * p.n32 + nblk * 2 + n) * p.nsteps) * ustep_b;
+  // ONE set of fragment registers (the register file is the limit: 128 accumulators + 24 + the transform's values): a phase's fragments are
+  // requested right after the previous phase's MFMAs were issued and land under this phase's transform + split (and the partner wave's MFMAs)
+  f32x4 ur[2][3];                                                                            // [n tile][split]
+  auto request_u = [&](int f, int step) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)step * ustep_b;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3)
+        if (s3 < NS) ur[n][s3] = b3_load16(RU, lane16, ubase[f][n] + so + (unsigned)s3 * 1024u);
+        else ur[n][s3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  f32x16 acc[2][2][2];                                                                       // [frequency][M tile][N tile]
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][m][n][r] = 0.f;
+
+  // one phase: frequency f of the wave, 16-channel step `sub` of the slice in region buffer rb
+  auto phase = [&](int buf, int f, int sub, auto next) __attribute__((always_inline)) {
+    unsigned vh[2][4], vm[2][4], vl[2][4];                                                   // [M tile][4 dwords = 8 bf16: the lane's MFMA B fragment]
+    // four lane addresses per phase (lane part + the wave's row / column offsets + the region buffer), everything else is an immediate
+    const float* paa = smem + (lbase + (buf * B3_REGION_F + oa[f][0]));
+    const float* pba = smem + (lbase + (buf * B3_REGION_F + oa[f][1]));
+    const float* pab = smem + (lbase + (buf * B3_REGION_F + ob[f][0]));
+    const float* pbb = smem + (lbase + (buf * B3_REGION_F + ob[f][1]));
+    // one channel quad at a time (four patch reads -> four values of V -> their three bf16 levels), fenced: left alone the scheduler hoists all
+    // sixteen reads of the phase to its top (64 registers the kernel does not have)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int o = (sub * 4 + e2) * B3_PLANE * 4 + m * (4 * 2 * 2 * 9 * 4);
+        const f32x4 daa = *reinterpret_cast<const f32x4*>(paa + o), dba = *reinterpret_cast<const f32x4*>(pba + o);
+        const f32x4 dab = *reinterpret_cast<const f32x4*>(pab + o), dbb = *reinterpret_cast<const f32x4*>(pbb + o);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ta = fmaf(sr, dba[e], daa[e]), tb = fmaf(sr, dbb[e], dab[e]);
+          v[e] = fmaf(scj[f], tb, ta);
+        }
+        unsigned h2[2], m2[2], l2[2];
+        b3_split4<NS>(v, h2, m2, l2);
+        vh[m][2 * e2] = h2[0]; vh[m][2 * e2 + 1] = h2[1]; vm[m][2 * e2] = m2[0]; vm[m][2 * e2 + 1] = m2[1]; vl[m][2 * e2] = l2[0]; vl[m][2 * e2 + 1] = l2[1];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    __builtin_amdgcn_s_setprio(1);
+    // smallest products first; consecutive MFMAs go to different accumulators
+    auto prod = [&](const unsigned (&vv)[2][4], int us) __attribute__((always_inline)) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[f][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3_frag(ur[n][us]), b3_frag(make_uint4(vv[m][0], vv[m][1], vv[m][2], vv[m][3])), acc[f][m][n], 0, 0, 0);
+    };
+    if (NPROD == 6) { prod(vl, 0); prod(vh, 2); prod(vm, 1); }
+    prod(vm, 0); prod(vh, 1); prod(vh, 0);
+    __builtin_amdgcn_s_setprio(0);
+    next();                                                                                 // the next phase's fragments (the MFMAs above have read theirs)
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------------------------------
+  const int nsl = p.Cin >> 5;
+  if (loader) {
+    const float* sp = p.in_ss + (long long)img * p.Cin * 2;
+    for (int i = tid; i < p.Cin / 2; i += 512) *reinterpret_cast<float4*>(ss_lds + i * 4) = *reinterpret_cast<const float4*>(sp + i * 4);
+  }
+  __syncthreads();                                                                          // ss_lds complete
+  {
+    f32x4 pr[3][2];
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) issue_items(pr[ph], ph, 0);
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) store_region(pr[ph], ph, 0, 0);
+  }
+  request_u(0, 0);
+  __syncthreads();
+
+  // Vector-memory program of a phase p -- every request unconditional, in this order:
+  //   transform(p) | MFMAs(p) (wait: fragments of p; the two region items requested behind them may still fly) | request U(p+1) |
+  //   normalise + store the region items of phase p-1 (wait: those two; six fragment requests younger) | request the items of phase p.
+  // The next slice's region thus trickles in two items per phase (phases 0-2), each with a full phase of latency cover, in eight registers.
+  // The last slice requests its own region again (dropped) so that the program, and with it every vmcnt the compiler derives, has ONE shape.
+#pragma unroll 1
+  for (int s = 0; s < nsl; ++s) {
+    const int rb = s & 1;
+    const bool more = s + 1 < nsl;
+    const int cn = (more ? s + 1 : s) * 32;
+    phase(rb, 0, 0, [&]() __attribute__((always_inline)) { request_u(1, 2 * s); __builtin_amdgcn_sched_barrier(0); issue_items(sreg, 0, cn); });
+    phase(rb, 1, 0, [&]() __attribute__((always_inline)) { request_u(0, 2 * s + 1); __builtin_amdgcn_sched_barrier(0);
+                                                          if (more) store_region(sreg, 0, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1]));
+                                                          __builtin_amdgcn_sched_barrier(0); issue_items(sreg, 1, cn); });
+    phase(rb, 0, 1, [&]() __attribute__((always_inline)) { request_u(1, 2 * s + 1); __builtin_amdgcn_sched_barrier(0);
+                                                          if (more) store_region(sreg, 1, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1]));
+                                                          __builtin_amdgcn_sched_barrier(0); issue_items(sreg, 2, cn); });
+    phase(rb, 1, 1, [&]() __attribute__((always_inline)) { request_u(0, more ? 2 * s + 2 : 2 * s + 1); __builtin_amdgcn_sched_barrier(0);
+                                                          if (more) store_region(sreg, 2, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1])); });
+    __syncthreads();
+  }
+  asm volatile("" :: "v"(ur[0][0]), "v"(ur[0][1]), "v"(ur[0][2]), "v"(ur[1][0]), "v"(ur[1][1]), "v"(ur[1][2]));   // the request past the last phase
+
+  // ---- epilogue: one pass per M tile ------------------------------------------------------------------------------------------------------
+  float* zb = smem;
+  float* red = smem + B3_XCH_F;
+  float* __restrict__ Yi = p.y + (long long)img * p.H * p.W * p.ldc;
+  const float* __restrict__ Ri = p.res ? p.res + (long long)img * p.H * p.W * p.ldres : nullptr;
+  const float* __restrict__ Mi = p.mul ? p.mul + (long long)img * p.H * p.W * p.ldmul : nullptr;
+  const int tl = tid >> 4, n4q = (tid & 15) * 4, nq = nblk * 64 + n4q;
+  const int tl_row = tl >> 3, tl_col = b3_tile_col(tl);
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + nq);
+  const float bn[4] = {bq.x, bq.y, bq.z, bq.w};
+  const int amode = p.act == SMX_ACT_NONE ? 0 : ((p.act == SMX_ACT_RELU || p.act == SMX_ACT_LRELU02) ? 1 : 2);
+  const float slope = p.act == SMX_ACT_RELU ? 0.f : 0.2f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    // residual (and SFT scale) of this thread's 2x2 pixels: requested before the exchange, consumed after the barrier
+    const int pix = (y0 + 2 * (4 * m + tl_row)) * p.W + x0 + 2 * tl_col;
+    float4 rr[2][2], mm[2][2];
+    if (Ri) {
+#pragma unroll
+      for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          rr[yy][q] = *reinterpret_cast<const float4*>(Ri + (pix + yy * p.W + q) * p.ldres + nq);
+          if (Mi) mm[yy][q] = *reinterpret_cast<const float4*>(Mi + (pix + yy * p.W + q) * p.ldmul + nq);
+        }
+    }
+    if (m > 0) __syncthreads();                                                             // the previous pass's exchange reads are done
+    // partial column sums of this wave's two frequencies: Z[0] = M0 + M1 + M2, Z[1] = M1 - M2 - M3
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 q0, q1;
+        const f32x16& a0 = acc[0][m][n]; const f32x16& a1 = acc[1][m][n];
+        if (jh == 0) {
+          q0 = make_float4(a0[4 * g] + a1[4 * g], a0[4 * g + 1] + a1[4 * g + 1], a0[4 * g + 2] + a1[4 * g + 2], a0[4 * g + 3] + a1[4 * g + 3]);
+          q1 = make_float4(a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]);
+        } else {
+          q0 = make_float4(a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]);
+          q1 = make_float4(-(a0[4 * g] + a1[4 * g]), -(a0[4 * g + 1] + a1[4 * g + 1]), -(a0[4 * g + 2] + a1[4 * g + 2]), -(a0[4 * g + 3] + a1[4 * g + 3]));
+        }
+        *reinterpret_cast<float4*>(zb + ((0 * 8 + wave) * 32 + t) * 68 + n * 32 + 8 * g + 4 * hh) = q0;
+        *reinterpret_cast<float4*>(zb + ((1 * 8 + wave) * 32 + t) * 68 + n * 32 + 8 * g + 4 * hh) = q1;
+      }
+    __syncthreads();
+    float4 o[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float4 z[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) z[w] = *reinterpret_cast<const float4*>(zb + ((q * 8 + w) * 32 + tl) * 68 + n4q);
+      const float zz[4][4] = {{z[0].x + z[1].x, z[0].y + z[1].y, z[0].z + z[1].z, z[0].w + z[1].w}, {z[2].x + z[3].x, z[2].y + z[3].y, z[2].z + z[3].z, z[2].w + z[3].w},
+                              {z[4].x + z[5].x, z[4].y + z[5].y, z[4].z + z[5].z, z[4].w + z[5].w}, {z[6].x + z[7].x, z[6].y + z[7].y, z[6].z + z[7].z, z[6].w + z[7].w}};
+      float a0[4], a1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] = zz[0][e] + zz[1][e] + zz[2][e] + bn[e];
+        a1[e] = zz[1][e] - zz[2][e] - zz[3][e] + bn[e];
+        if (amode == 1) { a0[e] = fmaxf(a0[e], 0.f) + slope * fminf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f) + slope * fminf(a1[e], 0.f); }
+        else if (amode == 2) { a0[e] = b3_act(a0[e], p.act); a1[e] = b3_act(a1[e], p.act); }
+      }
+      o[0][q] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+      o[1][q] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    }
+#pragma unroll
+    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (Mi) {
+          const float4 r4 = rr[yy][q], m4 = mm[yy][q];
+          o[yy][q] = make_float4(r4.x + p.sft_w * (r4.x * m4.x + o[yy][q].x), r4.y + p.sft_w * (r4.y * m4.y + o[yy][q].y),
+                                 r4.z + p.sft_w * (r4.z * m4.z + o[yy][q].z), r4.w + p.sft_w * (r4.w * m4.w + o[yy][q].w));
+        } else if (Ri) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
+        *reinterpret_cast<float4*>(Yi + (pix + yy * p.W + q) * p.ldc + nq) = o[yy][q];
+      }
+    if (p.stats) {
+      // GroupNorm partials of the consumer in the fp32 kernel's chunk format: one {mean, M2} per 8 x 16-pixel chunk (= this M tile) and channel
+      const float va4[4][4] = {{o[0][0].x, o[0][0].y, o[0][0].z, o[0][0].w}, {o[1][0].x, o[1][0].y, o[1][0].z, o[1][0].w},
+                               {o[0][1].x, o[0][1].y, o[0][1].z, o[0][1].w}, {o[1][1].x, o[1][1].y, o[1][1].z, o[1][1].w}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s0 = va4[0][e] + va4[1][e], d0 = va4[0][e] - va4[1][e], s1 = va4[2][e] + va4[3][e], d1 = va4[2][e] - va4[3][e], ds = s0 - s1;
+        red[(tl * 64 + n4q + e) * 2] = 0.25f * (s0 + s1);
+        red[(tl * 64 + n4q + e) * 2 + 1] = 0.5f * (d0 * d0 + d1 * d1) + 0.25f * ds * ds;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float a = 0.f, b = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) { a += red[(k * 64 + tid) * 2]; b += red[(k * 64 + tid) * 2 + 1]; }
+        a *= (1.f / 32.f);
+        float c2 = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) { const float d = red[(k * 64 + tid) * 2] - a; c2 += d * d; }
+        b += 4.f * c2;
+        const long long chunk = ((long long)img * (p.ty * 2) + by * 2 + m) * p.tx + bx;
+        float* o2 = p.stats + (chunk * p.Cout + nblk * 64 + tid) * 2;
+        o2[0] = a; o2[1] = b;
+      }
+    }
+  }
+}
+
+// fp32 fragment-ordered U ([16][n32][Cin/8][64][4], ops.Conv.winograd_u / smx_pack_winograd_u_f32) -> three bf16 planes in the order the
+// bf16 MFMA reads them: [16][n32][Cin/16][3][64 lanes][8]; lane l <-> row n = 32 nt + (l & 31), channels 16 s + 8 (l >> 5) + 0..7
+__global__ void winograd_bf3_pack_kernel(const float* __restrict__ u32, unsigned char* __restrict__ u3, int n32, int Cin, long long frags) {
+  const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);                        // (f, nt, step)
+  if (g >= frags) return;
+  const int lane = threadIdx.x & 63, row = lane & 31, hh = lane >> 5;
+  const int nsteps = Cin / 16;
+  const int step = (int)(g % nsteps);
+  const long long fn = g / nsteps;                                                           // f * n32 + nt
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int s8 = 2 * step + hh, half = e >> 2, el = e & 3;
+    v[e] = u32[((fn * (Cin / 8) + s8) * 64 + row + 32 * half) * 4 + el];
+  }
+  uint4 hi, mid, lo;
+  b3_split8<3>(v, hi, mid, lo);
+  unsigned char* o = u3 + g * 3072 + lane * 16;
+  *reinterpret_cast<uint4*>(o) = hi; *reinterpret_cast<uint4*>(o + 1024) = mid; *reinterpret_cast<uint4*>(o + 2048) = lo;
+  (void)n32;
+}
+
+}  // namespace
+
+extern "C" int64_t smx_winograd_bf3_u_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16) return 0;
+  return 16LL * (Cout / 32) * (Cin / 16) * 3072;
+}
+
+extern "C" int smx_winograd_bf3_pack(const float* u_f32, void* u3, int Cout, int Cin, void* stream) {
+  if (!u_f32 || !u3 || Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16) return SMX_EINVAL;
+  const long long frags = 16LL * (Cout / 32) * (Cin / 16);
+  SMX_LAUNCH(winograd_bf3_pack_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), 0, (hipStream_t)stream, u_f32, (unsigned char*)u3, Cout / 32, Cin, frags);
+  return smx_launch_status();
+}
+
+extern "C" int smx_winograd_bf3_shape_ok(int B, int H, int W, int Cin, int Cout, int lda, int ldc, int ldres, int ldmul) {
+  if (B <= 0 || H % 16 || W % 16 || Cin % 32 || Cin > 512 || Cout % 64 || lda % 4 || ldc % 4 || ldres % 4 || ldmul % 4) return 0;
+  if ((long long)B * (H / 16) * (W / 16) > 2147483647LL) return 0;
+  if ((long long)H * W * lda * 4 > 2147483647LL || (long long)H * W * ldc > 2147483647LL || (long long)H * W * ldres > 2147483647LL || (long long)H * W * ldmul > 2147483647LL) return 0;
+  if (smx_winograd_bf3_u_bytes(Cout, Cin) > 2147483647LL) return 0;
+  return 1;
+}
+
+static int winograd_bf3_launch(const float* x, int lda, const void* u3, const float* bias, const float* res, int ldres, const float* mul, int ldmul, float sft_w,
+                               float* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
+                               float* stats_part, int nprod, void* stream) {
+  if (!x || !u3 || !y || (nprod != 6 && nprod != 3)) return SMX_EINVAL;
+  if (!smx_winograd_bf3_shape_ok(B, H, W, Cin, Cout, lda, ldc, res ? ldres : 0, mul ? ldmul : 0)) return SMX_EINVAL;
+  if (lda < Cin || ldc < Cout || (res && ldres < Cout) || (mul && (!res || ldmul < Cout || act != SMX_ACT_NONE))) return SMX_EINVAL;
+  if ((((uintptr_t)x) | ((uintptr_t)u3) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)mul) | ((uintptr_t)bias) | ((uintptr_t)in_ss)) & 15) return SMX_EINVAL;
+  B3P p;
+  p.x = x; p.u = (const unsigned char*)u3; p.bias = bias; p.res = res; p.y = y; p.stats = stats_part; p.in_ss = in_ss; p.in_swish = in_swish;
+  p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
+  p.ty = H / 16; p.tx = W / 16; p.n32 = Cout / 32; p.nsteps = Cin / 16; p.mul = mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
+  p.u_bytes = (unsigned)smx_winograd_bf3_u_bytes(Cout, Cin);
+  const long long blocks = (long long)B * p.ty * p.tx;
+  p.xcd_group = (smx_tune(SMX_TUNE_WINO_XCD) != 0 && blocks % 8 == 0 && Cout > 64 && blocks * (Cout / 64) <= 0x7fffffffLL) ? 1 : 0;
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_err = hipFuncSetAttribute((const void*)(winograd_bf3_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS);
+    if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)(winograd_bf3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS);
+  });
+  if (attr_err != hipSuccess) return SMX_ELAUNCH;
+  dim3 grid((unsigned)blocks, Cout / 64);
+  if (nprod == 6) SMX_LAUNCH((winograd_bf3_kernel<6>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+  else SMX_LAUNCH((winograd_bf3_kernel<3>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+  return smx_launch_status();
+}
+
+extern "C" int smx_winograd_bf3_conv3x3_f32(const float* x, int lda, const void* u3, const float* bias, const float* res, int ldres, float* y, int ldc,
+                                            int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
+                                            float* stats_part, int nprod, void* stream) {
+  return winograd_bf3_launch(x, lda, u3, bias, res, ldres, nullptr, 0, 0.f, y, ldc, B, H, W, Cin, Cout, up2, act, in_ss, in_swish, stats_part, nprod, stream);
+}
+
+extern "C" int smx_winograd_bf3_conv3x3_sft_f32(const float* x, int lda, const void* u3, const float* bias, const float* dec, int lddec,
+                                                const float* scale, int ldscale, float w, float* y, int ldc, int B, int H, int W, int Cin, int Cout,
+                                                float* stats_part, int nprod, void* stream) {
+  if (!dec || !scale) return SMX_EINVAL;
+  return winograd_bf3_launch(x, lda, u3, bias, dec, lddec, scale, ldscale, w, y, ldc, B, H, W, Cin, Cout, 0, SMX_ACT_NONE, nullptr, 0, stats_part, nprod, stream);
+}

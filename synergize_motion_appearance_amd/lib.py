@@ -166,6 +166,11 @@ SIGNATURES = {
     "smx_maxpool2_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "smx_maxpool2_bwd_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "smx_chan_affine_f32": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _p]),
+    "smx_winograd_bf3_u_bytes": (_i64, [_i, _i]),
+    "smx_winograd_bf3_pack": (_i, [_p, _p, _i, _i, _p]),
+    "smx_winograd_bf3_shape_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "smx_winograd_bf3_conv3x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "smx_winograd_bf3_conv3x3_sft_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "smx_winograd_u_floats": (_i64, [_i, _i]),
     "smx_pack_winograd_u_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "smx_pack_batch": (_i, [_p, _i, _i, _p]),

@@ -131,13 +131,14 @@ WINOGRAD = bool(_knob("SMX_WINOGRAD", 1))
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
         self._u = None
         self._w16 = None
         self._u43 = None
+        self._u3 = None
         self._w16t = None
         self._w16rp = None
         self._wrp = None
@@ -254,6 +255,18 @@ class Conv:
             Up = Up.view(16, n32, 32, self.cin // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
             self._u = torch.cat([Up.view(-1), torch.zeros(1024, device=g.device, dtype=torch.float32)])   # prefetch pad (up to 3 units of 256 floats past the end)
         return self._u
+
+    def winograd_bf3_u(self):
+        """the three bf16 planes of `winograd_u` in bf16-MFMA fragment order (csrc/winograd_bf3.hip: smx_winograd_bf3_pack), built once per layer."""
+        if self._u3 is None:
+            lib = L.load()
+            n = int(lib.smx_winograd_bf3_u_bytes(self.cout, self.cin))
+            if n <= 0 or self.kh != 3 or self.kw != 3:
+                raise L.SmxError(f"winograd_bf3_u: not a 3x3 layer with Cout % 32 == 0 and Cin % 16 == 0 ({self.kh}x{self.kw}, {self.cin} -> {self.cout})")
+            u3 = torch.empty(n, device=self.w.device, dtype=torch.uint8)
+            L.check(lib.smx_winograd_bf3_pack(self.winograd_u().data_ptr(), u3.data_ptr(), self.cout, self.cin, _stream()), "smx_winograd_bf3_pack")
+            self._u3 = u3
+        return self._u3
 
     def winograd43_u(self):
         """U = G g G^T for F(4x4,3x3) (G 6x3: Lavin & Gray), fragment-ordered [36][Cout/32][Cin/8][64 lanes][4] like `winograd_u`;
@@ -481,6 +494,18 @@ def _wino43_ok(B, H, W, cin, cout, up2, lda, ldc, ldres):
             and ldres % 4 == 0 and B * (H // 16) * (W // 32) * (cout // 32) >= WINO43_MIN_BLOCKS)
 
 
+# fp32 3x3 convolutions on the BF16 matrix pipe with three-way split operands (csrc/winograd_bf3.hip): 0 = off, 6 = the fp32-grade six-product
+# form, 3 = the two-way split (comparison only).  WINO_BF3_MIN_BLOCKS: 16x16-pixel x 64-channel blocks a launch must have (one block per CU).
+WINO_BF3 = _knob("SMX_WINO_BF3", 0)
+WINO_BF3_MIN_BLOCKS = 512
+
+
+def _wino_bf3_ok(B, H, W, cin, cout, lda, ldc, ldres, ldmul, *ptrs):
+    return (WINO_BF3 in (3, 6) and H % 16 == 0 and W % 16 == 0 and cin % 32 == 0 and cin <= 512 and cout % 64 == 0
+            and lda % 4 == 0 and ldc % 4 == 0 and ldres % 4 == 0 and ldmul % 4 == 0 and all((q or 0) % 16 == 0 for q in ptrs)
+            and B * (H // 16) * (W // 16) * (cout // 64) >= WINO_BF3_MIN_BLOCKS)
+
+
 def _wino_wide(B, H, W, cout):
     """mirror of winograd_launch's block-shape rule (csrc/winograd.hip): 64-channel 'wide' blocks once >= 1024 of them exist --
     in this pipeline exactly the B=60 launches of the big layers; used to label profile rows only."""
@@ -550,6 +575,18 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
                 out._gn_part = part
             return out
         part = torch.empty((B, (He // 8) * (We // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
+        if _wino_bf3_ok(B, He, We, Cin, cv.cout, lda, ldc, ldr, 0, a_ptr, c_ptr, r_ptr, None if cv.b is None else cv.b.data_ptr(),
+                        None if in_ss is None else in_ss.data_ptr()):
+            if meta is not None:
+                meta.update(mfma_flops=2.0 * B * Ho * Wo * cv.cout * 4 * Cin * WINO_BF3, bf3=WINO_BF3)
+            L.check(_timed("gemm_conv", meta, L.load().smx_winograd_bf3_conv3x3_f32, a_ptr, lda, cv.winograd_bf3_u().data_ptr(),
+                           None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,
+                           int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish),
+                           None if part is None else part.data_ptr(), WINO_BF3, _stream()),
+                    "smx_winograd_bf3_conv3x3_f32")
+            if part is not None:
+                out._gn_part = part
+            return out
         L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                        None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,
                        int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish),
@@ -943,6 +980,13 @@ def conv_sft(x, cv, dec, scale, w=1.0):
     out = torch.empty((B, H, W, cv.cout), device=x.device, dtype=torch.float32)
     meta = {"flops": 2.0 * B * H * W * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * H * W * cv.cout * 4 * Cin,
             "M": B * H * W, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1, "wide": _wino_wide(B, H, W, cv.cout)} if _PROFILE is not None else None
+    if _wino_bf3_ok(B, H, W, Cin, cv.cout, lda, cv.cout, ldd, lds_, a_ptr, d_ptr, s_ptr, out.data_ptr(), None if cv.b is None else cv.b.data_ptr()):
+        if meta is not None:
+            meta.update(mfma_flops=2.0 * B * H * W * cv.cout * 4 * Cin * WINO_BF3, bf3=WINO_BF3)
+        L.check(_timed("gemm_conv", meta, L.load().smx_winograd_bf3_conv3x3_sft_f32, a_ptr, lda, cv.winograd_bf3_u().data_ptr(),
+                       None if cv.b is None else cv.b.data_ptr(), d_ptr, ldd, s_ptr, lds_, float(w), out.data_ptr(), cv.cout,
+                       B, H, W, Cin, cv.cout, None, WINO_BF3, _stream()), "smx_winograd_bf3_conv3x3_sft_f32")
+        return out
     L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_sft_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                    None if cv.b is None else cv.b.data_ptr(), d_ptr, ldd, s_ptr, lds_, float(w), out.data_ptr(), cv.cout,
                    B, H, W, Cin, cv.cout, None, _stream()), "smx_winograd_conv3x3_sft_f32")
