@@ -30,6 +30,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"wino_ws", "SMX_WINO_WS", 0},                // TOOLS BUILD ONLY: wide Winograd launches on the producer / consumer-split kernel (winograd_ws_kernel: persistent 8-wave blocks, MFMA waves + helper waves); ignored by the shipped library
   {"gemm_loader", "SMX_GEMM_LOADER", 1},        // gemm_conv: 1 = operand quads by buffer loads with SGPR bases / offsets where the layout allows (MODE 2), 0 = the float4 gather
   {"wino_xcd", "SMX_WINO_XCD", 1},              // wide Winograd: the output blocks of a spatial tile on ONE XCD at the same time (block ids regrouped 8 apart): its input region comes from HBM once
+  {"wino_bf3_shape", "SMX_WINO_BF3_SHAPE", -1}, // split-bf16 Winograd block shape: -1 auto (8x16 pixels x 128 channels when C_out % 128 == 0), 2 = always 16x16 pixels x 64 channels
 };
 bool g_init = false;
 void init_once() {

@@ -42,13 +42,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int B3_PLANE = 326;                          // float4 slots per channel-quad plane: 18 rows x 2 x-parities x 9 (+2: planes 6 bank groups apart)
-constexpr int B3_REGION_F = 8 * B3_PLANE * 4;          // floats per region buffer (32 channels)
-constexpr int B3_REGION_B = B3_REGION_F * 4;           // 41,728 B
+// Two block shapes, MT x NT = 4 MFMA tiles per frequency and wave either way:
+//   MT = 2: 16 x 16 pixels x  64 channels (any C_out % 64 == 0)                         -- region 18 x 18 pixels
+//   MT = 1:  8 x 16 pixels x 128 channels (C_out % 128 == 0): the input transform + split, the GroupNorm of the staging and the patch reads are
+//            per V element, and here a V element meets twice the output channels -- half the VALU work per MFMA (the split form is VALU-bound:
+//            profiles/r06_wino_bf3.txt); the price is twice the U bytes per MFMA from L2
+template <int MT> struct B3G {
+  static constexpr int RR = MT == 2 ? 18 : 10;           // region rows
+  static constexpr int PLANE = RR * 2 * 9 + 2;           // float4 slots per channel-quad plane: RR rows x 2 x-parities x 9 (+2: planes 6 bank groups apart)
+  static constexpr int REGION_F = 8 * PLANE * 4;         // floats per region buffer (32 channels)
+  static constexpr int REGION_B = REGION_F * 4;          // 41,728 B | 23,296 B
+  static constexpr int NT = 4 / MT;
+  static constexpr int NSET = MT == 2 ? 3 : 2;           // two-item staging sets per slice (rows 3k + r3, k = 2 set + q)
+};
 constexpr int B3_SS_B = 512 * 2 * 4;                   // GroupNorm scale / shift of the image (C_in <= 512)
 constexpr int B3_XCH_F = 2 * 8 * 32 * 68;              // exchange [2 q][8 waves][32 tiles][64 n, pitch 68]
 constexpr int B3_RED_F = 32 * 64 * 2;
-constexpr int B3_MAIN_B = 2 * B3_REGION_B + B3_SS_B;
+constexpr int B3_MAIN_B = 2 * B3G<2>::REGION_B + B3_SS_B;
 constexpr int B3_LDS = B3_XCH_F * 4 + B3_RED_F * 4;    // 155,648 B (the main loop's 87,552 B live inside the exchange's bytes)
 static_assert(B3_MAIN_B <= B3_XCH_F * 4, "main-loop LDS must fit under the exchange buffer");
 
@@ -132,9 +142,11 @@ __device__ __forceinline__ bf16x8 b3_frag(f32x4 v) { return __builtin_bit_cast(b
 // served in ({0-3,12-15,20-27} and {4-11,16-19,28-31}), so that every group reads four tile rows x four adjacent tile columns
 __device__ __forceinline__ int b3_tile_col(int t) { return 4 * (((t >> 2) ^ (t >> 3) ^ (t >> 4)) & 1) + (t & 3); }
 
-template <int NPROD>
+template <int NPROD, int MT>
 __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   constexpr int NS = NPROD == 6 ? 3 : 2;
+  constexpr int NT = B3G<MT>::NT, RR = B3G<MT>::RR, NSET = B3G<MT>::NSET;
+  constexpr int B3_PLANE = B3G<MT>::PLANE, B3_REGION_F = B3G<MT>::REGION_F, B3_REGION_B = B3G<MT>::REGION_B;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* smem_b = reinterpret_cast<unsigned char*>(smem);
   float* ss_lds = reinterpret_cast<float*>(smem_b + 2 * B3_REGION_B);
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   }
   const int bx = bid % p.tx; bid /= p.tx;
   const int by = bid % p.ty; const int img = bid / p.ty;
-  const int y0 = by * 16, x0 = bx * 16;
+  const int y0 = by * (8 * MT), x0 = bx * 16;
   const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
   const float* __restrict__ X = p.x + (long long)img * Hs * Ws * p.lda;
   const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, Hs * Ws * p.lda * 4, 0x00020000);
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   // ---- staging: 432 threads = 3 region rows x 18 pixels x 8 channel quads; item k is the row 3k + r3 ----------------------------------
   // The thread's staging geometry is RE-DERIVED from the lane id where it is used (once per slice, ~20 instructions): held in registers
   // across the phases it would be spilled, and a scratch reload is a vector-memory request in the middle of the hand-counted ones.
-  const bool interior = y0 >= 1 && y0 + 17 <= p.H && x0 >= 1 && x0 + 17 <= p.W;
+  const bool interior = y0 >= 1 && y0 + RR - 1 <= p.H && x0 >= 1 && x0 + 17 <= p.W;
   const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
   auto stage_geo = [&](int& l, int& r3, int& srx, int& sc4) __attribute__((always_inline)) {
     l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
         const bool ok = x_ok && iy >= 0 && iy < p.H;
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;                // the convolution's zero padding
       }
-      *reinterpret_cast<f32x4*>(rb + woff + k * 216) = v;
+      if (3 * k + r3 < RR) *reinterpret_cast<f32x4*>(rb + woff + k * 216) = v;                 // (MT = 1: ten rows -- the fourth item exists for r3 = 0 only)
     }
   };
   auto store_region = [&](const f32x4 (&rg)[2], int ph, int buf, int c0) __attribute__((always_inline)) {
@@ -256,38 +268,38 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   const __amdgpu_buffer_rsrc_t RU = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.u), 0, (int)p.u_bytes, 0x00020000);
   const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned ustep_b = 3u * 1024u;                                                       // bytes per (frequency, n tile, step)
-  unsigned ubase[2][2];                                                                      // [frequency of the wave][n tile]: byte offset of step 0
+  unsigned ubase[2][NT];                                                                     // [frequency of the wave][n tile]: byte offset of step 0
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-      ubase[f][n] = (unsigned)(((fi * 4 + 2 * jh + f) * p.n32 + nblk * 2 + n) * p.nsteps) * ustep_b;
+    for (int n = 0; n < NT; ++n)
+      ubase[f][n] = (unsigned)(((fi * 4 + 2 * jh + f) * p.n32 + nblk * NT + n) * p.nsteps) * ustep_b;
   // ONE set of fragment registers (the register file is the limit: 128 accumulators + 24 + the transform's values): a phase's fragments are
   // requested right after the previous phase's MFMAs were issued and land under this phase's transform + split (and the partner wave's MFMAs)
-  f32x4 ur[2][3];                                                                            // [n tile][split]
+  f32x4 ur[NT][3];                                                                           // [n tile][split]
   auto request_u = [&](int f, int step) __attribute__((always_inline)) {
     const unsigned so = (unsigned)step * ustep_b;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3)
         if (s3 < NS) ur[n][s3] = b3_load16(RU, lane16, ubase[f][n] + so + (unsigned)s3 * 1024u);
         else ur[n][s3] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  f32x16 acc[2][2][2];                                                                       // [frequency][M tile][N tile]
+  f32x16 acc[2][MT][NT];                                                                     // [frequency][M tile][N tile]
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][m][n][r] = 0.f;
 
   // one phase: frequency f of the wave, 16-channel step `sub` of the slice in region buffer rb
   auto phase = [&](int buf, int f, int sub, auto next) __attribute__((always_inline)) {
-    unsigned vh[2][4], vm[2][4], vl[2][4];                                                   // [M tile][4 dwords = 8 bf16: the lane's MFMA B fragment]
+    unsigned vh[MT][4], vm[MT][4], vl[MT][4];                                                // [M tile][4 dwords = 8 bf16: the lane's MFMA B fragment]
     // four lane addresses per phase (lane part + the wave's row / column offsets + the region buffer), everything else is an immediate
     const float* paa = smem + (lbase + (buf * B3_REGION_F + oa[f][0]));
     const float* pba = smem + (lbase + (buf * B3_REGION_F + oa[f][1]));
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
     // one channel quad at a time (four patch reads -> four values of V -> their three bf16 levels), fenced: left alone the scheduler hoists all
     // sixteen reads of the phase to its top (64 registers the kernel does not have)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int e2 = 0; e2 < 2; ++e2) {
         const int o = (sub * 4 + e2) * B3_PLANE * 4 + m * (4 * 2 * 2 * 9 * 4);
@@ -313,18 +325,23 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
         vh[m][2 * e2] = h2[0]; vh[m][2 * e2 + 1] = h2[1]; vm[m][2 * e2] = m2[0]; vm[m][2 * e2 + 1] = m2[1]; vl[m][2 * e2] = l2[0]; vl[m][2 * e2 + 1] = l2[1];
         __builtin_amdgcn_sched_barrier(0);
       }
-    __builtin_amdgcn_s_setprio(1);
+#ifndef B3_PRIO
+#define B3_PRIO 1     // 1: MFMA block at priority 1 (shipped), 0: no priority changes, 2: the transform at priority 1 instead
+#endif
+    if (B3_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if (B3_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     // smallest products first; consecutive MFMAs go to different accumulators
-    auto prod = [&](const unsigned (&vv)[2][4], int us) __attribute__((always_inline)) {
+    auto prod = [&](const unsigned (&vv)[MT][4], int us) __attribute__((always_inline)) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
           acc[f][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3_frag(ur[n][us]), b3_frag(make_uint4(vv[m][0], vv[m][1], vv[m][2], vv[m][3])), acc[f][m][n], 0, 0, 0);
     };
     if (NPROD == 6) { prod(vl, 0); prod(vh, 2); prod(vm, 1); }
     prod(vm, 0); prod(vh, 1); prod(vh, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (B3_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (B3_PRIO == 2) __builtin_amdgcn_s_setprio(1);
     next();                                                                                 // the next phase's fragments (the MFMAs above have read theirs)
   };
 
@@ -338,9 +355,9 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   {
     f32x4 pr[3][2];
 #pragma unroll
-    for (int ph = 0; ph < 3; ++ph) issue_items(pr[ph], ph, 0);
+    for (int ph = 0; ph < NSET; ++ph) issue_items(pr[ph], ph, 0);
 #pragma unroll
-    for (int ph = 0; ph < 3; ++ph) store_region(pr[ph], ph, 0, 0);
+    for (int ph = 0; ph < NSET; ++ph) store_region(pr[ph], ph, 0, 0);
   }
   request_u(0, 0);
   __syncthreads();
@@ -355,34 +372,41 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
     const int rb = s & 1;
     const bool more = s + 1 < nsl;
     const int cn = (more ? s + 1 : s) * 32;
+#ifdef B3_SKEW
+    if (wave >= 4) __builtin_amdgcn_s_sleep(B3_SKEW);                                       // experiment: the second wave of every SIMD half a phase behind the first
+#endif
     phase(rb, 0, 0, [&]() __attribute__((always_inline)) { request_u(1, 2 * s); __builtin_amdgcn_sched_barrier(0); issue_items(sreg, 0, cn); });
     phase(rb, 1, 0, [&]() __attribute__((always_inline)) { request_u(0, 2 * s + 1); __builtin_amdgcn_sched_barrier(0);
                                                           if (more) store_region(sreg, 0, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1]));
                                                           __builtin_amdgcn_sched_barrier(0); issue_items(sreg, 1, cn); });
     phase(rb, 0, 1, [&]() __attribute__((always_inline)) { request_u(1, 2 * s + 1); __builtin_amdgcn_sched_barrier(0);
                                                           if (more) store_region(sreg, 1, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1]));
-                                                          __builtin_amdgcn_sched_barrier(0); issue_items(sreg, 2, cn); });
+                                                          __builtin_amdgcn_sched_barrier(0); if (NSET > 2) issue_items(sreg, 2, cn); });
     phase(rb, 1, 1, [&]() __attribute__((always_inline)) { request_u(0, more ? 2 * s + 2 : 2 * s + 1); __builtin_amdgcn_sched_barrier(0);
-                                                          if (more) store_region(sreg, 2, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1])); });
+                                                          if (NSET > 2) { if (more) store_region(sreg, 2, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1])); } });
     __syncthreads();
   }
-  asm volatile("" :: "v"(ur[0][0]), "v"(ur[0][1]), "v"(ur[0][2]), "v"(ur[1][0]), "v"(ur[1][1]), "v"(ur[1][2]));   // the request past the last phase
+#pragma unroll
+  for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(ur[n][0]), "v"(ur[n][1]), "v"(ur[n][2]));   // the request past the last phase
 
-  // ---- epilogue: one pass per M tile ------------------------------------------------------------------------------------------------------
+  // ---- epilogue: two passes of 32 tiles x 64 channels: pass = M tile (MT = 2) | 64-channel half of the block's 128 (MT = 1) ------------------------------------------------------------------------------------------------------
   float* zb = smem;
   float* red = smem + B3_XCH_F;
   float* __restrict__ Yi = p.y + (long long)img * p.H * p.W * p.ldc;
   const float* __restrict__ Ri = p.res ? p.res + (long long)img * p.H * p.W * p.ldres : nullptr;
   const float* __restrict__ Mi = p.mul ? p.mul + (long long)img * p.H * p.W * p.ldmul : nullptr;
-  const int tl = tid >> 4, n4q = (tid & 15) * 4, nq = nblk * 64 + n4q;
+  const int tl = tid >> 4, n4q = (tid & 15) * 4;
   const int tl_row = tl >> 3, tl_col = b3_tile_col(tl);
-  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + nq);
-  const float bn[4] = {bq.x, bq.y, bq.z, bq.w};
   const int amode = p.act == SMX_ACT_NONE ? 0 : ((p.act == SMX_ACT_RELU || p.act == SMX_ACT_LRELU02) ? 1 : 2);
   const float slope = p.act == SMX_ACT_RELU ? 0.f : 0.2f;
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
+  for (int pass = 0; pass < 2; ++pass) {
+    constexpr int dummy_ = 0; (void)dummy_;
+    const int m = MT == 2 ? pass : 0, nb = MT == 2 ? 0 : 2 * pass;                            // M tile and first N tile of the pass
+    const int nq = nblk * (32 * NT) + nb * 32 + n4q;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + nq);
+    const float bn[4] = {bq.x, bq.y, bq.z, bq.w};
     // residual (and SFT scale) of this thread's 2x2 pixels: requested before the exchange, consumed after the barrier
     const int pix = (y0 + 2 * (4 * m + tl_row)) * p.W + x0 + 2 * tl_col;
     float4 rr[2][2], mm[2][2];
@@ -395,14 +419,14 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
           if (Mi) mm[yy][q] = *reinterpret_cast<const float4*>(Mi + (pix + yy * p.W + q) * p.ldmul + nq);
         }
     }
-    if (m > 0) __syncthreads();                                                             // the previous pass's exchange reads are done
+    if (pass > 0) __syncthreads();                                                          // the previous pass's exchange reads are done
     // partial column sums of this wave's two frequencies: Z[0] = M0 + M1 + M2, Z[1] = M1 - M2 - M3
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 q0, q1;
-        const f32x16& a0 = acc[0][m][n]; const f32x16& a1 = acc[1][m][n];
+        const f32x16& a0 = acc[0][m][nb + n]; const f32x16& a1 = acc[1][m][nb + n];
         if (jh == 0) {
           q0 = make_float4(a0[4 * g] + a1[4 * g], a0[4 * g + 1] + a1[4 * g + 1], a0[4 * g + 2] + a1[4 * g + 2], a0[4 * g + 3] + a1[4 * g + 3]);
           q1 = make_float4(a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]);
@@ -464,8 +488,8 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
 #pragma unroll 8
         for (int k = 0; k < 32; ++k) { const float d = red[(k * 64 + tid) * 2] - a; c2 += d * d; }
         b += 4.f * c2;
-        const long long chunk = ((long long)img * (p.ty * 2) + by * 2 + m) * p.tx + bx;
-        float* o2 = p.stats + (chunk * p.Cout + nblk * 64 + tid) * 2;
+        const long long chunk = ((long long)img * (p.ty * MT) + by * MT + m) * p.tx + bx;
+        float* o2 = p.stats + (chunk * p.Cout + nblk * (32 * NT) + nb * 32 + tid) * 2;
         o2[0] = a; o2[1] = b;
       }
     }
@@ -508,38 +532,49 @@ extern "C" int smx_winograd_bf3_pack(const float* u_f32, void* u3, int Cout, int
   return smx_launch_status();
 }
 
+// 0: not eligible; otherwise the M tiles per block the launcher uses: 1 (8 x 16 pixels x 128 channels, C_out % 128 == 0) | 2 (16 x 16 pixels x 64 channels)
 extern "C" int smx_winograd_bf3_shape_ok(int B, int H, int W, int Cin, int Cout, int lda, int ldc, int ldres, int ldmul) {
-  if (B <= 0 || H % 16 || W % 16 || Cin % 32 || Cin > 512 || Cout % 64 || lda % 4 || ldc % 4 || ldres % 4 || ldmul % 4) return 0;
-  if ((long long)B * (H / 16) * (W / 16) > 2147483647LL) return 0;
+  if (B <= 0 || H % 8 || W % 16 || Cin % 32 || Cin > 512 || Cout % 64 || lda % 4 || ldc % 4 || ldres % 4 || ldmul % 4) return 0;
+  const int shape = smx_tune(SMX_TUNE_WINO_BF3_SHAPE);
+  const int mt = (Cout % 128 == 0 && shape != 2) ? 1 : 2;
+  if (mt == 2 && H % 16) return 0;
+  if ((long long)B * (H / 8) * (W / 16) > 2147483647LL) return 0;
   if ((long long)H * W * lda * 4 > 2147483647LL || (long long)H * W * ldc > 2147483647LL || (long long)H * W * ldres > 2147483647LL || (long long)H * W * ldmul > 2147483647LL) return 0;
   if (smx_winograd_bf3_u_bytes(Cout, Cin) > 2147483647LL) return 0;
-  return 1;
+  return mt;
 }
 
 static int winograd_bf3_launch(const float* x, int lda, const void* u3, const float* bias, const float* res, int ldres, const float* mul, int ldmul, float sft_w,
                                float* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
                                float* stats_part, int nprod, void* stream) {
   if (!x || !u3 || !y || (nprod != 6 && nprod != 3)) return SMX_EINVAL;
-  if (!smx_winograd_bf3_shape_ok(B, H, W, Cin, Cout, lda, ldc, res ? ldres : 0, mul ? ldmul : 0)) return SMX_EINVAL;
+  const int mt = smx_winograd_bf3_shape_ok(B, H, W, Cin, Cout, lda, ldc, res ? ldres : 0, mul ? ldmul : 0);
+  if (!mt) return SMX_EINVAL;
   if (lda < Cin || ldc < Cout || (res && ldres < Cout) || (mul && (!res || ldmul < Cout || act != SMX_ACT_NONE))) return SMX_EINVAL;
   if ((((uintptr_t)x) | ((uintptr_t)u3) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)mul) | ((uintptr_t)bias) | ((uintptr_t)in_ss)) & 15) return SMX_EINVAL;
   B3P p;
   p.x = x; p.u = (const unsigned char*)u3; p.bias = bias; p.res = res; p.y = y; p.stats = stats_part; p.in_ss = in_ss; p.in_swish = in_swish;
   p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
-  p.ty = H / 16; p.tx = W / 16; p.n32 = Cout / 32; p.nsteps = Cin / 16; p.mul = mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
+  p.ty = H / (8 * mt); p.tx = W / 16; p.n32 = Cout / 32; p.nsteps = Cin / 16; p.mul = mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
   p.u_bytes = (unsigned)smx_winograd_bf3_u_bytes(Cout, Cin);
   const long long blocks = (long long)B * p.ty * p.tx;
-  p.xcd_group = (smx_tune(SMX_TUNE_WINO_XCD) != 0 && blocks % 8 == 0 && Cout > 64 && blocks * (Cout / 64) <= 0x7fffffffLL) ? 1 : 0;
+  const int nby = Cout / (mt == 1 ? 128 : 64);                                             // output blocks per spatial block
+  p.xcd_group = (smx_tune(SMX_TUNE_WINO_XCD) != 0 && blocks % 8 == 0 && nby > 1 && blocks * nby <= 0x7fffffffLL) ? 1 : 0;
   static std::once_flag attr_once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [] {
-    attr_err = hipFuncSetAttribute((const void*)(winograd_bf3_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS);
-    if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void*)(winograd_bf3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS);
+    const void* ks[4] = {(const void*)(winograd_bf3_kernel<6, 2>), (const void*)(winograd_bf3_kernel<3, 2>), (const void*)(winograd_bf3_kernel<6, 1>), (const void*)(winograd_bf3_kernel<3, 1>)};
+    for (int i = 0; i < 4 && attr_err == hipSuccess; ++i) attr_err = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS);
   });
   if (attr_err != hipSuccess) return SMX_ELAUNCH;
-  dim3 grid((unsigned)blocks, Cout / 64);
-  if (nprod == 6) SMX_LAUNCH((winograd_bf3_kernel<6>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
-  else SMX_LAUNCH((winograd_bf3_kernel<3>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+  dim3 grid((unsigned)blocks, nby);
+  if (mt == 2) {
+    if (nprod == 6) SMX_LAUNCH((winograd_bf3_kernel<6, 2>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+    else SMX_LAUNCH((winograd_bf3_kernel<3, 2>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+  } else {
+    if (nprod == 6) SMX_LAUNCH((winograd_bf3_kernel<6, 1>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+    else SMX_LAUNCH((winograd_bf3_kernel<3, 1>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+  }
   return smx_launch_status();
 }
 

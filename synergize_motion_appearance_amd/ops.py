@@ -501,9 +501,12 @@ WINO_BF3_MIN_BLOCKS = 512
 
 
 def _wino_bf3_ok(B, H, W, cin, cout, lda, ldc, ldres, ldmul, *ptrs):
-    return (WINO_BF3 in (3, 6) and H % 16 == 0 and W % 16 == 0 and cin % 32 == 0 and cin <= 512 and cout % 64 == 0
-            and lda % 4 == 0 and ldc % 4 == 0 and ldres % 4 == 0 and ldmul % 4 == 0 and all((q or 0) % 16 == 0 for q in ptrs)
-            and B * (H // 16) * (W // 16) * (cout // 64) >= WINO_BF3_MIN_BLOCKS)
+    """mirror of smx_winograd_bf3_shape_ok + the size threshold: blocks are 8x16 pixels x 128 channels when C_out % 128 == 0, else 16x16 x 64."""
+    if WINO_BF3 not in (3, 6) or cout % 64 or cin % 32 or cin > 512 or W % 16:
+        return False
+    mt = 1 if cout % 128 == 0 else 2
+    return (H % (8 * mt) == 0 and lda % 4 == 0 and ldc % 4 == 0 and ldres % 4 == 0 and ldmul % 4 == 0 and all((q or 0) % 16 == 0 for q in ptrs)
+            and B * (H // (8 * mt)) * (W // 16) * (cout // (128 if mt == 1 else 64)) >= WINO_BF3_MIN_BLOCKS)
 
 
 def _wino_wide(B, H, W, cout):
