@@ -542,7 +542,7 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     fam = {}
     for name, meta, ms in rec.rows:
         meta = meta or {}
-        key = ("winograd_wide" if meta.get("wide") else "winograd_nw1") if meta.get("wino") else name
+        key = ("winograd_bf3" if meta.get("bf3") else ("winograd_wide" if meta.get("wide") else "winograd_nw1")) if meta.get("wino") else name
         f = fam.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "mfma_flops": 0.0})
         f["calls"] += 1
         f["ms"] += ms
@@ -568,7 +568,11 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     g = fam[dom]
     tf_exec = g["mfma_flops"] / (g["ms"] * 1e-3) / 1e12
     tf_alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    if dom == "winograd_bf3":
+        peak = PEAK_BF16_MFMA_TFLOPS                     # fp32 operands, three-way split: six bf16 MFMA products per multiply, priced against the bf16 pipe
     kname = {"winograd": "winograd_wide_kernel / winograd_kernel<..> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
+             "winograd_bf3": "winograd_bf3_kernel<6, MT> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution of fp32 operands split three ways into bf16: six "
+                             "v_mfma_f32_32x32x16_bf16 products per multiply, fp32 accumulate; csrc/winograd_bf3.hip)",
              "conv3x3_bf16": "conv3x3_t32_kernel (16x32-pixel tiles, 16-channel slices, LDS-DMA weights; the big launches) / conv3x3_bf16_kernel<TH> (the small ones): "
                              "region-direct 3x3/s1/p1 convolution, v_mfma_f32_32x32x16_bf16",
              "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x2_f32)",
@@ -588,6 +592,11 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
                  "the same time (2.25x the executed rate by construction, not a utilisation).  On gfx950 an fp32 MFMA and a VALU instruction use the "
                  "same lanes and never overlap (profiles/r05_winograd_valu_vs_mfma.txt), so this fraction is bounded by MFMA / (MFMA + VALU) cycles of "
                  "the kernel -- about 0.80 for this one -- not by 1") if dom == "winograd" else
+                ("achieved/frac = flops the bf16 matrix pipe EXECUTES in this kernel: 6 products x 2*M*N*16/4*Cin per launch (F(2x2,3x3) multiplies, each as the six "
+                 "bf16 products of its three-way split fp32 operands) / its summed launch time, over the 2500 TF/s bf16 peak; achieved_algorithmic = the direct "
+                 "convolution's 2*M*N*9*Cin over the same time.  The kernel is bound by the VALU work of the split (5.5 instructions per transformed input element) "
+                 "and by its per-block prologue + epilogue, not by the matrix pipe: profiles/r06_wino_bf3.txt; its time per layer is 1.08-1.40x shorter than the "
+                 "fp32-MFMA kernel's at 0.65 of the fp32 pipe") if dom == "winograd_bf3" else
                 ("achieved = 2*M*N*K of the launches / their summed time (executed == algorithmic: a direct convolution).  By arithmetic intensity "
                  "(bf16 bytes of input + output per pixel against a 2500 TF / 8 TB/s = 312 flop/B ridge) the C_in >= 128 layers are MFMA-bound "
                  "(128->128 3x3: 576 flop/B), the 64->64 @ 256^2 layers sit at the ridge (288 flop/B) -- see kernels.*.algorithmic_GBps for the byte side"),
@@ -609,7 +618,7 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
                                                                      "all launches of the family, the B=1 source-encoder ones included)")
         if dom == "winograd" and "winograd_wide" in mfma_pmc["kernels"]:
             roof["mfma_pmc_batch_launches"] = mfma_pmc["kernels"]["winograd_wide"]        # the wide kernel = the full-batch (B = 300) launches alone
-    mm = ("winograd", "gemm_conv", "gemm_bf16", "conv3x3_bf16")          # every convolution / GEMM family of either dtype
+    mm = ("winograd", "winograd_bf3", "gemm_conv", "gemm_bf16", "conv3x3_bf16")          # every convolution / GEMM family of either dtype
     conv_ms = max(sum(fam[k]["ms"] for k in mm if k in fam), 1e-9)
     conv_fl = sum(fam[k]["flops"] for k in mm if k in fam)
     conv_family = {"algorithmic_gflop_per_frame": round(conv_fl / nprof / B / 1e9, 2),
@@ -618,6 +627,8 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     kern = {}
     for name, f in fam.items():
         e = {"calls_per_step": f["calls"] // nprof, "ms_per_step": round(f["ms"] / nprof, 3)}
+        if name == "winograd_bf3":
+            e["frac_of_bf16_pipe"] = round(f["mfma_flops"] / (f["ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
         avg_s = f["ms"] * 1e-3 / f["calls"]
         if f["bytes"]:
             e["algorithmic_GBps"] = round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)

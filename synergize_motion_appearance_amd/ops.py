@@ -494,9 +494,10 @@ def _wino43_ok(B, H, W, cin, cout, up2, lda, ldc, ldres):
             and ldres % 4 == 0 and B * (H // 16) * (W // 32) * (cout // 32) >= WINO43_MIN_BLOCKS)
 
 
-# fp32 3x3 convolutions on the BF16 matrix pipe with three-way split operands (csrc/winograd_bf3.hip): 0 = off, 6 = the fp32-grade six-product
-# form, 3 = the two-way split (comparison only).  WINO_BF3_MIN_BLOCKS: 16x16-pixel x 64-channel blocks a launch must have (one block per CU).
-WINO_BF3 = _knob("SMX_WINO_BF3", 0)
+# fp32 3x3 convolutions on the BF16 matrix pipe with three-way split operands (csrc/winograd_bf3.hip): 6 = the fp32-grade six-product form (default:
+# error against fp64 below the fp32-MFMA kernel's, 1.08-1.40x its speed per layer at B = 300, +11 % on the configs[1] step), 0 = off (the fp32-MFMA
+# kernels everywhere), 3 = the two-way split (comparison only, never the fp32 configuration).  WINO_BF3_MIN_BLOCKS: 16x16-pixel x 64-channel blocks a launch must have (one block per CU).
+WINO_BF3 = _knob("SMX_WINO_BF3", 6)
 WINO_BF3_MIN_BLOCKS = 512
 
 
@@ -516,7 +517,7 @@ def _wino_wide(B, H, W, cout):
 
 
 def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=None, out_hw=None,
-         d2s=None, tile=0, in_ss=None, in_swish=False, want_stats=False, mfma16=False, out_dtype=None, direct=False):
+         d2s=None, tile=0, in_ss=None, in_swish=False, want_stats=False, mfma16=False, out_dtype=None, direct=False, bf3=True):
     """y = act(conv(x) + bias) [+ res].  x [B,H,W,Cin] (slice ok) -> out [B,Ho,Wo,Cout] (slice ok).
     pad: (top, left) (default (kh//2, kw//2)); out_hw for asymmetric pads / strides.
     d2s=(p, C): un-patchify store, out is [B,Ho*p,Wo*p,C].
@@ -524,6 +525,7 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
     stride-1 launch; implicit-GEMM kernel only).
     direct: always the implicit-GEMM kernel (training: weights change every step, so the Winograd-domain / fragment-ordered
     packings of the inference engines are not built).
+    bf3=False: never the split-bf16 Winograd kernel (training: its three-plane weight pack is built once per layer, not per step).
     want_stats: the output feeds a GroupNorm -- on the fused Winograd path the epilogue also emits the
     per-block {sum, sum^2} partials and tags the returned tensor with them (`_gn_part`), so that
     `groupnorm_stats(y, ...)` is a finalize over a few KB instead of a read of y."""
@@ -578,7 +580,7 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
                 out._gn_part = part
             return out
         part = torch.empty((B, (He // 8) * (We // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
-        if _wino_bf3_ok(B, He, We, Cin, cv.cout, lda, ldc, ldr, 0, a_ptr, c_ptr, r_ptr, None if cv.b is None else cv.b.data_ptr(),
+        if bf3 and _wino_bf3_ok(B, He, We, Cin, cv.cout, lda, ldc, ldr, 0, a_ptr, c_ptr, r_ptr, None if cv.b is None else cv.b.data_ptr(),
                         None if in_ss is None else in_ss.data_ptr()):
             if meta is not None:
                 meta.update(mfma_flops=2.0 * B * Ho * Wo * cv.cout * 4 * Cin * WINO_BF3, bf3=WINO_BF3)

@@ -341,7 +341,7 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
     wino3 = (not m16) and WINOGRAD_TRAIN and kind == "conv" and (kh, kw, stride, pt, pl) == (3, 3, 1, 1, 1) and He % 8 == 0 and We % 16 == 0
     if wino3 and cin % 32 == 0:
         cv._u = _packed_u(tp, w, 0, cout, cin)
-    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=cv._u is None, **f16)
+    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=cv._u is None, bf3=False, **f16)
     Ho, Wo = (y.shape[1], y.shape[2]) if d2s is None else (H, W)
 
     def bwd():
@@ -385,7 +385,7 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
             dcv = mk(wt.view(cin, kh * kw * cout), kh, kw, cout, cin)
             if wino3 and cout % 32 == 0:
                 dcv._u = _packed_u(tp, w, 1, cout, cin)
-            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=dcv._u is None, **f16)
+            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=dcv._u is None, bf3=False, **f16)
             if up2:             # adjoint of nearest x2: sum of each 2x2 block
                 dx = scaled(tp, ops.avgpool2(dx), 4.0)
         else:                   # stride 2: zero-insert gather (smx_gemm_conv_f32 up2 = 2)
