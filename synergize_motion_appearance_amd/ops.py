@@ -246,14 +246,14 @@ class Conv:
         """U = G g G^T for F(2x2,3x3), fragment-ordered [16][ceil(Cout/32)][Cin/8][64 lanes][4]
         (lane l <-> row n = 32*nt + (l&31), channels 8s + 4*(l>>5) + 0..3); built once per layer."""
         if self._u is None:
-            g = self.w.view(self.cout, 3, 3, self.cin).double()
-            G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=g.device)
-            U = torch.einsum("ia,nabc,jb->ijnc", G, g, G).float()                     # [4,4,Cout,Cin]
-            n32 = (self.cout + 31) // 32
-            Up = torch.zeros((16, n32 * 32, self.cin), device=g.device, dtype=torch.float32)
-            Up[:, :self.cout] = U.reshape(16, self.cout, self.cin)
-            Up = Up.view(16, n32, 32, self.cin // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
-            self._u = torch.cat([Up.view(-1), torch.zeros(1024, device=g.device, dtype=torch.float32)])   # prefetch pad (up to 3 units of 256 floats past the end)
+            lib = L.load()
+            if self.kh != 3 or self.kw != 3 or self.cin % 8:
+                raise L.SmxError(f"winograd_u: not a 3x3 layer with Cin % 8 == 0 ({self.kh}x{self.kw}, Cin {self.cin})")
+            # the library's own pack kernel (fp64 products, one rounding: smx_pack_winograd_u_f32, the training step's) on the OIHW view of the weights
+            w_oihw = _dev(self.w).view(self.cout, 3, 3, self.cin).permute(0, 3, 1, 2).contiguous()
+            u = torch.empty(int(lib.smx_winograd_u_floats(self.cout, self.cin)), device=self.w.device, dtype=torch.float32)
+            L.check(lib.smx_pack_winograd_u_f32(w_oihw.data_ptr(), u.data_ptr(), self.cout, self.cin, 0, _stream()), "smx_pack_winograd_u_f32")
+            self._u = u
         return self._u
 
     def winograd_bf3_u(self):

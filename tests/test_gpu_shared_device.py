@@ -63,6 +63,50 @@ def test_sparse_motion_is_bit_stable_next_to_another_process_running_the_bf16_co
         agg.wait()
 
 
+def test_fp32_winograd_kernels_are_bit_stable_next_to_another_process_running_the_bf16_convolution(tmp_path, monkeypatch):
+    """the fp32 configuration's 3x3 kernels as the victim of the same neighbour: `winograd_wide_kernel` (csrc/winograd.hip is the one file still built
+    WITH packed fp32 instructions -- its input transform and loader use them; round 5 only had a `winograd_kernel<1>` victim on record) and both shapes of
+    the split-bf16 kernel (built without them).  References are computed BEFORE the neighbour starts; every later launch must reproduce them bit for bit."""
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from synergize_motion_appearance_amd import ops
+    monkeypatch.setattr(ops, "WINO_BF3_MIN_BLOCKS", 1)
+    g = torch.Generator().manual_seed(11)
+    Bv = 64
+    x = torch.randn((Bv, 64, 64, 128), generator=g).cuda()
+    res = torch.randn((Bv, 64, 64, 128), generator=g).cuda()
+    cv128 = ops.Conv.from_torch((torch.randn((128, 128, 3, 3), generator=g) / 34.0).cuda(), (0.1 * torch.randn((128,), generator=g)).cuda())
+    cv64 = ops.Conv.from_torch((torch.randn((64, 128, 3, 3), generator=g) / 34.0).cuda(), (0.1 * torch.randn((64,), generator=g)).cuda())
+    ss = ops.groupnorm_stats(x, torch.ones(128, device="cuda"), torch.zeros(128, device="cuda"))
+
+    def victims():
+        outs, kinds = [], []
+        for mode, cv, r in ((0, cv128, res), (6, cv128, res), (6, cv64, None)):
+            monkeypatch.setattr(ops, "WINO_BF3", mode)
+            with ops.profile() as rec:
+                y = ops.conv(x, cv, in_ss=ss, in_swish=True, res=r, want_stats=True)
+            outs += [y.clone(), y._gn_part.clone()]
+            kinds.append((rec.rows[0][1].get("bf3"), rec.rows[0][1].get("wide")))
+        return outs, kinds
+    ref, kinds = victims()
+    assert kinds == [(None, 1), (6, 1), (6, 1)], kinds            # the wide fp32-MFMA kernel, then the split kernel at 8x16x128 and at 16x16x64 blocks
+    torch.cuda.synchronize()
+    log = tmp_path / "aggressor.log"
+    with open(log, "w") as f:
+        agg = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "aggressor.py"), "t32", "40"], cwd=REPO, env=ENV, stdout=f, stderr=subprocess.STDOUT)
+    try:
+        assert _wait_for(str(log), "launches per call"), open(log).read()[-2000:]
+        wrong, n, t0 = torch.zeros(len(ref), dtype=torch.long), 0, time.time()
+        while time.time() - t0 < 12.0:
+            outs, _ = victims()
+            wrong += torch.stack([(a != b).sum() for a, b in zip(outs, ref)]).cpu()
+            n += 1
+        assert agg.poll() is None, "the neighbour process ended before the measurement did:\n" + open(log).read()[-2000:]
+        assert n >= 50 and wrong.tolist() == [0] * len(ref), (n, wrong.tolist())
+    finally:
+        agg.kill()
+        agg.wait()
+
+
 def test_two_bf16_pipelines_side_by_side_are_bit_stable():
     """two copies of tools/preempt_repro.py: each renders ONE batch again and again on the production kernel set and compares every pass with its first"""
     assert torch.cuda.is_available(), "needs an MI355X"
