@@ -503,25 +503,33 @@ def render_leg(args, dtype, world, rank, dev, dist, collective, net_g, me, drv, 
         off = n_mine - fr_last.shape[0]
         picks = sorted({0, fr_last.shape[0] // 2, fr_last.shape[0] - 1})
 
+        LSB_BAR = 42                                          # bf16: the definition's own autocast distance at 256x256 (max 0.33 on [-1,1]; 127.5 LSB per unit)
+        is512 = getattr(args, "img_size", 256) == 512
+
         def compare(batch_out):
-            worst, ndiff, ntot, dsum = 0, 0, 0, 0.0
+            worst, ndiff, ntot, dsum, nout = 0, 0, 0, 0.0, 0
             for i in picks:
                 one = driver.render_frames(states[j_last], fr_last[i:i + 1], net_g, me, True, True, batch=1)
                 d = (one[0].int() - batch_out[off + i].int()).abs()
                 worst, ndiff, ntot, dsum = max(worst, int(d.max())), ndiff + int((d > 0).sum()), ntot + d.numel(), dsum + float(d.sum())
-            return worst, ndiff, ntot, dsum
-        lsb_bar = 84 if getattr(args, "img_size", 256) == 512 else 42       # bf16: the definition's own autocast distance (256: max 0.33, 512: max 0.66 on [-1,1]; 127.5 LSB per unit)
-        is_bad = lambda w_, s_, n_: (w_ > 1) if dtype == "f32" else (s_ / n_ >= 1.5 or w_ > lsb_bar)   # noqa: E731
-        worst, ndiff, ntot, dsum = compare(out)
+                nout += int((d > LSB_BAR).sum())
+            return worst, ndiff, ntot, dsum, nout
+        # bf16 bars: mean < 1.5 LSB and worst pixel <= 42 LSB.  configs[3] (512x512: four times the pixels, its own definition at max 0.66 under autocast,
+        # tests/test_gpu_n4_512.py) may have a FEW pixels between 42 and 84 LSB -- at most 1 in 100,000 bytes, none above 84: a bounded outlier count, not a
+        # doubled bar (a bad tile or lane is thousands of pixels)
+        def is_bad(w_, s_, n_, o_):
+            if dtype == "f32":
+                return w_ > 1
+            return s_ / n_ >= 1.5 or (w_ > LSB_BAR and not (is512 and w_ <= 2 * LSB_BAR and o_ * 100000 <= n_))
+        worst, ndiff, ntot, dsum, nout = compare(out)
         consistency = {"frames_checked": len(picks), "max_lsb_vs_b1": worst, "mean_lsb_vs_b1": round(dsum / ntot, 5), "bytes_differing": ndiff,
-                       "bytes": ntot, "what": f"frames {picks} of the last timed batch (B={n_mine}) re-rendered one at a time; uint8 outputs compared"}
+                       "bytes": ntot, "bytes_above_42_lsb": nout,
+                       "what": f"frames {picks} of the last timed batch (B={n_mine}) re-rendered one at a time; uint8 outputs compared"}
         # fp32: another batch size only reorders fp32 sums (<= 1 LSB).  bf16 storage: a reordered sum can round to the other
         # neighbour (2^-8) and the flip propagates through ~100 layers, so two bf16 evaluations are as far from each other as
         # each is from fp32; the bar there is the reference-under-autocast error (tests/golden/autocast_bf16.npz: mean 0.0078,
-        # max 0.33 on [-1,1] = 1.0 / 42 LSB): mean < 1.5 LSB, worst pixel <= 42 LSB.  configs[3] (512x512) has four times the pixels and its
-        # own definition sits at max 0.66 under autocast (tests/test_gpu_n4_512.py, DESIGN section 7 "N4"): worst pixel <= 84 LSB there
-        # (round 5: 51 LSB at one pixel of 2.4 M, mean 0.6 -- the 42 of the 256 configuration was being applied to both)
-        bad = is_bad(worst, dsum, ntot)
+        # max 0.33 on [-1,1] = 1.0 / 42 LSB)
+        bad = is_bad(worst, dsum, ntot, nout)
         if bad:
             raise SystemExit(f"[bench] batch consistency FAILED ({dtype}): B={n_mine} output differs from B=1 by {worst} LSB (mean {dsum / ntot:.3f})")
     return {"dt": dt, "fps": fps, "frames_total": frames_total, "rank_times": rank_times, "consistency": consistency, "states": states,

@@ -794,24 +794,16 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
   if (dh == 4) {
     if (L % 64 || S % 32 || S > 4096) return SMX_EINVAL;       // all keys of a head live in LDS: 4096 (the 512 variant's 64x64 tokens) = 141 KB
     const size_t lds = (size_t)S * 33 + 4 * 64 * 6 * sizeof(float);
-    static std::once_flag attr_once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(attr_once, [] {
+    {
       const void* fns[] = {(const void*)(attn_mfma4_kernel<T, true>), (const void*)(attn_mfma4_kernel<T, false>), (const void*)(attn_valu4_kernel<T>)};
-      for (const void* f : fns)
-        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 36 + 4 * 64 * 6 * (int)sizeof(float));
-    });
-    if (attr_err != hipSuccess) return SMX_ELAUNCH;
+      for (const void* f : fns) SMX_HIP(smx_max_dynamic_lds(f, 4096 * 36 + 4 * 64 * 6 * (int)sizeof(float)));
+    }
     if constexpr (sizeof(T) == 2) {
       if (smx_tune(SMX_TUNE_ATTN4_MFMA) == 1 && S % 128 == 0) {          // bf16 storage: the 4x4x4 bf16 MFMA form (knob 2: the fp32 4x4x1 form on bf16 storage)
-        static std::once_flag attr16_once;
-        static hipError_t attr16_err = hipSuccess;
-        std::call_once(attr16_once, [] {
+        {
           const void* fns[] = {(const void*)(attn_mfma4_bf16_kernel<true>), (const void*)(attn_mfma4_bf16_kernel<false>)};
-          for (const void* f : fns)
-            if (attr16_err == hipSuccess) attr16_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 20 + 4 * 64 * 6 * (int)sizeof(float));
-        });
-        if (attr16_err != hipSuccess) return SMX_ELAUNCH;
+          for (const void* f : fns) SMX_HIP(smx_max_dynamic_lds(f, 4096 * 20 + 4 * 64 * 6 * (int)sizeof(float)));
+        }
         if (key_mask) SMX_LAUNCH(attn_mfma4_bf16_kernel<true>, dim3(L / 64, B * H), dim3(256), (size_t)S * 20 + 4 * 64 * 6 * sizeof(float), st, p);
         else SMX_LAUNCH(attn_mfma4_bf16_kernel<false>, dim3(L / 64, B * H), dim3(256), (size_t)S * 16 + 4 * 64 * 6 * sizeof(float), st, p);
         return smx_launch_status();
@@ -860,8 +852,7 @@ extern "C" int smx_attnblock_bf16(const void* q, int ldq, int64_t q_bs, const vo
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)o & 7)) return SMX_EINVAL;
   AP<bf16_t> p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, nullptr, q_bs, k_bs, vt_bs, o_bs, ldq, ldk, ldvt, ldo, 1, L, S, scale};
   constexpr int LDS = 4 * (32 * 256 * 2 + 256 * 32 * 2);     // 4 stages x 32 KB
-  static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)attnblock16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  SMX_HIP(smx_max_dynamic_lds((const void*)attnblock16_kernel<256>, LDS));
   SMX_LAUNCH(attnblock16_kernel<256>, dim3(L / 128, B), dim3(512), LDS, (hipStream_t)stream, p);
   return smx_launch_status();
 }
@@ -874,8 +865,7 @@ extern "C" int smx_attnblock_f32(const float* q, int ldq, int64_t q_bs, const fl
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o) & 15) return SMX_EINVAL;
   AP<float> p{q, k, vt, o, nullptr, q_bs, k_bs, vt_bs, o_bs, ldq, ldk, ldvt, ldo, 1, L, S, scale};
   constexpr int LDS = 2 * (32 * 256 * 4 + 256 * 32 * 4);     // 2 stages x 64 KB
-  static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)attnblock32_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  SMX_HIP(smx_max_dynamic_lds((const void*)attnblock32_kernel<256>, LDS));
   SMX_LAUNCH(attnblock32_kernel<256>, dim3(L / 128, B), dim3(256), LDS, (hipStream_t)stream, p);
   return smx_launch_status();
 }

@@ -480,21 +480,18 @@ static int conv3x3_bf16_launch(const void* x, int lda, const void* w, int ldw, c
   if (blocks > 2147483647LL || (long long)(up2 ? H / 2 : H) * (up2 ? W / 2 : W) * lda > 2147483647LL) return SMX_EINVAL;
   if ((long long)H * W * ldc > 2147483647LL || (long long)H * W * (res ? ldres : 0) > 2147483647LL || (long long)H * W * (mul ? ldmul : 0) > 2147483647LL ||
       (long long)Cout * ldw > 2147483647LL) return SMX_EINVAL;
-  static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<16>::LDS_B)); attr = true; }
+  SMX_HIP(smx_max_dynamic_lds((const void*)conv3x3_bf16_kernel<16>, Geo<16>::LDS_B));
   p.ntiles = (int)blocks; p.tpb = 1;
   dim3 grid((unsigned)blocks, (Cout + BN - 1) / BN);
   constexpr int SLAB_LDS = Geo<16>::RPX * 80 + 9 * BN * 80;            // 72,000 B (>= the 69,632 B epilogue exchange)
   if (f32io) {
-    static bool attr3 = false;
-    if (!attr3) { SMX_HIP(hipFuncSetAttribute((const void*)(conv3x3_bf16_kernel<16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS)); attr3 = true; }
+    SMX_HIP(smx_max_dynamic_lds((const void*)(conv3x3_bf16_kernel<16, true, true>), SLAB_LDS));
     if (TH == 16) SMX_LAUNCH((conv3x3_bf16_kernel<16, true, true>), grid, dim3(NT), SLAB_LDS, (hipStream_t)stream, p);
     else SMX_LAUNCH((conv3x3_bf16_kernel<8, false, true>), grid, dim3(NT), Geo<8>::LDS_B, (hipStream_t)stream, p);
     return smx_launch_status();
   }
   if (TH == 16 && Cin % 32 == 0 && smx_tune(SMX_TUNE_CONV16_SLAB)) {
-    static bool attr2 = false;
-    if (!attr2) { SMX_HIP(hipFuncSetAttribute((const void*)(conv3x3_bf16_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_LDS)); attr2 = true; }
+    SMX_HIP(smx_max_dynamic_lds((const void*)(conv3x3_bf16_kernel<16, true>), SLAB_LDS));
     SMX_LAUNCH((conv3x3_bf16_kernel<16, true>), grid, dim3(NT), SLAB_LDS, (hipStream_t)stream, p);
   }
   else if (TH == 16) SMX_LAUNCH(conv3x3_bf16_kernel<16>, grid, dim3(NT), Geo<16>::LDS_B, (hipStream_t)stream, p);

@@ -594,8 +594,7 @@ static int conv3x3_t32_launch(const void* x, int lda, const void* wp, const floa
 #else
   if (abl) return SMX_EINVAL;
 #endif
-  static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_t32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)); attr = true; }
+  SMX_HIP(smx_max_dynamic_lds((const void*)conv3x3_t32_kernel<0>, LDS_B));
   SMX_LAUNCH(conv3x3_t32_kernel<0>, dim3((unsigned)blocks), dim3(NT), LDS_B, (hipStream_t)stream, p);
   return smx_launch_status();
 }

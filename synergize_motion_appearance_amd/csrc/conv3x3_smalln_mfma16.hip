@@ -189,8 +189,7 @@ extern "C" int smx_conv3x3_smalln_mfma_bf16(const void* x, int lda, const void* 
   p.Cin = Cin; p.N = Cout; p.act = act; p.in_swish = in_swish; p.tiles_y = H / TH; p.tiles_x = W / TW;
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL) return SMX_EINVAL;
-  static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv3x3_smalln_mfma16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)); attr = true; }
+  SMX_HIP(smx_max_dynamic_lds((const void*)conv3x3_smalln_mfma16_kernel, LDS_B));
   SMX_LAUNCH(conv3x3_smalln_mfma16_kernel, dim3((unsigned)blocks), dim3(256), LDS_B, (hipStream_t)stream, p);
   return smx_launch_status();
 }

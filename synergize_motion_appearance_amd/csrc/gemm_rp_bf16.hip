@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256) void gemm_rp_pack_kernel(const bf16_t* __restr
 template <int KS, int NT, bool D2S = false>
 int rp_launch(const RP& p, hipStream_t st) {
   constexpr int LDS = 2 * TM * KS * 32 + 4 * EX_F * 4;
-  static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)gemm_rp_bf16_kernel<KS, NT, D2S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  SMX_HIP(smx_max_dynamic_lds((const void*)gemm_rp_bf16_kernel<KS, NT, D2S>, LDS));
   const int ny = p.N / (128 * NT);
   int gx = 512 / ny; if (gx < 1) gx = 1; if (gx > p.tiles) gx = p.tiles;
   SMX_LAUNCH((gemm_rp_bf16_kernel<KS, NT, D2S>), dim3(gx, ny), dim3(256), LDS, st, p);

@@ -160,8 +160,7 @@ __global__ __launch_bounds__(256) void gemm_rp_f32_pack_kernel(const float* __re
 template <int KG, int NW, bool D2S = false>
 int rpf_launch(const RPF& p, hipStream_t st) {
   constexpr int LDS = 2 * TM * KG * 32 + NW * EX_F * 4;
-  static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)gemm_rp_f32_kernel<KG, NW, D2S>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  SMX_HIP(smx_max_dynamic_lds((const void*)gemm_rp_f32_kernel<KG, NW, D2S>, LDS));
   const int ny = p.N / (32 * NW);
   int gx = (NW == 8 ? 256 : 512) / ny; if (gx < 1) gx = 1; if (gx > p.tiles) gx = p.tiles;
   SMX_LAUNCH((gemm_rp_f32_kernel<KG, NW, D2S>), dim3(gx, ny), dim3(64 * NW), LDS, st, p);

@@ -41,6 +41,23 @@ enum { SMX_TUNE_WINO_NW = 0, SMX_TUNE_WINO_ABLATE, SMX_TUNE_GEMM_VARIANT, SMX_TU
        SMX_TUNE_WARP_ROWS, SMX_TUNE_WARP_REORDER, SMX_TUNE_ATTN16, SMX_TUNE_WINO_WIDE, SMX_TUNE_WINO_NT, SMX_TUNE_ATTN4_MFMA, SMX_TUNE_CONV16_SLAB, SMX_TUNE_ATTN_BWD_MFMA, SMX_TUNE_VQ_SPLIT, SMX_TUNE_WARP_NT, SMX_TUNE_WGRAD_REGION, SMX_TUNE_WGRAD_SLOTS, SMX_TUNE_WINO_STAGGER, SMX_TUNE_WINO_WS, SMX_TUNE_GEMM_LOADER, SMX_TUNE_WINO_XCD, SMX_TUNE_WINO_BF3_SHAPE, SMX_TUNE_COUNT };
 int smx_tune(int key);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: set it once per (kernel, device) of this translation unit,
+// under a lock (a process that moves to another GPU, or two threads racing on a first call, must not launch without it)
+#include <mutex>
+static inline hipError_t smx_max_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static struct { const void* fn; int dev; } done[64];
+  static int n = 0;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(mu);
+  for (int i = 0; i < n; ++i) if (done[i].fn == fn && done[i].dev == dev) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && n < 64) { done[n].fn = fn; done[n].dev = dev; ++n; }
+  return e;
+}
+
 static inline int smx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // region form of the 3x3 / s1 / p1 weight gradient (train_wgrad_region.hip), dispatched by train_gemm.hip's wgrad_launch

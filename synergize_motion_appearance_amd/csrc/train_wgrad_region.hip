@@ -236,12 +236,8 @@ int smx_wgrad_region_launch(bool bf16, const float* dy, int ldy, const float* x,
   p.dy = dy; p.x = x; p.ws = ws; p.bias_ws = bias_ws; p.ldy = ldy; p.ldx = ldx; p.Cout = Cout; p.Cin = Cin; p.K = 9 * Cin;
   p.B = M / (Ho * Wo); p.H = Ho; p.W = Wo; p.Hin = Hin; p.Win = Win; p.up2 = up2;
   p.nseg = Wo / 32; p.units = p.B * p.nseg * Ho; p.uper = uper; p.msplit = msplit; p.tiles_ci = Cin / 64;
-  static bool attr = false;
-  if (!attr) {
-    SMX_HIP(hipFuncSetAttribute((const void*)wgrad_region_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F * 4));
-    SMX_HIP(hipFuncSetAttribute((const void*)wgrad_region_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F * 4));
-    attr = true;
-  }
+  SMX_HIP(smx_max_dynamic_lds((const void*)wgrad_region_kernel<false>, LDS_F * 4));
+  SMX_HIP(smx_max_dynamic_lds((const void*)wgrad_region_kernel<true>, LDS_F * 4));
   const dim3 grid((unsigned)((Cout / 64) * (Cin / 64)), (unsigned)msplit);
   if (bf16) SMX_LAUNCH(wgrad_region_kernel<true>, grid, dim3(256), LDS_F * 4, (hipStream_t)stream, p);
   else SMX_LAUNCH(wgrad_region_kernel<false>, grid, dim3(256), LDS_F * 4, (hipStream_t)stream, p);

@@ -1325,14 +1325,8 @@ static int winograd_launch(const float* x, int lda, const float* u_packed, const
   // the timing-only ablation / trace instantiations (they skip loads or barriers, or overwrite the GroupNorm partials with
   // cycle stamps: WRONG results by design) exist only in the tools build (-DSMX_TOOLS, tools/wino_bench.py / wino_trace.py)
   if (abl != 0) return SMX_EINVAL;
-  static std::once_flag attr_once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(attr_once, [] {
-    attr_err = hipFuncSetAttribute((const void*)(winograd_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-    if (attr_err == hipSuccess)
-      attr_err = hipFuncSetAttribute((const void*)(winograd_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
-  });
-  if (attr_err != hipSuccess) return SMX_ELAUNCH;
+  SMX_HIP(smx_max_dynamic_lds((const void*)(winograd_wide_kernel<0>), 98304));
+  SMX_HIP(smx_max_dynamic_lds((const void*)(winograd_kernel<2, 0>), WIDE_LDS));
   if (nw == 2 && wide > 0) {
     dim3 grid((unsigned)blocks, (Cout + 63) / 64);
     const size_t wlds = wide == 5 ? 98304 : WIDE_LDS;          // wide == 5 (tools): the same kernel at one block per CU

@@ -417,10 +417,7 @@ extern "C" int smx_winograd43_conv3x3_f32(const float* x, int lda, const float* 
 #endif
   const long long blocks = (long long)B * p.tiles_y * p.tiles_x;
   if (blocks > 2147483647LL) return SMX_EINVAL;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)winograd43_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4); });
-  if (attr_err != hipSuccess) return SMX_ELAUNCH;
+  SMX_HIP(smx_max_dynamic_lds((const void*)winograd43_kernel, LDS_FLOATS * 4));
   SMX_LAUNCH(winograd43_kernel, dim3((unsigned)blocks, Cout / 32), dim3(NTHR), (size_t)LDS_FLOATS * 4, (hipStream_t)stream, p);
   return smx_launch_status();
 }

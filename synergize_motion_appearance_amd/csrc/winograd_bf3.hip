@@ -560,13 +560,10 @@ static int winograd_bf3_launch(const float* x, int lda, const void* u3, const fl
   const long long blocks = (long long)B * p.ty * p.tx;
   const int nby = Cout / (mt == 1 ? 128 : 64);                                             // output blocks per spatial block
   p.xcd_group = (smx_tune(SMX_TUNE_WINO_XCD) != 0 && blocks % 8 == 0 && nby > 1 && blocks * nby <= 0x7fffffffLL) ? 1 : 0;
-  static std::once_flag attr_once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(attr_once, [] {
+  {
     const void* ks[4] = {(const void*)(winograd_bf3_kernel<6, 2>), (const void*)(winograd_bf3_kernel<3, 2>), (const void*)(winograd_bf3_kernel<6, 1>), (const void*)(winograd_bf3_kernel<3, 1>)};
-    for (int i = 0; i < 4 && attr_err == hipSuccess; ++i) attr_err = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS);
-  });
-  if (attr_err != hipSuccess) return SMX_ELAUNCH;
+    SMX_HIP(smx_max_dynamic_lds(ks[(mt == 1 ? 2 : 0) + (nprod == 3 ? 1 : 0)], B3_LDS));
+  }
   dim3 grid((unsigned)blocks, nby);
   if (mt == 2) {
     if (nprod == 6) SMX_LAUNCH((winograd_bf3_kernel<6, 2>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);

@@ -121,14 +121,19 @@ class ReducePlan:
         self.segs = []           # recorded: [{"items": [(sig, ws, record)], "waves": [(device table, n items, n blocks)]}]
         self.cur = []
         self.replay = False
+        self.complete = False    # the recording step ran to its end (set by the trainer: `finish`); a recording that died after its first flush is not a plan
         self.seg_i = self.item_i = 0
+
+    def finish(self):
+        """the step this plan belongs to ended normally."""
+        self.complete = True
 
     def begin(self, tp):
         if self._owner != id(tp.G):
-            self._owner, self.segs, self.cur, self.replay = id(tp.G), [], [], False
+            self._owner, self.segs, self.cur, self.replay, self.complete = id(tp.G), [], [], False, False
         else:
-            if self.cur:                                 # a recording step died half-way (an exception): record again from scratch
-                self.segs, self.cur = [], []
+            if self.cur or not self.complete:            # a recording step died half-way (an exception, possibly AFTER its first flush): record again from scratch
+                self.segs, self.cur, self.complete = [], [], False
             self.replay = bool(self.segs)
         self.seg_i = self.item_i = 0
 

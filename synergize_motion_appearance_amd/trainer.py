@@ -579,6 +579,8 @@ class TrainStep:
                "_out_nhwc": st["out"], "_gt_nhwc": gt}
         if eq:
             out["kp_transformed"] = {"value": kp_t[0], "jacobian": kp_t[1]}
+        if rp is not None:
+            rp.finish()
         return losses, out
 
     def disc_backward(self, out_nhwc, gt_nhwc):
@@ -595,6 +597,8 @@ class TrainStep:
         tp.acc(l_real, one)
         tp.acc(l_fake, one.clone())
         tp.backward()
+        if rp is not None:
+            rp.finish()
         return {"l_d_real": l_real, "out_d_real": pr.mean().reshape(1), "l_d_fake": l_fake, "out_d_fake": pf.mean().reshape(1)}
 
     GRAPH_WARMUP = 2

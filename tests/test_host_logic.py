@@ -567,3 +567,22 @@ def test_round5_measurement_plumbing_host_side():
         v = C.c_int(-99)
         assert lib.smx_get_tuning(knob.encode(), C.byref(v)) == 0 and v.value == want, (knob, v.value)
     assert lib.smx_get_tuning(b"no_such_knob", C.byref(C.c_int(0))) != 0
+
+
+def test_reduce_plan_discards_a_recording_that_did_not_finish():
+    """train_ops.ReducePlan: a recording step that raised AFTER its first flush (segs = [seg0], cur = []) must not be replayed as a plan --
+    only a step the trainer marked finished is (advisor, round 5)."""
+    from synergize_motion_appearance_amd.train_ops import ReducePlan
+
+    class TP:
+        G = object()
+    tp, rp = TP(), ReducePlan()
+    rp.begin(tp)
+    assert not rp.replay
+    rp.segs.append({"items": [], "waves": []})          # the first backward piece flushed, then the step died (no finish())
+    rp.begin(tp)
+    assert not rp.replay and rp.segs == [] and not rp.complete
+    rp.segs.append({"items": [], "waves": []})
+    rp.finish()                                          # a recording that ran to its end
+    rp.begin(tp)
+    assert rp.replay and len(rp.segs) == 1
