@@ -536,6 +536,34 @@ def render_leg(args, dtype, world, rank, dev, dist, collective, net_g, me, drv, 
             "work": work, "step": step, "total_units": total_units}
 
 
+def scaling_proxy(args, leg, net_g, me, drv, full_fps):
+    """What ONE GPU does at the per-GPU batch sizes of the strong-scaling job (configs[1]'s 300 frames of one source over N GPUs = 300 / N frames per GPU
+    and step): frames/s at B = 150 / 75 / 38 against B = 300, i.e. the whole per-GPU term of the N-GPU prediction -- frames are independent
+    (/root/reference/basicsr/demo.py:117-131) and the only exchange is one broadcast of the packed source state per source.  Measured here, on one GPU, with the
+    source state already encoded (as on a non-owner rank after the broadcast)."""
+    from synergize_motion_appearance_amd import driver
+    states = leg["states"]
+    rows = {}
+    for n_gpu, b in ((2, 150), (4, 75), (8, 38)):
+        nst = max(3, (2 * CLIP) // b)
+        frames = [drv[(i * b) % (CLIP - b):(i * b) % (CLIP - b) + b] for i in range(nst + 2)]
+        for fr in frames[:2]:
+            driver.render_frames(states[0], fr, net_g, me, True, True, batch=b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for fr in frames[2:]:
+            driver.render_frames(states[0], fr, net_g, me, True, True, batch=b)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fps = nst * b / dt
+        rows[f"B{b}"] = {"frames_per_step_per_gpu": b, "as_in_n_gpus": n_gpu, "fps_one_gpu": round(fps, 1), "ms_per_step": round(1e3 * dt / nst, 2),
+                         "per_gpu_efficiency": round(fps / full_fps, 4), "predicted_strong_scaling_factor": round(n_gpu * fps / full_fps, 2)}
+    return {"what": "frames/s of ONE GPU at the per-GPU batch of the N-GPU strong-scaling job, against its own B = 300 rate; predicted factor = N x that ratio "
+                    "(upper bound: the source-state broadcast, 28.3 MB once per source, and the closing barrier are not in it -- measured separately: "
+                    "tests/test_gpu_rccl.py, DESIGN section 6)",
+            "B300_fps": round(full_fps, 1), "rows": rows}
+
+
 def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     """instrumented pass (HIP events around every launch on the launch stream) over min(K,3) steps of the leg just timed
     -> (roofline dict of the dominant kernel, conv/GEMM family summary, per-family kernel table)."""
@@ -795,6 +823,8 @@ def main():
         "rank_times_s": {"max": round(max(rt), 4), "min": round(min(rt), 4), "per_rank": [round(x, 4) for x in rt],
                          "what": "each rank's own wall time for the timed region (prologue + K steps, device-synchronised) before the closing barrier"},
     }
+    if rank == 0 and world == 1 and args.batch == DEFAULT_BATCH and args.img_size == 256 and not args.no_consistency:
+        result["per_gpu_efficiency"] = scaling_proxy(args, leg, net_g, me, drv, fps)
     if leg["consistency"] is not None:
         result["batch_consistency"] = leg["consistency"]
     if one_device:
@@ -851,6 +881,8 @@ def main():
                "value": round(leg16["fps"], 3), "unit": "frames/s", "dtype": "bf16", "steps": K, "warmup": W,
                "ms_per_step": round(1e3 * leg16["dt"] / K, 3), "batch_consistency": leg16["consistency"],
                "tolerance": "tests/test_gpu_bf16.py: within 1.25x of the reference's own CPU-autocast(bf16) error (tests/golden/autocast_bf16.npz)"}
+        if args.batch == DEFAULT_BATCH and not args.no_consistency:
+            sub["per_gpu_efficiency"] = scaling_proxy(args, leg16, net_g, me, drv, leg16["fps"])
         if not args.no_roofline:
             r16, c16, k16 = roofline_leg(args, "bf16", leg16, dev, Pg, with_vq=False)
             sub["roofline"], sub["conv_gemm_family"] = r16, c16
