@@ -46,7 +46,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: v_mfma_f32_32x32x16_bf16 dense pe
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
 CLIP = 300                       # frames of the driving clip (BASELINE.json configs[1])
 DEFAULT_BATCH = 300              # frames per step: the whole clip in flight (HBM holds it many times over); 60 until round 3 (545 -> 565 frames/s)
-PROFILE_TAG = "r05"              # profiles/<tag>_{traffic,mfma}_pmc[_bf16].json: the committed counter summaries this run quotes
+PROFILE_TAG = "r06"              # profiles/<tag>_{traffic,mfma}_pmc[_bf16].json: the committed counter summaries this run quotes
 
 
 def build_nets(device, img_size=256):
@@ -396,9 +396,9 @@ def load_profile_json(name):
 # kernel family -> the objects of libsmx.so that hold its kernels: a committed counter summary is quoted for a family only while those
 # objects are the ones the counters were taken on (profiles/*_pmc.json "library_build" == lib/build_stamp.json)
 _GEMM_OBJS = ("gemm_conv.o", "gemm_rp_f32.o", "conv7_bf16x3.o", "conv_small.o")
-FAMILY_OBJECTS = {"winograd": ("winograd.o",), "winograd_wide": ("winograd.o",), "winograd_nw1": ("winograd.o",), "warp": ("warp_resize.o",),
+FAMILY_OBJECTS = {"winograd_bf3": ("winograd_bf3.o",), "winograd": ("winograd.o",), "winograd_wide": ("winograd.o",), "winograd_nw1": ("winograd.o",), "warp": ("warp_resize.o",),
                   "gemm_conv": _GEMM_OBJS, "gemm_bf16": ("gemm_bf16.o", "gemm_rp_bf16.o"),
-                  "conv_gemm_family": _GEMM_OBJS + ("winograd.o", "gemm_bf16.o", "gemm_rp_bf16.o", "conv3x3_bf16.o", "conv3x3_bf16_t32.o", "conv3x3_smalln_mfma16.o", "conv7_c2_bf16.o"),
+                  "conv_gemm_family": _GEMM_OBJS + ("winograd.o", "winograd_bf3.o", "gemm_bf16.o", "gemm_rp_bf16.o", "conv3x3_bf16.o", "conv3x3_bf16_t32.o", "conv3x3_smalln_mfma16.o", "conv7_c2_bf16.o"),
                   "conv3x3_bf16": ("conv3x3_bf16.o", "conv3x3_bf16_t32.o"), "conv7_x3": ("conv7_bf16x3.o",),
                   "attention": ("attention.o",), "attention_mfma": ("attention.o",), "attention_mfma16": ("attention.o",), "attnblock": ("attention.o",),
                   "groupnorm": ("norm_softmax.o",), "layernorm": ("norm_softmax.o",), "vq": ("vq.o",)}

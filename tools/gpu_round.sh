@@ -1,5 +1,6 @@
 #!/bin/bash
-# One gpurun call: GPU tests, bench (+shape table), rocprofv3 kernel stats, PMC passes (MFMA + traffic).
+# One gpurun call: GPU tests, rocprofv3 kernel stats, PMC passes (MFMA + traffic) and their summaries, THEN the bench (+shape table) -- so that the bench record
+# quotes counters of its own build and box (round 5's record carried `traffic: null` because the order was the other way round).
 # usage: tools/gpu_round.sh <tag> [tests|notests] [pmc|nopmc] [extra bench args...]
 TAG=${1:-r02a}; TESTS=${2:-tests}; PMC=${3:-pmc}; shift 3 || true
 OUT=$PWD/gpurun_out; mkdir -p $OUT; R0=$PWD
@@ -8,17 +9,6 @@ if [ "$TESTS" = "tests" ]; then
   timeout 3000 python -m pytest tests -m gpu -x -q > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_$TAG.log
   tail -5 $OUT/pytest_$TAG.log
 fi
-timeout 900 python bench.py --dump-shapes $OUT/shapes_$TAG.txt "$@" > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$?"
-python - <<PY
-import json
-try:
-    j = json.loads([l for l in open("$OUT/bench_$TAG.json") if l.startswith("{")][-1])
-    print("fps", j["value"], "ms/step", j["ms_per_step"], "roofline", {k: j.get("roofline", {}).get(k) for k in ("achieved", "frac", "achieved_algorithmic", "share_of_step_time")},
-          "pcie", j.get("value_incl_pcie"), "cons", j.get("batch_consistency", {}).get("max_lsb_vs_b1"), "cpu", (j.get("cpu_baseline") or {}).get("value"))
-except Exception as e:
-    print("bench parse failed", e)
-PY
-head -12 $OUT/shapes_$TAG.txt
 BENCH="python $PWD/bench.py --steps 2 --warmup 1 --profile-only $@"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_$TAG; timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o run --output-format csv -- $BENCH > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
@@ -32,6 +22,23 @@ if [ "$PMC" = "pmc" ]; then
   # summarised HERE, on the library these counters were taken on (the JSON carries its per-object build digests; bench.py refuses a mismatch)
   python $R0/tools/pmc_traffic.py $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG $OUT/traffic_pmc_$TAG.json > /dev/null 2>&1; echo "traffic summary rc=$?"
   python $R0/tools/pmc_mfma.py $OUT/pmc_mfma_$TAG $OUT/mfma_pmc_$TAG.json "$BENCH" > /dev/null 2>&1; echo "mfma summary rc=$?"
+  # the bench below quotes THESE counters (same library build, same box): profiles/<round>_{traffic,mfma}_pmc[_bf16].json
+  RT=${TAG%%_*}; SFX=""; case "$TAG" in *_bf16) SFX="_bf16";; esac
+  cp $OUT/traffic_pmc_$TAG.json $R0/profiles/${RT}_traffic_pmc$SFX.json; cp $OUT/mfma_pmc_$TAG.json $R0/profiles/${RT}_mfma_pmc$SFX.json
 fi
+cd $R0
+
+cd $R0
+timeout 900 python bench.py --dump-shapes $OUT/shapes_$TAG.txt "$@" > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$?"
+python - <<PY
+import json
+try:
+    j = json.loads([l for l in open("$OUT/bench_$TAG.json") if l.startswith("{")][-1])
+    print("fps", j["value"], "ms/step", j["ms_per_step"], "roofline", {k: j.get("roofline", {}).get(k) for k in ("achieved", "frac", "achieved_algorithmic", "share_of_step_time")},
+          "pcie", j.get("value_incl_pcie"), "cons", j.get("batch_consistency", {}).get("max_lsb_vs_b1"), "cpu", (j.get("cpu_baseline") or {}).get("value"))
+except Exception as e:
+    print("bench parse failed", e)
+PY
+head -12 $OUT/shapes_$TAG.txt
 find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} head -12 {} | cut -c1-160
 du -sh $OUT/prof_$TAG
