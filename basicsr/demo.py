@@ -67,7 +67,8 @@ def read_clip(path):
         names = sorted(n for n in os.listdir(path) if n.lower().endswith(FRAME_EXT))
         if not names:
             raise RuntimeError(f"{path}: no PNG frames")
-        frames = [read_rgb(osp.join(path, n)) for n in names]
+        from synergize_motion_appearance_amd.png import pool
+        frames = list(pool().map(read_rgb, [osp.join(path, n) for n in names]))     # decoded on the codec thread pool
         if len({f.shape for f in frames}) != 1:
             raise RuntimeError(f"{path}: frames differ in size")
         return np.stack(frames), DEFAULT_FPS
@@ -85,6 +86,39 @@ def read_clip(path):
         pass
     reader.close()
     return np.stack(frames), fps
+
+
+def clip_loaders(path):
+    """a folder of PNG frames -> (zero-argument loaders in name order, frame (H, W)): the frames are decoded later, on the codec pool."""
+    names = sorted(n for n in os.listdir(path) if n.lower().endswith(FRAME_EXT))
+    if not names:
+        raise RuntimeError(f"{path}: no PNG frames")
+    first = read_rgb(osp.join(path, names[0]))
+    return [(lambda q=osp.join(path, n): read_rgb(q)) for n in names], first.shape[:2]
+
+
+@torch.no_grad()
+def animate_folder(net_g, me, source_rgb, frames_dir, out_dir, relative, adapt_scale, anchor=0, batch=60, level=1):
+    """folder of PNG driving frames -> folder of PNG result frames, streaming: the frames are decoded on the codec thread pool ahead of the GPU
+    (driver.LazyFrames -> pinned staging buffers), rendered in batches, and every finished batch is handed back to the pool for encoding while
+    the next one renders (reference demo.py:166-185 reads the whole clip, :103-134 loops, :222 writes it).  -> number of frames written"""
+    from synergize_motion_appearance_amd.png import pool, write_png
+    dev = next(net_g.parameters()).device
+    loaders, hw = clip_loaders(frames_dir)
+    lazy = driver.LazyFrames(loaders, hw)
+    lazy.prefetch()
+    src = ops.frames_u8_to_nchw(torch.from_numpy(source_rgb)[None].to(dev), (256, 256))
+    first = ops.frames_u8_to_nchw(torch.from_numpy(np.ascontiguousarray(lazy.frame(anchor)))[None].to(dev), (256, 256)) if (relative or adapt_scale) else None
+    state = driver.encode_source_state(net_g, me, src, first, adapt_scale)
+    pipe = driver.FramePipeline(net_g, me, batch=min(batch, len(lazy)), frame_hw=hw, relative=relative, adapt_movement_scale=adapt_scale)
+    os.makedirs(out_dir, exist_ok=True)
+    futs = []
+    for a, chunk in pipe.stream(state, lazy):
+        arr = chunk.numpy().copy()                              # the pinned buffer is recycled two batches later
+        futs += [pool().submit(write_png, osp.join(out_dir, f"{a + i:06d}.png"), arr[i], level) for i in range(arr.shape[0])]
+    for f in futs:
+        f.result()
+    return len(futs)
 
 
 def load_checkpoint(net, path, strict=True, key="params"):
@@ -134,6 +168,18 @@ def main(argv=None):
     dev = torch.device("cuda", torch.cuda.current_device())
     net_g, me = build_from_config(config, dev)
     source = read_rgb(opt.source_image)
+    try:
+        import imageio  # noqa: F401
+        have_imageio = True
+    except ImportError:
+        have_imageio = False
+    if osp.isdir(opt.driving_video) and not have_imageio and opt.visual_video is None:
+        # PNG folder in, PNG folder out: the streaming path (decode | H2D | render | D2H | encode overlapped)
+        anchor = 0 if opt.best_frame is None else int(opt.best_frame)
+        out_dir = str(opt.result_video) + ".frames"
+        n = animate_folder(net_g, me, source, opt.driving_video, out_dir, opt.relative, opt.adapt_scale, anchor, opt.batch)
+        print(f"{n} frames -> {out_dir}")
+        return None
     clip, fps = read_clip(opt.driving_video)
     anchor = 0 if opt.best_frame is None else int(opt.best_frame)
     if not 0 <= anchor < len(clip):

@@ -179,6 +179,11 @@ int smx_winograd_conv3x3_sft_f32(const float* x, int lda, const float* u_packed,
                                  const float* dec, int lddec, const float* scale, int ldscale, float w,
                                  float* y, int ldc, int B, int H, int W, int Cin, int Cout,
                                  float* stats_part, void* stream);
+/* Host-side (no device work): PNG scanline reconstruction, filter types 0-4 of RFC 2083, 8 bits per sample -- the inner loop of the frame reader either
+ * side of the animation loop (reference basicsr/demo.py:166-185 reads the clip; the in-tree codec is synergize_motion_appearance_amd/png.py).  raw: h rows of
+ * (1 filter byte + stride bytes) = the inflated IDAT stream; out: h rows of stride bytes; bpp = bytes per pixel.  Called through ctypes it runs
+ * without the interpreter lock (driver.LazyFrames decodes on a thread pool). */
+int smx_png_unfilter_u8(const uint8_t* raw, int h, int stride, int bpp, uint8_t* out);
 /* The same two convolutions on the BF16 matrix pipe with fp32-grade arithmetic ("bf16x6", csrc/winograd_bf3.hip): every fp32 operand is
  * split exactly into three bf16 values (U at pack time, the transformed input in registers) and a product is the six bf16 MFMA products
  * down to 2^-24 -- same call sites (/root/reference/basicsr/archs/vqgan_arch.py:168-191, appmotioncodebook_arch.py:49-51), same

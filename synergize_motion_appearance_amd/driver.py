@@ -314,6 +314,46 @@ def _host_copy(dst, src):
         dst.copy_(src)
 
 
+class LazyFrames:
+    """A driving clip that is still being decoded: `loaders` are zero-argument callables returning uint8 RGB [H,W,3] arrays (e.g. PNG files of a folder);
+    they run on the codec thread pool (png.pool()) a bounded number of batches ahead of the consumer, and `copy_into` fills a (pinned) staging buffer
+    with frames [a, a + n) as FramePipeline.stream asks for them -- decode, H2D copy, rendering and the D2H copy of different batches overlap."""
+
+    def __init__(self, loaders, frame_hw, ahead=192):
+        from .png import pool
+        self.loaders, self.hw, self.ahead = list(loaders), tuple(frame_hw), int(ahead)
+        self.shape = (len(self.loaders), self.hw[0], self.hw[1], 3)
+        self._pool, self._futs, self._next = pool(), {}, 0
+
+    def __len__(self):
+        return len(self.loaders)
+
+    def _submit_to(self, upto):
+        upto = min(upto, len(self.loaders))
+        while self._next < upto:
+            self._futs[self._next] = self._pool.submit(self.loaders[self._next])
+            self._next += 1
+
+    def prefetch(self, n=None):
+        self._submit_to(self.ahead if n is None else n)
+
+    def frame(self, i):
+        self._submit_to(i + 1)
+        f = self._futs[i].result()
+        img = np.asarray(f)
+        img = np.repeat(img[:, :, None], 3, 2) if img.ndim == 2 else img[..., :3]
+        if tuple(img.shape[:2]) != self.hw:
+            raise ValueError(f"frame {i} is {img.shape[:2]}, the clip is {self.hw}")
+        return img
+
+    def copy_into(self, dst, a, n):
+        self._submit_to(a + n + self.ahead)
+        d = dst.numpy()
+        for i in range(n):
+            d[i] = self.frame(a + i)
+            self._futs.pop(a + i, None)
+
+
 class FramePipeline:
     """N3 -- the host I/O around the loop (demo.py:166-185 in, :222 out) as an MI355X pipeline: uint8 driving frames leave
     pinned host memory one byte per sample, are resized / normalised ON the device, rendered in batches, and the uint8 result
@@ -381,9 +421,11 @@ class FramePipeline:
     def stream(self, state: SourceState, frames):
         """generator: yields (start_index, uint8 host tensor [n,256,256,3]) per batch, in order.  The yielded tensor is a view
         of a pinned staging buffer that is recycled two batches later: copy it if it must outlive that."""
-        frames = torch.as_tensor(frames)
-        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3 or tuple(frames.shape[1:3]) != self.hw:
-            raise ValueError(f"frames must be uint8 [N,{self.hw[0]},{self.hw[1]},3], got {frames.dtype} {tuple(frames.shape)}")
+        lazy = isinstance(frames, LazyFrames)
+        if not lazy:
+            frames = torch.as_tensor(frames)
+        if (not lazy and (frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3)) or tuple(frames.shape[1:3]) != self.hw:
+            raise ValueError(f"frames must be uint8 [N,{self.hw[0]},{self.hw[1]},3], got {getattr(frames, 'dtype', 'lazy')} {tuple(frames.shape)}")
         N, B = frames.shape[0], self.B
         cur = torch.cuda.current_stream(self.dev)
         # the staging buffers came from the caching allocator, whose reuse is only ordered on the stream that allocated them:
@@ -397,7 +439,10 @@ class FramePipeline:
             a, n, k = i * B, min(B, N - i * B), i & 1
             if in_free[k] is not None:
                 in_free[k].synchronize()                         # compute has consumed the device copy staged from this host buffer
-            _host_copy(self.pin_in[k][:n], frames[a:a + n])      # host memcpy into pinned memory (a decoder would write here directly)
+            if lazy:
+                frames.copy_into(self.pin_in[k][:n], a, n)       # the decoders' output goes straight into pinned memory
+            else:
+                _host_copy(self.pin_in[k][:n], frames[a:a + n])  # host memcpy into pinned memory
             with torch.cuda.stream(self.s_h2d):
                 self.dev_in[k][:n].copy_(self.pin_in[k][:n], non_blocking=True)
                 h2d = torch.cuda.Event()
@@ -426,7 +471,8 @@ class FramePipeline:
 
     def run(self, state: SourceState, frames, out=None):
         """all frames -> one uint8 host tensor [N,256,256,3] (`out` may be a preallocated, e.g. pinned, destination)."""
-        frames = torch.as_tensor(frames)
+        if not isinstance(frames, LazyFrames):
+            frames = torch.as_tensor(frames)
         if out is None:
             out = torch.empty((frames.shape[0], self.img, self.img, 3), dtype=torch.uint8)
         for a, chunk in self.stream(state, frames):

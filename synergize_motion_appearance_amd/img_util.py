@@ -101,12 +101,11 @@ def mimsave(visualizations, file_path, auto_mkdir=True, fps=None):
     try:
         import imageio
     except ImportError:
-        from .png import encode_png
+        from .png import encode_many
         d = str(file_path) + ".frames"
         os.makedirs(d, exist_ok=True)
-        for i, fr in enumerate(visualizations):
-            with open(os.path.join(d, f"{i:06d}.png"), "wb") as f:
-                f.write(encode_png(np.asarray(fr)))
+        frames = list(visualizations)
+        encode_many(frames, [os.path.join(d, f"{i:06d}.png") for i in range(len(frames))])     # on the codec thread pool (zlib releases the interpreter lock)
         return d
     return imageio.mimwrite(file_path, visualizations, **({} if fps is None else {"fps": fps}))
 

@@ -554,14 +554,18 @@ def test_round5_measurement_plumbing_host_side():
     import bench
     from synergize_motion_appearance_amd import lib as L
     prof = os.path.join(REPO, "profiles")
-    for name in ("r05_traffic_pmc.json", "r05_traffic_pmc_bf16.json", "r05_mfma_pmc.json", "r05_mfma_pmc_bf16.json"):
+    names = [f"{tag}_{kind}_pmc{sfx}.json" for tag in ("r05", bench.PROFILE_TAG) for kind in ("traffic", "mfma") for sfx in ("", "_bf16")]
+    names = [n for n in dict.fromkeys(names) if os.path.exists(os.path.join(prof, n))]
+    assert len(names) >= 4
+    for name in names:
         j = json.load(open(os.path.join(prof, name)))
         fams = j.get("families") or j.get("kernels")
         assert fams and isinstance(j.get("library_build"), dict) and j["library_build"], name
         for f in fams:
             objs = bench.FAMILY_OBJECTS.get(f)
             assert objs, (name, f)
-            assert all(o in j["library_build"] for o in objs), (name, f, objs)
+            # (round 5's summaries predate csrc/winograd_bf3.hip: its object is only asked of the summaries taken since)
+            assert all(o in j["library_build"] for o in objs if not (name.startswith("r05_") and o == "winograd_bf3.o")), (name, f, objs)
     lib = L.load()
     for knob, want in (("gemm_loader", 1), ("wino_ws", 0), ("wino_stagger", 0), ("wino_wide", 1)):
         v = C.c_int(-99)
@@ -586,3 +590,39 @@ def test_reduce_plan_discards_a_recording_that_did_not_finish():
     rp.finish()                                          # a recording that ran to its end
     rp.begin(tp)
     assert rp.replay and len(rp.segs) == 1
+
+
+def test_png_codec_native_unfilter_equals_the_python_restatement():
+    """png.decode_png through the library's scanline loop (smx_png_unfilter_u8: runs without the interpreter lock on the codec thread pool) on a stream that
+    uses all five filter types == the numpy / Python restatement == the image; encode -> decode round trip; the threaded folder helpers."""
+    import struct
+    import tempfile
+    import zlib
+    from synergize_motion_appearance_amd import png
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 255, (21, 17, 3), dtype=np.uint8)
+    assert np.array_equal(png.decode_png(png.encode_png(img, level=1)), img)
+    h, w, c = img.shape
+    rows, prev = [], np.zeros(w * c, np.int32)
+    for y in range(h):
+        line, ft = img[y].reshape(-1).astype(np.int32), y % 5
+        out = np.zeros_like(line)
+        for x in range(w * c):
+            a, b, cc = (line[x - c] if x >= c else 0), prev[x], (prev[x - c] if x >= c else 0)
+            pp = a + b - cc
+            pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - cc)
+            pred = [0, a, b, (a + b) >> 1, a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)][ft]
+            out[x] = (line[x] - pred) & 255
+        rows.append(bytes([ft]) + out.astype(np.uint8).tobytes())
+        prev = line
+    raw = b"".join(rows)
+    blob = png._SIG + png._chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + png._chunk(b"IDAT", zlib.compress(raw)) + png._chunk(b"IEND", b"")
+    assert np.array_equal(png.decode_png(blob), img)
+    r = np.frombuffer(raw, np.uint8).reshape(h, 1 + w * c)
+    assert np.array_equal(png._unfilter_py(r, h, w * c, c).reshape(h, w, c), img)
+    with tempfile.TemporaryDirectory() as d:
+        frames = [rng.integers(0, 255, (8, 9, 3), dtype=np.uint8) for _ in range(7)]
+        paths = [os.path.join(d, f"{i:03d}.png") for i in range(7)]
+        png.encode_many(frames, paths)
+        back = png.decode_many(paths)
+        assert all(np.array_equal(a, b) for a, b in zip(frames, back))
