@@ -98,10 +98,11 @@ def clip_loaders(path):
 
 
 @torch.no_grad()
-def animate_folder(net_g, me, source_rgb, frames_dir, out_dir, relative, adapt_scale, anchor=0, batch=60, level=1):
+def animate_folder(net_g, me, source_rgb, frames_dir, out_dir, relative, adapt_scale, anchor=0, batch=60, level=1, pipe=None):
     """folder of PNG driving frames -> folder of PNG result frames, streaming: the frames are decoded on the codec thread pool ahead of the GPU
     (driver.LazyFrames -> pinned staging buffers), rendered in batches, and every finished batch is handed back to the pool for encoding while
-    the next one renders (reference demo.py:166-185 reads the whole clip, :103-134 loops, :222 writes it).  -> number of frames written"""
+    the next one renders (reference demo.py:166-185 reads the whole clip, :103-134 loops, :222 writes it).  `pipe`: a FramePipeline to reuse (a server
+    animating clip after clip keeps its captured hipGraph and staging buffers).  -> number of frames written"""
     from synergize_motion_appearance_amd.png import pool, write_png
     dev = next(net_g.parameters()).device
     loaders, hw = clip_loaders(frames_dir)
@@ -110,7 +111,8 @@ def animate_folder(net_g, me, source_rgb, frames_dir, out_dir, relative, adapt_s
     src = ops.frames_u8_to_nchw(torch.from_numpy(source_rgb)[None].to(dev), (256, 256))
     first = ops.frames_u8_to_nchw(torch.from_numpy(np.ascontiguousarray(lazy.frame(anchor)))[None].to(dev), (256, 256)) if (relative or adapt_scale) else None
     state = driver.encode_source_state(net_g, me, src, first, adapt_scale)
-    pipe = driver.FramePipeline(net_g, me, batch=min(batch, len(lazy)), frame_hw=hw, relative=relative, adapt_movement_scale=adapt_scale)
+    if pipe is None:
+        pipe = driver.FramePipeline(net_g, me, batch=min(batch, len(lazy)), frame_hw=hw, relative=relative, adapt_movement_scale=adapt_scale)
     os.makedirs(out_dir, exist_ok=True)
     futs = []
     for a, chunk in pipe.stream(state, lazy):

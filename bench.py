@@ -865,20 +865,25 @@ def main():
                     os.makedirs(din)
                     frames = u8.numpy()
                     encode_many(list(frames), [os.path.join(din, f"{i:06d}.png") for i in range(CLIP)], level=1)
+                    nrep = max(1, min(K * B, 1200) // CLIP)                                  # like value_incl_pcie: the clip again and again (hard links of the same files)
+                    for r_ in range(1, nrep):
+                        for i in range(CLIP):
+                            os.link(os.path.join(din, f"{i:06d}.png"), os.path.join(din, f"{r_ * CLIP + i:06d}.png"))
                     s8 = ops.to_uint8(src_cpu[None].to(dev).permute(0, 2, 3, 1).contiguous(), -1.0, 1.0)[0].cpu().numpy()
-                    bsz = min(B, 100)
-                    animate_folder(net_g, me, s8, din, dout, True, True, 0, bsz)           # warm: graph capture at this batch, codec pool
+                    bsz = min(B, 60)
+                    fpipe = driver.FramePipeline(net_g, me, batch=bsz, frame_hw=(px, px))
+                    animate_folder(net_g, me, s8, din, dout, True, True, 0, bsz, pipe=fpipe)           # warm: graph capture at this batch, codec pool
                     best = None
                     for _ in range(2):
                         shutil.rmtree(dout)
                         torch.cuda.synchronize()
                         t2 = time.perf_counter()
-                        n = animate_folder(net_g, me, s8, din, dout, True, True, 0, bsz)
+                        n = animate_folder(net_g, me, s8, din, dout, True, True, 0, bsz, pipe=fpipe)
                         dt3 = time.perf_counter() - t2
                         best = dt3 if best is None else min(best, dt3)
                     result["value_file_to_file"] = round(n / best, 3)
-                    result["value_file_to_file_note"] = (f"frames/s from a folder of {CLIP} PNG driving frames to a folder of PNG result frames through basicsr/demo.py's streaming path "
-                                                         f"(animate_folder: source encode included, batch {bsz}, {default_workers()} codec threads, zlib level 1, RAM-backed directory); "
+                    result["value_file_to_file_note"] = (f"frames/s from a folder of {nrep * CLIP} PNG driving frames (the {CLIP}-frame clip x {nrep}) to a folder of PNG result frames through basicsr/demo.py's streaming path "
+                                                         f"(animate_folder on a reused FramePipeline: source encode, pipeline fill and drain included, batch {bsz}, {default_workers()} codec threads, zlib level 1, RAM-backed directory); "
                                                          "best of 2")
                 finally:
                     shutil.rmtree(root, ignore_errors=True)

@@ -37,13 +37,14 @@ if "--from-png" in sys.argv:
         din, dout = os.path.join(root, "in"), os.path.join(root, "out")
         os.makedirs(din)
         encode_many(list(u8), [os.path.join(din, f"{i:06d}.png") for i in range(n)], level=1)
-        animate_folder(net_g, me, s8, din, dout, True, True, 0, B)          # warm: graph capture, pools
+        pipe = driver.FramePipeline(net_g, me, batch=B, frame_hw=(256, 256))
+        animate_folder(net_g, me, s8, din, dout, True, True, 0, B, pipe=pipe)          # warm: graph capture, pools
         ts = []
         for _ in range(3):
             shutil.rmtree(dout)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            animate_folder(net_g, me, s8, din, dout, True, True, 0, B)
+            animate_folder(net_g, me, s8, din, dout, True, True, 0, B, pipe=pipe)
             ts.append(time.perf_counter() - t0)
         print(f"{dt}: folder -> folder, {n} frames, batch {B}, {default_workers()} codec threads: {n / min(ts):.1f} frames/s (best of 3; {[round(n / t, 1) for t in ts]})")
     finally:
