@@ -305,26 +305,35 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
     const float* pba = smem + (lbase + (buf * B3_REGION_F + oa[f][1]));
     const float* pab = smem + (lbase + (buf * B3_REGION_F + ob[f][0]));
     const float* pbb = smem + (lbase + (buf * B3_REGION_F + ob[f][1]));
-    // one channel quad at a time (four patch reads -> four values of V -> their three bf16 levels), fenced: left alone the scheduler hoists all
-    // sixteen reads of the phase to its top (64 registers the kernel does not have)
+    // one channel quad at a time (four patch reads -> four values of V -> their three bf16 levels), with the NEXT quad's reads issued before this quad's
+    // arithmetic (an in-order wave that reads and then waits pays the LDS round trip once per quad: four times a phase); fenced, because left alone
+    // the scheduler hoists all sixteen reads of the phase to its top (64 registers the kernel does not have)
+    constexpr int NQ = 2 * MT;
+    f32x4 rd[2][4];
+    auto quad_reads = [&](int q, f32x4 (&d)[4]) __attribute__((always_inline)) {
+      const int m = q >> 1, e2 = q & 1;
+      const int o = (sub * 4 + e2) * B3_PLANE * 4 + m * (4 * 2 * 2 * 9 * 4);
+      d[0] = *reinterpret_cast<const f32x4*>(paa + o); d[1] = *reinterpret_cast<const f32x4*>(pba + o);
+      d[2] = *reinterpret_cast<const f32x4*>(pab + o); d[3] = *reinterpret_cast<const f32x4*>(pbb + o);
+    };
+    quad_reads(0, rd[0]);
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int q = 0; q < NQ; ++q) {
+      const int m = q >> 1, e2 = q & 1;
+      if (q + 1 < NQ) quad_reads(q + 1, rd[(q + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 (&d)[4] = rd[q & 1];
+      float v[4];
 #pragma unroll
-      for (int e2 = 0; e2 < 2; ++e2) {
-        const int o = (sub * 4 + e2) * B3_PLANE * 4 + m * (4 * 2 * 2 * 9 * 4);
-        const f32x4 daa = *reinterpret_cast<const f32x4*>(paa + o), dba = *reinterpret_cast<const f32x4*>(pba + o);
-        const f32x4 dab = *reinterpret_cast<const f32x4*>(pab + o), dbb = *reinterpret_cast<const f32x4*>(pbb + o);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float ta = fmaf(sr, dba[e], daa[e]), tb = fmaf(sr, dbb[e], dab[e]);
-          v[e] = fmaf(scj[f], tb, ta);
-        }
-        unsigned h2[2], m2[2], l2[2];
-        b3_split4<NS>(v, h2, m2, l2);
-        vh[m][2 * e2] = h2[0]; vh[m][2 * e2 + 1] = h2[1]; vm[m][2 * e2] = m2[0]; vm[m][2 * e2 + 1] = m2[1]; vl[m][2 * e2] = l2[0]; vl[m][2 * e2 + 1] = l2[1];
-        __builtin_amdgcn_sched_barrier(0);
+      for (int e = 0; e < 4; ++e) {
+        const float ta = fmaf(sr, d[1][e], d[0][e]), tb = fmaf(sr, d[3][e], d[2][e]);
+        v[e] = fmaf(scj[f], tb, ta);
       }
+      unsigned h2[2], m2[2], l2[2];
+      b3_split4<NS>(v, h2, m2, l2);
+      vh[m][2 * e2] = h2[0]; vh[m][2 * e2 + 1] = h2[1]; vm[m][2 * e2] = m2[0]; vm[m][2 * e2 + 1] = m2[1]; vl[m][2 * e2] = l2[0]; vl[m][2 * e2 + 1] = l2[1];
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #ifndef B3_PRIO
 #define B3_PRIO 1     // 1: MFMA block at priority 1 (shipped), 0: no priority changes, 2: the transform at priority 1 instead
 #endif
@@ -347,19 +356,20 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
 
   // ---- prologue ------------------------------------------------------------------------------------------------------------------------
   const int nsl = p.Cin >> 5;
-  if (loader) {
-    const float* sp = p.in_ss + (long long)img * p.Cin * 2;
-    for (int i = tid; i < p.Cin / 2; i += 512) *reinterpret_cast<float4*>(ss_lds + i * 4) = *reinterpret_cast<const float4*>(sp + i * 4);
-  }
-  __syncthreads();                                                                          // ss_lds complete
   {
+    // one memory round trip, not three: the first region, the first fragments and the GroupNorm scale / shift table are all requested before anything waits
     f32x4 pr[3][2];
 #pragma unroll
     for (int ph = 0; ph < NSET; ++ph) issue_items(pr[ph], ph, 0);
+    request_u(0, 0);
+    if (loader) {
+      const float* sp = p.in_ss + (long long)img * p.Cin * 2;
+      for (int i = tid; i < p.Cin / 2; i += 512) *reinterpret_cast<float4*>(ss_lds + i * 4) = *reinterpret_cast<const float4*>(sp + i * 4);
+    }
+    __syncthreads();                                                                        // ss_lds complete
 #pragma unroll
     for (int ph = 0; ph < NSET; ++ph) store_region(pr[ph], ph, 0, 0);
   }
-  request_u(0, 0);
   __syncthreads();
 
   // Vector-memory program of a phase p -- every request unconditional, in this order:

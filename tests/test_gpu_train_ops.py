@@ -580,6 +580,8 @@ def test_batched_split_reduce_equals_the_per_layer_launches(T):
         if pieces == 2:
             tp.backward(stop_at=cut)
         tp.backward()
+        if plan is not None:
+            plan.finish()                                  # what the trainer does at the end of a step that ran through (only such a recording is replayed)
         torch.cuda.synchronize()
         return {k: v.clone() for k, v in G.items()}
     ref = run(None)
