@@ -42,6 +42,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef B3_ABL
+#define B3_ABL 0      // tools builds only (tools/wino_bf3_{trace,ablate}.sh; WRONG results by design): timing-only ablation mask -- 1 no transform / split, 2 no MFMAs, 4 no region loads,
+#endif                // 8 no U requests, 16 no epilogue; 64: s_memtime stamps of the block's phases written over the GroupNorm partials
+
 // Two block shapes, MT x NT = 4 MFMA tiles per frequency and wave either way:
 //   MT = 2: 16 x 16 pixels x  64 channels (any C_out % 64 == 0)                         -- region 18 x 18 pixels
 //   MT = 1:  8 x 16 pixels x 128 channels (C_out % 128 == 0): the input transform + split, the GroupNorm of the staging and the patch reads are
@@ -152,6 +156,9 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   float* ss_lds = reinterpret_cast<float*>(smem_b + 2 * B3_REGION_B);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long tstamp[5] = {0, 0, 0, 0, 0};
+  auto mark = [&](int k) __attribute__((always_inline)) { if (B3_ABL & 64) tstamp[k] = __builtin_readcyclecounter(); };
+  mark(0);
   const int fi = wave >> 1, jh = wave & 1;
   const int hh = lane >> 5, t = lane & 31;
   const int trl = t >> 3, tc = b3_tile_col(t);
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
     for (int q = 0; q < 2; ++q) {
       int iy = min(max(y0 - 1 + 3 * (2 * ph + q) + r3, 0), p.H - 1);
       if (p.up2) iy >>= 1;
-      rg[q] = b3_load16(RX, (unsigned)(iy * Ws * p.lda + gcol) * 4u, 0u);
+      if (B3_ABL & 4) rg[q] = f32x4{1.f, 2.f, 3.f, 4.f}; else rg[q] = b3_load16(RX, (unsigned)(iy * Ws * p.lda + gcol) * 4u, 0u);
     }
   };
   auto store_items = [&](const f32x4 (&rg)[2], int ph, float* rb, int c0, auto mode, auto inside) __attribute__((always_inline)) {
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3)
-        if (s3 < NS) ur[n][s3] = b3_load16(RU, lane16, ubase[f][n] + so + (unsigned)s3 * 1024u);
+        if (s3 < NS) { if (B3_ABL & 8) ur[n][s3] = f32x4{1.f, 1.f, 1.f, 1.f}; else ur[n][s3] = b3_load16(RU, lane16, ubase[f][n] + so + (unsigned)s3 * 1024u); }
         else ur[n][s3] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
@@ -316,10 +323,11 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
       d[0] = *reinterpret_cast<const f32x4*>(paa + o); d[1] = *reinterpret_cast<const f32x4*>(pba + o);
       d[2] = *reinterpret_cast<const f32x4*>(pab + o); d[3] = *reinterpret_cast<const f32x4*>(pbb + o);
     };
-    quad_reads(0, rd[0]);
+    if (!(B3_ABL & 1)) quad_reads(0, rd[0]);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int m = q >> 1, e2 = q & 1;
+      if (B3_ABL & 1) { vh[m][2 * e2] = 0x3f803f80u + m; vh[m][2 * e2 + 1] = 0x3f803f80u + q; vm[m][2 * e2] = 0x3c003c00u; vm[m][2 * e2 + 1] = 0x3c003c00u + q; vl[m][2 * e2] = 0x38003800u; vl[m][2 * e2 + 1] = 0x38003800u + m; continue; }
       if (q + 1 < NQ) quad_reads(q + 1, rd[(q + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       const f32x4 (&d)[4] = rd[q & 1];
@@ -345,7 +353,8 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[f][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3_frag(ur[n][us]), b3_frag(make_uint4(vv[m][0], vv[m][1], vv[m][2], vv[m][3])), acc[f][m][n], 0, 0, 0);
+          if (B3_ABL & 2) acc[f][m][n][0] += __uint_as_float(vv[m][0]) * ur[n][us].x;
+          else acc[f][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3_frag(ur[n][us]), b3_frag(make_uint4(vv[m][0], vv[m][1], vv[m][2], vv[m][3])), acc[f][m][n], 0, 0, 0);
     };
     if (NPROD == 6) { prod(vl, 0); prod(vh, 2); prod(vm, 1); }
     prod(vm, 0); prod(vh, 1); prod(vh, 0);
@@ -372,6 +381,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   }
   __syncthreads();
 
+  mark(1);
   // Vector-memory program of a phase p -- every request unconditional, in this order:
   //   transform(p) | MFMAs(p) (wait: fragments of p; the two region items requested behind them may still fly) | request U(p+1) |
   //   normalise + store the region items of phase p-1 (wait: those two; six fragment requests younger) | request the items of phase p.
@@ -396,8 +406,17 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
                                                           if (NSET > 2) { if (more) store_region(sreg, 2, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1])); } });
     __syncthreads();
   }
+  mark(2);
 #pragma unroll
   for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(ur[n][0]), "v"(ur[n][1]), "v"(ur[n][2]));   // the request past the last phase
+  if (B3_ABL & 16) { float t0 = 0.f;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) t0 += acc[f][m][n][f + 2 * m + 4 * n];
+    if (t0 == 123.456f) p.y[0] = 1.f; return; }
 
   // ---- epilogue: two passes of 32 tiles x 64 channels: pass = M tile (MT = 2) | 64-channel half of the block's 128 (MT = 1) ------------------------------------------------------------------------------------------------------
   float* zb = smem;
@@ -478,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
         } else if (Ri) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
         *reinterpret_cast<float4*>(Yi + (pix + yy * p.W + q) * p.ldc + nq) = o[yy][q];
       }
-    if (p.stats) {
+    if (p.stats && !(B3_ABL & 64)) {
       // GroupNorm partials of the consumer in the fp32 kernel's chunk format: one {mean, M2} per 8 x 16-pixel chunk (= this M tile) and channel
       const float va4[4][4] = {{o[0][0].x, o[0][0].y, o[0][0].z, o[0][0].w}, {o[1][0].x, o[1][0].y, o[1][0].z, o[1][0].w},
                                {o[0][1].x, o[0][1].y, o[0][1].z, o[0][1].w}, {o[1][1].x, o[1][1].y, o[1][1].z, o[1][1].w}};
@@ -503,6 +522,12 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
         o2[0] = a; o2[1] = b;
       }
     }
+  }
+  if ((B3_ABL & 64) && p.stats && lane == 0) {
+    mark(3);
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = tstamp[k];
   }
 }
 
