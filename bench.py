@@ -808,6 +808,10 @@ def main():
         "metric": f"reenactment frames/sec at {px}x{px}", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 3),
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "arithmetic": ("fp32 operands, fp32 accumulation everywhere; the big 3x3 convolutions multiply on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 values and "
+                       "the six products down to 2^-24 kept (csrc/winograd_bf3.hip) -- measured against fp64 their error is below the fp32-MFMA kernel's (tests/test_gpu_wino_bf3.py), "
+                       "every other contraction is fp32 MFMA / VALU" if dname == "f32" else
+                       "bf16 storage + bf16 MFMA with fp32 accumulation (keypoints / flows / normalisation statistics / softmax / output image fp32)"),
         "config": {"workload": (f"BASELINE.json configs[{cfg_ix}]: {px}x{px}, {n_src} source(s) x 300-frame driving clip, {dname}, options/test{'' if px == 256 else '_512'}.yml, "
                                 "name-keyed random-init weights"), "frames_per_step": B, "frames_total": leg["frames_total"],
                    "sources": n_src,

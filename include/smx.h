@@ -189,8 +189,11 @@ int smx_png_unfilter_u8(const uint8_t* raw, int h, int stride, int bpp, uint8_t*
  * down to 2^-24 -- same call sites (/root/reference/basicsr/archs/vqgan_arch.py:168-191, appmotioncodebook_arch.py:49-51), same
  * arguments and epilogues as smx_winograd_conv3x3_f32 / _sft_f32.  u3 = smx_winograd_bf3_pack(u_packed of the fp32 kernel):
  * [16][Cout/32][Cin/16][3 splits][64 lanes][8] bf16, smx_winograd_bf3_u_bytes bytes.  nprod: 6 (fp32-grade) or 3 (two-way split,
- * ~2^-17, for comparison only).  Shapes: smx_winograd_bf3_shape_ok (H % 16 == 0, W % 16 == 0, Cin % 32 == 0, Cin <= 512,
- * Cout % 64 == 0, every row stride % 4 == 0; all pointers 16 B-aligned); stats_part chunks are the fp32 kernel's (8 x 16 pixels). */
+ * ~2^-17, for comparison only).  Shapes: smx_winograd_bf3_shape_ok returns 0 (not eligible) or the M tiles per block the launcher
+ * will use -- 1: 8 x 16 pixels x 128 channels (Cout % 128 == 0, H % 8 == 0), 2: 16 x 16 pixels x 64 channels (Cout % 64 == 0, H % 16 == 0);
+ * always W % 16 == 0, Cin % 32 == 0, Cin <= 512, every row stride % 4 == 0, all pointers 16 B-aligned.  One 8-wave block per CU: meant
+ * for launches of >= 2 x 256 blocks (the host layer keeps smaller launches on smx_winograd_conv3x3_f32).  stats_part chunks are the
+ * fp32 kernel's (8 x 16 pixels). */
 int64_t smx_winograd_bf3_u_bytes(int Cout, int Cin);
 int smx_winograd_bf3_pack(const float* u_packed, void* u3, int Cout, int Cin, void* stream);
 int smx_winograd_bf3_shape_ok(int B, int H, int W, int Cin, int Cout, int lda, int ldc, int ldres, int ldmul);

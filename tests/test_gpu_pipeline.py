@@ -207,8 +207,14 @@ def test_bench_batch_of_60_equals_single_frame_runs(nets, B):
     src, drv = synth_clip(B, seed=123)
     src, drv = src.cuda(), drv.cuda()
     st = driver.encode_source_state(net_g, me, src, drv[0:1], True)
-    u8, fl = driver.render_frames(st, drv, net_g, me, True, True, batch=B, want="both")
+    from synergize_motion_appearance_amd import ops
+    with ops.profile() as rec:
+        u8, fl = driver.render_frames(st, drv, net_g, me, True, True, batch=B, want="both")
     assert u8.shape == (B, 256, 256, 3) and fl.shape == (B, 3, 256, 256)
+    # round 6: at these batch sizes the big 3x3 launches run on the split-bf16 Winograd kernel (the B = 1 runs below on the fp32-MFMA one): the comparison
+    # that follows is between the two arithmetic paths
+    n_bf3 = sum(1 for r in rec.rows if r[0] == "gemm_conv" and (r[1] or {}).get("bf3") == 6)
+    assert ops.WINO_BF3 == 6 and n_bf3 >= 60, n_bf3
     for i in (0, B // 2 + 1, B - 1):
         u1, f1 = driver.render_frames(st, drv[i:i + 1], net_g, me, True, True, batch=1, want="both")
         assert maxabs(fl[i:i + 1].cpu(), f1.cpu()) < 2e-4, i
@@ -385,6 +391,36 @@ def test_demo_entry_from_png_folder_end_to_end(nets, tmp_path):
         assert np.array_equal(decode_png(open(os.path.join(str(tmp_path / "res.mp4") + ".frames", written[2]), "rb").read()), out[2])
         vis = decode_png(open(os.path.join(str(tmp_path / "vis.mp4") + ".frames", written[2]), "rb").read())
         assert vis.shape == (256, 768, 3) and np.array_equal(vis[:, 512:], out[2]) and np.array_equal(vis[:, 256:512], d8[2]) and np.array_equal(vis[:, :256], s8)
+
+
+def test_demo_entry_streams_a_png_folder_to_a_png_folder(nets, tmp_path):
+    """the same entry without --visual_video: PNG folder in, PNG folder out through the streaming path (frames decoded on the codec thread pool straight into the
+    pinned staging buffers, rendered, encoded on the pool): the files it writes are exactly what `animate_batched` renders from the same uint8 inputs."""
+    import importlib.util
+    from synergize_motion_appearance_amd import ops
+    from synergize_motion_appearance_amd.driver import animate_batched
+    from synergize_motion_appearance_amd.png import encode_png, decode_png
+    net_g, me = nets
+    src, drv = clip()
+    to_u8 = lambda t: ((t.clamp(-1, 1) + 1) * 127.5).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous().numpy()
+    s8, d8 = to_u8(src[None])[0], to_u8(drv)
+    (tmp_path / "source.png").write_bytes(encode_png(s8))
+    os.makedirs(tmp_path / "drv")
+    for i, f in enumerate(d8):
+        (tmp_path / "drv" / f"{i:03d}.png").write_bytes(encode_png(f))
+    cfg = yaml.safe_load(open(os.path.join(REPO, "options/test.yml")))
+    yaml.safe_dump(cfg, open(tmp_path / "demo.yml", "w"))
+    spec = importlib.util.spec_from_file_location("smx_demo2", os.path.join(REPO, "basicsr", "demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    n = demo.animate_folder(net_g, me, s8, str(tmp_path / "drv"), str(tmp_path / "out"), True, True, anchor=2, batch=3)
+    assert n == drv.shape[0]
+    norm = lambda a: ops.frames_u8_to_nchw(torch.from_numpy(a).cuda(), (256, 256))
+    ref = animate_batched(norm(s8[None])[0], norm(d8), net_g, me, True, True, batch=3, anchor_idx=2).cpu().numpy()
+    names = sorted(os.listdir(tmp_path / "out"))
+    assert names == [f"{i:06d}.png" for i in range(n)]
+    for i, nm in enumerate(names):
+        assert np.array_equal(decode_png(open(tmp_path / "out" / nm, "rb").read()), ref[i]), i
 
 
 def test_checkpoint_like_statistics_end_to_end():
