@@ -179,6 +179,18 @@ int smx_winograd_conv3x3_sft_f32(const float* x, int lda, const float* u_packed,
                                  const float* dec, int lddec, const float* scale, int ldscale, float w,
                                  float* y, int ldc, int B, int H, int W, int Cin, int Cout,
                                  float* stats_part, void* stream);
+/* smx_gemm_rp_f32 / smx_gemm_rp_d2s_f32 on the BF16 matrix pipe with fp32-grade arithmetic (csrc/gemm_rp_bf3.hip): both operands split exactly three ways
+ * into bf16, six MFMA products per multiply (down to 2^-24), fp32 accumulation -- the arithmetic of smx_winograd_bf3_conv3x3_f32; same call sites (the token
+ * Linears of /root/reference/basicsr/archs/appmotioncodebook_arch.py:69-70, 101-115 and the other K = 128 / 256 1x1 convolutions), same arguments.
+ * wp = smx_gemm_rp_bf3_pack(w [N][ldw] fp32): [N/32][K/16][3 levels][64 lanes][8] bf16, smx_gemm_rp_bf3_pack_bytes bytes.  Shapes (smx_gemm_rp_bf3_ok):
+ * M % 32 == 0; K == 256 with N % 128 == 0, or K == 128 with N % 256 == 0; all pointers (bias too) 16 B-aligned, row strides % 4 == 0. */
+int smx_gemm_rp_bf3_ok(long long M, int N, int K);
+int64_t smx_gemm_rp_bf3_pack_bytes(int N, int K);
+int smx_gemm_rp_bf3_pack(const float* w, int ldw, void* wp, int N, int K, void* stream);
+int smx_gemm_rp_bf3(const float* a, int lda, const void* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
+                    long long M, int N, int K, int act, void* stream);
+int smx_gemm_rp_d2s_bf3(const float* a, int lda, const void* wp, const float* bias, float* c, int ldc, long long M, int N, int K, int act,
+                        int d2s_p, int d2s_c, int Ho, int Wo, void* stream);
 /* Host-side (no device work): PNG scanline reconstruction, filter types 0-4 of RFC 2083, 8 bits per sample -- the inner loop of the frame reader either
  * side of the animation loop (reference basicsr/demo.py:166-185 reads the clip; the in-tree codec is synergize_motion_appearance_amd/png.py).  raw: h rows of
  * (1 filter byte + stride bytes) = the inflated IDAT stream; out: h rows of stride bytes; bpp = bytes per pixel.  Called through ctypes it runs

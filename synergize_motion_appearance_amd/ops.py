@@ -131,7 +131,7 @@ WINOGRAD = bool(_knob("SMX_WINOGRAD", 1))
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3", "_wrp3")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -139,6 +139,7 @@ class Conv:
         self._w16 = None
         self._u43 = None
         self._u3 = None
+        self._wrp3 = None
         self._w16t = None
         self._w16rp = None
         self._wrp = None
@@ -210,6 +211,16 @@ class Conv:
             L.check(L.load().smx_gemm_rp_f32_pack(self.w.data_ptr(), self.w.shape[1], wp.data_ptr(), self.cout, self.cin, _stream()), "smx_gemm_rp_f32_pack")
             self._wrp = wp
         return self._wrp
+
+    @property
+    def w_rp3(self):
+        """the three bf16 levels of a 1x1 layer's fp32 weights in MFMA fragment order for the split-bf16 row-panel kernel (smx_gemm_rp_bf3_pack), built once per layer."""
+        if self._wrp3 is None:
+            lib = L.load()
+            wp = torch.empty(int(lib.smx_gemm_rp_bf3_pack_bytes(self.cout, self.cin)), device=self.w.device, dtype=torch.uint8)
+            L.check(lib.smx_gemm_rp_bf3_pack(_dev(self.w).data_ptr(), self.w.shape[1], wp.data_ptr(), self.cout, self.cin, _stream()), "smx_gemm_rp_bf3_pack")
+            self._wrp3 = wp
+        return self._wrp3
 
     @property
     def w16_rp(self):
@@ -329,6 +340,7 @@ CONV16_F32_REGION = _knob("SMX_CONV16_F32_REGION", 1)   # fp32-storage form of t
 
 
 GEMM_RP = _knob("SMX_GEMM_RP", 1)          # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
+GEMM_RP_BF3 = _knob("SMX_GEMM_RP_BF3", 1)  # the same launches on the bf16 MFMA with three-way split fp32 operands, six products (csrc/gemm_rp_bf3.hip); 0 = the fp32-MFMA kernel
 GEMM16_RP = _knob("SMX_GEMM16_RP", 1)      # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
 GEMM16_RP_MIN_ROWS = 16384                                           # below: too few 32-row tiles to fill the persistent blocks (tests lower it)
 
@@ -499,6 +511,7 @@ def _wino43_ok(B, H, W, cin, cout, up2, lda, ldc, ldres):
 # kernels everywhere), 3 = the two-way split (comparison only, never the fp32 configuration).  WINO_BF3_MIN_BLOCKS: 16x16-pixel x 64-channel blocks a launch must have (one block per CU).
 WINO_BF3 = _knob("SMX_WINO_BF3", 6)
 WINO_BF3_MIN_BLOCKS = 512
+GEMM_RP_BF3_MIN_ROWS = 32 * 512               # the split row-panel GEMM: persistent blocks, one per CU -- at least two 32-row tiles each
 
 
 def _wino_bf3_ok(B, H, W, cin, cout, lda, ldc, ldres, ldmul, *ptrs):
@@ -623,6 +636,20 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
         x = groupnorm_apply(x, in_ss, in_swish)
         a_ptr, lda = _pix(x, "conv input")
     M, K = B * Ho * Wo, cv.kh * cv.kw * Cin
+    rp3 = (GEMM_RP and GEMM_RP_BF3 and bf3 and not direct and tile == 0 and cv.kh == 1 and cv.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not up2
+           and (Ho, Wo) == (H, W) and M >= GEMM_RP_BF3_MIN_ROWS and L.load().smx_gemm_rp_bf3_ok(M, cv.cout, K) and lda % 4 == 0 and ldc % 4 == 0
+           and a_ptr % 16 == 0 and c_ptr % 16 == 0 and (cv.b is None or cv.b.data_ptr() % 16 == 0))
+    if rp3 and not d2s and (res is None or (ldr % 4 == 0 and r_ptr % 16 == 0)):
+        # the short-K token Linears / 1x1 convolutions of the fp32 configuration: fp32-grade products on the bf16 matrix pipe (three-way split operands)
+        meta = {"flops": 2.0 * M * cv.cout * K, "mfma_flops": 12.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "rp": 1, "bf3": 6} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_bf3, a_ptr, lda, cv.w_rp3.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       r_ptr, ldr, c_ptr, ldc, M, cv.cout, K, act, _stream()), "smx_gemm_rp_bf3")
+        return out
+    if rp3 and d2s and res is None and d2s[1] % 16 == 0:
+        meta = {"flops": 2.0 * M * cv.cout * K, "mfma_flops": 12.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "rp": 1, "bf3": 6} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_d2s_bf3, a_ptr, lda, cv.w_rp3.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       c_ptr, ldc, M, cv.cout, K, act, d2s[0], d2s[1], Ho, Wo, _stream()), "smx_gemm_rp_d2s_bf3")
+        return out
     if (GEMM_RP and not direct and tile == 0 and cv.kh == 1 and cv.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not up2 and not d2s
             and (Ho, Wo) == (H, W) and M >= GEMM16_RP_MIN_ROWS and L.load().smx_gemm_rp_f32_ok(M, cv.cout, K) and lda % 4 == 0 and ldc % 4 == 0
             and a_ptr % 16 == 0 and c_ptr % 16 == 0 and (res is None or (ldr % 4 == 0 and r_ptr % 16 == 0))):

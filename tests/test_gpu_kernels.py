@@ -301,10 +301,11 @@ def test_patch_embed_and_unpatchify(ops):
 
 @pytest.mark.parametrize("B,K,N,act,with_res,sliced", [(8, 256, 256, 0, True, False), (4, 256, 512, 4, False, True), (8, 128, 128, 0, False, False),
                                                       (4, 128, 256, 1, True, True), (5, 256, 128, 0, True, False)])
-def test_row_panel_gemm_f32(ops, B, K, N, act, with_res, sliced):
+def test_row_panel_gemm_f32(ops, monkeypatch, B, K, N, act, with_res, sliced):
     """csrc/gemm_rp_f32.hip (persistent row-panel kernel for the K = 128 / 256 1x1 layers, fp32 MFMA) against the fp64 product; bias /
     activation / residual; channel-slice views (ld > C); == the implicit GEMM to summation order; and it is the kernel that ran."""
     H = W = 64
+    monkeypatch.setattr(ops, "GEMM_RP_BF3", 0)      # this kernel, not its split-bf16 successor (tests/test_gpu_gemm_bf3.py)
     rows = ops.GEMM16_RP_MIN_ROWS
     ops.GEMM16_RP_MIN_ROWS = 1024
     try:
@@ -336,8 +337,9 @@ def test_row_panel_gemm_f32(ops, B, K, N, act, with_res, sliced):
         ops.GEMM16_RP_MIN_ROWS = rows
 
 
-def test_row_panel_gemm_f32_unpatchify_store(ops):
+def test_row_panel_gemm_f32_unpatchify_store(ops, monkeypatch):
     """the fp32 row-panel kernel with the un-patchify (depth-to-space) store == the implicit GEMM's d2s store (summation order only)."""
+    monkeypatch.setattr(ops, "GEMM_RP_BF3", 0)
     rows = ops.GEMM16_RP_MIN_ROWS
     ops.GEMM16_RP_MIN_ROWS = 1024
     try:
