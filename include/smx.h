@@ -264,6 +264,11 @@ int smx_layernorm_pos_f32(const float* x, const float* gamma, const float* beta,
 int smx_attention_f32(const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
                       const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs,
                       const uint8_t* key_mask, int B, int H, int L, int S, int dh, float scale, void* stream);
+/* Which arithmetic smx_attention_f32 takes for a launch: 0 = exact fp32 products on v_mfma_f32_32x32x2_f32 (attn_mfma_kernel), 3 / 2 = fp32-grade products on
+ * the bf16 matrix pipe (attn_bf3_kernel: q, k, v and the probabilities split exactly into three bf16 levels, six MFMA products per multiply; 2 = the
+ * probabilities on two levels, five products for P V).  d_head 32, S % 64 == 0, >= 512 blocks of 128 queries; tuning knob "attn_bf3" (3 | 2, + 16 = any
+ * launch size, 0 = off).  Same call site: nn.MultiheadAttention of /root/reference/basicsr/archs/appmotioncodebook_arch.py:69-70, 101-115. */
+int smx_attention_f32_uses_bf3(int B, int H, int L, int S, int dh);
 
 /* Row softmax in place over [R][S] (ld = row stride): softmax(scale * s + mask) with an
  * optional key-padding mask uint8 [R / rows_per_mask][S] (1 = -inf).  F.softmax at

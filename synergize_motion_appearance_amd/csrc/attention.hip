@@ -297,6 +297,182 @@ __global__ __launch_bounds__(256, 2) void attn_mfma16_kernel(AP<bf16_t> p) {
   }
 }
 
+// d_head = 32 on fp32 storage with fp32-grade products on the BF16 matrix pipe ("bf16x6", the arithmetic of csrc/winograd_bf3.hip / gemm_rp_bf3.hip): every
+// operand is split exactly three ways into bf16 (x = x1 + x2 + x3) and a product is the six bf16 MFMA products down to 2^-24.  The fp32 kernel above is
+// matrix-bound (64 fp32 MFMAs = 4096 pipe cycles per wave and 64 keys); here the same keys cost 48 bf16 MFMAs (1536 cycles) and the work moves to the VALU:
+//   * Q^T (pre-scaled by scale * log2 e in fp32, like the fp32 kernel) is split once per block into registers;
+//   * a K / V tile of 64 keys is split while it is staged (each thread 8 floats of one key of each: global -> registers one tile ahead -> three bf16 level
+//     planes in LDS; V is written transposed, in the S^T accumulator's key order, like attn_mfma16_kernel);
+//   * P^T = exp2(S^T - m) is split in registers straight from the S^T accumulators (NP = 3 levels: six products; NP = 2: P carries 16 significand bits and the
+//     PV product is five);
+//   * the S^T tiles of the two key halves alternate on the pipe; the O^T accumulation runs on two chains.
+// Softmax statistics fp32 and lane-local exactly as in the kernels above; fully masked rows give NaN like the reference.
+__device__ __forceinline__ unsigned ab3_cvt2(float a, float b) { return cvt2_bf16(a, b); }
+// eight fp32 -> NL bf16 level fragments (round to nearest even at every level)
+template <int NL>
+__device__ __forceinline__ void ab3_split8(const float (&v)[8], uint4 (&lv)[3]) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h[q] = ab3_cvt2(v[2 * q], v[2 * q + 1]);
+    const float r0 = v[2 * q] - __uint_as_float(h[q] << 16), r1 = v[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u);
+    m[q] = ab3_cvt2(r0, r1);
+    l[q] = NL > 2 ? ab3_cvt2(r0 - __uint_as_float(m[q] << 16), r1 - __uint_as_float(m[q] & 0xffff0000u)) : 0u;
+  }
+  lv[0] = make_uint4(h[0], h[1], h[2], h[3]); lv[1] = make_uint4(m[0], m[1], m[2], m[3]); lv[2] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ bf16x8 ab3_f(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <bool MASK, int NP>
+__global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AP<float> p) {
+  constexpr int DH = 32, TK = 64, KROW = DH * 2 + 16, VROW = TK * 2 + 16;  // LDS row bytes (padded)
+  constexpr int KPL = TK * KROW, VPL = DH * VROW;                         // one level plane
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][3 * KPL];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[2][3 * VPL];
+  __shared__ uint8_t Ms[2][TK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int hh = lane >> 5;
+  const float* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq + h * DH;
+  const float* K = p.k + b * p.k_bs + h * DH;
+  const float* V = p.v + b * p.v_bs + h * DH;
+  const uint8_t* M = (MASK && p.mask) ? p.mask + (long long)b * p.S : nullptr;
+
+  uint4 qf[2][3];
+  {
+    const float sc = p.scale * 1.44269504088896340736f;                   // scores in log2 units
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const float4 a0 = *reinterpret_cast<const float4*>(Q + kk * 16 + hh * 8), a1 = *reinterpret_cast<const float4*>(Q + kk * 16 + hh * 8 + 4);
+      const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+      ab3_split8<3>(v, qf[kk]);
+    }
+  }
+  f32x16 oacc, oacb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = oacb[r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  // staging: 64 keys x 4 groups of 8 floats = 256 groups of K, of V: one of each per thread
+  const int skey = threadIdx.x >> 2, sc4 = threadIdx.x & 3;
+  const int kq = skey & 15;
+  const int vcol = (skey & ~15) + (kq < 4 ? kq : kq < 8 ? kq + 4 : kq < 12 ? kq - 4 : kq);       // per 16 keys the order {0-3, 8-11, 4-7, 12-15}
+  float4 kreg[2], vreg[2]; uint8_t mreg = 0;
+  auto load_tile = [&](int key0) {
+    const float* kp = K + (long long)(key0 + skey) * p.ldk + sc4 * 8;
+    const float* vp = V + (long long)(key0 + skey) * p.ldv + sc4 * 8;
+    kreg[0] = *reinterpret_cast<const float4*>(kp); kreg[1] = *reinterpret_cast<const float4*>(kp + 4);
+    vreg[0] = *reinterpret_cast<const float4*>(vp); vreg[1] = *reinterpret_cast<const float4*>(vp + 4);
+    if (MASK && M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
+  };
+  auto store_tile = [&](int buf) {
+    {
+      const float v[8] = {kreg[0].x, kreg[0].y, kreg[0].z, kreg[0].w, kreg[1].x, kreg[1].y, kreg[1].z, kreg[1].w};
+      uint4 lv[3];
+      ab3_split8<3>(v, lv);
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) *reinterpret_cast<uint4*>(&Ks[buf][s3 * KPL + skey * KROW + sc4 * 16]) = lv[s3];
+    }
+    {
+      const float v[8] = {vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w, vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w};
+      uint4 lv[3];
+      ab3_split8<3>(v, lv);
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const uint32_t w4[4] = {lv[s3].x, lv[s3].y, lv[s3].z, lv[s3].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)                                       // transpose: V[key][8 sc4 + e] -> Vt[8 sc4 + e][col(key)]
+          *reinterpret_cast<uint16_t*>(&Vt[buf][s3 * VPL + (sc4 * 8 + e) * VROW + vcol * 2]) = (uint16_t)(e & 1 ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffffu);
+      }
+    }
+    if (MASK && threadIdx.x < TK) Ms[buf][threadIdx.x] = M ? mreg : 0;
+  };
+
+  const int ntiles = p.S / TK;
+  load_tile(0); store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile((t + 1) * TK);
+    // S^T = K Q^T for the two 32-key halves of the tile, the halves alternating on the pipe; smallest products first
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 kf[2][3];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) kf[u][s3] = *reinterpret_cast<const uint4*>(&Ks[buf][s3 * KPL + (u * 32 + (lane & 31)) * KROW + hh * 16 + kk * 32]);
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // (K level, Q level): k1q3 k3q1 k2q2 k1q2 k2q1 k1q1
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab3_f(kf[u][PA[pr]]), ab3_f(qf[kk][PB[pr]]), s[u], 0, 0, 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (MASK) {
+          const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (Ms[buf][key]) s[u][r] = -INFINITY;
+        }
+        tmax = fmaxf(tmax, s[u][r]);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const bool dead = MASK && (m_new == -INFINITY);                       // every key so far masked
+    const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
+    float psum = 0.f;
+    uint4 pf[4][3];                                                       // P^T fragments: 4 groups of 16 keys x levels
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float e[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { e[r] = dead ? 0.f : __builtin_amdgcn_exp2f(s[u][r] - m_new); psum += e[r]; }
+      // accumulator regs 0-7 = keys {0-3, 8-11} + 4 hh of the first 16, regs 8-15 = the same of the second 16
+      const float e0[8] = {e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]}, e1[8] = {e[8], e[9], e[10], e[11], e[12], e[13], e[14], e[15]};
+      ab3_split8<NP>(e0, pf[2 * u]);
+      ab3_split8<NP>(e1, pf[2 * u + 1]);
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum; m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[r] *= alpha; oacb[r] *= alpha; }
+    // O^T += V^T P^T: A = V^T rows d = lane & 31, this lane's 8 key slots of each 16-key group; two chains (the leading products / the 2^-16-class ones)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint4 vf[3];
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) vf[s3] = *reinterpret_cast<const uint4*>(&Vt[buf][s3 * VPL + (lane & 31) * VROW + hh * 16 + g * 32]);
+      if (NP > 2) oacb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab3_f(vf[0]), ab3_f(pf[g][2]), oacb, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab3_f(vf[1]), ab3_f(pf[g][0]), oacc, 0, 0, 0);
+      oacb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab3_f(vf[2]), ab3_f(pf[g][0]), oacb, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab3_f(vf[0]), ab3_f(pf[g][1]), oacc, 0, 0, 0);
+      oacb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab3_f(vf[1]), ab3_f(pf[g][1]), oacb, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab3_f(vf[0]), ab3_f(pf[g][0]), oacc, 0, 0, 0);
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  float* O = p.o + b * p.o_bs + (long long)qrow * p.ldo + h * DH;
+  const float inv = 1.f / l;                                              // l == 0 (fully masked row) -> NaN like the reference
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 w = make_float4((oacc[4 * g] + oacb[4 * g]) * inv, (oacc[4 * g + 1] + oacb[4 * g + 1]) * inv, (oacc[4 * g + 2] + oacb[4 * g + 2]) * inv,
+                           (oacc[4 * g + 3] + oacb[4 * g + 3]) * inv);
+    if (l == 0.f) w = make_float4(NAN, NAN, NAN, NAN);
+    *reinterpret_cast<float4*>(O + 8 * g + 4 * hh) = w;
+  }
+}
+
 // The vqgan AttnBlock core (archs/vqgan_arch.py:229-253: ONE head of d = C = 256 over the 32 x 32 tokens) on bf16 storage, fused:
 // softmax(q k^T / sqrt(C)) v as one kernel, the [B, N, N] score tensor never exists (the three-launch form wrote and re-read 1.26 GB of
 // fp32 scores per call at B = 300).  Same swapped-product scheme as attn_mfma16_kernel with the d axis 8 tiles wide: Q^T fragments
@@ -782,6 +958,15 @@ __global__ __launch_bounds__(256, 2) void attn_mfma4_bf16_kernel(AP<bf16_t> p) {
 
 }  // namespace
 
+/* which arithmetic smx_attention_f32 takes for this launch: 0 = exact fp32 products on the fp32 MFMA, 3 / 2 = split-bf16 (six products everywhere / P on two
+ * levels) -- knob attn_bf3 (3 | 2, + 16 = at any launch size; 0 = off), d_head 32, S % 64 == 0, at least 512 blocks of 128 queries. */
+extern "C" int smx_attention_f32_uses_bf3(int B, int H, int L, int S, int dh) {
+  const int knob = smx_tune(SMX_TUNE_ATTN_BF3), np = knob & 15;
+  if (dh != 32 || (np != 2 && np != 3) || B <= 0 || H <= 0 || L <= 0 || L % 128 || S <= 0 || S % 64) return 0;
+  if (!(knob & 16) && (long long)(L / 128) * B * H < 512) return 0;
+  return np;
+}
+
 namespace {
 template <typename T>
 int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int64_t k_bs, const T* v, int ldv, int64_t v_bs, T* o, int ldo,
@@ -820,6 +1005,13 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
       if constexpr (sizeof(T) == 2) {
         if ((ldq | ldk | ldv) % 8 || ((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return SMX_EINVAL;
         SMX_LAUNCH(attn_mfma16_kernel<32>, dim3(L / 128, B * H), dim3(256), 0, st, p);
+      }
+    }
+    else if (sizeof(T) == 4 && smx_attention_f32_uses_bf3(B, H, L, S, dh) && !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)) {
+      if constexpr (sizeof(T) == 4) {                         // fp32 storage, big launches: fp32-grade products on the bf16 matrix pipe
+        const int np = smx_attention_f32_uses_bf3(B, H, L, S, dh);
+        if (key_mask) { if (np == 2) SMX_LAUNCH((attn_bf3_kernel<true, 2>), dim3(L / 128, B * H), dim3(256), 0, st, p); else SMX_LAUNCH((attn_bf3_kernel<true, 3>), dim3(L / 128, B * H), dim3(256), 0, st, p); }
+        else { if (np == 2) SMX_LAUNCH((attn_bf3_kernel<false, 2>), dim3(L / 128, B * H), dim3(256), 0, st, p); else SMX_LAUNCH((attn_bf3_kernel<false, 3>), dim3(L / 128, B * H), dim3(256), 0, st, p); }
       }
     }
     else if (dh == 32 && !key_mask) SMX_LAUNCH((attn_mfma_kernel<T, 32, false>), dim3(L / 128, B * H), dim3(256), 0, st, p);

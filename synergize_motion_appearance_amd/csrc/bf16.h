@@ -8,6 +8,14 @@ typedef uint16_t bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// the pair (a, b) rounded to bf16 in ONE v_cvt_pk_bf16_f32 (a in the low half), as a vector conversion the compiler sees -- pack2's two scalar conversions
+// cost an instruction each, and an inline-asm v_cvt_pk_bf16_f32 is invisible to the hazard recognizer: attn_bf3_kernel<false, 2> computed garbage with it
+// (tools/scratch/attn_variant.sh), so no split kernel uses the asm form
+__device__ __forceinline__ uint32_t cvt2_bf16(float a, float b) {
+  const f32x2_t f = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   bf16x2_t v = {(__bf16)a, (__bf16)b};

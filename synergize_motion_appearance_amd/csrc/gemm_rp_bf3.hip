@@ -12,11 +12,13 @@
 //     wave's step is 3 ds_read_b128 (fetched one step ahead) + 6 MFMAs on two accumulator chains (a filler between two MFMAs on ONE accumulator stalls the
 //     pipe).  Measured against splitting in every wave straight from an fp32 LDS tile (the first form of this kernel: 44 VALU instructions per step and wave,
 //     redundant across the column tiles): 1.27x / 1.05x became 1.96x / 1.49x over the fp32-MFMA kernel on 256 -> 256 / 256 -> 1024;
+//     Also measured and kept out: an alternating schedule (two barriers per tile, the two waves of a SIMD never multiplying at the same time -- one runs its 48
+//     MFMAs while the other finishes the previous tile and splits its share of the next): 0.85x on K = 256, 1.15x on K = 128 -- one wave alone does not keep
+//     the pipe fed through its ds_read waits, two interleaved ones do;
 //   * K = 256: the two K halves of a column tile are the two waves of one SIMD and meet in the epilogue (4.5 KB LDS hand-over, one per tile parity); bias /
 //     activation / residual, 16-B stores of whole 128-B lines, optional un-patchify (depth-to-space) store as in gemm_rp_f32.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include "smx.h"
 #include "smx_common.h"
 #include "bf16.h"
@@ -48,11 +50,7 @@ __device__ __forceinline__ float rpb_act(float v, int act) {
   }
 }
 
-__device__ __forceinline__ unsigned rpb_cvt2(float a, float b) {       // one v_cvt_pk_bf16_f32 per pair (opaque: hipcc would convert the even element twice)
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+__device__ __forceinline__ unsigned rpb_cvt2(float a, float b) { return cvt2_bf16(a, b); }   // one v_cvt_pk_bf16_f32 per pair
 // eight fp32 values -> their three bf16 levels (round to nearest even at every level), as three MFMA fragments
 __device__ __forceinline__ void rpb_split8(const float (&v)[8], uint4& hi, uint4& mid, uint4& lo) {
   unsigned h[4], m[4], l[4];
@@ -160,8 +158,11 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_bf3_kernel(RPB p) {
       acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][1]), rpb_frag(xm), acb, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xh), acc, 0, 0, 0);
       // the next tile's levels, under this tile's MFMAs (the registers were loaded a whole tile ago)
-      if (GPT == 2 ? (i == 2 || i == 5) : (i == 3)) split_store(GPT == 2 ? (i == 5) : 0, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);       // steps stay in this order: reads of step i + 1 ahead of the MFMAs of step i
+      if (GPT == 2 ? (i == 2 || i == 5) : (i == 3)) {
+        split_store(GPT == 2 ? (i == 5) : 0, buf ^ 1);      // one block between two steps (which steps does not matter: measured)
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (t + 2 * gx < p.tiles) fetch(t + 2 * gx);
 #pragma unroll
@@ -211,180 +212,6 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_bf3_kernel(RPB p) {
   }
 }
 
-// The alternating schedule: the two waves of a SIMD (w and w + 4) never multiply at the same time.  A tile period is two half-phases split by barriers: in the
-// first the upper four waves run their 48 MFMAs with the matrix pipe to themselves while the lower four finish the PREVIOUS tile (hand-over add, transpose,
-// bias / activation / residual, stores) and split their share of the NEXT tile into LDS; in the second the roles swap.
-template <int KSPLIT, bool D2S = false>
-__global__ __launch_bounds__(512, 2) void gemm_rp_bf3pp_kernel(RPB p) {
-  constexpr int NW = 8, NTB = NW / KSPLIT;
-  constexpr int K = 128 * KSPLIT;
-  constexpr int CPR = K / 8;
-  constexpr int LROW = K * 2;
-  constexpr int LEVEL = TM * LROW;
-  constexpr int LBUF = 3 * LEVEL;
-  constexpr int GPT = KSPLIT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* Ex = reinterpret_cast<float*>(smem + 2 * LBUF);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = wave % NTB, kh = wave / NTB;
-  const int grp = wave >> 2;                   // 1: multiplies in the first half-phase; 0: in the second (K = 256: grp == kh, the finishing half is group 0)
-  const int n0 = (blockIdx.y * NTB + nt) * 32;
-
-  uint4 wf[KSW][3];
-  {
-    const uint4* wp = reinterpret_cast<const uint4*>(p.wp) + ((long long)(n0 / 32) * (K / 16) + kh * KSW) * 3 * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < KSW; ++i)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) wf[i][s] = wp[(i * 3 + s) * 64];
-  }
-  int gsrc[GPT], gdst[GPT];
-#pragma unroll
-  for (int j = 0; j < GPT; ++j) {
-    const int g = tid + 512 * j, row = g / CPR, c = g % CPR;
-    gsrc[j] = row * p.lda + c * 8;
-    gdst[j] = row * LROW + ((c ^ (row & 15)) << 4);
-  }
-  float4 raw[GPT][2];
-  auto fetch = [&](int t) {
-    const float* base = p.a + (long long)t * TM * p.lda;
-#pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-      raw[j][0] = *reinterpret_cast<const float4*>(base + gsrc[j]);
-      raw[j][1] = *reinterpret_cast<const float4*>(base + gsrc[j] + 4);
-    }
-  };
-  auto split_store = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-      const float v[8] = {raw[j][0].x, raw[j][0].y, raw[j][0].z, raw[j][0].w, raw[j][1].x, raw[j][1].y, raw[j][1].z, raw[j][1].w};
-      uint4 h, m, l;
-      rpb_split8(v, h, m, l);
-      unsigned char* d = smem + buf * LBUF + gdst[j];
-      *reinterpret_cast<uint4*>(d) = h; *reinterpret_cast<uint4*>(d + LEVEL) = m; *reinterpret_cast<uint4*>(d + 2 * LEVEL) = l;
-    }
-  };
-  const int arow = lane & 31, ahalf = lane >> 5;
-  const int erow = lane >> 1, eh = lane & 1;
-  int d_p1 = 0, d_p2 = 0, d_oc = 0;
-  if (D2S) {
-    const int nc = n0 + 16 * eh, dq = nc / p.d2s_c;
-    d_oc = nc - dq * p.d2s_c; d_p1 = dq / p.d2s_p; d_p2 = dq - d_p1 * p.d2s_p;
-  }
-  float4 bq[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) bq[q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + 16 * eh + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-  auto multiply = [&](int buf) {
-    f32x16 acb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = acb[r] = 0.f;
-    const unsigned char* ab = smem + buf * LBUF + arow * LROW;
-    uint4 xf[2][3];
-    auto frag = [&](int i, uint4 (&x)[3]) {
-      const unsigned char* q = ab + (((2 * (kh * KSW + i) + ahalf) ^ (arow & 15)) << 4);
-      x[0] = *reinterpret_cast<const uint4*>(q); x[1] = *reinterpret_cast<const uint4*>(q + LEVEL); x[2] = *reinterpret_cast<const uint4*>(q + 2 * LEVEL);
-    };
-    frag(0, xf[0]);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < KSW; ++i) {
-      if (i + 1 < KSW) frag(i + 1, xf[(i + 1) & 1]);
-      const uint4 xh = xf[i & 1][0], xm = xf[i & 1][1], xl = xf[i & 1][2];
-      acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xl), acb, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][1]), rpb_frag(xh), acc, 0, 0, 0);
-      acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][2]), rpb_frag(xh), acb, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xm), acc, 0, 0, 0);
-      acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][1]), rpb_frag(xm), acb, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xh), acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acb[r];
-  };
-  // tile t's accumulators (in acc) -> C; `hand`: add the other K half's hand-over first (it sits in `ex`)
-  auto finish = [&](int t, float* ex, bool hand) {
-    if (hand) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 o = *reinterpret_cast<const float4*>(ex + arow * EXP + 8 * g + 4 * ahalf);
-        acc[4 * g] += o.x; acc[4 * g + 1] += o.y; acc[4 * g + 2] += o.z; acc[4 * g + 3] += o.w;
-      }
-    }
-    const long long grow = (long long)t * TM + erow;
-    const int nc = n0 + 16 * eh;
-    float4 rq[4];
-    if (p.res) {
-      const float* rp = p.res + grow * p.ldres + nc;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rq[q] = *reinterpret_cast<const float4*>(rp + 4 * q);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4*>(ex + arow * EXP + 8 * g + 4 * ahalf) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-    float* cp = p.c + grow * p.ldc + nc;
-    if (D2S) {
-      const int hw = p.Ho * p.Wo;
-      const int img = (int)(grow / hw), rem = (int)(grow - (long long)img * hw);
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      const long long opix = ((long long)img * (p.Ho * p.d2s_p) + oy * p.d2s_p + d_p1) * (p.Wo * p.d2s_p) + ox * p.d2s_p + d_p2;
-      cp = p.c + opix * p.ldc + d_oc;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 x = *reinterpret_cast<const float4*>(ex + erow * EXP + 16 * eh + 4 * q);
-      x.x += bq[q].x; x.y += bq[q].y; x.z += bq[q].z; x.w += bq[q].w;
-      if (p.act != SMX_ACT_NONE) { x.x = rpb_act(x.x, p.act); x.y = rpb_act(x.y, p.act); x.z = rpb_act(x.z, p.act); x.w = rpb_act(x.w, p.act); }
-      if (p.res) { x.x += rq[q].x; x.y += rq[q].y; x.z += rq[q].z; x.w += rq[q].w; }
-      *reinterpret_cast<float4*>(cp + 4 * q) = x;
-    }
-  };
-
-  const int gx = gridDim.x;
-  int t = blockIdx.x, it = 0, tprev = 0;
-#pragma unroll
-  for (int j = 0; j < GPT; ++j) raw[j][0] = raw[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (t < p.tiles) {
-    fetch(t);
-    split_store(0);
-    if (t + gx < p.tiles) fetch(t + gx);
-  }
-  __syncthreads();
-  for (; t < p.tiles; tprev = t, t += gx, ++it) {
-    const int buf = it & 1;
-    float* exc = Ex + (nt * 2 + buf) * EX_F;           // this tile's exchange tile
-    float* exp_ = Ex + (nt * 2 + (buf ^ 1)) * EX_F;    // the previous tile's
-    // ---- first half-phase: group 1 multiplies tile t; group 0 finishes tile t - gx and stages its share of tile t + gx
-    if (grp == 1) {
-      multiply(buf);
-      if (KSPLIT == 2) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(exc + arow * EXP + 8 * g + 4 * ahalf) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-      }
-    } else {
-      split_store(buf ^ 1);
-      if (t + 2 * gx < p.tiles) fetch(t + 2 * gx);
-      if (it > 0) finish(tprev, exp_, KSPLIT == 2);
-    }
-    __syncthreads();
-    // ---- second half-phase: group 0 multiplies tile t; group 1 stages its share of tile t + gx (and, with whole-K waves, finishes tile t)
-    if (grp == 0) {
-      multiply(buf);
-    } else {
-      split_store(buf ^ 1);
-      if (t + 2 * gx < p.tiles) fetch(t + 2 * gx);
-      if (KSPLIT == 1) finish(t, exc, false);
-    }
-    __syncthreads();
-  }
-  if (grp == 0 && it > 0) finish(tprev, Ex + (nt * 2 + ((it - 1) & 1)) * EX_F, KSPLIT == 2);
-}
-
 // W [N][ldw] (row n: K contiguous floats) -> [N/32][K/16][3 levels][64 lanes][8 bf16]: lane l of (n-tile, step i) holds row 32 nt + (l & 31),
 // k = 16 i + 8 (l >> 5) + 0..7
 __global__ __launch_bounds__(256) void gemm_rp_bf3_pack_kernel(const float* __restrict__ w, int ldw, uint4* __restrict__ wp, int N, int K) {
@@ -410,12 +237,6 @@ int rpb_launch(const RPB& p, hipStream_t st) {
   SMX_HIP(smx_max_dynamic_lds((const void*)gemm_rp_bf3_kernel<KSPLIT, D2S>, LDS));
   const int ny = p.N / (32 * (8 / KSPLIT));
   int gx = 256 / ny; if (gx < 1) gx = 1; if (gx > p.tiles) gx = p.tiles;
-  static const int pp = getenv("SMX_RP_BF3_PP") ? atoi(getenv("SMX_RP_BF3_PP")) : 1;
-  if (pp) {
-    SMX_HIP(smx_max_dynamic_lds((const void*)gemm_rp_bf3pp_kernel<KSPLIT, D2S>, LDS));
-    SMX_LAUNCH((gemm_rp_bf3pp_kernel<KSPLIT, D2S>), dim3(gx, ny), dim3(512), LDS, st, p);
-    return smx_launch_status();
-  }
   SMX_LAUNCH((gemm_rp_bf3_kernel<KSPLIT, D2S>), dim3(gx, ny), dim3(512), LDS, st, p);
   return smx_launch_status();
 }

@@ -38,7 +38,7 @@ static inline int smx_launch_status() {
 
 // tuning table (tuning.hip): plain ints read by the launchers; set via smx_set_tuning / SMX_* env at first use
 enum { SMX_TUNE_WINO_NW = 0, SMX_TUNE_WINO_ABLATE, SMX_TUNE_GEMM_VARIANT, SMX_TUNE_GEMM_XCD_SWIZZLE,
-       SMX_TUNE_WARP_ROWS, SMX_TUNE_WARP_REORDER, SMX_TUNE_ATTN16, SMX_TUNE_WINO_WIDE, SMX_TUNE_WINO_NT, SMX_TUNE_ATTN4_MFMA, SMX_TUNE_CONV16_SLAB, SMX_TUNE_ATTN_BWD_MFMA, SMX_TUNE_VQ_SPLIT, SMX_TUNE_WARP_NT, SMX_TUNE_WGRAD_REGION, SMX_TUNE_WGRAD_SLOTS, SMX_TUNE_WINO_STAGGER, SMX_TUNE_WINO_WS, SMX_TUNE_GEMM_LOADER, SMX_TUNE_WINO_XCD, SMX_TUNE_WINO_BF3_SHAPE, SMX_TUNE_COUNT };
+       SMX_TUNE_WARP_ROWS, SMX_TUNE_WARP_REORDER, SMX_TUNE_ATTN16, SMX_TUNE_WINO_WIDE, SMX_TUNE_WINO_NT, SMX_TUNE_ATTN4_MFMA, SMX_TUNE_CONV16_SLAB, SMX_TUNE_ATTN_BWD_MFMA, SMX_TUNE_VQ_SPLIT, SMX_TUNE_WARP_NT, SMX_TUNE_WGRAD_REGION, SMX_TUNE_WGRAD_SLOTS, SMX_TUNE_WINO_STAGGER, SMX_TUNE_WINO_WS, SMX_TUNE_GEMM_LOADER, SMX_TUNE_WINO_XCD, SMX_TUNE_WINO_BF3_SHAPE, SMX_TUNE_ATTN_BF3, SMX_TUNE_COUNT };
 int smx_tune(int key);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: set it once per (kernel, device) of this translation unit,

@@ -116,13 +116,9 @@ __device__ __forceinline__ void b3_split8(const float (&f)[8], uint4& hi, uint4&
   }
 }
 
-// the same split on four values, with the conversion opaque to the compiler (one v_cvt_pk_bf16_f32 per PAIR and level: left to itself hipcc converts
-// the even element a second time to form its fp32 image) -- 22 VALU instructions per four values
-__device__ __forceinline__ unsigned b3_cvt2(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// the same split on four values: one v_cvt_pk_bf16_f32 per PAIR and level (cvt2_bf16: a vector conversion -- two scalar ones convert the even element a second
+// time to form its fp32 image) -- 22 VALU instructions per four values
+__device__ __forceinline__ unsigned b3_cvt2(float a, float b) { return cvt2_bf16(a, b); }
 template <int NS>
 __device__ __forceinline__ void b3_split4(const float (&v)[4], unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
   float r[4];

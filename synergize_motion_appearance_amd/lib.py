@@ -85,6 +85,7 @@ SIGNATURES = {
     "smx_groupnorm_swish_nhwc_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
     "smx_layernorm_pos_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "smx_attention_f32": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "smx_attention_f32_uses_bf3": (_i, [_i, _i, _i, _i, _i]),
     "smx_softmax_rows_f32": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
     "smx_warp_nhwc_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "smx_resize_bilinear_ac_nhwc_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -243,6 +243,7 @@ def _packed_u(tp, ref, mode, cout, cin):
     return tp.packed[ck]
 
 
+TRAIN_BF3 = bool(int(__import__('os').environ.get('SMX_TRAIN_BF3', '0')))   # the training step's convolutions on the split-bf16 kernels too (default: the exact fp32-MFMA kernels)
 WINOGRAD_TRAIN = True       # 3x3 / stride-1 forward and data-gradient convolutions on the fused Winograd kernel (False: implicit GEMM)
 
 
@@ -346,7 +347,7 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
     wino3 = (not m16) and WINOGRAD_TRAIN and kind == "conv" and (kh, kw, stride, pt, pl) == (3, 3, 1, 1, 1) and He % 8 == 0 and We % 16 == 0
     if wino3 and cin % 32 == 0:
         cv._u = _packed_u(tp, w, 0, cout, cin)
-    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=cv._u is None, bf3=False, **f16)
+    y = ops.conv(x, cv, stride=stride, pad=(pt, pl), up2=bool(up2), act=act, res=res, out_hw=out_hw, d2s=d2s, direct=cv._u is None, bf3=TRAIN_BF3, **f16)
     Ho, Wo = (y.shape[1], y.shape[2]) if d2s is None else (H, W)
 
     def bwd():
@@ -390,7 +391,7 @@ def conv(tp, x, w, b=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=N
             dcv = mk(wt.view(cin, kh * kw * cout), kh, kw, cout, cin)
             if wino3 and cout % 32 == 0:
                 dcv._u = _packed_u(tp, w, 1, cout, cin)
-            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=dcv._u is None, bf3=False, **f16)
+            dx = ops.conv(g2, dcv, pad=(kh - 1 - pt, kw - 1 - pl), out_hw=(He, We), direct=dcv._u is None, bf3=TRAIN_BF3, **f16)
             if up2:             # adjoint of nearest x2: sum of each 2x2 block
                 dx = scaled(tp, ops.avgpool2(dx), 4.0)
         else:                   # stride 2: zero-insert gather (smx_gemm_conv_f32 up2 = 2)
