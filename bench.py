@@ -396,9 +396,9 @@ def load_profile_json(name):
 # kernel family -> the objects of libsmx.so that hold its kernels: a committed counter summary is quoted for a family only while those
 # objects are the ones the counters were taken on (profiles/*_pmc.json "library_build" == lib/build_stamp.json)
 _GEMM_OBJS = ("gemm_conv.o", "gemm_rp_f32.o", "conv7_bf16x3.o", "conv_small.o")
-FAMILY_OBJECTS = {"winograd_bf3": ("winograd_bf3.o",), "winograd": ("winograd.o",), "winograd_wide": ("winograd.o",), "winograd_nw1": ("winograd.o",), "warp": ("warp_resize.o",),
+FAMILY_OBJECTS = {"winograd_bf3": ("winograd_bf3.o",), "gemm_bf3": ("gemm_rp_bf3.o",), "attention_bf3": ("attention.o",), "winograd": ("winograd.o",), "winograd_wide": ("winograd.o",), "winograd_nw1": ("winograd.o",), "warp": ("warp_resize.o",),
                   "gemm_conv": _GEMM_OBJS, "gemm_bf16": ("gemm_bf16.o", "gemm_rp_bf16.o"),
-                  "conv_gemm_family": _GEMM_OBJS + ("winograd.o", "winograd_bf3.o", "gemm_bf16.o", "gemm_rp_bf16.o", "conv3x3_bf16.o", "conv3x3_bf16_t32.o", "conv3x3_smalln_mfma16.o", "conv7_c2_bf16.o"),
+                  "conv_gemm_family": _GEMM_OBJS + ("winograd.o", "winograd_bf3.o", "gemm_rp_bf3.o", "gemm_bf16.o", "gemm_rp_bf16.o", "conv3x3_bf16.o", "conv3x3_bf16_t32.o", "conv3x3_smalln_mfma16.o", "conv7_c2_bf16.o"),
                   "conv3x3_bf16": ("conv3x3_bf16.o", "conv3x3_bf16_t32.o"), "conv7_x3": ("conv7_bf16x3.o",),
                   "attention": ("attention.o",), "attention_mfma": ("attention.o",), "attention_mfma16": ("attention.o",), "attnblock": ("attention.o",),
                   "groupnorm": ("norm_softmax.o",), "layernorm": ("norm_softmax.o",), "vq": ("vq.o",)}
@@ -579,6 +579,8 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     for name, meta, ms in rec.rows:
         meta = meta or {}
         key = ("winograd_bf3" if meta.get("bf3") else ("winograd_wide" if meta.get("wide") else "winograd_nw1")) if meta.get("wino") else name
+        if name == "gemm_conv" and meta.get("rp") and meta.get("bf3"):
+            key = "gemm_bf3"                               # the K = 128 / 256 1x1 layers on the bf16 pipe with split operands (csrc/gemm_rp_bf3.hip)
         f = fam.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "mfma_flops": 0.0})
         f["calls"] += 1
         f["ms"] += ms
@@ -654,7 +656,7 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
                                                                      "all launches of the family, the B=1 source-encoder ones included)")
         if dom == "winograd" and "winograd_wide" in mfma_pmc["kernels"]:
             roof["mfma_pmc_batch_launches"] = mfma_pmc["kernels"]["winograd_wide"]        # the wide kernel = the full-batch (B = 300) launches alone
-    mm = ("winograd", "winograd_bf3", "gemm_conv", "gemm_bf16", "conv3x3_bf16")          # every convolution / GEMM family of either dtype
+    mm = ("winograd", "winograd_bf3", "gemm_conv", "gemm_bf3", "gemm_bf16", "conv3x3_bf16")          # every convolution / GEMM family of either dtype
     conv_ms = max(sum(fam[k]["ms"] for k in mm if k in fam), 1e-9)
     conv_fl = sum(fam[k]["flops"] for k in mm if k in fam)
     conv_family = {"algorithmic_gflop_per_frame": round(conv_fl / nprof / B / 1e9, 2),
@@ -663,7 +665,7 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     kern = {}
     for name, f in fam.items():
         e = {"calls_per_step": f["calls"] // nprof, "ms_per_step": round(f["ms"] / nprof, 3)}
-        if name == "winograd_bf3":
+        if name in ("winograd_bf3", "gemm_bf3") or (name.startswith("attention") and f["mfma_flops"] > f["flops"] > 0):
             e["frac_of_bf16_pipe"] = round(f["mfma_flops"] / (f["ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
         avg_s = f["ms"] * 1e-3 / f["calls"]
         if f["bytes"]:
@@ -808,8 +810,9 @@ def main():
         "metric": f"reenactment frames/sec at {px}x{px}", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 3),
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
-        "arithmetic": ("fp32 operands, fp32 accumulation everywhere; the big 3x3 convolutions multiply on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 values and "
-                       "the six products down to 2^-24 kept (csrc/winograd_bf3.hip) -- measured against fp64 their error is below the fp32-MFMA kernel's (tests/test_gpu_wino_bf3.py), "
+        "arithmetic": ("fp32 operands, fp32 accumulation everywhere; the big launches of the 3x3 convolutions (csrc/winograd_bf3.hip), of the K = 128 / 256 1x1 layers (gemm_rp_bf3.hip) and of the "
+                       "d_head = 32 attention (attn_bf3_kernel) multiply on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 values and the six products down to 2^-24 kept "
+                       "-- measured against fp64 their error is not above the fp32-MFMA kernels' (tests/test_gpu_wino_bf3.py, test_gpu_gemm_bf3.py, test_gpu_attn_bf3.py), "
                        "every other contraction is fp32 MFMA / VALU" if dname == "f32" else
                        "bf16 storage + bf16 MFMA with fp32 accumulation (keypoints / flows / normalisation statistics / softmax / output image fp32)"),
         "config": {"workload": (f"BASELINE.json configs[{cfg_ix}]: {px}x{px}, {n_src} source(s) x 300-frame driving clip, {dname}, options/test{'' if px == 256 else '_512'}.yml, "

@@ -10,6 +10,6 @@ cp $G/traffic_pmc_${RT}_$TAG.json $P/${RT}_traffic_pmc.json; cp $G/mfma_pmc_${RT
 cp $G/traffic_pmc_${RT}_${TAG}_bf16.json $P/${RT}_traffic_pmc_bf16.json; cp $G/mfma_pmc_${RT}_${TAG}_bf16.json $P/${RT}_mfma_pmc_bf16.json
 cp $G/shapes_${RT}_$TAG.txt $P/${RT}_gemm_shapes.txt; cp $G/shapes_${RT}_${TAG}_bf16.txt.bf16 $P/${RT}_gemm_shapes_bf16.txt 2>/dev/null
 cp $G/train_bench_$TAG.txt $P/${RT}_train_bench.txt; cp $G/vq_bench_$TAG.txt $P/${RT}_vq_bench.txt
-cp $G/wino_split_$TAG.txt $P/${RT}_wino_split.txt; cp $G/file_to_file_$TAG.txt $P/${RT}_file_to_file.txt
+cp $G/wino_split_$TAG.txt $P/${RT}_wino_split.txt; cp $G/gemm_split_$TAG.txt $P/${RT}_gemm_split.txt; cp $G/attn_split_$TAG.txt $P/${RT}_attn_split.txt; cp $G/file_to_file_$TAG.txt $P/${RT}_file_to_file.txt
 tail -3 $G/pytest_${RT}_$TAG.log > $P/${RT}_pytest_gpu.txt
 ls -la $P | grep " ${RT}_" | awk '{print $5, $9}'

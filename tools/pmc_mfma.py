@@ -18,7 +18,7 @@ import sys
 
 SIMDS, XCDS, SPEC_GHZ = 1024, 8, 2.4
 PEAK = {"F32": 157.3, "BF16": 2500.0}
-FAMILIES = (("winograd_bf3_kernel", "winograd_bf3"), ("winograd_wide_kernel", "winograd"), ("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("gemm_rp_bf16_kernel", "gemm_bf16"), ("gemm_rp_f32_kernel", "gemm_conv"), ("conv7_bf16x3", "conv7_x3"), ("attnblock16", "attnblock"),
+FAMILIES = (("winograd_bf3_kernel", "winograd_bf3"), ("winograd_wide_kernel", "winograd"), ("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("gemm_rp_bf16_kernel", "gemm_bf16"), ("gemm_rp_f32_kernel", "gemm_conv"), ("gemm_rp_bf3_kernel", "gemm_bf3"), ("attn_bf3_kernel", "attention_bf3"), ("conv7_bf16x3", "conv7_x3"), ("attnblock16", "attnblock"),
             ("conv3x3_bf16_kernel", "conv3x3_bf16"), ("conv3x3_t32_kernel", "conv3x3_bf16"), ("attn_mfma16", "attention_mfma16"), ("attn_mfma", "attention_mfma"), ("vq_kernel", "vq"))
 
 

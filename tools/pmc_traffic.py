@@ -32,7 +32,7 @@ def variant(name):
 
 
 def family(name):
-    for key, fam in (("winograd_bf3_kernel", "winograd_bf3"), ("winograd_", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("gemm_rp_bf16_kernel", "gemm_bf16"), ("gemm_rp_f32_kernel", "gemm_conv"), ("conv7_bf16x3", "conv7_x3"), ("attnblock16", "attnblock"), ("conv3x3_bf16", "conv3x3_bf16"), ("conv3x3_t32", "conv3x3_bf16"), ("attn_", "attention"),
+    for key, fam in (("winograd_bf3_kernel", "winograd_bf3"), ("winograd_", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("gemm_rp_bf16_kernel", "gemm_bf16"), ("gemm_rp_f32_kernel", "gemm_conv"), ("gemm_rp_bf3_kernel", "gemm_bf3"), ("conv7_bf16x3", "conv7_x3"), ("attnblock16", "attnblock"), ("conv3x3_bf16", "conv3x3_bf16"), ("conv3x3_t32", "conv3x3_bf16"), ("attn_", "attention"),
                      ("warp_", "warp"), ("gn_", "groupnorm"), ("layernorm", "layernorm")):
         if key in name:
             return fam
@@ -69,7 +69,7 @@ def main(fetch_dir, write_dir, out):
         res[fam] = {"launches_profiled": v["launches"], "fetch_bytes_per_launch_corrected": 2.0 * 1024 * v["fetch_kb_raw"] / n,
                     "fetch_bytes_per_launch_raw": 1024 * v["fetch_kb_raw"] / n, "write_bytes_per_launch": 1024 * v["write_kb"] / max(v["wlaunches"], 1)}
         res[fam]["hbm_bytes_per_launch"] = res[fam]["fetch_bytes_per_launch_corrected"] + res[fam]["write_bytes_per_launch"]
-    conv = {k: res[k] for k in ("winograd", "winograd_bf3", "gemm_conv") if k in res}
+    conv = {k: res[k] for k in ("winograd", "winograd_bf3", "gemm_conv", "gemm_bf3") if k in res}
     nl = sum(v["launches_profiled"] for v in conv.values())
     if nl:
         res["conv_gemm_family"] = {"launches_profiled": nl,
