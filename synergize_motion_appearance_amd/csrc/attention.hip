@@ -323,8 +323,9 @@ __device__ __forceinline__ void ab3_split8(const float (&v)[8], uint4 (&lv)[3]) 
 }
 __device__ __forceinline__ bf16x8 ab3_f(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <bool MASK, int NP>
-__global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AP<float> p) {
+// NW = waves per block (4: 128 queries, two blocks per CU | 8: 256 queries, one block per CU -- the K / V split is shared by twice the queries)
+template <bool MASK, int NP, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bf3_kernel(AP<float> p) {
   constexpr int DH = 32, TK = 64, KROW = DH * 2 + 16, VROW = TK * 2 + 16;  // LDS row bytes (padded)
   constexpr int KPL = TK * KROW, VPL = DH * VROW;                         // one level plane
   __shared__ __attribute__((aligned(16))) unsigned char Ks[2][3 * KPL];
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AP<float> p) {
   __shared__ uint8_t Ms[2][TK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
-  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int qrow = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
   const int hh = lane >> 5;
   const float* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq + h * DH;
   const float* K = p.k + b * p.k_bs + h * DH;
@@ -354,37 +355,39 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AP<float> p) {
   for (int r = 0; r < 16; ++r) oacc[r] = oacb[r] = 0.f;
   float m = -INFINITY, l = 0.f;
 
-  // staging: 64 keys x 4 groups of 8 floats = 256 groups of K, of V: one of each per thread
-  const int skey = threadIdx.x >> 2, sc4 = threadIdx.x & 3;
+  // staging: a tile is 64 keys x 32 floats of K and of V.  NW = 4: 256 groups of 8 floats, one of each operand per thread; NW = 8: 512 groups of 4
+  constexpr int GF = NW == 4 ? 8 : 4, GPK = DH / GF;                      // floats per group, groups per key
+  const int skey = threadIdx.x / GPK, sg = threadIdx.x % GPK;
   const int kq = skey & 15;
   const int vcol = (skey & ~15) + (kq < 4 ? kq : kq < 8 ? kq + 4 : kq < 12 ? kq - 4 : kq);       // per 16 keys the order {0-3, 8-11, 4-7, 12-15}
-  float4 kreg[2], vreg[2]; uint8_t mreg = 0;
+  float4 kreg[GF / 4], vreg[GF / 4]; uint8_t mreg = 0;
   auto load_tile = [&](int key0) {
-    const float* kp = K + (long long)(key0 + skey) * p.ldk + sc4 * 8;
-    const float* vp = V + (long long)(key0 + skey) * p.ldv + sc4 * 8;
-    kreg[0] = *reinterpret_cast<const float4*>(kp); kreg[1] = *reinterpret_cast<const float4*>(kp + 4);
-    vreg[0] = *reinterpret_cast<const float4*>(vp); vreg[1] = *reinterpret_cast<const float4*>(vp + 4);
+    const float* kp = K + (long long)(key0 + skey) * p.ldk + sg * GF;
+    const float* vp = V + (long long)(key0 + skey) * p.ldv + sg * GF;
+#pragma unroll
+    for (int i = 0; i < GF / 4; ++i) { kreg[i] = *reinterpret_cast<const float4*>(kp + 4 * i); vreg[i] = *reinterpret_cast<const float4*>(vp + 4 * i); }
     if (MASK && M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
   };
   auto store_tile = [&](int buf) {
-    {
-      const float v[8] = {kreg[0].x, kreg[0].y, kreg[0].z, kreg[0].w, kreg[1].x, kreg[1].y, kreg[1].z, kreg[1].w};
-      uint4 lv[3];
-      ab3_split8<3>(v, lv);
+    float kv[8], vv[8];
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) *reinterpret_cast<uint4*>(&Ks[buf][s3 * KPL + skey * KROW + sc4 * 16]) = lv[s3];
+    for (int i = 0; i < 8; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < GF / 4; ++i) {
+      kv[4 * i] = kreg[i].x; kv[4 * i + 1] = kreg[i].y; kv[4 * i + 2] = kreg[i].z; kv[4 * i + 3] = kreg[i].w;
+      vv[4 * i] = vreg[i].x; vv[4 * i + 1] = vreg[i].y; vv[4 * i + 2] = vreg[i].z; vv[4 * i + 3] = vreg[i].w;
     }
-    {
-      const float v[8] = {vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w, vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w};
-      uint4 lv[3];
-      ab3_split8<3>(v, lv);
+    uint4 kl[3], vl[3];
+    ab3_split8<3>(kv, kl);                                                // (GF == 4: the upper half is zeros the compiler drops)
+    ab3_split8<3>(vv, vl);
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) {
-        const uint32_t w4[4] = {lv[s3].x, lv[s3].y, lv[s3].z, lv[s3].w};
+    for (int s3 = 0; s3 < 3; ++s3) {
+      unsigned char* kd = &Ks[buf][s3 * KPL + skey * KROW + sg * (2 * GF)];
+      if (GF == 8) *reinterpret_cast<uint4*>(kd) = kl[s3]; else *reinterpret_cast<uint2*>(kd) = make_uint2(kl[s3].x, kl[s3].y);
+      const uint32_t w4[4] = {vl[s3].x, vl[s3].y, vl[s3].z, vl[s3].w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e)                                       // transpose: V[key][8 sc4 + e] -> Vt[8 sc4 + e][col(key)]
-          *reinterpret_cast<uint16_t*>(&Vt[buf][s3 * VPL + (sc4 * 8 + e) * VROW + vcol * 2]) = (uint16_t)(e & 1 ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffffu);
-      }
+      for (int e = 0; e < GF; ++e)                                        // transpose: V[key][GF sg + e] -> Vt[GF sg + e][col(key)]
+        *reinterpret_cast<uint16_t*>(&Vt[buf][s3 * VPL + (sg * GF + e) * VROW + vcol * 2]) = (uint16_t)(e & 1 ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffffu);
     }
     if (MASK && threadIdx.x < TK) Ms[buf][threadIdx.x] = M ? mreg : 0;
   };
@@ -444,8 +447,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AP<float> p) {
     }
     psum += __shfl_xor(psum, 32, 64);
     l = l * alpha + psum; m = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {             // no lane's running maximum moved (the usual tile after the first few): nothing to rescale
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[r] *= alpha; oacb[r] *= alpha; }
+      for (int r = 0; r < 16; ++r) { oacc[r] *= alpha; oacb[r] *= alpha; }
+    }
     // O^T += V^T P^T: A = V^T rows d = lane & 31, this lane's 8 key slots of each 16-key group; two chains (the leading products / the 2^-16-class ones)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma4_bf16_kernel(AP<bf16_t> p) {
 }  // namespace
 
 /* which arithmetic smx_attention_f32 takes for this launch: 0 = exact fp32 products on the fp32 MFMA, 3 / 2 = split-bf16 (six products everywhere / P on two
- * levels) -- knob attn_bf3 (3 | 2, + 16 = at any launch size; 0 = off), d_head 32, S % 64 == 0, at least 512 blocks of 128 queries. */
+ * levels) -- knob attn_bf3 (3 | 2, + 16 = at any launch size, + 32 = 128-query blocks; 0 = off), d_head 32, S % 64 == 0, at least 512 blocks' worth of 128 queries. */
 extern "C" int smx_attention_f32_uses_bf3(int B, int H, int L, int S, int dh) {
   const int knob = smx_tune(SMX_TUNE_ATTN_BF3), np = knob & 15;
   if (dh != 32 || (np != 2 && np != 3) || B <= 0 || H <= 0 || L <= 0 || L % 128 || S <= 0 || S % 64) return 0;
@@ -1010,8 +1015,12 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
     else if (sizeof(T) == 4 && smx_attention_f32_uses_bf3(B, H, L, S, dh) && !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)) {
       if constexpr (sizeof(T) == 4) {                         // fp32 storage, big launches: fp32-grade products on the bf16 matrix pipe
         const int np = smx_attention_f32_uses_bf3(B, H, L, S, dh);
-        if (key_mask) { if (np == 2) SMX_LAUNCH((attn_bf3_kernel<true, 2>), dim3(L / 128, B * H), dim3(256), 0, st, p); else SMX_LAUNCH((attn_bf3_kernel<true, 3>), dim3(L / 128, B * H), dim3(256), 0, st, p); }
-        else { if (np == 2) SMX_LAUNCH((attn_bf3_kernel<false, 2>), dim3(L / 128, B * H), dim3(256), 0, st, p); else SMX_LAUNCH((attn_bf3_kernel<false, 3>), dim3(L / 128, B * H), dim3(256), 0, st, p); }
+        const int nw = (smx_tune(SMX_TUNE_ATTN_BF3) & 32) || L % 256 ? 4 : 8;        // knob + 32: the 128-query blocks
+#define AB3_GO(MK, NPV) do { if (nw == 8) SMX_LAUNCH((attn_bf3_kernel<MK, NPV, 8>), dim3(L / 256, B * H), dim3(512), 0, st, p); \
+                             else SMX_LAUNCH((attn_bf3_kernel<MK, NPV, 4>), dim3(L / 128, B * H), dim3(256), 0, st, p); } while (0)
+        if (key_mask) { if (np == 2) AB3_GO(true, 2); else AB3_GO(true, 3); }
+        else { if (np == 2) AB3_GO(false, 2); else AB3_GO(false, 3); }
+#undef AB3_GO
       }
     }
     else if (dh == 32 && !key_mask) SMX_LAUNCH((attn_mfma_kernel<T, 32, false>), dim3(L / 128, B * H), dim3(256), 0, st, p);

@@ -52,11 +52,13 @@ def ran(rec):
 
 
 @pytest.mark.parametrize("S,shared,masked,np_", [(1024, False, True, 3), (256, True, False, 3), (768, True, False, 3), (1024, False, False, 3),
-                                                 (1024, False, True, 2), (512, True, False, 2)])
+                                                 (1024, False, True, 2), (512, True, False, 2), (1024, False, True, 3 + 32), (512, True, False, 2 + 32),
+                                                 (1024, False, False, 3 + 32)])
 def test_split_attention_vs_explicit_softmax(ops, knob, S, shared, masked, np_):
     """the split kernel == softmax(q k^T / sqrt(d)) v per head at the fp32 kernel's bar; and it is the kernel that ran."""
     B, H, N, E, dh = 2, 8, 1024, 256, 32
-    knob(16 + np_)
+    knob(16 + np_)                                  # (+ 32: the 128-query block shape; default 256 queries per block)
+    np_ &= 15
     q = rnd(f"bq{S}", (B, N, E))
     kv = rnd(f"bkv{S}", ((1 if shared else B), 1024, 2 * E))
     mask = None
