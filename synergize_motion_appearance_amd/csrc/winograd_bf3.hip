@@ -504,15 +504,29 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
         red[(tl * 64 + n4q + e) * 2 + 1] = 0.5f * (d0 * d0 + d1 * d1) + 0.25f * ds * ds;
       }
       __syncthreads();
-      if (tid < 64) {
-        float a = 0.f, b = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) { a += red[(k * 64 + tid) * 2]; b += red[(k * 64 + tid) * 2 + 1]; }
-        a *= (1.f / 32.f);
+      // 32 tile entries {mean, M2; 4 values each} per channel -> one chunk entry, in two levels (Chan's merge with equal counts): every wave folds four
+      // entries of each of the 64 channels (all 512 threads busy: the one-level form kept 64 threads in a 64-read serial loop), then 64 threads fold the eight
+      float* red2 = zb;                                                   // (the exchange planes are free: every thread read its share before the barrier above)
+      {
+        float mk[4], m2 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float2 e2 = *reinterpret_cast<const float2*>(red + ((4 * wave + k) * 64 + lane) * 2); mk[k] = e2.x; m2 += e2.y; a4 += e2.x; }
+        a4 *= 0.25f;
         float c2 = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) { const float d = red[(k * 64 + tid) * 2] - a; c2 += d * d; }
-        b += 4.f * c2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float d = mk[k] - a4; c2 += d * d; }
+        *reinterpret_cast<float2*>(red2 + (wave * 64 + lane) * 2) = make_float2(a4, m2 + 4.f * c2);      // 16 values
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float mk[8], a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float2 e2 = *reinterpret_cast<const float2*>(red2 + (k * 64 + tid) * 2); mk[k] = e2.x; a += e2.x; b += e2.y; }
+        a *= 0.125f;
+        float c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = mk[k] - a; c2 += d * d; }
+        b += 16.f * c2;
         const long long chunk = ((long long)img * (p.ty * MT) + by * MT + m) * p.tx + bx;
         float* o2 = p.stats + (chunk * p.Cout + nblk * (32 * NT) + nb * 32 + tid) * 2;
         o2[0] = a; o2[1] = b;
