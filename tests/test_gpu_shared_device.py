@@ -66,7 +66,7 @@ def test_sparse_motion_is_bit_stable_next_to_another_process_running_the_bf16_co
 def test_fp32_winograd_kernels_are_bit_stable_next_to_another_process_running_the_bf16_convolution(tmp_path, monkeypatch):
     """the fp32 configuration's 3x3 kernels as the victim of the same neighbour: `winograd_wide_kernel` (csrc/winograd.hip is the one file still built
     WITH packed fp32 instructions -- its input transform and loader use them; round 5 only had a `winograd_kernel<1>` victim on record) and both shapes of
-    the split-bf16 kernel (built without them).  References are computed BEFORE the neighbour starts; every later launch must reproduce them bit for bit."""
+    the split-bf16 kernel (built without them), plus the split row-panel GEMM and the split attention.  References are computed BEFORE the neighbour starts; every later launch must reproduce them bit for bit."""
     assert torch.cuda.is_available(), "needs an MI355X"
     from synergize_motion_appearance_amd import ops
     monkeypatch.setattr(ops, "WINO_BF3_MIN_BLOCKS", 1)
@@ -77,6 +77,11 @@ def test_fp32_winograd_kernels_are_bit_stable_next_to_another_process_running_th
     cv128 = ops.Conv.from_torch((torch.randn((128, 128, 3, 3), generator=g) / 34.0).cuda(), (0.1 * torch.randn((128,), generator=g)).cuda())
     cv64 = ops.Conv.from_torch((torch.randn((64, 128, 3, 3), generator=g) / 34.0).cuda(), (0.1 * torch.randn((64,), generator=g)).cuda())
     ss = ops.groupnorm_stats(x, torch.ones(128, device="cuda"), torch.zeros(128, device="cuda"))
+    # the other two split kernels of round 6 (built without packed fp32 like the split Winograd): the K = 256 row-panel GEMM and the d_head-32 attention
+    tok = torch.randn((Bv, 1024, 256), generator=g).cuda()
+    lin = ops.Conv((torch.randn((256, 256), generator=g) / 16.0).cuda().contiguous(), (0.1 * torch.randn((256,), generator=g)).cuda(), 1, 1, 256, 256)
+    qkv = torch.randn((Bv, 1024, 768), generator=g).cuda()
+    old_attn = ops.set_tuning("attn_bf3", 3)
 
     def victims():
         outs, kinds = [], []
@@ -86,9 +91,15 @@ def test_fp32_winograd_kernels_are_bit_stable_next_to_another_process_running_th
                 y = ops.conv(x, cv, in_ss=ss, in_swish=True, res=r, want_stats=True)
             outs += [y.clone(), y._gn_part.clone()]
             kinds.append((rec.rows[0][1].get("bf3"), rec.rows[0][1].get("wide")))
+        with ops.profile() as rec:
+            outs.append(ops.conv(tok.view(Bv, 32, 32, 256), lin, act=4).clone())
+            outs.append(ops.attention(qkv[..., :256], qkv[..., 256:512], qkv[..., 512:], 8, 32, 1024).clone())
+        kinds += [(r_[1].get("bf3"), r_[1].get("rp")) for r_ in rec.rows]
         return outs, kinds
     ref, kinds = victims()
-    assert kinds == [(None, 1), (6, 1), (6, 1)], kinds            # the wide fp32-MFMA kernel, then the split kernel at 8x16x128 and at 16x16x64 blocks
+    ops.set_tuning("attn_bf3", old_attn)
+    # the wide fp32-MFMA kernel, the split Winograd kernel at 8x16x128 and at 16x16x64 blocks, the split row-panel GEMM, the split attention
+    assert kinds == [(None, 1), (6, 1), (6, 1), (6, 1), (3, None)], kinds
     torch.cuda.synchronize()
     log = tmp_path / "aggressor.log"
     with open(log, "w") as f:
