@@ -208,6 +208,13 @@ int smx_png_unfilter_u8(const uint8_t* raw, int h, int stride, int bpp, uint8_t*
  * fp32 kernel's (8 x 16 pixels). */
 int64_t smx_winograd_bf3_u_bytes(int Cout, int Cin);
 int smx_winograd_bf3_pack(const float* u_packed, void* u3, int Cout, int Cin, void* stream);
+/* nprod = 4 of smx_winograd_bf3_conv3x3_f32 ("f16x3"): the same kernel with IEEE-half levels -- every fp32 operand as TWO halves (11 + 11 significand bits), three
+ * v_mfma_f32_32x32x16_f16 products per multiply (h1 g1 + h1 g2 + h2 g1; the dropped terms are 2^-22 relative).  U is scaled by a power of two chosen on the device
+ * from max |U| so that its second level stays a normal half (the epilogue divides it out, exactly); the transformed input is taken as it is, so the form is
+ * for launches whose input is O(1) by construction (the fused GroupNorm + swish loader: in_ss != NULL).  Pack: smx_winograd_f16_pack(u_f32 as for
+ * smx_winograd_bf3_pack) -> 16 header bytes + the same record layout, smx_winograd_f16_u_bytes bytes; pass it as `u3` with nprod = 4. */
+int64_t smx_winograd_f16_u_bytes(int Cout, int Cin);
+int smx_winograd_f16_pack(const float* u_f32, void* up, int Cout, int Cin, void* stream);
 int smx_winograd_bf3_shape_ok(int B, int H, int W, int Cin, int Cout, int lda, int ldc, int ldres, int ldmul);
 int smx_winograd_bf3_conv3x3_f32(const float* x, int lda, const void* u3, const float* bias, const float* res, int ldres, float* y, int ldc,
                                  int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,

@@ -16,6 +16,15 @@ __device__ __forceinline__ uint32_t cvt2_bf16(float a, float b) {
   const f32x2_t f = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// the pair rounded to IEEE half in one v_cvt_pk_f16_f32 (round to nearest even), and a packed pair widened back
+__device__ __forceinline__ uint32_t cvt2_f16(float a, float b) {
+  const f32x2_t f = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2_t));
+}
+__device__ __forceinline__ float f16lo(uint32_t h) { return (float)__builtin_bit_cast(f16x2_t, h)[0]; }
+__device__ __forceinline__ float f16hi(uint32_t h) { return (float)__builtin_bit_cast(f16x2_t, h)[1]; }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   bf16x2_t v = {(__bf16)a, (__bf16)b};

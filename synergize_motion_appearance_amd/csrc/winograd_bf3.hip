@@ -76,6 +76,7 @@ struct B3P {
   int xcd_group;
   const float* mul; int ldmul; float sft_w;
   unsigned u_bytes;
+  const float* u_hdr;               // NPROD = 4: {max |U| bits, 1 / (the power of two U was scaled by)} in front of the packed planes
 };
 
 __device__ __forceinline__ float b3_act(float v, int act) {
@@ -119,11 +120,17 @@ __device__ __forceinline__ void b3_split8(const float (&f)[8], uint4& hi, uint4&
 // the same split on four values: one v_cvt_pk_bf16_f32 per PAIR and level (cvt2_bf16: a vector conversion -- two scalar ones convert the even element a second
 // time to form its fp32 image) -- 22 VALU instructions per four values
 __device__ __forceinline__ unsigned b3_cvt2(float a, float b) { return cvt2_bf16(a, b); }
-template <int NS>
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void b3_split4(const float (&v)[4], unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
   float r[4];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
+    if (F16) {                                  // two IEEE-half levels (11 + 11 significand bits): 12 VALU instructions per four values
+      hi[q] = cvt2_f16(v[2 * q], v[2 * q + 1]);
+      mid[q] = cvt2_f16(v[2 * q] - f16lo(hi[q]), v[2 * q + 1] - f16hi(hi[q]));
+      lo[q] = 0u;
+      continue;
+    }
     hi[q] = b3_cvt2(v[2 * q], v[2 * q + 1]);
     r[2 * q] = v[2 * q] - __uint_as_float(hi[q] << 16);
     r[2 * q + 1] = v[2 * q + 1] - __uint_as_float(hi[q] & 0xffff0000u);
@@ -137,6 +144,8 @@ __device__ __forceinline__ void b3_split4(const float (&v)[4], unsigned (&hi)[2]
 
 __device__ __forceinline__ bf16x8 b3_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ bf16x8 b3_frag(f32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f16x8_t b3_fragh(uint4 v) { return __builtin_bit_cast(f16x8_t, v); }
+__device__ __forceinline__ f16x8_t b3_fragh(f32x4 v) { return __builtin_bit_cast(f16x8_t, v); }
 
 // tile index (MFMA column 0..31 of an M tile) -> (tile row 0..3, tile column 0..7): columns 0-3 / 4-7 follow the lane groups a ds_read_b128 is
 // served in ({0-3,12-15,20-27} and {4-11,16-19,28-31}), so that every group reads four tile rows x four adjacent tile columns
@@ -145,6 +154,7 @@ __device__ __forceinline__ int b3_tile_col(int t) { return 4 * (((t >> 2) ^ (t >
 template <int NPROD, int MT>
 __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   constexpr int NS = NPROD == 6 ? 3 : 2;
+  constexpr bool F16 = NPROD == 4;             // NPROD = 4: IEEE-half levels (two of them, three products; U arrives scaled by a power of two: p.u_scale_inv)
   constexpr int NT = B3G<MT>::NT, RR = B3G<MT>::RR, NSET = B3G<MT>::NSET;
   constexpr int B3_PLANE = B3G<MT>::PLANE, B3_REGION_F = B3G<MT>::REGION_F, B3_REGION_B = B3G<MT>::REGION_B;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -177,6 +187,12 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   // across the phases it would be spilled, and a scratch reload is a vector-memory request in the middle of the hand-counted ones.
   const bool interior = y0 >= 1 && y0 + RR - 1 <= p.H && x0 >= 1 && x0 + 17 <= p.W;
   const int loader = p.in_ss ? (p.in_swish ? 2 : 1) : 0;
+  // NPROD = 4, raw (not normalised) input: the block scales its input by a power of two sv so that the largest value of the first 32-channel slice lands in (2, 4]
+  // -- the second half level of every value within 2^-5 of that maximum stays a normal half, and 12 bits of headroom remain before a half overflows.  A later slice that
+  // outgrows the headroom raises a flag (ss_lds[8]); the block then rescales region, accumulators and sv by an exact power of two (dyn_rescale below).
+  float sv = 1.f, omax = 0.f;
+  bool unscaled = false;                       // the first slice was all zeros: the first slice that is not sets the scale (same path as the rescale)
+  const bool dyn = F16 && loader == 0;
   auto stage_geo = [&](int& l, int& r3, int& srx, int& sc4) __attribute__((always_inline)) {
     l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(l));                                                            // opaque: computed here, not carried
@@ -217,6 +233,10 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
     for (int q = 0; q < 2; ++q) {
       const int k = 2 * ph + q;
       f32x4 v = rg[q];
+      if (F16 && MODE == 0) {
+        v *= sv;
+        omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
       if (MODE >= 1) {
         v = __builtin_elementwise_fma(v, sc, sh);
         if (MODE == 2) {
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
         v[e] = fmaf(scj[f], tb, ta);
       }
       unsigned h2[2], m2[2], l2[2];
-      b3_split4<NS>(v, h2, m2, l2);
+      b3_split4<NS, F16>(v, h2, m2, l2);
       vh[m][2 * e2] = h2[0]; vh[m][2 * e2 + 1] = h2[1]; vm[m][2 * e2] = m2[0]; vm[m][2 * e2 + 1] = m2[1]; vl[m][2 * e2] = l2[0]; vl[m][2 * e2 + 1] = l2[1];
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -350,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           if (B3_ABL & 2) acc[f][m][n][0] += __uint_as_float(vv[m][0]) * ur[n][us].x;
+          else if (F16) acc[f][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b3_fragh(ur[n][us]), b3_fragh(make_uint4(vv[m][0], vv[m][1], vv[m][2], vv[m][3])), acc[f][m][n], 0, 0, 0);
           else acc[f][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3_frag(ur[n][us]), b3_frag(make_uint4(vv[m][0], vv[m][1], vv[m][2], vv[m][3])), acc[f][m][n], 0, 0, 0);
     };
     if (NPROD == 6) { prod(vl, 0); prod(vh, 2); prod(vm, 1); }
@@ -371,7 +392,25 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
       const float* sp = p.in_ss + (long long)img * p.Cin * 2;
       for (int i = tid; i < p.Cin / 2; i += 512) *reinterpret_cast<float4*>(ss_lds + i * 4) = *reinterpret_cast<const float4*>(sp + i * 4);
     }
+    if (dyn) {                                                                              // largest |value| of the first slice's region (every thread holds six items of it)
+      float tm = 0.f;
+#pragma unroll
+      for (int ph = 0; ph < NSET; ++ph)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tm = fmaxf(tm, fmaxf(fmaxf(fabsf(pr[ph][q].x), fabsf(pr[ph][q].y)), fmaxf(fabsf(pr[ph][q].z), fabsf(pr[ph][q].w))));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));
+      if (lane == 0) ss_lds[wave] = tm;
+      if (tid == 0) ss_lds[8] = 0.f;
+    }
     __syncthreads();                                                                        // ss_lds complete
+    if (dyn) {
+      float bm = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) bm = fmaxf(bm, ss_lds[w]);
+      sv = (bm > 0.f && bm < 3.0e38f) ? exp2f(2.f - ceilf(log2f(bm))) : 1.f;
+      unscaled = !(bm > 0.f);
+    }
 #pragma unroll
     for (int ph = 0; ph < NSET; ++ph) store_region(pr[ph], ph, 0, 0);
   }
@@ -400,7 +439,32 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
                                                           __builtin_amdgcn_sched_barrier(0); if (NSET > 2) issue_items(sreg, 2, cn); });
     phase(rb, 1, 1, [&]() __attribute__((always_inline)) { request_u(0, more ? 2 * s + 2 : 2 * s + 1); __builtin_amdgcn_sched_barrier(0);
                                                           if (NSET > 2) { if (more) store_region(sreg, 2, rb ^ 1, cn); else asm volatile("" :: "v"(sreg[0]), "v"(sreg[1])); } });
+    if (dyn && (omax > 4096.f || (unscaled && omax > 0.f))) ss_lds[8] = 1.f;                                              // (4 x 4096 is still a quarter of the largest half)
     __syncthreads();
+    if (dyn && ss_lds[8] != 0.f) {
+      // rare: the next slice outgrew the headroom.  Exact power-of-two rescale of everything that carries sv: the region just staged, the accumulators, sv itself
+      float tm = omax;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));
+      if (lane == 0) ss_lds[wave] = tm;
+      __syncthreads();
+      float bm = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) bm = fmaxf(bm, ss_lds[w]);
+      const float t = (bm > 0.f && bm < 3.0e38f) ? exp2f(2.f - ceilf(log2f(bm))) : 1.f;
+      unscaled = unscaled && !(bm > 0.f);
+      float* nbuf = smem + (rb ^ 1) * B3_REGION_F;
+      for (int i = tid * 4; i < B3_REGION_F; i += 2048) { f32x4 v = *reinterpret_cast<f32x4*>(nbuf + i); v *= t; *reinterpret_cast<f32x4*>(nbuf + i) = v; }
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[f][m][n] *= t;
+      sv *= t; omax *= t;
+      __syncthreads();
+      if (tid == 0) ss_lds[8] = 0.f;
+    }
   }
   mark(2);
 #pragma unroll
@@ -422,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
   const float* __restrict__ Mi = p.mul ? p.mul + (long long)img * p.H * p.W * p.ldmul : nullptr;
   const int tl = tid >> 4, n4q = (tid & 15) * 4;
   const int tl_row = tl >> 3, tl_col = b3_tile_col(tl);
+  const float uinv = F16 ? p.u_hdr[1] / sv : 1.f;                                              // undo the power-of-two scales of U (pack) and of the input (sv): exact                                                  // undo the power-of-two scale of the half-precision U planes (exact)
   const int amode = p.act == SMX_ACT_NONE ? 0 : ((p.act == SMX_ACT_RELU || p.act == SMX_ACT_LRELU02) ? 1 : 2);
   const float slope = p.act == SMX_ACT_RELU ? 0.f : 0.2f;
 #pragma unroll
@@ -474,8 +539,8 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
       float a0[4], a1[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a0[e] = zz[0][e] + zz[1][e] + zz[2][e] + bn[e];
-        a1[e] = zz[1][e] - zz[2][e] - zz[3][e] + bn[e];
+        a0[e] = F16 ? fmaf(zz[0][e] + zz[1][e] + zz[2][e], uinv, bn[e]) : zz[0][e] + zz[1][e] + zz[2][e] + bn[e];
+        a1[e] = F16 ? fmaf(zz[1][e] - zz[2][e] - zz[3][e], uinv, bn[e]) : zz[1][e] - zz[2][e] - zz[3][e] + bn[e];
         if (amode == 1) { a0[e] = fmaxf(a0[e], 0.f) + slope * fminf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f) + slope * fminf(a1[e], 0.f); }
         else if (amode == 2) { a0[e] = b3_act(a0[e], p.act); a1[e] = b3_act(a1[e], p.act); }
       }
@@ -563,7 +628,61 @@ __global__ void winograd_bf3_pack_kernel(const float* __restrict__ u32, unsigned
   (void)n32;
 }
 
+// NPROD = 4 pack: max |U| (bits, by atomicMax) -> the power of two that brings it into [2^11, 2^12) -> two IEEE-half levels of U x that scale in planes 0 / 1 of
+// the same record layout; header {max bits, 1 / scale} in the 16 bytes in front of the records
+__global__ void winograd_f16_absmax_kernel(const float* __restrict__ u32, long long n, unsigned* __restrict__ hdr) {
+  unsigned m = 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = max(m, __float_as_uint(u32[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(hdr, m);
+}
+__global__ void winograd_f16_pack_kernel(const float* __restrict__ u32, unsigned char* __restrict__ up, int n32, int Cin, long long frags) {
+  const float umax = __uint_as_float(reinterpret_cast<const unsigned*>(up)[0]);
+  const float su = (umax > 0.f && umax < 3.0e38f) ? exp2f(11.f - floorf(log2f(umax))) : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(up)[1] = 1.f / su;
+  const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);                        // (f, nt, step)
+  if (g >= frags) return;
+  const int lane = threadIdx.x & 63, row = lane & 31, hh = lane >> 5;
+  const int nsteps = Cin / 16;
+  const int step = (int)(g % nsteps);
+  const long long fn = g / nsteps;
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = 2 * q + j, s8 = 2 * step + hh, half = e >> 2, el = e & 3;
+      v[j] = u32[((fn * (Cin / 8) + s8) * 64 + row + 32 * half) * 4 + el] * su;
+    }
+    h[q] = cvt2_f16(v[0], v[1]);
+    l[q] = cvt2_f16(v[0] - f16lo(h[q]), v[1] - f16hi(h[q]));
+  }
+  unsigned char* o = up + 16 + g * 3072 + lane * 16;
+  *reinterpret_cast<uint4*>(o) = make_uint4(h[0], h[1], h[2], h[3]); *reinterpret_cast<uint4*>(o + 1024) = make_uint4(l[0], l[1], l[2], l[3]);
+  *reinterpret_cast<uint4*>(o + 2048) = make_uint4(0u, 0u, 0u, 0u);
+  (void)n32;
+}
+
 }  // namespace
+
+/* The half-precision pack of smx_winograd_bf3_conv3x3_f32's nprod = 4 arithmetic ("f16x3"): U scaled by a power of two (chosen on the device from max |U|) and split
+ * into two IEEE-half levels; 16 header bytes + the record layout of smx_winograd_bf3_pack. */
+extern "C" int64_t smx_winograd_f16_u_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16) return 0;
+  return 16 + 16LL * (Cout / 32) * (Cin / 16) * 3072;
+}
+
+extern "C" int smx_winograd_f16_pack(const float* u_f32, void* up, int Cout, int Cin, void* stream) {
+  if (!u_f32 || !up || Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16 || ((uintptr_t)up & 15)) return SMX_EINVAL;
+  const long long frags = 16LL * (Cout / 32) * (Cin / 16), n = 16LL * Cout * Cin;
+  SMX_HIP(hipMemsetAsync(up, 0, 16, (hipStream_t)stream));
+  int gb = (int)((n + 255) / 256); if (gb > 2048) gb = 2048;
+  SMX_LAUNCH(winograd_f16_absmax_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, u_f32, n, (unsigned*)up);
+  SMX_LAUNCH(winograd_f16_pack_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), 0, (hipStream_t)stream, u_f32, (unsigned char*)up, Cout / 32, Cin, frags);
+  return smx_launch_status();
+}
 
 extern "C" int64_t smx_winograd_bf3_u_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16) return 0;
@@ -592,7 +711,7 @@ extern "C" int smx_winograd_bf3_shape_ok(int B, int H, int W, int Cin, int Cout,
 static int winograd_bf3_launch(const float* x, int lda, const void* u3, const float* bias, const float* res, int ldres, const float* mul, int ldmul, float sft_w,
                                float* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
                                float* stats_part, int nprod, void* stream) {
-  if (!x || !u3 || !y || (nprod != 6 && nprod != 3)) return SMX_EINVAL;
+  if (!x || !u3 || !y || (nprod != 6 && nprod != 3 && nprod != 4)) return SMX_EINVAL;
   const int mt = smx_winograd_bf3_shape_ok(B, H, W, Cin, Cout, lda, ldc, res ? ldres : 0, mul ? ldmul : 0);
   if (!mt) return SMX_EINVAL;
   if (lda < Cin || ldc < Cout || (res && ldres < Cout) || (mul && (!res || ldmul < Cout || act != SMX_ACT_NONE))) return SMX_EINVAL;
@@ -602,19 +721,24 @@ static int winograd_bf3_launch(const float* x, int lda, const void* u3, const fl
   p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
   p.ty = H / (8 * mt); p.tx = W / 16; p.n32 = Cout / 32; p.nsteps = Cin / 16; p.mul = mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
   p.u_bytes = (unsigned)smx_winograd_bf3_u_bytes(Cout, Cin);
+  p.u_hdr = nullptr;
+  if (nprod == 4) { p.u_hdr = (const float*)u3; p.u = (const unsigned char*)u3 + 16; }       // the half-precision pack carries a 16-byte header
   const long long blocks = (long long)B * p.ty * p.tx;
   const int nby = Cout / (mt == 1 ? 128 : 64);                                             // output blocks per spatial block
   p.xcd_group = (smx_tune(SMX_TUNE_WINO_XCD) != 0 && blocks % 8 == 0 && nby > 1 && blocks * nby <= 0x7fffffffLL) ? 1 : 0;
   {
-    const void* ks[4] = {(const void*)(winograd_bf3_kernel<6, 2>), (const void*)(winograd_bf3_kernel<3, 2>), (const void*)(winograd_bf3_kernel<6, 1>), (const void*)(winograd_bf3_kernel<3, 1>)};
-    SMX_HIP(smx_max_dynamic_lds(ks[(mt == 1 ? 2 : 0) + (nprod == 3 ? 1 : 0)], B3_LDS));
+    const void* ks[6] = {(const void*)(winograd_bf3_kernel<6, 2>), (const void*)(winograd_bf3_kernel<3, 2>), (const void*)(winograd_bf3_kernel<4, 2>),
+                         (const void*)(winograd_bf3_kernel<6, 1>), (const void*)(winograd_bf3_kernel<3, 1>), (const void*)(winograd_bf3_kernel<4, 1>)};
+    SMX_HIP(smx_max_dynamic_lds(ks[(mt == 1 ? 3 : 0) + (nprod == 6 ? 0 : nprod == 3 ? 1 : 2)], B3_LDS));
   }
   dim3 grid((unsigned)blocks, nby);
   if (mt == 2) {
     if (nprod == 6) SMX_LAUNCH((winograd_bf3_kernel<6, 2>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+    else if (nprod == 4) SMX_LAUNCH((winograd_bf3_kernel<4, 2>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
     else SMX_LAUNCH((winograd_bf3_kernel<3, 2>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
   } else {
     if (nprod == 6) SMX_LAUNCH((winograd_bf3_kernel<6, 1>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
+    else if (nprod == 4) SMX_LAUNCH((winograd_bf3_kernel<4, 1>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
     else SMX_LAUNCH((winograd_bf3_kernel<3, 1>), grid, dim3(512), B3_LDS, (hipStream_t)stream, p);
   }
   return smx_launch_status();

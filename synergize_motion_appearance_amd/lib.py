@@ -173,6 +173,8 @@ SIGNATURES = {
     "smx_gemm_rp_bf3": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
     "smx_gemm_rp_d2s_bf3": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_png_unfilter_u8": (_i, [_p, _i, _i, _i, _p]),
+    "smx_winograd_f16_u_bytes": (_i64, [_i, _i]),
+    "smx_winograd_f16_pack": (_i, [_p, _p, _i, _i, _p]),
     "smx_winograd_bf3_u_bytes": (_i64, [_i, _i]),
     "smx_winograd_bf3_pack": (_i, [_p, _p, _i, _i, _p]),
     "smx_winograd_bf3_shape_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),

@@ -131,7 +131,7 @@ WINOGRAD = bool(_knob("SMX_WINOGRAD", 1))
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3", "_wrp3")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3", "_wrp3", "_u3h")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -139,6 +139,7 @@ class Conv:
         self._w16 = None
         self._u43 = None
         self._u3 = None
+        self._u3h = None
         self._wrp3 = None
         self._w16t = None
         self._w16rp = None
@@ -278,6 +279,15 @@ class Conv:
             L.check(lib.smx_winograd_bf3_pack(self.winograd_u().data_ptr(), u3.data_ptr(), self.cout, self.cin, _stream()), "smx_winograd_bf3_pack")
             self._u3 = u3
         return self._u3
+
+    def winograd_f16_u(self):
+        """U scaled by a power of two and split into two IEEE-half levels for the f16x3 form of the split Winograd kernel (smx_winograd_f16_pack), built once."""
+        if self._u3h is None:
+            lib = L.load()
+            up = torch.empty(int(lib.smx_winograd_f16_u_bytes(self.cout, self.cin)), device=self.w.device, dtype=torch.uint8)
+            L.check(lib.smx_winograd_f16_pack(self.winograd_u().data_ptr(), up.data_ptr(), self.cout, self.cin, _stream()), "smx_winograd_f16_pack")
+            self._u3h = up
+        return self._u3h
 
     def winograd43_u(self):
         """U = G g G^T for F(4x4,3x3) (G 6x3: Lavin & Gray), fragment-ordered [36][Cout/32][Cin/8][64 lanes][4] like `winograd_u`;
@@ -511,6 +521,7 @@ def _wino43_ok(B, H, W, cin, cout, up2, lda, ldc, ldres):
 # kernels everywhere), 3 = the two-way split (comparison only, never the fp32 configuration).  WINO_BF3_MIN_BLOCKS: 16x16-pixel x 64-channel blocks a launch must have (one block per CU).
 WINO_BF3 = _knob("SMX_WINO_BF3", 6)
 WINO_BF3_MIN_BLOCKS = 512
+WINO_F16 = _knob("SMX_WINO_F16", 2)          # the split kernel's f16x3 form (two half levels, three products): 1 = launches fed through the fused GroupNorm (+ swish) loader, 2 = every launch (raw inputs get a per-block power-of-two scale)
 GEMM_RP_BF3_MIN_ROWS = 32 * 512               # the split row-panel GEMM: persistent blocks, one per CU -- at least two 32-row tiles each
 
 
@@ -595,12 +606,14 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
         part = torch.empty((B, (He // 8) * (We // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
         if bf3 and _wino_bf3_ok(B, He, We, Cin, cv.cout, lda, ldc, ldr, 0, a_ptr, c_ptr, r_ptr, None if cv.b is None else cv.b.data_ptr(),
                         None if in_ss is None else in_ss.data_ptr()):
+            # normalised input (O(1) by construction) -> the half-precision form: 3 products instead of 6 at the same measured error (tests/test_gpu_wino_bf3.py)
+            npr = 4 if (WINO_BF3 == 6 and (WINO_F16 == 2 or (WINO_F16 == 1 and in_ss is not None))) else WINO_BF3
             if meta is not None:
-                meta.update(mfma_flops=2.0 * B * Ho * Wo * cv.cout * 4 * Cin * WINO_BF3, bf3=WINO_BF3)
-            L.check(_timed("gemm_conv", meta, L.load().smx_winograd_bf3_conv3x3_f32, a_ptr, lda, cv.winograd_bf3_u().data_ptr(),
+                meta.update(mfma_flops=2.0 * B * Ho * Wo * cv.cout * 4 * Cin * (3 if npr == 4 else npr), bf3=npr)
+            L.check(_timed("gemm_conv", meta, L.load().smx_winograd_bf3_conv3x3_f32, a_ptr, lda, (cv.winograd_f16_u() if npr == 4 else cv.winograd_bf3_u()).data_ptr(),
                            None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, B, He, We, Cin, cv.cout,
                            int(up2), act, None if in_ss is None else in_ss.data_ptr(), int(in_swish),
-                           None if part is None else part.data_ptr(), WINO_BF3, _stream()),
+                           None if part is None else part.data_ptr(), npr, _stream()),
                     "smx_winograd_bf3_conv3x3_f32")
             if part is not None:
                 out._gn_part = part
@@ -1013,11 +1026,12 @@ def conv_sft(x, cv, dec, scale, w=1.0):
     meta = {"flops": 2.0 * B * H * W * cv.cout * 9 * Cin, "mfma_flops": 2.0 * B * H * W * cv.cout * 4 * Cin,
             "M": B * H * W, "N": cv.cout, "K": 9 * Cin, "nb": 1, "k": 3, "wino": 1, "wide": _wino_wide(B, H, W, cv.cout)} if _PROFILE is not None else None
     if _wino_bf3_ok(B, H, W, Cin, cv.cout, lda, cv.cout, ldd, lds_, a_ptr, d_ptr, s_ptr, out.data_ptr(), None if cv.b is None else cv.b.data_ptr()):
+        npr = 4 if (WINO_BF3 == 6 and WINO_F16 == 2) else WINO_BF3
         if meta is not None:
-            meta.update(mfma_flops=2.0 * B * H * W * cv.cout * 4 * Cin * WINO_BF3, bf3=WINO_BF3)
-        L.check(_timed("gemm_conv", meta, L.load().smx_winograd_bf3_conv3x3_sft_f32, a_ptr, lda, cv.winograd_bf3_u().data_ptr(),
+            meta.update(mfma_flops=2.0 * B * H * W * cv.cout * 4 * Cin * (3 if npr == 4 else npr), bf3=npr)
+        L.check(_timed("gemm_conv", meta, L.load().smx_winograd_bf3_conv3x3_sft_f32, a_ptr, lda, (cv.winograd_f16_u() if npr == 4 else cv.winograd_bf3_u()).data_ptr(),
                        None if cv.b is None else cv.b.data_ptr(), d_ptr, ldd, s_ptr, lds_, float(w), out.data_ptr(), cv.cout,
-                       B, H, W, Cin, cv.cout, None, WINO_BF3, _stream()), "smx_winograd_bf3_conv3x3_sft_f32")
+                       B, H, W, Cin, cv.cout, None, npr, _stream()), "smx_winograd_bf3_conv3x3_sft_f32")
         return out
     L.check(_timed("gemm_conv", meta, L.load().smx_winograd_conv3x3_sft_f32, a_ptr, lda, cv.winograd_u().data_ptr(),
                    None if cv.b is None else cv.b.data_ptr(), d_ptr, ldd, s_ptr, lds_, float(w), out.data_ptr(), cv.cout,

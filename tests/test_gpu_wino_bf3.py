@@ -187,3 +187,119 @@ def test_bf3_is_deterministic_and_leaves_small_launches_alone(ops, bf3, monkeypa
     with ops.profile() as rec:
         ops.conv(x[:1], cv)
     assert ran_bf3(rec) == [None]
+
+
+# ---- the f16x3 form (nprod = 4: two IEEE-half levels, three products; csrc/winograd_bf3.hip) ----------------------------------------------------------------
+@pytest.fixture
+def f16(ops, monkeypatch):
+    def _set(level):
+        monkeypatch.setattr(ops, "WINO_BF3", 6)
+        monkeypatch.setattr(ops, "WINO_F16", level)
+        monkeypatch.setattr(ops, "WINO_BF3_MIN_BLOCKS", 1)
+    return _set
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_up{int(c[5])}_act{c[6]}_res{int(c[7])}" for c in CASES])
+def test_f16x3_conv3x3_vs_conv2d(ops, f16, case):
+    """the half-precision three-product form on RAW inputs (per-block power-of-two input scale) == F.conv2d at the fp32 Winograd kernel's bar, every epilogue."""
+    B, Cin, Cout, H, W, up2, act, with_res = case
+    f16(2)
+    x = rnd(f"b3x{case}", (B, Cin, H, W))
+    w = rnd(f"b3w{case}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd(f"b3b{case}", (Cout,), 0.1)
+    xe = F.interpolate(x, scale_factor=2.0, mode="nearest") if up2 else x
+    ref = F.conv2d(xe, w, b, padding=1)
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: O.swish, 4: F.gelu}[act](ref)
+    r = rnd(f"b3r{case}", tuple(ref.shape)) if with_res else None
+    if with_res:
+        ref = ref + r
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    with ops.profile() as rec:
+        y = ops.conv(nhwc(x), cv, up2=up2, act=act, res=None if r is None else nhwc(r))
+    assert ran_bf3(rec) == [4]
+    assert maxabs(nchw(y), ref) < 5e-5
+
+
+def test_f16x3_fused_groupnorm_loader_and_partials(ops, f16):
+    """through the fused GroupNorm (+ swish) loader (level 1: only such launches take the form) and with the GroupNorm partials of the consumer."""
+    f16(1)
+    for (B, C, Co, H, sw) in ((2, 64, 64, 32, True), (1, 128, 64, 64, True), (2, 256, 128, 16, False), (1, 32, 64, 16, True)):
+        x = rnd(f"g3x{C}{H}", (B, C, H, H)) * 1.5 + 0.2
+        g, bt = 1 + 0.1 * rnd(f"g3g{C}", (C,)), 0.1 * rnd(f"g3b{C}", (C,))
+        w = rnd(f"g3w{C}{Co}", (Co, C, 3, 3), 1.0 / math.sqrt(9 * C))
+        b = rnd(f"g3bb{Co}", (Co,), 0.1)
+        hn = F.group_norm(x, 32, g, bt, 1e-6)
+        ref = F.conv2d(O.swish(hn) if sw else hn, w, b, padding=1)
+        xin = nhwc(x)
+        ss = ops.groupnorm_stats(xin, g.cuda(), bt.cuda())
+        cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+        with ops.profile() as rec:
+            y = ops.conv(xin, cv, in_ss=ss, in_swish=sw, want_stats=True)
+            y0 = ops.conv(xin, cv)                                              # a raw launch stays on the six-product form at level 1
+        assert ran_bf3(rec) == [4, 6]
+        assert maxabs(nchw(y), ref) < 5e-5
+        yc = y.cpu().double()
+        blocks = yc.view(B, H // 8, 8, H // 16, 16, Co).permute(0, 1, 3, 5, 2, 4).reshape(B, -1, Co, 128)
+        bm = blocks.mean(-1)
+        assert maxabs(y._gn_part[..., 0].cpu(), bm) < 2e-6 and maxabs(y._gn_part[..., 1].cpu(), ((blocks - bm[..., None]) ** 2).sum(-1)) < 2e-4
+
+
+@pytest.mark.parametrize("name,Cin,Cout,H,mk", [
+    ("plain", 128, 128, 64, lambda x: x * 1.7), ("plain64", 64, 64, 64, lambda x: x * 1.7), ("deep", 512, 256, 32, lambda x: x * 1.7),
+    ("tiny", 128, 64, 32, lambda x: x * 1e-4), ("huge", 64, 64, 32, lambda x: x * 3e3),
+    ("grows 1e5 after the first slice", 128, 128, 32, lambda x: torch.cat([x[:, :32] * 1e-3, x[:, 32:] * 100.0], 1)),
+    ("grows in the last slices", 256, 128, 32, lambda x: torch.cat([x[:, :200], x[:, 200:] * 3e4], 1)),
+    ("first slice zero", 64, 64, 32, lambda x: torch.cat([x[:, :32] * 0, x[:, 32:] * 1e-3], 1))])
+def test_f16x3_not_less_accurate_than_the_fp32_mfma_kernel(ops, f16, monkeypatch, name, Cin, Cout, H, mk):
+    """against an fp64 convolution of the SAME fp32 operands, raw inputs of every scale: the three-product half form's error is within 1.25x of the fp32-MFMA
+    Winograd kernel's (measured: below it, and at or below the six-product bf16 form's).  The input scale is the block's own: tiny and huge tensors, a tensor
+    whose later channel slices outgrow the first by 1e5 (the exact power-of-two rescale of region and accumulators runs) and a first slice of zeros included."""
+    B = 2
+    x = mk(rnd(f"h3x{Cin}{H}", (B, Cin, H, H)))
+    w = rnd(f"h3w{Cin}{Cout}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd(f"h3b{Cout}", (Cout,), 0.1) * float(x.abs().mean())
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    monkeypatch.setattr(ops, "WINO_BF3", 0)
+    y32 = ops.conv(nhwc(x), cv)
+    f16(2)
+    with ops.profile() as rec:
+        y16 = ops.conv(nhwc(x), cv)
+    assert ran_bf3(rec) == [4]
+    e32 = float((nchw(y32).double() - ref).abs().max()); e16 = float((nchw(y16).double() - ref).abs().max())
+    r32 = float((nchw(y32).double() - ref).pow(2).mean().sqrt()); r16 = float((nchw(y16).double() - ref).pow(2).mean().sqrt())
+    scale = float(ref.pow(2).mean().sqrt())
+    print(f"\n{name}: max|err| vs fp64  fp32-MFMA {e32:.3e}  f16x3 {e16:.3e}   rms {r32:.3e} {r16:.3e}   (output rms {scale:.2e})")
+    assert e16 <= 1.25 * e32 + 1e-7 * scale and r16 <= 1.1 * r32 + 1e-8 * scale
+
+
+def test_f16x3_pack_scales_u_by_a_power_of_two(ops):
+    """header {max |U| bits, 1 / scale}; scale = the power of two that puts max |U| into [2^11, 2^12); level 0 + level 1 == U x scale to 2^-21 of each value."""
+    w = rnd("p16w", (64, 32, 3, 3), 0.3)
+    cv = ops.Conv.from_torch(w.cuda(), None)
+    u = cv.winograd_u()[:16 * 2 * 4 * 256].view(16, 2, 4, 2, 32, 4).cpu()          # [f][nt][c8][half][row][4]
+    raw = cv.winograd_f16_u().cpu()
+    hdr = raw[:16].view(torch.float32)
+    umax = float(u.abs().max())
+    assert float(raw[:4].view(torch.float32)[0]) == umax
+    inv = float(hdr[1]); su = 1.0 / inv
+    assert math.log2(su) == round(math.log2(su)) and 2 ** 11 <= umax * su < 2 ** 12
+    lv = raw[16:].view(torch.float16).view(16, 2, 2, 3, 64, 8).double()                # [f][nt][step][plane][lane][8]
+    tot = lv[:, :, :, 0] + lv[:, :, :, 1]
+    exp = (u.double() * su).view(16, 2, 2, 2, 2, 32, 4).permute(0, 1, 2, 3, 5, 4, 6).reshape(16, 2, 2, 64, 8)
+    assert float((tot - exp).abs().max()) <= 2 ** -21 * umax * su and float(lv[:, :, :, 2].abs().max()) == 0.0
+
+
+def test_f16x3_sft_epilogue_and_determinism(ops, f16):
+    f16(2)
+    B, C, H, W = 2, 128, 32, 32
+    x = rnd("f3x", (B, C, H, W)); dec = rnd("f3d", (B, C, H, W)); sc = rnd("f3s", (B, C, H, W))
+    w = rnd("f3w", (C, C, 3, 3), 1.0 / math.sqrt(9 * C)); b = rnd("f3b", (C,), 0.1)
+    ref = dec + 0.7 * (dec * sc + F.conv2d(x, w, b, padding=1))
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    with ops.profile() as rec:
+        y = ops.conv_sft(nhwc(x), cv, nhwc(dec), nhwc(sc), 0.7)
+    assert ran_bf3(rec) == [4]
+    assert maxabs(nchw(y), ref) < 5e-5
+    assert torch.equal(y, ops.conv_sft(nhwc(x), cv, nhwc(dec), nhwc(sc), 0.7))
+
