@@ -191,6 +191,16 @@ int smx_gemm_rp_bf3(const float* a, int lda, const void* wp, const float* bias, 
                     long long M, int N, int K, int act, void* stream);
 int smx_gemm_rp_d2s_bf3(const float* a, int lda, const void* wp, const float* bias, float* c, int ldc, long long M, int N, int K, int act,
                         int d2s_p, int d2s_c, int Ho, int Wo, void* stream);
+/* smx_gemm_rp_bf3 / smx_gemm_rp_d2s_bf3 in the "f16x3" arithmetic (csrc/gemm_rp_bf3.hip, F16 = true): every operand as two IEEE-half levels, three
+ * v_mfma_f32_32x32x16_f16 products per multiply.  The weights are scaled by a power of two at pack time (chosen on the device from max |W|; 16 header bytes in
+ * front of smx_gemm_rp_bf3_pack's record layout), every A row by its own power of two inside the kernel: fp32-grade products for inputs of any magnitude
+ * (tests/test_gpu_gemm_bf3.py: error against fp64 below the fp32-MFMA kernel's).  Same shapes, arguments and call sites as the bf3 entry points. */
+int64_t smx_gemm_rp_f16_pack_bytes(int N, int K);
+int smx_gemm_rp_f16_pack(const float* w, int ldw, void* wp, int N, int K, void* stream);
+int smx_gemm_rp_f16(const float* a, int lda, const void* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
+                    long long M, int N, int K, int act, void* stream);
+int smx_gemm_rp_d2s_f16(const float* a, int lda, const void* wp, const float* bias, float* c, int ldc, long long M, int N, int K, int act,
+                        int d2s_p, int d2s_c, int Ho, int Wo, void* stream);
 /* Host-side (no device work): PNG scanline reconstruction, filter types 0-4 of RFC 2083, 8 bits per sample -- the inner loop of the frame reader either
  * side of the animation loop (reference basicsr/demo.py:166-185 reads the clip; the in-tree codec is synergize_motion_appearance_amd/png.py).  raw: h rows of
  * (1 filter byte + stride bytes) = the inflated IDAT stream; out: h rows of stride bytes; bpp = bytes per pixel.  Called through ctypes it runs

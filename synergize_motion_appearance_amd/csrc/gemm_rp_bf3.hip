@@ -64,9 +64,12 @@ __device__ __forceinline__ void rpb_split8(const float (&v)[8], uint4& hi, uint4
   hi = make_uint4(h[0], h[1], h[2], h[3]); mid = make_uint4(m[0], m[1], m[2], m[3]); lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 __device__ __forceinline__ bf16x8 rpb_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f16x8_t rpb_fragh(uint4 v) { return __builtin_bit_cast(f16x8_t, v); }
 
 // KSPLIT = K / 128 (1 | 2): waves per column tile; 8 waves per block = 8 / KSPLIT column tiles
-template <int KSPLIT, bool D2S = false>
+// F16: the "f16x3" arithmetic -- two IEEE-half levels per operand, three products (h1 g1 + h1 g2 + h2 g1).  The weights arrive scaled by a power of two (pack header),
+// every A row is scaled by its own power of two (its largest |value| into [2, 4): found by the half-wave that stages the row, kept in LDS for the epilogue)
+template <int KSPLIT, bool D2S = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_rp_bf3_kernel(RPB p) {
   constexpr int NW = 8, NTB = NW / KSPLIT;
   constexpr int K = 128 * KSPLIT;
@@ -77,18 +80,20 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_bf3_kernel(RPB p) {
   constexpr int GPT = KSPLIT;                  // 8-float groups per thread and tile (32 x K / 8 / 512)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Ex = reinterpret_cast<float*>(smem + 2 * LBUF);
+  float* Rs = Ex + NTB * 2 * EX_F;             // F16: 1 / (row scale), [2 buffers][32 rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wave % NTB, kh = wave / NTB;  // the two K halves of a column tile are waves w and w + 4: one SIMD, so every SIMD carries one finishing wave
   const int n0 = (blockIdx.y * NTB + nt) * 32;
 
   uint4 wf[KSW][3];
   {
-    const uint4* wp = reinterpret_cast<const uint4*>(p.wp) + ((long long)(n0 / 32) * (K / 16) + kh * KSW) * 3 * 64 + lane;
+    const uint4* wp = reinterpret_cast<const uint4*>(p.wp + (F16 ? 16 : 0)) + ((long long)(n0 / 32) * (K / 16) + kh * KSW) * 3 * 64 + lane;
 #pragma unroll
     for (int i = 0; i < KSW; ++i)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) wf[i][s] = wp[(i * 3 + s) * 64];
+      for (int s = 0; s < 3; ++s) wf[i][s] = (!F16 || s < 2) ? wp[(i * 3 + s) * 64] : make_uint4(0u, 0u, 0u, 0u);
   }
+  const float winv = F16 ? reinterpret_cast<const float*>(p.wp)[1] : 1.f;
   // staging: group g = tid + 512 j -> row g / CPR, chunk g % CPR
   int gsrc[GPT], gdst[GPT];
 #pragma unroll
@@ -107,10 +112,29 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_bf3_kernel(RPB p) {
     }
   };
   auto split_store = [&](int j, int buf) {
-    const float v[8] = {raw[j][0].x, raw[j][0].y, raw[j][0].z, raw[j][0].w, raw[j][1].x, raw[j][1].y, raw[j][1].z, raw[j][1].w};
+    float v[8] = {raw[j][0].x, raw[j][0].y, raw[j][0].z, raw[j][0].w, raw[j][1].x, raw[j][1].y, raw[j][1].z, raw[j][1].w};
+    unsigned char* d = smem + buf * LBUF + gdst[j];
+    if (F16) {
+      // the row's largest |value|: its CPR groups sit in CPR consecutive lanes
+      float m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+#pragma unroll
+      for (int o = CPR / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      const int e = __builtin_amdgcn_frexp_expf(m);                      // m = f 2^e, f in [0.5, 1) (0 for m = 0): m x 2^(2 - e) in [2, 4)
+      const float sc = __builtin_amdgcn_ldexpf(1.f, 2 - e);
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a0 = v[2 * q] * sc, a1 = v[2 * q + 1] * sc;
+        h[q] = cvt2_f16(a0, a1);
+        l[q] = cvt2_f16(a0 - f16lo(h[q]), a1 - f16hi(h[q]));
+      }
+      *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]); *reinterpret_cast<uint4*>(d + LEVEL) = make_uint4(l[0], l[1], l[2], l[3]);
+      const int g = tid + 512 * j;
+      if (g % CPR == 0) Rs[buf * 32 + g / CPR] = __builtin_amdgcn_ldexpf(1.f, e - 2);
+      return;
+    }
     uint4 h, m, l;
     rpb_split8(v, h, m, l);
-    unsigned char* d = smem + buf * LBUF + gdst[j];
     *reinterpret_cast<uint4*>(d) = h; *reinterpret_cast<uint4*>(d + LEVEL) = m; *reinterpret_cast<uint4*>(d + 2 * LEVEL) = l;
   };
   const int arow = lane & 31, ahalf = lane >> 5;
@@ -144,26 +168,34 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_bf3_kernel(RPB p) {
     uint4 xf[2][3];                            // the A fragments one step ahead of their MFMAs
     auto frag = [&](int i, uint4 (&x)[3]) {
       const unsigned char* q = ab + (((2 * (kh * KSW + i) + ahalf) ^ (arow & 15)) << 4);
-      x[0] = *reinterpret_cast<const uint4*>(q); x[1] = *reinterpret_cast<const uint4*>(q + LEVEL); x[2] = *reinterpret_cast<const uint4*>(q + 2 * LEVEL);
+      x[0] = *reinterpret_cast<const uint4*>(q); x[1] = *reinterpret_cast<const uint4*>(q + LEVEL);
+      if (!F16) x[2] = *reinterpret_cast<const uint4*>(q + 2 * LEVEL);
     };
     frag(0, xf[0]);
 #pragma unroll
     for (int i = 0; i < KSW; ++i) {
       if (i + 1 < KSW) frag(i + 1, xf[(i + 1) & 1]);
       const uint4 xh = xf[i & 1][0], xm = xf[i & 1][1], xl = xf[i & 1][2];
-      acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xl), acb, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][1]), rpb_frag(xh), acc, 0, 0, 0);
-      acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][2]), rpb_frag(xh), acb, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xm), acc, 0, 0, 0);
-      acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][1]), rpb_frag(xm), acb, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xh), acc, 0, 0, 0);
-      // the next tile's levels, under this tile's MFMAs (the registers were loaded a whole tile ago)
+      if (F16) {                               // three products, the chains alternating from step to step so that no two consecutive MFMAs share an accumulator
+        f32x16& c0 = (i & 1) ? acc : acb; f32x16& c1 = (i & 1) ? acb : acc;
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(rpb_fragh(wf[i][0]), rpb_fragh(xm), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(rpb_fragh(wf[i][1]), rpb_fragh(xh), c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(rpb_fragh(wf[i][0]), rpb_fragh(xh), c0, 0, 0, 0);
+      } else {
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xl), acb, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][1]), rpb_frag(xh), acc, 0, 0, 0);
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][2]), rpb_frag(xh), acb, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xm), acc, 0, 0, 0);
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][1]), rpb_frag(xm), acb, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rpb_frag(wf[i][0]), rpb_frag(xh), acc, 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);       // steps stay in this order: reads of step i + 1 ahead of the MFMAs of step i
       if (GPT == 2 ? (i == 2 || i == 5) : (i == 3)) {
         split_store(GPT == 2 ? (i == 5) : 0, buf ^ 1);      // one block between two steps (which steps does not matter: measured)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    const float rsc = F16 ? Rs[buf * 32 + erow] * winv : 1.f;             // this tile's row scale (written a tile ago), read BEFORE the barrier: the next tile's overwrites it after
     if (t + 2 * gx < p.tiles) fetch(t + 2 * gx);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acb[r];                     // the 2^-16-class chain into the leading one
@@ -204,7 +236,8 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_bf3_kernel(RPB p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 x = *reinterpret_cast<const float4*>(ex + erow * EXP + 16 * eh + 4 * q);
-      x.x += bq[q].x; x.y += bq[q].y; x.z += bq[q].z; x.w += bq[q].w;
+      if (F16) { x.x = fmaf(x.x, rsc, bq[q].x); x.y = fmaf(x.y, rsc, bq[q].y); x.z = fmaf(x.z, rsc, bq[q].z); x.w = fmaf(x.w, rsc, bq[q].w); }
+      else { x.x += bq[q].x; x.y += bq[q].y; x.z += bq[q].z; x.w += bq[q].w; }
       if (p.act != SMX_ACT_NONE) { x.x = rpb_act(x.x, p.act); x.y = rpb_act(x.y, p.act); x.z = rpb_act(x.z, p.act); x.w = rpb_act(x.w, p.act); }
       if (p.res) { x.x += rq[q].x; x.y += rq[q].y; x.z += rq[q].z; x.w += rq[q].w; }
       *reinterpret_cast<float4*>(cp + 4 * q) = x;
@@ -231,13 +264,45 @@ __global__ __launch_bounds__(256) void gemm_rp_bf3_pack_kernel(const float* __re
   }
 }
 
-template <int KSPLIT, bool D2S = false>
+// the f16x3 pack: max |W| (bits, atomicMax) -> the power of two that brings it into [2^11, 2^12) -> two IEEE-half levels of W x that scale in levels 0 / 1 of the
+// same record layout; 16 header bytes {max bits, 1 / scale} in front
+__global__ void gemm_rp_f16_absmax_kernel(const float* __restrict__ w, int ldw, int N, int K, unsigned* __restrict__ hdr) {
+  unsigned m = 0u;
+  const long long n = (long long)N * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = max(m, __float_as_uint(w[(i / K) * ldw + i % K]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(hdr, m);
+}
+__global__ __launch_bounds__(256) void gemm_rp_f16_pack_kernel(const float* __restrict__ w, int ldw, unsigned char* __restrict__ wpb, int N, int K) {
+  const float wmax = __uint_as_float(reinterpret_cast<const unsigned*>(wpb)[0]);
+  const float su = (wmax > 0.f && wmax < 3.0e38f) ? __builtin_amdgcn_ldexpf(1.f, 12 - __builtin_amdgcn_frexp_expf(wmax)) : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(wpb)[1] = 1.f / su;
+  uint4* wp = reinterpret_cast<uint4*>(wpb + 16);
+  const int KS = K / 16;
+  const long long total = (long long)(N / 32) * KS * 64;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const long long f = i >> 6;
+    const int g = (int)(f % KS), nt = (int)(f / KS);
+    const float* src = w + (long long)(nt * 32 + (lane & 31)) * ldw + g * 16 + (lane >> 5) * 8;
+    const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+    const float v[8] = {a0.x * su, a0.y * su, a0.z * su, a0.w * su, a1.x * su, a1.y * su, a1.z * su, a1.w * su};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { h[q] = cvt2_f16(v[2 * q], v[2 * q + 1]); l[q] = cvt2_f16(v[2 * q] - f16lo(h[q]), v[2 * q + 1] - f16hi(h[q])); }
+    uint4* o = wp + (f * 3) * 64 + lane;
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]); o[64] = make_uint4(l[0], l[1], l[2], l[3]); o[128] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+template <int KSPLIT, bool D2S = false, bool F16 = false>
 int rpb_launch(const RPB& p, hipStream_t st) {
-  constexpr int LDS = 2 * 3 * TM * 128 * KSPLIT * 2 + (8 / KSPLIT) * 2 * EX_F * 4;       // 133 KB (K = 256) | 122 KB (K = 128): one block per CU
-  SMX_HIP(smx_max_dynamic_lds((const void*)gemm_rp_bf3_kernel<KSPLIT, D2S>, LDS));
+  constexpr int LDS = 2 * 3 * TM * 128 * KSPLIT * 2 + (8 / KSPLIT) * 2 * EX_F * 4 + 256;  // 133 KB (K = 256) | 122 KB (K = 128): one block per CU
+  SMX_HIP(smx_max_dynamic_lds((const void*)gemm_rp_bf3_kernel<KSPLIT, D2S, F16>, LDS));
   const int ny = p.N / (32 * (8 / KSPLIT));
   int gx = 256 / ny; if (gx < 1) gx = 1; if (gx > p.tiles) gx = p.tiles;
-  SMX_LAUNCH((gemm_rp_bf3_kernel<KSPLIT, D2S>), dim3(gx, ny), dim3(512), LDS, st, p);
+  SMX_LAUNCH((gemm_rp_bf3_kernel<KSPLIT, D2S, F16>), dim3(gx, ny), dim3(512), LDS, st, p);
   return smx_launch_status();
 }
 
@@ -258,7 +323,7 @@ extern "C" int smx_gemm_rp_bf3_pack(const float* w, int ldw, void* wp, int N, in
 }
 
 static int rp_bf3_launch(const float* a, int lda, const void* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
-                         long long M, int N, int K, int act, int d2s_p, int d2s_c, int Ho, int Wo, void* stream) {
+                         long long M, int N, int K, int act, int d2s_p, int d2s_c, int Ho, int Wo, void* stream, bool f16 = false) {
   if (!a || !wp || !c || !smx_gemm_rp_bf3_ok(M, N, K)) return SMX_EINVAL;
   if (d2s_p) {
     if (d2s_p < 1 || d2s_c <= 0 || d2s_c % 16 || N != d2s_p * d2s_p * d2s_c || ldc < d2s_c || res || Ho <= 0 || Wo <= 0 || M % ((long long)Ho * Wo)) return SMX_EINVAL;
@@ -271,6 +336,10 @@ static int rp_bf3_launch(const float* a, int lda, const void* wp, const float* b
   p.lda = lda; p.ldres = res ? ldres : 0; p.ldc = ldc; p.M = (int)M; p.N = N; p.K = K; p.act = act; p.tiles = (int)(M / TM);
   p.d2s_p = d2s_p; p.d2s_c = d2s_c; p.Ho = Ho; p.Wo = Wo;
   hipStream_t st = (hipStream_t)stream;
+  if (f16) {
+    if (d2s_p) return K == 256 ? rpb_launch<2, true, true>(p, st) : rpb_launch<1, true, true>(p, st);
+    return K == 256 ? rpb_launch<2, false, true>(p, st) : rpb_launch<1, false, true>(p, st);
+  }
   if (d2s_p) return K == 256 ? rpb_launch<2, true>(p, st) : rpb_launch<1, true>(p, st);
   return K == 256 ? rpb_launch<2>(p, st) : rpb_launch<1>(p, st);
 }
@@ -285,3 +354,31 @@ extern "C" int smx_gemm_rp_d2s_bf3(const float* a, int lda, const void* wp, cons
   if (d2s_p < 1) return SMX_EINVAL;
   return rp_bf3_launch(a, lda, wp, bias, nullptr, 0, c, ldc, M, N, K, act, d2s_p, d2s_c, Ho, Wo, stream);
 }
+
+/* The same launches in the "f16x3" arithmetic: two IEEE-half levels per operand, three v_mfma_f32_32x32x16_f16 products per multiply.  wp = smx_gemm_rp_f16_pack
+ * (16 header bytes + the record layout of smx_gemm_rp_bf3_pack; W scaled by a power of two chosen on the device); every A row is scaled by its own power of two
+ * inside the kernel, so inputs of any magnitude keep fp32-grade products. */
+extern "C" int64_t smx_gemm_rp_f16_pack_bytes(int N, int K) { const int64_t b = smx_gemm_rp_bf3_pack_bytes(N, K); return b ? b + 16 : 0; }
+
+extern "C" int smx_gemm_rp_f16_pack(const float* w, int ldw, void* wp, int N, int K, void* stream) {
+  if (!w || !wp || N <= 0 || N % 32 || K <= 0 || K % 16 || ldw < K || ldw % 4 || ((uintptr_t)w & 15) || ((uintptr_t)wp & 15)) return SMX_EINVAL;
+  SMX_HIP(hipMemsetAsync(wp, 0, 16, (hipStream_t)stream));
+  const long long n = (long long)N * K, total = (long long)(N / 32) * (K / 16) * 64;
+  int gb = smx_cdiv(n, 256); if (gb > 2048) gb = 2048;
+  SMX_LAUNCH(gemm_rp_f16_absmax_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, (unsigned*)wp);
+  int g = smx_cdiv(total, 256); if (g > 4096) g = 4096;
+  SMX_LAUNCH(gemm_rp_f16_pack_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, w, ldw, (unsigned char*)wp, N, K);
+  return smx_launch_status();
+}
+
+extern "C" int smx_gemm_rp_f16(const float* a, int lda, const void* wp, const float* bias, const float* res, int ldres, float* c, int ldc,
+                               long long M, int N, int K, int act, void* stream) {
+  return rp_bf3_launch(a, lda, wp, bias, res, ldres, c, ldc, M, N, K, act, 0, 0, 0, 0, stream, true);
+}
+
+extern "C" int smx_gemm_rp_d2s_f16(const float* a, int lda, const void* wp, const float* bias, float* c, int ldc, long long M, int N, int K, int act,
+                                   int d2s_p, int d2s_c, int Ho, int Wo, void* stream) {
+  if (d2s_p < 1) return SMX_EINVAL;
+  return rp_bf3_launch(a, lda, wp, bias, nullptr, 0, c, ldc, M, N, K, act, d2s_p, d2s_c, Ho, Wo, stream, true);
+}
+

@@ -167,6 +167,10 @@ SIGNATURES = {
     "smx_maxpool2_f32": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "smx_maxpool2_bwd_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "smx_chan_affine_f32": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _p]),
+    "smx_gemm_rp_f16_pack_bytes": (_i64, [_i, _i]),
+    "smx_gemm_rp_f16_pack": (_i, [_p, _i, _p, _i, _i, _p]),
+    "smx_gemm_rp_f16": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
+    "smx_gemm_rp_d2s_f16": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_gemm_rp_bf3_ok": (_i, [_i64, _i, _i]),
     "smx_gemm_rp_bf3_pack_bytes": (_i64, [_i, _i]),
     "smx_gemm_rp_bf3_pack": (_i, [_p, _i, _p, _i, _i, _p]),

@@ -131,7 +131,7 @@ WINOGRAD = bool(_knob("SMX_WINOGRAD", 1))
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3", "_wrp3", "_u3h")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3", "_wrp3", "_u3h", "_wrp3h")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -140,6 +140,7 @@ class Conv:
         self._u43 = None
         self._u3 = None
         self._u3h = None
+        self._wrp3h = None
         self._wrp3 = None
         self._w16t = None
         self._w16rp = None
@@ -222,6 +223,16 @@ class Conv:
             L.check(lib.smx_gemm_rp_bf3_pack(_dev(self.w).data_ptr(), self.w.shape[1], wp.data_ptr(), self.cout, self.cin, _stream()), "smx_gemm_rp_bf3_pack")
             self._wrp3 = wp
         return self._wrp3
+
+    @property
+    def w_rp3h(self):
+        """a 1x1 layer's weights scaled by a power of two and split into two IEEE-half levels for the f16x3 row-panel kernel (smx_gemm_rp_f16_pack), built once."""
+        if self._wrp3h is None:
+            lib = L.load()
+            wp = torch.empty(int(lib.smx_gemm_rp_f16_pack_bytes(self.cout, self.cin)), device=self.w.device, dtype=torch.uint8)
+            L.check(lib.smx_gemm_rp_f16_pack(_dev(self.w).data_ptr(), self.w.shape[1], wp.data_ptr(), self.cout, self.cin, _stream()), "smx_gemm_rp_f16_pack")
+            self._wrp3h = wp
+        return self._wrp3h
 
     @property
     def w16_rp(self):
@@ -350,6 +361,7 @@ CONV16_F32_REGION = _knob("SMX_CONV16_F32_REGION", 1)   # fp32-storage form of t
 
 
 GEMM_RP = _knob("SMX_GEMM_RP", 1)          # fp32 row-panel kernel (csrc/gemm_rp_f32.hip); 0 = implicit GEMM
+GEMM_RP_F16 = _knob("SMX_GEMM_RP_F16", 1)  # the split row-panel launches in the f16x3 form (two half levels, three products; per-row input scale); 0 = the six-product bf16 form
 GEMM_RP_BF3 = _knob("SMX_GEMM_RP_BF3", 1)  # the same launches on the bf16 MFMA with three-way split fp32 operands, six products (csrc/gemm_rp_bf3.hip); 0 = the fp32-MFMA kernel
 GEMM16_RP = _knob("SMX_GEMM16_RP", 1)      # row-panel kernel (csrc/gemm_rp_bf16.hip) for the K = 128 / 256 1x1 layers; 0 = implicit GEMM
 GEMM16_RP_MIN_ROWS = 16384                                           # below: too few 32-row tiles to fill the persistent blocks (tests lower it)
@@ -654,14 +666,16 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
            and a_ptr % 16 == 0 and c_ptr % 16 == 0 and (cv.b is None or cv.b.data_ptr() % 16 == 0))
     if rp3 and not d2s and (res is None or (ldr % 4 == 0 and r_ptr % 16 == 0)):
         # the short-K token Linears / 1x1 convolutions of the fp32 configuration: fp32-grade products on the bf16 matrix pipe (three-way split operands)
-        meta = {"flops": 2.0 * M * cv.cout * K, "mfma_flops": 12.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "rp": 1, "bf3": 6} if _PROFILE is not None else None
-        L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_bf3, a_ptr, lda, cv.w_rp3.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
-                       r_ptr, ldr, c_ptr, ldc, M, cv.cout, K, act, _stream()), "smx_gemm_rp_bf3")
+        npr = 4 if GEMM_RP_F16 else 6
+        meta = {"flops": 2.0 * M * cv.cout * K, "mfma_flops": (6.0 if npr == 4 else 12.0) * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "rp": 1, "bf3": npr} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_f16 if npr == 4 else L.load().smx_gemm_rp_bf3, a_ptr, lda, (cv.w_rp3h if npr == 4 else cv.w_rp3).data_ptr(),
+                       None if cv.b is None else cv.b.data_ptr(), r_ptr, ldr, c_ptr, ldc, M, cv.cout, K, act, _stream()), "smx_gemm_rp_bf3")
         return out
     if rp3 and d2s and res is None and d2s[1] % 16 == 0:
-        meta = {"flops": 2.0 * M * cv.cout * K, "mfma_flops": 12.0 * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "rp": 1, "bf3": 6} if _PROFILE is not None else None
-        L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_d2s_bf3, a_ptr, lda, cv.w_rp3.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
-                       c_ptr, ldc, M, cv.cout, K, act, d2s[0], d2s[1], Ho, Wo, _stream()), "smx_gemm_rp_d2s_bf3")
+        npr = 4 if GEMM_RP_F16 else 6
+        meta = {"flops": 2.0 * M * cv.cout * K, "mfma_flops": (6.0 if npr == 4 else 12.0) * M * cv.cout * K, "M": M, "N": cv.cout, "K": K, "nb": 1, "k": 1, "rp": 1, "bf3": npr} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_gemm_rp_d2s_f16 if npr == 4 else L.load().smx_gemm_rp_d2s_bf3, a_ptr, lda, (cv.w_rp3h if npr == 4 else cv.w_rp3).data_ptr(),
+                       None if cv.b is None else cv.b.data_ptr(), c_ptr, ldc, M, cv.cout, K, act, d2s[0], d2s[1], Ho, Wo, _stream()), "smx_gemm_rp_d2s_bf3")
         return out
     if (GEMM_RP and not direct and tile == 0 and cv.kh == 1 and cv.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not up2 and not d2s
             and (Ho, Wo) == (H, W) and M >= GEMM16_RP_MIN_ROWS and L.load().smx_gemm_rp_f32_ok(M, cv.cout, K) and lda % 4 == 0 and ldc % 4 == 0

@@ -28,6 +28,7 @@ def ops():
 def small(ops, monkeypatch):
     monkeypatch.setattr(ops, "GEMM_RP_BF3_MIN_ROWS", 32)
     monkeypatch.setattr(ops, "GEMM16_RP_MIN_ROWS", 1024)
+    monkeypatch.setattr(ops, "GEMM_RP_F16", 0)          # the six-product bf16 form; the f16x3 form has its own tests below
 
 
 def rnd(name, shape, scale=1.0):
@@ -131,3 +132,71 @@ def test_split_gemm_is_deterministic_and_refuses_bad_arguments(ops, small):
     y = torch.empty((8192, 256), device="cuda")
     assert Lb.smx_gemm_rp_bf3(x.data_ptr() + 4, 256, cv.w_rp3.data_ptr(), None, None, 0, y.data_ptr(), 256, 8192, 256, 256, 0, None) != 0   # misaligned rows
     assert Lb.smx_gemm_rp_bf3(x.data_ptr(), 256, cv.w_rp3.data_ptr(), None, None, 0, y.data_ptr(), 128, 8192, 256, 256, 0, None) != 0      # ldc < N
+
+
+# ---- the f16x3 form (two IEEE-half levels, three products; per-row input scale) ------------------------------------------------------------------------------
+@pytest.fixture
+def half(ops, monkeypatch):
+    monkeypatch.setattr(ops, "GEMM_RP_BF3_MIN_ROWS", 32)
+    monkeypatch.setattr(ops, "GEMM16_RP_MIN_ROWS", 1024)
+    monkeypatch.setattr(ops, "GEMM_RP_F16", 1)
+
+
+@pytest.mark.parametrize("B,K,N,act,with_res,sliced", [(8, 256, 256, 0, True, False), (4, 256, 512, 4, False, True), (8, 128, 256, 0, False, False),
+                                                      (4, 128, 512, 1, True, True), (5, 256, 128, 0, True, False)])
+def test_f16x3_row_panel_gemm(ops, half, B, K, N, act, with_res, sliced):
+    H, W = 64, 48
+    xw = rnd(f"r3x{K}{N}", (B, H, W, K + (24 if sliced else 0))).cuda()
+    x = xw[..., 8:8 + K] if sliced else xw
+    w = rnd(f"r3w{K}{N}", (N, K), 1.0 / math.sqrt(K))
+    b = rnd(f"r3b{K}{N}", (N,), 0.2)
+    rw = rnd(f"r3r{K}{N}", (B, H, W, N + (16 if sliced else 0))).cuda()
+    res = (rw[..., 16:] if sliced else rw) if with_res else None
+    cv = ops.Conv(w.cuda().contiguous(), b.cuda(), 1, 1, K, N)
+    out = torch.full((B, H, W, N + 8), 5.0, device="cuda")
+    with ops.profile() as rec:
+        ops.conv(x, cv, out=out[..., 4:4 + N], act=act, res=res)
+    assert ran(rec) == [(1, 4)], rec.rows
+    ref = x.cpu().reshape(-1, K).double() @ w.double().T + b.double()
+    ref = {0: lambda t: t, 1: torch.relu, 4: F.gelu}[act](ref)
+    if res is not None:
+        ref = ref + res.cpu().reshape(-1, N).double()
+    assert maxabs(out[..., 4:4 + N].cpu().reshape(-1, N), ref.float()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float(out[..., :4].min()) == 5.0 and float(out[..., 4 + N:].max()) == 5.0
+
+
+def test_f16x3_unpatchify_store(ops, half, monkeypatch):
+    for (p_, C_, B, K) in ((8, 64, 3, 256), (4, 128, 2, 256), (4, 32, 2, 128)):
+        N = p_ * p_ * C_
+        x = rnd(f"d3x{p_}{K}", (B, 32, 32, K)).cuda()
+        cv = ops.Conv(rnd(f"d3w{p_}{K}", (N, K), 1.0 / math.sqrt(K)).cuda().contiguous(), rnd(f"d3b{p_}", (N,), 0.2).cuda(), 1, 1, K, N)
+        with ops.profile() as rec:
+            y = ops.conv(x, cv, d2s=(p_, C_), act=2)
+        assert ran(rec) == [(1, 4)] and tuple(y.shape) == (B, 32 * p_, 32 * p_, C_)
+        monkeypatch.setattr(ops, "GEMM_RP", 0)
+        y0 = ops.conv(x, cv, d2s=(p_, C_), act=2)
+        monkeypatch.setattr(ops, "GEMM_RP", 1)
+        assert maxabs(y0, y) < 2e-5 * max(1.0, float(y0.abs().max()))
+
+
+@pytest.mark.parametrize("name,K,N,mk", [("plain", 256, 256, lambda x: x * 1.7), ("k128", 128, 256, lambda x: x * 1.7), ("wide", 256, 1024, lambda x: x * 1.7),
+                                         ("tiny rows and huge rows", 256, 256, lambda x: x * torch.logspace(-6, 5, x.shape[0] * x.shape[1] * x.shape[2]).view(*x.shape[:3], 1)),
+                                         ("zero rows", 256, 128, lambda x: x * (torch.arange(x.shape[2]) % 3 != 0).float().view(1, 1, -1, 1))])
+def test_f16x3_gemm_not_less_accurate_than_the_fp32_mfma_kernel(ops, half, monkeypatch, name, K, N, mk):
+    """against the fp64 product of the SAME fp32 operands; rows of every magnitude in one launch (each row carries its own power-of-two scale): the error of every
+    row, relative to that row's own output scale, is within 1.25x of the fp32-MFMA row-panel kernel's."""
+    x = mk(rnd(f"a3x{K}", (4, 64, 64, K))).cuda()
+    w = rnd(f"a3w{K}{N}", (N, K), 1.0 / math.sqrt(K))
+    cv = ops.Conv(w.cuda().contiguous(), None, 1, 1, K, N)
+    ref = x.cpu().reshape(-1, K).double() @ w.double().T
+    with ops.profile() as rec:
+        y16 = ops.conv(x, cv)
+    assert ran(rec) == [(1, 4)]
+    monkeypatch.setattr(ops, "GEMM_RP_BF3", 0)
+    y32 = ops.conv(x, cv)
+    rs = ref.pow(2).mean(1).sqrt().clamp_min(1e-30)                      # every row judged against its own scale
+    e16 = ((y16.cpu().reshape(-1, N).double() - ref).abs().max(1).values / rs); e32 = ((y32.cpu().reshape(-1, N).double() - ref).abs().max(1).values / rs)
+    print(f"\n{name}: worst row-relative max error  fp32-MFMA {float(e32.max()):.3e}  f16x3 {float(e16.max()):.3e}   mean {float(e32.mean()):.3e} {float(e16.mean()):.3e}")
+    assert float(e16.max()) <= 1.25 * float(e32.max()) + 1e-7 and float(e16.mean()) <= 1.1 * float(e32.mean()) + 1e-8
+    assert bool(torch.isfinite(y16).all())
+

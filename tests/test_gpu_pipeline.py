@@ -213,7 +213,7 @@ def test_bench_batch_of_60_equals_single_frame_runs(nets, B):
     assert u8.shape == (B, 256, 256, 3) and fl.shape == (B, 3, 256, 256)
     # round 6: at these batch sizes the big 3x3 launches run on the split-bf16 Winograd kernel (the B = 1 runs below on the fp32-MFMA one): the comparison
     # that follows is between the two arithmetic paths
-    n_bf3 = sum(1 for r in rec.rows if r[0] == "gemm_conv" and (r[1] or {}).get("bf3") == 6)
+    n_bf3 = sum(1 for r in rec.rows if r[0] == "gemm_conv" and (r[1] or {}).get("bf3") in (4, 6))      # 6: bf16x6, 4: f16x3 (the default since the end of round 6)
     assert ops.WINO_BF3 == 6 and n_bf3 >= 60, n_bf3
     for i in (0, B // 2 + 1, B - 1):
         u1, f1 = driver.render_frames(st, drv[i:i + 1], net_g, me, True, True, batch=1, want="both")

@@ -85,8 +85,9 @@ def test_fp32_winograd_kernels_are_bit_stable_next_to_another_process_running_th
 
     def victims():
         outs, kinds = [], []
-        for mode, cv, r in ((0, cv128, res), (6, cv128, res), (6, cv64, None)):
-            monkeypatch.setattr(ops, "WINO_BF3", mode)
+        for mode, cv, r in ((0, cv128, res), (6, cv128, res), (6, cv64, None), (4, cv128, res)):
+            monkeypatch.setattr(ops, "WINO_BF3", 6 if mode == 4 else mode)
+            monkeypatch.setattr(ops, "WINO_F16", 2 if mode == 4 else 0)
             with ops.profile() as rec:
                 y = ops.conv(x, cv, in_ss=ss, in_swish=True, res=r, want_stats=True)
             outs += [y.clone(), y._gn_part.clone()]
@@ -98,8 +99,8 @@ def test_fp32_winograd_kernels_are_bit_stable_next_to_another_process_running_th
         return outs, kinds
     ref, kinds = victims()
     ops.set_tuning("attn_bf3", old_attn)
-    # the wide fp32-MFMA kernel, the split Winograd kernel at 8x16x128 and at 16x16x64 blocks, the split row-panel GEMM, the split attention
-    assert kinds == [(None, 1), (6, 1), (6, 1), (6, 1), (3, None)], kinds
+    # the wide fp32-MFMA kernel, the split Winograd kernel at 8x16x128 and at 16x16x64 blocks (bf16x6) and in its f16x3 form, the split row-panel GEMM, the split attention
+    assert kinds[:4] == [(None, 1), (6, 1), (6, 1), (4, 1)] and kinds[4][0] in (4, 6) and kinds[4][1] == 1 and kinds[5] == (3, None), kinds
     torch.cuda.synchronize()
     log = tmp_path / "aggressor.log"
     with open(log, "w") as f:

@@ -30,6 +30,7 @@ def bf3(ops, monkeypatch):
     """route eligible launches to the split kernel (any size), restore afterwards."""
     def _set(nprod):
         monkeypatch.setattr(ops, "WINO_BF3", nprod)
+        monkeypatch.setattr(ops, "WINO_F16", 0)              # the bf16 forms; the f16x3 form has its own tests at the end of this file
         monkeypatch.setattr(ops, "WINO_BF3_MIN_BLOCKS", 1)
     return _set
 
