@@ -478,6 +478,213 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bf3_kernel(AP<float> p) 
   }
 }
 
+// The same kernel in the "f16x3" arithmetic: every operand as TWO IEEE-half levels (11 + 11 significand bits), three v_mfma_f32_32x32x16_f16 products per multiply
+// (a1 b1 + a1 b2 + a2 b1; the dropped terms are 2^-22 relative) -- half the MFMAs and a 3-instruction split per value instead of 5.5.  A half's range needs care:
+//   * scores: what matters is the ABSOLUTE error of s = q . k (log2 units); q (pre-scaled) and k are taken as they are -- below 2^-3 a value's second level is a
+//     subnormal half with an absolute error <= 2^-25, far below the 2^-22 relative error of the values that dominate a score;
+//   * P' = 2^10 exp2(s - m): the 2^10 rides in the exponent argument and cancels in O = sum(P' v) / sum(P');
+//   * V is scaled by a power of two sv chosen by the block from its first 64 keys (largest |v| into [2, 4)); a later tile that outgrows the 2^12 headroom raises a
+//     flag; the block picks a new sv, stages that tile again from the fp32 values still in registers, and the O accumulators follow the scale of the tile they take in
+//     (exact power-of-two rescale).
+__device__ __forceinline__ void ah_split8(const float (&v)[8], uint4& h, uint4& l) {
+  unsigned hh_[4], ll_[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    hh_[q] = cvt2_f16(v[2 * q], v[2 * q + 1]);
+    ll_[q] = cvt2_f16(v[2 * q] - f16lo(hh_[q]), v[2 * q + 1] - f16hi(hh_[q]));
+  }
+  h = make_uint4(hh_[0], hh_[1], hh_[2], hh_[3]); l = make_uint4(ll_[0], ll_[1], ll_[2], ll_[3]);
+}
+__device__ __forceinline__ f16x8_t ah_f(uint4 v) { return __builtin_bit_cast(f16x8_t, v); }
+
+template <bool MASK, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_f16_kernel(AP<float> p) {
+  constexpr int DH = 32, TK = 64, KROW = DH * 2 + 16, VROW = TK * 2 + 16;
+  constexpr int KPL = TK * KROW, VPL = DH * VROW;
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][2 * KPL];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[2][2 * VPL];
+  __shared__ uint8_t Ms[2][TK];
+  __shared__ float Red[NW + 1];                                           // wave maxima of |V| (scale decisions), [NW]: the growth flag
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+  const int qrow = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
+  const int hh = lane >> 5;
+  const float* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq + h * DH;
+  const float* K = p.k + b * p.k_bs + h * DH;
+  const float* V = p.v + b * p.v_bs + h * DH;
+  const uint8_t* M = (MASK && p.mask) ? p.mask + (long long)b * p.S : nullptr;
+
+  uint4 qf[2][2];
+  {
+    const float sc = p.scale * 1.44269504088896340736f;                   // scores in log2 units
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const float4 a0 = *reinterpret_cast<const float4*>(Q + kk * 16 + hh * 8), a1 = *reinterpret_cast<const float4*>(Q + kk * 16 + hh * 8 + 4);
+      const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+      ah_split8(v, qf[kk][0], qf[kk][1]);
+    }
+  }
+  f32x16 oacc, oacb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = oacb[r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  constexpr int GF = NW == 4 ? 8 : 4, GPK = DH / GF;
+  const int skey = threadIdx.x / GPK, sg = threadIdx.x % GPK;
+  const int kq = skey & 15;
+  const int vcol = (skey & ~15) + (kq < 4 ? kq : kq < 8 ? kq + 4 : kq < 12 ? kq - 4 : kq);
+  float4 kreg[GF / 4], vreg[GF / 4]; uint8_t mreg = 0;
+  float sv = 1.f, osv = 1.f, svbuf[2] = {1.f, 1.f}, omax = 0.f;           // V scale of the coming stores | of the O accumulators | of each staged tile; largest scaled |v| stored
+  bool unscaled = false;
+  auto load_tile = [&](int key0) {
+    const float* kp = K + (long long)(key0 + skey) * p.ldk + sg * GF;
+    const float* vp = V + (long long)(key0 + skey) * p.ldv + sg * GF;
+#pragma unroll
+    for (int i = 0; i < GF / 4; ++i) { kreg[i] = *reinterpret_cast<const float4*>(kp + 4 * i); vreg[i] = *reinterpret_cast<const float4*>(vp + 4 * i); }
+    if (MASK && M && threadIdx.x < TK) mreg = M[key0 + threadIdx.x];
+  };
+  auto store_tile = [&](int buf) {
+    float kv[8], vv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < GF / 4; ++i) {
+      kv[4 * i] = kreg[i].x; kv[4 * i + 1] = kreg[i].y; kv[4 * i + 2] = kreg[i].z; kv[4 * i + 3] = kreg[i].w;
+      vv[4 * i] = vreg[i].x * sv; vv[4 * i + 1] = vreg[i].y * sv; vv[4 * i + 2] = vreg[i].z * sv; vv[4 * i + 3] = vreg[i].w * sv;
+      omax = fmaxf(omax, fmaxf(fmaxf(fabsf(vv[4 * i]), fabsf(vv[4 * i + 1])), fmaxf(fabsf(vv[4 * i + 2]), fabsf(vv[4 * i + 3]))));
+    }
+    uint4 kl[2], vl[2];
+    ah_split8(kv, kl[0], kl[1]);
+    ah_split8(vv, vl[0], vl[1]);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      unsigned char* kd = &Ks[buf][s2 * KPL + skey * KROW + sg * (2 * GF)];
+      if (GF == 8) *reinterpret_cast<uint4*>(kd) = kl[s2]; else *reinterpret_cast<uint2*>(kd) = make_uint2(kl[s2].x, kl[s2].y);
+      const uint32_t w4[4] = {vl[s2].x, vl[s2].y, vl[s2].z, vl[s2].w};
+#pragma unroll
+      for (int e = 0; e < GF; ++e)
+        *reinterpret_cast<uint16_t*>(&Vt[buf][s2 * VPL + (sg * GF + e) * VROW + vcol * 2]) = (uint16_t)(e & 1 ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffffu);
+    }
+    if (MASK && threadIdx.x < TK) Ms[buf][threadIdx.x] = M ? mreg : 0;
+    svbuf[buf] = sv;
+  };
+  // the block's largest |value|: `mine` reduced over the block (two barriers inside)
+  auto block_max = [&](float mine) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine = fmaxf(mine, __shfl_xor(mine, o, 64));
+    __syncthreads();
+    if (lane == 0) Red[wave] = mine;
+    __syncthreads();
+    float bm = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) bm = fmaxf(bm, Red[w]);
+    return bm;
+  };
+
+  const int ntiles = p.S / TK;
+  load_tile(0);
+  {
+    float tm = 0.f;
+#pragma unroll
+    for (int i = 0; i < GF / 4; ++i) tm = fmaxf(tm, fmaxf(fmaxf(fabsf(vreg[i].x), fabsf(vreg[i].y)), fmaxf(fabsf(vreg[i].z), fabsf(vreg[i].w))));
+    const float bm = block_max(tm);
+    if (threadIdx.x == 0) Red[NW] = 0.f;
+    unscaled = !(bm > 0.f && bm < 3.0e38f);
+    sv = unscaled ? 1.f : __builtin_amdgcn_ldexpf(1.f, 2 - __builtin_amdgcn_frexp_expf(bm));
+    osv = sv;
+  }
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile((t + 1) * TK);
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 kf[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) kf[u][s2] = *reinterpret_cast<const uint4*>(&Ks[buf][s2 * KPL + (u * 32 + (lane & 31)) * KROW + hh * 16 + kk * 32]);
+      constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};               // (K level, Q level): k1q2 k2q1 k1q1
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_f(kf[u][PA[pr]]), ah_f(qf[kk][PB[pr]]), s[u], 0, 0, 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (MASK) {
+          const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (Ms[buf][key]) s[u][r] = -INFINITY;
+        }
+        tmax = fmaxf(tmax, s[u][r]);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const bool dead = MASK && (m_new == -INFINITY);
+    const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m - m_new);
+    const float mo = 10.f - m_new;                                        // P' = 2^10 P
+    float psum = 0.f;
+    uint4 pf[4][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float e[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { e[r] = dead ? 0.f : __builtin_amdgcn_exp2f(s[u][r] + mo); psum += e[r]; }
+      const float e0[8] = {e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]}, e1[8] = {e[8], e[9], e[10], e[11], e[12], e[13], e[14], e[15]};
+      ah_split8(e0, pf[2 * u][0], pf[2 * u][1]);
+      ah_split8(e1, pf[2 * u + 1][0], pf[2 * u + 1][1]);
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum; m = m_new;
+    float resc = alpha;                                                   // softmax rescale x (rarely) the step to this tile's V scale
+    if (svbuf[buf] != osv) { resc *= svbuf[buf] / osv; osv = svbuf[buf]; }
+    if (__builtin_amdgcn_ballot_w64(resc != 1.f) != 0ull) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[r] *= resc; oacb[r] *= resc; }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint4 vf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) vf[s2] = *reinterpret_cast<const uint4*>(&Vt[buf][s2 * VPL + (lane & 31) * VROW + hh * 16 + g * 32]);
+      f32x16& c0 = (g & 1) ? oacc : oacb; f32x16& c1 = (g & 1) ? oacb : oacc;
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_f(vf[0]), ah_f(pf[g][1]), c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_f(vf[1]), ah_f(pf[g][0]), c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_f(vf[0]), ah_f(pf[g][0]), c0, 0, 0, 0);
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    if (omax > 4096.f || (unscaled && omax > 0.f)) Red[NW] = 1.f;
+    __syncthreads();
+    if (Red[NW] != 0.f) {                                                 // rare: a tile outgrew the headroom (or the first tiles were all zero): new scale for the tiles after it
+      const float bm = block_max(omax) / sv;                             // (true magnitude; finite: omax is taken before the conversion to half)
+      if (bm > 0.f && bm < 3.0e38f) { sv = __builtin_amdgcn_ldexpf(1.f, 2 - __builtin_amdgcn_frexp_expf(bm)); unscaled = false; }
+      omax = 0.f;
+      if (t + 1 < ntiles) store_tile(buf ^ 1);                           // the tile just staged may hold overflowed halves: stage it again (its fp32 values are still in registers)
+      if (threadIdx.x == 0) Red[NW] = 0.f;
+      __syncthreads();
+    }
+  }
+  float* O = p.o + b * p.o_bs + (long long)qrow * p.ldo + h * DH;
+  const float inv = 1.f / (l * osv);                                      // l == 0 (fully masked row) -> NaN like the reference
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 w = make_float4((oacc[4 * g] + oacb[4 * g]) * inv, (oacc[4 * g + 1] + oacb[4 * g + 1]) * inv, (oacc[4 * g + 2] + oacb[4 * g + 2]) * inv,
+                           (oacc[4 * g + 3] + oacb[4 * g + 3]) * inv);
+    if (l == 0.f) w = make_float4(NAN, NAN, NAN, NAN);
+    *reinterpret_cast<float4*>(O + 8 * g + 4 * hh) = w;
+  }
+}
+
 // The vqgan AttnBlock core (archs/vqgan_arch.py:229-253: ONE head of d = C = 256 over the 32 x 32 tokens) on bf16 storage, fused:
 // softmax(q k^T / sqrt(C)) v as one kernel, the [B, N, N] score tensor never exists (the three-launch form wrote and re-read 1.26 GB of
 // fp32 scores per call at B = 300).  Same swapped-product scheme as attn_mfma16_kernel with the d axis 8 tiles wide: Q^T fragments
@@ -967,7 +1174,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma4_bf16_kernel(AP<bf16_t> p) {
  * levels) -- knob attn_bf3 (3 | 2, + 16 = at any launch size, + 32 = 128-query blocks; 0 = off), d_head 32, S % 64 == 0, at least 512 blocks' worth of 128 queries. */
 extern "C" int smx_attention_f32_uses_bf3(int B, int H, int L, int S, int dh) {
   const int knob = smx_tune(SMX_TUNE_ATTN_BF3), np = knob & 15;
-  if (dh != 32 || (np != 2 && np != 3) || B <= 0 || H <= 0 || L <= 0 || L % 128 || S <= 0 || S % 64) return 0;
+  if (dh != 32 || (np != 2 && np != 3 && np != 4) || B <= 0 || H <= 0 || L <= 0 || L % 128 || S <= 0 || S % 64) return 0;
   if (!(knob & 16) && (long long)(L / 128) * B * H < 512) return 0;
   return np;
 }
@@ -1018,7 +1225,11 @@ int attention_launch(const T* q, int ldq, int64_t q_bs, const T* k, int ldk, int
         const int nw = (smx_tune(SMX_TUNE_ATTN_BF3) & 32) || L % 256 ? 4 : 8;        // knob + 32: the 128-query blocks
 #define AB3_GO(MK, NPV) do { if (nw == 8) SMX_LAUNCH((attn_bf3_kernel<MK, NPV, 8>), dim3(L / 256, B * H), dim3(512), 0, st, p); \
                              else SMX_LAUNCH((attn_bf3_kernel<MK, NPV, 4>), dim3(L / 128, B * H), dim3(256), 0, st, p); } while (0)
-        if (key_mask) { if (np == 2) AB3_GO(true, 2); else AB3_GO(true, 3); }
+        if (np == 4) {
+          if (key_mask) { if (nw == 8) SMX_LAUNCH((attn_f16_kernel<true, 8>), dim3(L / 256, B * H), dim3(512), 0, st, p); else SMX_LAUNCH((attn_f16_kernel<true, 4>), dim3(L / 128, B * H), dim3(256), 0, st, p); }
+          else { if (nw == 8) SMX_LAUNCH((attn_f16_kernel<false, 8>), dim3(L / 256, B * H), dim3(512), 0, st, p); else SMX_LAUNCH((attn_f16_kernel<false, 4>), dim3(L / 128, B * H), dim3(256), 0, st, p); }
+        }
+        else if (key_mask) { if (np == 2) AB3_GO(true, 2); else AB3_GO(true, 3); }
         else { if (np == 2) AB3_GO(false, 2); else AB3_GO(false, 3); }
 #undef AB3_GO
       }

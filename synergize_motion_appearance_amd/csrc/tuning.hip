@@ -31,7 +31,7 @@ Knob g_knobs[SMX_TUNE_COUNT] = {
   {"gemm_loader", "SMX_GEMM_LOADER", 1},        // gemm_conv: 1 = operand quads by buffer loads with SGPR bases / offsets where the layout allows (MODE 2), 0 = the float4 gather
   {"wino_xcd", "SMX_WINO_XCD", 1},              // wide Winograd: the output blocks of a spatial tile on ONE XCD at the same time (block ids regrouped 8 apart): its input region comes from HBM once
   {"wino_bf3_shape", "SMX_WINO_BF3_SHAPE", -1}, // split-bf16 Winograd block shape: -1 auto (8x16 pixels x 128 channels when C_out % 128 == 0), 2 = always 16x16 pixels x 64 channels
-  {"attn_bf3", "SMX_ATTN_BF3", 3},                // fp32 storage, d_head 32, >= 512 blocks: split-bf16 attention (3 = six products everywhere, 2 = P on two levels, + 16 = at any launch size, + 32 = 128-query blocks instead of 256, 0 = the fp32-MFMA kernel)
+  {"attn_bf3", "SMX_ATTN_BF3", 4},                // fp32 storage, d_head 32, >= 512 blocks: split attention (4 = f16x3: two half levels, three products; 3 = bf16 six products everywhere, 2 = bf16 with P on two levels, + 16 = at any launch size, + 32 = 128-query blocks instead of 256, 0 = the fp32-MFMA kernel)
 };
 bool g_init = false;
 void init_once() {

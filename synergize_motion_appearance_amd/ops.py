@@ -1150,7 +1150,7 @@ def attention(q, k, v, nhead, dh, S, *, k_shared=False, mask=None, k_off=0, scal
     if _PROFILE is not None and q.dtype == torch.float32:
         np_ = int(L.load().smx_attention_f32_uses_bf3(B, nhead, Lq, S, dh))          # split-bf16 arithmetic: 6 (+ 6 | 5) bf16 products per multiply
         if np_:
-            meta.update(bf3=np_, mfma_flops=(6 + (6 if np_ == 3 else 5)) * 2.0 * B * nhead * Lq * S * dh)
+            meta.update(bf3=np_, mfma_flops=(6 if np_ == 4 else 6 + (6 if np_ == 3 else 5)) * 2.0 * B * nhead * Lq * S * dh)    # products per multiply, S and P V together
     L.check(_timed(f"attention_d{dh}", meta, _fn("smx_attention", q), qp, ldq, Lq * ldq, kp + es * k_off, ldk, kbs, vp, ldv, vbs,
                    o.data_ptr(), E, Lq * E, None if mask is None else mask.data_ptr(), B, nhead, Lq, S, dh,
                    dh ** -0.5 if scale is None else scale, _stream()), "attention")

@@ -53,7 +53,8 @@ def ran(rec):
 
 @pytest.mark.parametrize("S,shared,masked,np_", [(1024, False, True, 3), (256, True, False, 3), (768, True, False, 3), (1024, False, False, 3),
                                                  (1024, False, True, 2), (512, True, False, 2), (1024, False, True, 3 + 32), (512, True, False, 2 + 32),
-                                                 (1024, False, False, 3 + 32)])
+                                                 (1024, False, False, 3 + 32), (1024, False, True, 4), (256, True, False, 4), (768, True, False, 4), (1024, False, False, 4),
+                                                 (1024, False, True, 4 + 32), (512, True, False, 4 + 32)])
 def test_split_attention_vs_explicit_softmax(ops, knob, S, shared, masked, np_):
     """the split kernel == softmax(q k^T / sqrt(d)) v per head at the fp32 kernel's bar; and it is the kernel that ran."""
     B, H, N, E, dh = 2, 8, 1024, 256, 32
@@ -73,7 +74,7 @@ def test_split_attention_vs_explicit_softmax(ops, knob, S, shared, masked, np_):
     with ops.profile() as rec:
         o = ops.attention(q.cuda(), kd, vd, H, dh, S, k_shared=shared, mask=None if mask is None else mask.to(torch.uint8).cuda())
     assert ran(rec) == [np_]
-    assert maxabs(o.cpu(), ref) < (5e-6 if np_ == 3 else 1e-5)
+    assert maxabs(o.cpu(), ref) < (1e-5 if np_ == 2 else 5e-6)
 
 
 def test_split_attention_not_less_accurate_than_the_fp32_mfma_kernel(ops, knob):
@@ -85,36 +86,63 @@ def test_split_attention_not_less_accurate_than_the_fp32_mfma_kernel(ops, knob):
     ref = reference(q, kv[..., :E], kv[..., E:], H, dh, None)
     qd, kvd = q.cuda(), kv.cuda()
     out = {}
-    for v in (0, 16 + 3, 16 + 2):
+    for v in (0, 16 + 3, 16 + 2, 16 + 4):
         knob(v)
         with ops.profile() as rec:
             out[v] = ops.attention(qd, kvd[..., :E], kvd[..., E:], H, dh, N).cpu().double()
         assert ran(rec) == [(v & 15) or None]
-    e32, e6, e5 = (float((out[v] - ref).abs().max()) for v in (0, 19, 18))
-    r32, r6, r5 = (float((out[v] - ref).pow(2).mean().sqrt()) for v in (0, 19, 18))
-    print(f"\nmax|err| vs fp64  fp32-MFMA {e32:.3e}  bf16x6 {e6:.3e}  P on two levels {e5:.3e}   rms {r32:.3e} {r6:.3e} {r5:.3e}")
+    e32, e6, e5, e4 = (float((out[v] - ref).abs().max()) for v in (0, 19, 18, 20))
+    r32, r6, r5, r4 = (float((out[v] - ref).pow(2).mean().sqrt()) for v in (0, 19, 18, 20))
+    print(f"\nmax|err| vs fp64  fp32-MFMA {e32:.3e}  bf16x6 {e6:.3e}  P on two levels {e5:.3e}  f16x3 {e4:.3e}   rms {r32:.3e} {r6:.3e} {r5:.3e} {r4:.3e}")
     assert e6 <= 1.25 * e32 + 1e-7 and r6 <= 1.1 * r32 + 1e-8
+    assert e4 <= 1.25 * e32 + 1e-7 and r4 <= 1.1 * r32 + 1e-8
     assert e5 < 1e-5
+
+
+@pytest.mark.parametrize("name,mk", [("tiny values", lambda v: v * 1e-4), ("huge values", lambda v: v * 3e3),
+                                     ("values grow 1e5 after the first tile", lambda v: torch.cat([v[:, :64] * 1e-3, v[:, 64:] * 100.0], 1)),
+                                     ("first tiles zero", lambda v: torch.cat([v[:, :128] * 0, v[:, 128:] * 1e-3], 1))])
+def test_f16x3_attention_keeps_its_accuracy_at_every_value_scale(ops, knob, name, mk):
+    """the V operand is scaled by the block (first tile -> power of two; a later tile that outgrows the headroom sets a new scale, the accumulators follow exactly):
+    against fp64, relative to the output's own scale, within 1.25x of the fp32-MFMA kernel."""
+    B, H, N, E, dh = 2, 8, 1024, 256, 32
+    q = rnd("vq", (B, N, E)) * 2.0
+    k = rnd("vk", (B, N, E))
+    v = mk(rnd("vv", (B, N, E)))
+    ref = reference(q, k, v, H, dh, None)
+    out = {}
+    for kn in (0, 16 + 4):
+        knob(kn)
+        with ops.profile() as rec:
+            out[kn] = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, dh, N).cpu().double()
+        assert ran(rec) == [(kn & 15) or None]
+    sc = float(ref.pow(2).mean().sqrt())
+    e32, e4 = float((out[0] - ref).abs().max()) / sc, float((out[20] - ref).abs().max()) / sc
+    r32, r4 = float((out[0] - ref).pow(2).mean().sqrt()) / sc, float((out[20] - ref).pow(2).mean().sqrt()) / sc
+    print(f"\n{name}: relative max error  fp32-MFMA {e32:.3e}  f16x3 {e4:.3e}   rms {r32:.3e} {r4:.3e}")
+    assert bool(torch.isfinite(out[20]).all()) and e4 <= 1.25 * e32 + 1e-7 and r4 <= 1.1 * r32 + 1e-8
 
 
 def test_split_attention_fully_masked_rows_and_partly_masked_tiles(ops, knob):
     """every key masked -> NaN like the reference (0 / 0); a mask that blanks whole 64-key tiles (the first two and one in the middle) == the reference."""
     B, H, N, E, dh = 2, 8, 1024, 256, 32
-    knob(16 + 3)
     q, kv = rnd("nq3", (B, N, E)), rnd("nkv3", (B, N, 2 * E))
-    o = ops.attention(q.cuda(), kv.cuda()[..., :E], kv.cuda()[..., E:], H, dh, N, mask=torch.ones((B, N), dtype=torch.uint8, device="cuda"))
-    assert bool(torch.isnan(o).all())
     mask = torch.zeros((B, N), dtype=torch.bool)
     mask[0, :128] = True; mask[0, 512:576] = True; mask[1, 960:] = True; mask[1, 3::2] = True
     ref = reference(q, kv[..., :E], kv[..., E:], H, dh, mask).float()
-    o = ops.attention(q.cuda(), kv.cuda()[..., :E], kv.cuda()[..., E:], H, dh, N, mask=mask.to(torch.uint8).cuda())
-    assert maxabs(o.cpu(), ref) < 5e-6
+    for kn in (16 + 3, 16 + 4):
+        knob(kn)
+        o = ops.attention(q.cuda(), kv.cuda()[..., :E], kv.cuda()[..., E:], H, dh, N, mask=torch.ones((B, N), dtype=torch.uint8, device="cuda"))
+        assert bool(torch.isnan(o).all())
+        o = ops.attention(q.cuda(), kv.cuda()[..., :E], kv.cuda()[..., E:], H, dh, N, mask=mask.to(torch.uint8).cuda())
+        assert maxabs(o.cpu(), ref) < 5e-6
 
 
 def test_split_attention_dispatch_rule(ops, knob):
     """default knob: big launches only (>= 512 blocks of 128 queries), d_head 32, S % 64 == 0; deterministic."""
     from synergize_motion_appearance_amd import lib
     Lb = lib.load()
+    assert ops.set_tuning("attn_bf3", 4) == 4 and Lb.smx_attention_f32_uses_bf3(60, 8, 1024, 1024, 32) == 4          # the default: the f16x3 kernel
     knob(3)
     assert Lb.smx_attention_f32_uses_bf3(60, 8, 1024, 1024, 32) == 3 and Lb.smx_attention_f32_uses_bf3(4, 8, 1024, 1024, 32) == 0
     assert Lb.smx_attention_f32_uses_bf3(60, 8, 1024, 1024, 4) == 0 and Lb.smx_attention_f32_uses_bf3(60, 8, 1024, 1056, 32) == 0

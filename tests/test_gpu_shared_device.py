@@ -81,7 +81,7 @@ def test_fp32_winograd_kernels_are_bit_stable_next_to_another_process_running_th
     tok = torch.randn((Bv, 1024, 256), generator=g).cuda()
     lin = ops.Conv((torch.randn((256, 256), generator=g) / 16.0).cuda().contiguous(), (0.1 * torch.randn((256,), generator=g)).cuda(), 1, 1, 256, 256)
     qkv = torch.randn((Bv, 1024, 768), generator=g).cuda()
-    old_attn = ops.set_tuning("attn_bf3", 3)
+    old_attn = ops.set_tuning("attn_bf3", 4)
 
     def victims():
         outs, kinds = [], []
@@ -100,7 +100,7 @@ def test_fp32_winograd_kernels_are_bit_stable_next_to_another_process_running_th
     ref, kinds = victims()
     ops.set_tuning("attn_bf3", old_attn)
     # the wide fp32-MFMA kernel, the split Winograd kernel at 8x16x128 and at 16x16x64 blocks (bf16x6) and in its f16x3 form, the split row-panel GEMM, the split attention
-    assert kinds[:4] == [(None, 1), (6, 1), (6, 1), (4, 1)] and kinds[4][0] in (4, 6) and kinds[4][1] == 1 and kinds[5] == (3, None), kinds
+    assert kinds[:4] == [(None, 1), (6, 1), (6, 1), (4, 1)] and kinds[4][0] in (4, 6) and kinds[4][1] == 1 and kinds[5][0] in (3, 4), kinds
     torch.cuda.synchronize()
     log = tmp_path / "aggressor.log"
     with open(log, "w") as f:

@@ -22,7 +22,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 
-lines = ["B    S     kind          fp32-MFMA ms  TF     x6 ms   TF(alg)  speed-up   P-2-level ms  speed-up   x6, 128-query blocks ms   max|x6 - fp32|"]
+lines = ["B    S     kind          fp32-MFMA ms  TF     x6 ms   TF(alg)  speed-up   P-2-level ms  speed-up   x6, 128-query blocks ms   f16x3 ms  speed-up   max|x6 - fp32|"]
 for (B, S, kind) in ((60, 1024, "self"), (60, 1024, "self+mask"), (60, 1024, "shared ctx"), (60, 256, "shared ctx"), (300, 1024, "self"), (38, 1024, "self")):
     q = synth_input(f"q{B}", (B, 1024, 256)).cuda()
     shared = kind == "shared ctx"
@@ -33,12 +33,12 @@ for (B, S, kind) in ((60, 1024, "self"), (60, 1024, "self+mask"), (60, 1024, "sh
         mask = torch.zeros((B, S), dtype=torch.uint8, device="cuda"); mask[:, 900:] = 1
     f = lambda: ops.attention(q, k, v, 8, 32, S, k_shared=shared, mask=mask)
     res, t = {}, {}
-    for knob in (0, 19, 18, 51):
+    for knob in (0, 19, 18, 51, 20):
         old = ops.set_tuning("attn_bf3", knob)
         res[knob] = f().clone(); t[knob] = timeit(f)
         ops.set_tuning("attn_bf3", old)
     fl = 4.0 * B * 8 * 1024 * S * 32
-    lines.append(f"{B:<4d} {S:<5d} {kind:<13s} {t[0]:8.3f}    {fl / t[0] / 1e9:6.1f} {t[19]:8.3f}  {fl / t[19] / 1e9:6.1f}   {t[0] / t[19]:5.2f}x   {t[18]:8.3f}      {t[0] / t[18]:5.2f}x    {t[51]:8.3f}                {float((res[19] - res[0]).abs().max()):.2e}")
+    lines.append(f"{B:<4d} {S:<5d} {kind:<13s} {t[0]:8.3f}    {fl / t[0] / 1e9:6.1f} {t[19]:8.3f}  {fl / t[19] / 1e9:6.1f}   {t[0] / t[19]:5.2f}x   {t[18]:8.3f}      {t[0] / t[18]:5.2f}x    {t[51]:8.3f}                {t[20]:8.3f}   {t[0] / t[20]:5.2f}x    {float((res[19] - res[0]).abs().max()):.2e}")
 txt = "\n".join(lines)
 print(txt)
 if len(sys.argv) > 1:

@@ -13,7 +13,7 @@ BENCH="python $PWD/bench.py --steps 2 --warmup 1 --profile-only $@"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_$TAG; timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o run --output-format csv -- $BENCH > $OUT/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
 if [ "$PMC" = "pmc" ]; then
-  rm -rf $OUT/pmc_mfma_$TAG; timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_mfma_$TAG -o run --output-format csv -- $BENCH > $OUT/pmc_mfma_$TAG.log 2>&1; echo "pmc mfma rc=$?"
+  rm -rf $OUT/pmc_mfma_$TAG; timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_mfma_$TAG -o run --output-format csv -- $BENCH > $OUT/pmc_mfma_$TAG.log 2>&1; echo "pmc mfma rc=$?"
   rm -rf $OUT/pmc_fetch_$TAG; timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$TAG -o run --output-format csv -- $BENCH > $OUT/pmc_fetch_$TAG.log 2>&1; echo "pmc fetch rc=$?"
   rm -rf $OUT/pmc_write_$TAG; timeout 900 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$TAG -o run --output-format csv -- $BENCH > $OUT/pmc_write_$TAG.log 2>&1; echo "pmc write rc=$?"
   # drop the multi-hundred-MB raw traces, keep the counter csv

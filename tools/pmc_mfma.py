@@ -3,7 +3,7 @@
 usage: pmc_mfma.py <pmc_dir> <out.json> [command string]
 
 Counters expected in ONE pass (SQ has 8 slots, GRBM 2; see MI355X_MICROARCH.md "rocprofv3 PMC slots"):
-  SQ_INSTS_VALU_MFMA_MOPS_F32 (or _BF16)  matrix ops in units of 512 flops (a v_mfma_f32_32x32x2_f32 = 4096 flops = 8)
+  SQ_INSTS_VALU_MFMA_MOPS_F32 (or _BF16 / _F16)  matrix ops in units of 512 flops (a v_mfma_f32_32x32x2_f32 = 4096 flops = 8)
   SQ_VALU_MFMA_BUSY_CYCLES                 cycles the matrix pipe is busy, summed over the chip's 1024 SIMDs (64 per 32x32x2 f32 MFMA)
   SQ_INSTS_MFMA, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES (optional)
   GRBM_GUI_ACTIVE                          active shader-clock cycles summed over the 8 XCDs
@@ -17,8 +17,8 @@ import json
 import sys
 
 SIMDS, XCDS, SPEC_GHZ = 1024, 8, 2.4
-PEAK = {"F32": 157.3, "BF16": 2500.0}
-FAMILIES = (("winograd_bf3_kernel", "winograd_bf3"), ("winograd_wide_kernel", "winograd"), ("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("gemm_rp_bf16_kernel", "gemm_bf16"), ("gemm_rp_f32_kernel", "gemm_conv"), ("gemm_rp_bf3_kernel", "gemm_bf3"), ("attn_bf3_kernel", "attention_bf3"), ("conv7_bf16x3", "conv7_x3"), ("attnblock16", "attnblock"),
+PEAK = {"F32": 157.3, "BF16": 2500.0, "F16": 2500.0}
+FAMILIES = (("winograd_bf3_kernel", "winograd_bf3"), ("winograd_wide_kernel", "winograd"), ("winograd_kernel", "winograd"), ("gemm_conv_kernel", "gemm_conv"), ("gemm_bf16_kernel", "gemm_bf16"), ("gemm_rp_bf16_kernel", "gemm_bf16"), ("gemm_rp_f32_kernel", "gemm_conv"), ("gemm_rp_bf3_kernel", "gemm_bf3"), ("attn_bf3_kernel", "attention_bf3"), ("attn_f16_kernel", "attention_bf3"), ("conv7_bf16x3", "conv7_x3"), ("attnblock16", "attnblock"),
             ("conv3x3_bf16_kernel", "conv3x3_bf16"), ("conv3x3_t32_kernel", "conv3x3_bf16"), ("attn_mfma16", "attention_mfma16"), ("attn_mfma", "attention_mfma"), ("vq_kernel", "vq"))
 
 
@@ -68,7 +68,7 @@ def main(pmc_dir, out, command=""):
         gui = c.get("GRBM_GUI_ACTIVE", 0.0)
         if gui:
             e["shader_clock_GHz"] = round(gui / XCDS / dur_s / 1e9, 3)
-        for dt in ("F32", "BF16"):
+        for dt in ("F32", "BF16", "F16"):
             mops = c.get(f"SQ_INSTS_VALU_MFMA_MOPS_{dt}", 0.0)
             if mops:
                 tf = mops * 512.0 / dur_s / 1e12
