@@ -607,10 +607,11 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
     tf_exec = g["mfma_flops"] / (g["ms"] * 1e-3) / 1e12
     tf_alg = g["flops"] / (g["ms"] * 1e-3) / 1e12
     if dom == "winograd_bf3":
-        peak = PEAK_BF16_MFMA_TFLOPS                     # fp32 operands, three-way split: six bf16 MFMA products per multiply, priced against the bf16 pipe
+        peak = PEAK_BF16_MFMA_TFLOPS                     # fp32 operands split into half-precision levels, priced against the 16-bit matrix pipe (f16 and bf16 MFMAs run at one rate)
     kname = {"winograd": "winograd_wide_kernel / winograd_kernel<..> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution, v_mfma_f32_32x32x2_f32)",
-             "winograd_bf3": "winograd_bf3_kernel<6, MT> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution of fp32 operands split three ways into bf16: six "
-                             "v_mfma_f32_32x32x16_bf16 products per multiply, fp32 accumulate; csrc/winograd_bf3.hip)",
+             "winograd_bf3": "winograd_bf3_kernel<4, MT> (fused Winograd F(2x2,3x3) 3x3/s1/p1 convolution of fp32 operands split into two IEEE-half levels, power-of-two "
+                             "scaled: three v_mfma_f32_32x32x16_f16 products per multiply, fp32 accumulate; csrc/winograd_bf3.hip -- <6, MT>, three bf16 levels / six products, when "
+                             "the f16x3 form is switched off)",
              "conv3x3_bf16": "conv3x3_t32_kernel (16x32-pixel tiles, 16-channel slices, LDS-DMA weights; the big launches) / conv3x3_bf16_kernel<TH> (the small ones): "
                              "region-direct 3x3/s1/p1 convolution, v_mfma_f32_32x32x16_bf16",
              "gemm_conv": "gemm_conv_kernel<BM,BN,..> (implicit-GEMM convolution / batched NT GEMM, v_mfma_f32_32x32x2_f32)",
@@ -630,11 +631,11 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
                  "the same time (2.25x the executed rate by construction, not a utilisation).  On gfx950 an fp32 MFMA and a VALU instruction use the "
                  "same lanes and never overlap (profiles/r05_winograd_valu_vs_mfma.txt), so this fraction is bounded by MFMA / (MFMA + VALU) cycles of "
                  "the kernel -- about 0.80 for this one -- not by 1") if dom == "winograd" else
-                ("achieved/frac = flops the bf16 matrix pipe EXECUTES in this kernel: 6 products x 2*M*N*16/4*Cin per launch (F(2x2,3x3) multiplies, each as the six "
-                 "bf16 products of its three-way split fp32 operands) / its summed launch time, over the 2500 TF/s bf16 peak; achieved_algorithmic = the direct "
-                 "convolution's 2*M*N*9*Cin over the same time.  The kernel is bound by the VALU work of the split (5.5 instructions per transformed input element) "
-                 "and by its per-block prologue + epilogue, not by the matrix pipe: profiles/r06_wino_bf3.txt; its time per layer is 1.08-1.40x shorter than the "
-                 "fp32-MFMA kernel's at 0.65 of the fp32 pipe") if dom == "winograd_bf3" else
+                ("achieved/frac = flops the 16-bit matrix pipe EXECUTES in this kernel: (products per multiply: 3 in the f16x3 form, 6 in the bf16x6 form) x 2*M*N*16/4*Cin per "
+                 "launch (F(2x2,3x3) multiplies, each as the products of its split fp32 operands) / its summed launch time, over the 2500 TF/s peak; achieved_algorithmic = the "
+                 "direct convolution's 2*M*N*9*Cin over the same time.  The kernel is bound by the VALU work of transform + split and by its per-block prologue + epilogue, not by "
+                 "the matrix pipe: profiles/r06_wino_bf3_trace.txt; per layer it is 1.4-2.1x faster than the "
+                 "fp32-MFMA kernel (which runs at 0.65 of the fp32 pipe)") if dom == "winograd_bf3" else
                 ("achieved = 2*M*N*K of the launches / their summed time (executed == algorithmic: a direct convolution).  By arithmetic intensity "
                  "(bf16 bytes of input + output per pixel against a 2500 TF / 8 TB/s = 312 flop/B ridge) the C_in >= 128 layers are MFMA-bound "
                  "(128->128 3x3: 576 flop/B), the 64->64 @ 256^2 layers sit at the ridge (288 flop/B) -- see kernels.*.algorithmic_GBps for the byte side"),
@@ -811,8 +812,9 @@ def main():
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 3),
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
         "arithmetic": ("fp32 operands, fp32 accumulation everywhere; the big launches of the 3x3 convolutions (csrc/winograd_bf3.hip), of the K = 128 / 256 1x1 layers (gemm_rp_bf3.hip) and of the "
-                       "d_head = 32 attention (attn_bf3_kernel) multiply on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 values and the six products down to 2^-24 kept "
-                       "-- measured against fp64 their error is not above the fp32-MFMA kernels' (tests/test_gpu_wino_bf3.py, test_gpu_gemm_bf3.py, test_gpu_attn_bf3.py), "
+                       "d_head = 32 attention (attn_f16_kernel) multiply on the 16-bit matrix pipe in the f16x3 form: every fp32 operand as two IEEE-half levels (22 significand bits) under a power-of-two "
+                       "scale chosen per weight tensor / input block / row, three products per multiply -- measured against fp64 their error is BELOW the fp32-MFMA kernels' at every input scale "
+                       "(tests/test_gpu_wino_bf3.py, test_gpu_gemm_bf3.py, test_gpu_attn_bf3.py; the bf16 three-level / six-product forms stay selectable), "
                        "every other contraction is fp32 MFMA / VALU" if dname == "f32" else
                        "bf16 storage + bf16 MFMA with fp32 accumulation (keypoints / flows / normalisation statistics / softmax / output image fp32)"),
         "config": {"workload": (f"BASELINE.json configs[{cfg_ix}]: {px}x{px}, {n_src} source(s) x 300-frame driving clip, {dname}, options/test{'' if px == 256 else '_512'}.yml, "

@@ -28,14 +28,16 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-lines = ["M        K    N     d2s        fp32-MFMA ms  TF    split ms  TF(x6)  speed-up  max|diff|"]
+lines = ["M        K    N     d2s        fp32-MFMA ms  TF    f16x3 ms  TF(x3)  speed-up   bf16x6 ms  speed-up  max|f16x3 - fp32|"]
 for (M, K, N, d2s) in SHAPES:
     H = 32 if M % 1024 == 0 and M // 1024 <= 64 else (64 if M // 4096 <= 64 else 128)
     B = M // (H * H)
     x = synth_input(f"gx{M}{K}", (B, H, H, K)).cuda()
     cv = ops.Conv((synth_input(f"gw{K}{N}", (N, K)) / math.sqrt(K)).cuda().contiguous(), synth_input(f"gb{N}", (N,)).cuda(), 1, 1, K, N)
     out = ops.conv(x, cv, d2s=d2s)
-    ops.GEMM_RP_BF3 = 1
+    ops.GEMM_RP_BF3, ops.GEMM_RP_F16 = 1, 0
+    tb = timeit(lambda: ops.conv(x, cv, out=out, d2s=d2s))
+    ops.GEMM_RP_F16 = 1
     with ops.profile() as rec:
         y6 = ops.conv(x, cv, out=out, d2s=d2s)
     used = [r[1].get("bf3") for r in rec.rows]
@@ -45,7 +47,7 @@ for (M, K, N, d2s) in SHAPES:
     t32 = timeit(lambda: ops.conv(x, cv, out=out, d2s=d2s))
     y32 = ops.conv(x, cv, d2s=d2s)
     fl = 2.0 * M * K * N
-    lines.append(f"{M:<8d} {K:<4d} {N:<5d} {str(d2s):<10s} {t32:8.3f}     {fl / t32 / 1e9:6.1f} {t6:8.3f}  {6 * fl / t6 / 1e9:6.1f}  {t32 / t6:6.2f}x   {float((y6 - y32).abs().max()):.2e}  {used}")
+    lines.append(f"{M:<8d} {K:<4d} {N:<5d} {str(d2s):<10s} {t32:8.3f}     {fl / t32 / 1e9:6.1f} {t6:8.3f}  {3 * fl / t6 / 1e9:6.1f}  {t32 / t6:6.2f}x   {tb:8.3f}  {t32 / tb:6.2f}x   {float((y6 - y32).abs().max()):.2e}  {used}")
 txt = "\n".join(lines)
 print(txt)
 if len(sys.argv) > 1:

@@ -31,8 +31,8 @@ def timed(fn, n=5):
 
 
 print(f"B={B}  {'plain conv' if PLAIN else 'ResBlock form (GN+swish loader, residual, GN partials)'}")
-print("cin cout  s : fp32-MFMA us (frac of 157.3 TF fp32 pipe) | bf16x6 us (frac of 2500 TF bf16 pipe, 6 products) speedup | bf16x3 us speedup | "
-      "max|err| vs fp64 on a 2-image sample: fp32-MFMA, x6, x3")
+print("cin cout  s : fp32-MFMA us (frac of 157.3 TF fp32 pipe) | f16x3 us (frac of 2500 TF 16-bit pipe, 3 products) speedup | bf16x6 us (6 products) speedup | bf16x3 us speedup | "
+      "max|err| vs fp64 on a 2-image sample: fp32-MFMA, f16x3, bf16x6, bf16x3")
 ops.WINO_BF3_MIN_BLOCKS = 1
 for cin, cout, s in SHAPES:
     x = torch.randn((B, s, s, cin), device="cuda")
@@ -47,8 +47,8 @@ for cin, cout, s in SHAPES:
     ref = F.conv2d(xs.permute(0, 3, 1, 2).double(), cv.w.view(cout, 3, 3, cin).permute(0, 3, 1, 2).double(), cv.b.double(), padding=1).permute(0, 2, 3, 1)
     row, errs = [], []
     t0 = None
-    for mode in (0, 6, 3):
-        ops.WINO_BF3 = mode
+    for mode in (0, 4, 6, 3):
+        ops.WINO_BF3, ops.WINO_F16 = (6, 2) if mode == 4 else (mode, 0)
         t = timed(call)
         e = float((ops.conv(xs, cv).double() - ref).abs().max())
         errs.append(f"{e:.2e}")
@@ -56,7 +56,7 @@ for cin, cout, s in SHAPES:
             t0 = t
             row.append(f"{1e3 * t:8.1f} ({fl / t / 1e9 / 157.3:.3f})")
         else:
-            row.append(f"{1e3 * t:8.1f} ({fl * mode / t / 1e9 / 2500:.3f}) {t0 / t:4.2f}x")
-    ops.WINO_BF3 = 0
+            row.append(f"{1e3 * t:8.1f} ({fl * (3 if mode == 4 else mode) / t / 1e9 / 2500:.3f}) {t0 / t:4.2f}x")
+    ops.WINO_BF3, ops.WINO_F16 = 0, 0
     print(f"{cin:3d} {cout:4d} {s:3d} : " + " | ".join(row) + " | " + " ".join(errs), flush=True)
     del x, out, res
