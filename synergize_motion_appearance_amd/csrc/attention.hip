@@ -685,6 +685,186 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_f16_kernel(AP<float> p) 
   }
 }
 
+// The fused AttnBlock core of the fp32 configuration (ONE head of d = 256, V given transposed: what attnblock32_kernel computes on the fp32 MFMA at 0.98 of that
+// pipe) in the f16x3 arithmetic of attn_f16_kernel: q (pre-scaled), k as they are, P' = 2^10 P, V^T under the block's power-of-two scale (re-staged / followed by the
+// accumulators when a tile outgrows it).  One wave per SIMD: a wave owns 32 queries, the two-level Q^T fragments (128 registers) and all eight O^T tiles (128); per
+// 32-key tile 96 half MFMAs (48 for S^T on two chains, 48 for O^T, two d tiles alternating) against the fp32 kernel's 256 MFMAs of twice the length.
+__global__ __launch_bounds__(256, 1) void attnblock_f16_kernel(AP<float> p) {
+  constexpr int DH = 256, TK = 32, NKK = DH / 16, NDT = DH / 32;
+  constexpr int KROW = DH * 2 + 16, VROW = TK * 2 + 16;                   // LDS row bytes (padded): 528 | 80
+  constexpr int KPL = TK * KROW, VPL = DH * VROW;                         // one level plane: 16,896 | 20,480 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;                                               // [2 buffers][2 levels][KPL]
+  unsigned char* Vt = smem + 4 * KPL;                                     // [2 buffers][2 levels][VPL]
+  float* Red = reinterpret_cast<float*>(smem + 4 * KPL + 4 * VPL);        // [4 wave maxima][flag]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int hh = lane >> 5;
+  const float* Q = p.q + b * p.q_bs + (long long)qrow * p.ldq;
+  const float* K = p.k + b * p.k_bs;
+  const float* V = p.v + b * p.v_bs;                                      // V^T: [d][key]
+
+  uint4 qf[NKK][2];
+  {
+    const float sc = p.scale * 1.44269504088896340736f;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const float4 a0 = *reinterpret_cast<const float4*>(Q + kk * 16 + hh * 8), a1 = *reinterpret_cast<const float4*>(Q + kk * 16 + hh * 8 + 4);
+      const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+      ah_split8(v, qf[kk][0], qf[kk][1]);
+    }
+  }
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  float sv = 1.f, osv = 1.f, svbuf[2] = {1.f, 1.f}, omax = 0.f;
+  bool unscaled = false;
+
+  // staging: K tile 32 keys x 32 chunks of 8 floats, V^T tile 256 rows x 4 chunks of 8 keys: four chunks of each per thread
+  float4 kreg[4][2], vreg[4][2];
+  auto load_tile = [&](int key0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = tid + 256 * j;
+      const float* kp = K + (long long)(key0 + (g >> 5)) * p.ldk + (g & 31) * 8;
+      const float* vp = V + (long long)(g >> 2) * p.ldv + key0 + (g & 3) * 8;
+      kreg[j][0] = *reinterpret_cast<const float4*>(kp); kreg[j][1] = *reinterpret_cast<const float4*>(kp + 4);
+      vreg[j][0] = *reinterpret_cast<const float4*>(vp); vreg[j][1] = *reinterpret_cast<const float4*>(vp + 4);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = tid + 256 * j;
+      const float kv[8] = {kreg[j][0].x, kreg[j][0].y, kreg[j][0].z, kreg[j][0].w, kreg[j][1].x, kreg[j][1].y, kreg[j][1].z, kreg[j][1].w};
+      float vv[8] = {vreg[j][0].x * sv, vreg[j][0].y * sv, vreg[j][0].z * sv, vreg[j][0].w * sv, vreg[j][1].x * sv, vreg[j][1].y * sv, vreg[j][1].z * sv, vreg[j][1].w * sv};
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) omax = fmaxf(omax, fmaxf(fabsf(vv[e]), fabsf(vv[e + 1])));
+      uint4 kl[2], vl[2];
+      ah_split8(kv, kl[0], kl[1]);
+      ah_split8(vv, vl[0], vl[1]);
+      // V^T row d, keys 8 kc .. 8 kc + 7 of the tile: per 16 keys the columns run {0-3, 8-11, 4-7, 12-15} (the S^T accumulator's key order)
+      const int d = g >> 2, kc = g & 3;
+      unsigned char* vd = Vt + (buf * 2) * VPL + d * VROW + (kc >> 1) * 32 + (kc & 1) * 8;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        *reinterpret_cast<uint4*>(Ks + (buf * 2 + s2) * KPL + (g >> 5) * KROW + (g & 31) * 16) = kl[s2];
+        *reinterpret_cast<uint2*>(vd + s2 * VPL) = make_uint2(vl[s2].x, vl[s2].y);
+        *reinterpret_cast<uint2*>(vd + s2 * VPL + 16) = make_uint2(vl[s2].z, vl[s2].w);
+      }
+    }
+    svbuf[buf] = sv;
+  };
+  auto block_max = [&](float mine) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine = fmaxf(mine, __shfl_xor(mine, o, 64));
+    __syncthreads();
+    if (lane == 0) Red[wave] = mine;
+    __syncthreads();
+    return fmaxf(fmaxf(Red[0], Red[1]), fmaxf(Red[2], Red[3]));
+  };
+
+  const int ntiles = p.S / TK;
+  load_tile(0);
+  {
+    float tm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) tm = fmaxf(tm, fmaxf(fmaxf(fabsf(vreg[j][i].x), fabsf(vreg[j][i].y)), fmaxf(fabsf(vreg[j][i].z), fabsf(vreg[j][i].w))));
+    const float bm = block_max(tm);
+    if (tid == 0) Red[4] = 0.f;
+    unscaled = !(bm > 0.f && bm < 3.0e38f);
+    sv = unscaled ? 1.f : __builtin_amdgcn_ldexpf(1.f, 2 - __builtin_amdgcn_frexp_expf(bm));
+    osv = sv;
+  }
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile((t + 1) * TK);
+    // S^T = K Q^T on two chains (consecutive MFMAs never share an accumulator)
+    f32x16 sa, sb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.f;
+    const unsigned char* kb = Ks + (buf * 2) * KPL + (lane & 31) * KROW + hh * 16;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const uint4 k1 = *reinterpret_cast<const uint4*>(kb + kk * 32), k2 = *reinterpret_cast<const uint4*>(kb + KPL + kk * 32);
+      f32x16& c0 = (kk & 1) ? sa : sb; f32x16& c1 = (kk & 1) ? sb : sa;
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_f(k1), ah_f(qf[kk][1]), c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_f(k2), ah_f(qf[kk][0]), c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_f(k1), ah_f(qf[kk][0]), c0, 0, 0, 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] += sb[r]; tmax = fmaxf(tmax, sa[r]); }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    const float mo = 10.f - m_new;                                        // P' = 2^10 P
+    float psum = 0.f, e[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { e[r] = __builtin_amdgcn_exp2f(sa[r] + mo); psum += e[r]; }
+    uint4 pf[2][2];
+    {
+      const float e0[8] = {e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]}, e1[8] = {e[8], e[9], e[10], e[11], e[12], e[13], e[14], e[15]};
+      ah_split8(e0, pf[0][0], pf[0][1]);
+      ah_split8(e1, pf[1][0], pf[1][1]);
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum; m = m_new;
+    float resc = alpha;
+    if (svbuf[buf] != osv) { resc *= svbuf[buf] / osv; osv = svbuf[buf]; }
+    if (__builtin_amdgcn_ballot_w64(resc != 1.f) != 0ull) {
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= resc;
+    }
+    // O^T += V^T P^T: two d tiles at a time, their MFMAs alternating
+    const unsigned char* vb = Vt + (buf * 2) * VPL + (lane & 31) * VROW + hh * 16;
+#pragma unroll
+    for (int dp = 0; dp < NDT / 2; ++dp)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        uint4 vf[2][2];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) vf[q2][s2] = *reinterpret_cast<const uint4*>(vb + s2 * VPL + (2 * dp + q2) * 32 * VROW + g * 32);
+        constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};               // (V level, P level): v1p2 v2p1 v1p1
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2)
+            oacc[2 * dp + q2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_f(vf[q2][PA[pr]]), ah_f(pf[g][PB[pr]]), oacc[2 * dp + q2], 0, 0, 0);
+      }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    if (omax > 4096.f || (unscaled && omax > 0.f)) Red[4] = 1.f;
+    __syncthreads();
+    if (Red[4] != 0.f) {
+      const float bm = block_max(omax) / sv;
+      if (bm > 0.f && bm < 3.0e38f) { sv = __builtin_amdgcn_ldexpf(1.f, 2 - __builtin_amdgcn_frexp_expf(bm)); unscaled = false; }
+      omax = 0.f;
+      if (t + 1 < ntiles) store_tile(buf ^ 1);
+      if (tid == 0) Red[4] = 0.f;
+      __syncthreads();
+    }
+  }
+  float* O = p.o + b * p.o_bs + (long long)qrow * p.ldo;
+  const float inv = 1.f / (l * osv);
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(O + d * 32 + 8 * g + 4 * hh) = make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+}
+
 // The vqgan AttnBlock core (archs/vqgan_arch.py:229-253: ONE head of d = C = 256 over the 32 x 32 tokens) on bf16 storage, fused:
 // softmax(q k^T / sqrt(C)) v as one kernel, the [B, N, N] score tensor never exists (the three-launch form wrote and re-read 1.26 GB of
 // fp32 scores per call at B = 300).  Same swapped-product scheme as attn_mfma16_kernel with the d axis 8 tiles wide: Q^T fragments
@@ -1276,6 +1456,13 @@ extern "C" int smx_attnblock_f32(const float* q, int ldq, int64_t q_bs, const fl
   if (ldq % 4 || ldk % 4 || ldvt % 4 || ldo % 4 || ldq < d || ldk < d || ldvt < S || ldo < d || q_bs % 4 || k_bs % 4 || vt_bs % 4 || o_bs % 4) return SMX_EINVAL;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o) & 15) return SMX_EINVAL;
   AP<float> p{q, k, vt, o, nullptr, q_bs, k_bs, vt_bs, o_bs, ldq, ldk, ldvt, ldo, 1, L, S, scale};
+  if ((smx_tune(SMX_TUNE_ATTN_BF3) & 15) == 4 && ((smx_tune(SMX_TUNE_ATTN_BF3) & 16) || (long long)(L / 128) * B >= 256)) {
+    // big launches: the f16x3 kernel (knob attn_bf3 = 4, the default; + 16: at any launch size)
+    constexpr int LDS16 = 4 * 32 * (256 * 2 + 16) + 4 * 256 * (32 * 2 + 16) + 32;
+    SMX_HIP(smx_max_dynamic_lds((const void*)attnblock_f16_kernel, LDS16));
+    SMX_LAUNCH(attnblock_f16_kernel, dim3(L / 128, B), dim3(256), LDS16, (hipStream_t)stream, p);
+    return smx_launch_status();
+  }
   constexpr int LDS = 2 * (32 * 256 * 4 + 256 * 32 * 4);     // 2 stages x 64 KB
   SMX_HIP(smx_max_dynamic_lds((const void*)attnblock32_kernel<256>, LDS));
   SMX_LAUNCH(attnblock32_kernel<256>, dim3(L / 128, B), dim3(256), LDS, (hipStream_t)stream, p);

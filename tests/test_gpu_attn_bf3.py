@@ -154,3 +154,42 @@ def test_split_attention_dispatch_rule(ops, knob):
         a = ops.attention(q, kv[..., :256], kv[..., 256:], 8, 32, 1024)
     assert ran(rec) == [3]
     assert torch.equal(a, ops.attention(q, kv[..., :256], kv[..., 256:], 8, 32, 1024))
+
+
+# ---- the fused AttnBlock core (one head of d = 256, V transposed) in the f16x3 arithmetic: attnblock_f16_kernel ----------------------------------------------
+def _attnblock(ops, qk, vt, C_, N, sc):
+    from synergize_motion_appearance_amd import lib as L_
+    B = qk.shape[0]
+    o = torch.empty((B, N, C_), device="cuda")
+    L_.check(L_.load().smx_attnblock_f32(qk.data_ptr(), 2 * C_, N * 2 * C_, qk.data_ptr() + 4 * C_, 2 * C_, N * 2 * C_, vt.data_ptr(), N, C_ * N,
+                                         o.data_ptr(), C_, N * C_, B, N, N, C_, sc, ops._stream()), "smx_attnblock_f32")
+    return o
+
+
+@pytest.mark.parametrize("name,mk", [("plain", lambda v: v), ("one key dominates", lambda v: v), ("tiny values", lambda v: v * 1e-4), ("huge values", lambda v: v * 3e3),
+                                     ("values grow 1e5 after the first tile", lambda v: torch.cat([v[..., :32] * 1e-3, v[..., 32:] * 100.0], -1)),
+                                     ("first tiles zero", lambda v: torch.cat([v[..., :64] * 0, v[..., 64:] * 1e-3], -1))])
+def test_f16x3_attnblock_core(ops, knob, name, mk):
+    """softmax(q k^T / 4) v for ONE head of d = 256 (archs/vqgan_arch.py:229-253) against fp64: the f16x3 kernel's error, relative to the output's scale, is
+    within 1.25x of the fp32-MFMA kernel's (attnblock32_kernel), for values of every scale (V^T is scaled by the block; re-staged when a tile outgrows it)."""
+    C_, N, B = 256, 1024, 2
+    qk = torch.zeros((B, N, 2 * C_))
+    qk[..., :C_] = rnd("ab_q", (B, N, C_)); qk[..., C_:] = rnd("ab_k", (B, N, C_))
+    if name == "one key dominates":
+        qk[:, -1, C_:] *= 6.0
+    vt = mk(rnd("ab_v", (B, C_, N)))
+    sc = 0.25
+    ref = torch.bmm(torch.softmax(torch.bmm(qk[..., :C_].double(), qk[..., C_:].double().transpose(1, 2)) * sc, dim=2), vt.double().transpose(1, 2))
+    qkc, vtc = qk.cuda().contiguous(), vt.cuda().contiguous()
+    out = {}
+    for kn in (0, 16 + 4):
+        knob(kn)
+        out[kn] = _attnblock(ops, qkc, vtc, C_, N, sc).cpu().double()
+    s_ = float(ref.pow(2).mean().sqrt())
+    e32, e4 = float((out[0] - ref).abs().max()) / s_, float((out[20] - ref).abs().max()) / s_
+    r32, r4 = float((out[0] - ref).pow(2).mean().sqrt()) / s_, float((out[20] - ref).pow(2).mean().sqrt()) / s_
+    print(f"\n{name}: relative max error  fp32-MFMA {e32:.3e}  f16x3 {e4:.3e}   rms {r32:.3e} {r4:.3e}")
+    assert not torch.equal(out[0], out[20])                                                   # two different kernels ran
+    assert bool(torch.isfinite(out[20]).all()) and e4 <= 1.25 * e32 + 1e-7 and r4 <= 1.1 * r32 + 1e-8
+    assert float((out[20] - ref).abs().max()) < 3e-5 * max(float(ref.abs().max()), 1e-30)
+

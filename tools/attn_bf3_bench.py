@@ -43,3 +43,22 @@ txt = "\n".join(lines)
 print(txt)
 if len(sys.argv) > 1:
     open(sys.argv[1], "w").write(txt + "\n")
+
+# the fused AttnBlock core (one head of d = 256, V transposed)
+from synergize_motion_appearance_amd import lib as L_
+lines2 = ["AttnBlock core (d = 256, 1024 tokens): B   fp32-MFMA ms  TF    f16x3 ms  speed-up   max|diff|"]
+for B in (60, 300):
+    qk = synth_input(f"abqk{B}", (B, 1024, 512)).cuda(); vt = synth_input(f"abv{B}", (B, 256, 1024)).cuda(); o = torch.empty((B, 1024, 256), device="cuda")
+    f = lambda: L_.check(L_.load().smx_attnblock_f32(qk.data_ptr(), 512, 1024 * 512, qk.data_ptr() + 1024, 512, 1024 * 512, vt.data_ptr(), 1024, 256 * 1024,
+                                                     o.data_ptr(), 256, 1024 * 256, B, 1024, 1024, 256, 0.0625, ops._stream()), "smx_attnblock_f32")
+    r, tt = {}, {}
+    for knob in (0, 20):
+        old = ops.set_tuning("attn_bf3", knob)
+        f(); r[knob] = o.clone(); tt[knob] = timeit(f)
+        ops.set_tuning("attn_bf3", old)
+    fl = 4.0 * B * 1024 * 1024 * 256
+    lines2.append(f"{B:<4d} {tt[0]:8.3f}  {fl / tt[0] / 1e9:6.1f} {tt[20]:8.3f}   {tt[0] / tt[20]:5.2f}x   {float((r[20] - r[0]).abs().max()):.2e}")
+print("\n".join(lines2))
+if len(sys.argv) > 1:
+    open(sys.argv[1], "a").write("\n".join(lines2) + "\n")
+
