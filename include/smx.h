@@ -140,6 +140,13 @@ long long smx_conv7_bf16x3_pack_elems(int Cin, int N);
 int smx_conv7_bf16x3_pack(const float* w, void* wp, int Cin, int N, void* stream);
 int smx_conv7_bf16x3_f32(const float* x, int lda, const void* wp, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
                          int N, int pad, int act, void* stream);
+/* smx_conv7_bf16x3_f32 in the "f16x3" arithmetic (csrc/conv7_bf16x3.hip, F16 = true): two IEEE-half levels per operand, three v_mfma_f32_32x32x16_f16 products --
+ * fp32-grade (error against fp64 below smx_conv7_f32's: tests/test_gpu_kernels.py), so the fp32 configuration's 7x7 heads (archs/keypoint_detector_arch.py:60-86,
+ * archs/dense_motion_arch.py:118-161) run here for big launches.  wp = smx_conv7_f16_pack(w [N][7][7][Cin]): 16 header bytes + smx_conv7_bf16x3_pack's layout
+ * (2 * smx_conv7_bf16x3_pack_elems(Cin, N) + 16 bytes); weights scaled by a power of two on the device, the input by the block.  Arguments as smx_conv7_bf16x3_f32. */
+int smx_conv7_f16_pack(const float* w, void* wp, int Cin, int N, void* stream);
+int smx_conv7_f16_f32(const float* x, int lda, const void* wp, const float* bias, float* y, int ldc, int B, int H, int W, int Cin,
+                      int N, int pad, int act, void* stream);
 /* the fp32 configuration's form of the same two heads: exact fp32 products (v_mfma_f32_32x32x2_f32), the same region-direct staging;
  * wp from smx_conv7_f32_pack (smx_conv7_bf16x3_pack_elems(Cin, N) / 2 floats) */
 int smx_conv7_f32_pack(const float* w, float* wp, int Cin, int N, void* stream);

@@ -120,6 +120,8 @@ SIGNATURES = {
     "smx_conv7_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_conv7_bf16x3_pack_elems": (_i64, [_i, _i]),
     "smx_conv7_bf16x3_pack": (_i, [_p, _p, _i, _i, _p]),
+    "smx_conv7_f16_pack": (_i, [_p, _p, _i, _i, _p]),
+    "smx_conv7_f16_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_conv7_bf16x3_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smx_gemm_rp_f32_ok": (_i, [_i64, _i, _i]),
     "smx_gemm_rp_f32_pack": (_i, [_p, _i, _p, _i, _i, _p]),

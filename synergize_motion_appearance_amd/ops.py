@@ -121,6 +121,7 @@ def _knob(name, default):
 
 
 SMALLN = bool(_knob("SMX_SMALLN", 1))
+CONV7_F16 = _knob("SMX_CONV7_F16", 1)               # fp32 configuration: the big launches of the 7x7 heads in the f16x3 arithmetic (conv7_bf16x3_kernel<NT, true>); 0 = conv7_f32 / implicit GEMM
 CONV7_F32 = _knob("SMX_CONV7_F32", 1)               # fp32 configuration: the 7x7 heads on conv7_f32_kernel (0 = implicit GEMM)
 CONV7_C2 = _knob("SMX_CONV7_C2", 1)                 # bf16 configuration: BasicMotionEncoder.convf1 on csrc/conv7_c2_bf16.hip (0 = implicit GEMM)
 SMALLN_MFMA_MIN_BLOCKS = 512                                          # 8 x 32-pixel tiles; below: the VALU kernel (tests lower it)
@@ -131,7 +132,7 @@ WINOGRAD = bool(_knob("SMX_WINOGRAD", 1))
 
 class Conv:
     """A packed convolution / linear layer: weights [Cout][kh][kw][Cin] (k contiguous), bias."""
-    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3", "_wrp3", "_u3h", "_wrp3h")
+    __slots__ = ("w", "b", "kh", "kw", "cin", "cout", "_u", "_w16", "_u43", "_w16t", "_w16rp", "_wrp", "_w7x3", "_wsn16", "_w7c2", "_w7c2f", "_w7f", "_u3", "_wrp3", "_u3h", "_wrp3h", "_w7h")
 
     def __init__(self, w, b, kh, kw, cin, cout):
         self.w, self.b, self.kh, self.kw, self.cin, self.cout = w, b, kh, kw, cin, cout
@@ -141,6 +142,7 @@ class Conv:
         self._u3 = None
         self._u3h = None
         self._wrp3h = None
+        self._w7h = None
         self._wrp3 = None
         self._w16t = None
         self._w16rp = None
@@ -204,6 +206,18 @@ class Conv:
             L.check(L.load().smx_conv7_bf16x3_pack(self.w.data_ptr(), wp.data_ptr(), self.cin, self.cout, _stream()), "smx_conv7_bf16x3_pack")
             self._w7x3 = wp
         return self._w7x3
+
+    @property
+    def w7_f16(self):
+        """a 7x7 layer's weights scaled by a power of two and split into two IEEE-half levels in the fragment order of csrc/conv7_bf16x3.hip (smx_conv7_f16_pack)."""
+        if self._w7h is None:
+            n = int(L.load().smx_conv7_bf16x3_pack_elems(self.cin, self.cout))
+            if n <= 0 or self.kh != 7 or self.kw != 7:
+                raise L.SmxError(f"w7_f16: not a 7x7 layer with N <= 96 ({self.kh}x{self.kw}, N {self.cout})")
+            wp = torch.empty(2 * n + 16, device=self.w.device, dtype=torch.uint8)
+            L.check(L.load().smx_conv7_f16_pack(self.w.data_ptr(), wp.data_ptr(), self.cin, self.cout, _stream()), "smx_conv7_f16_pack")
+            self._w7h = wp
+        return self._w7h
 
     @property
     def w_rp(self):
@@ -637,6 +651,16 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
                 "smx_winograd_conv3x3_f32")
         if part is not None:
             out._gn_part = part
+        return out
+    if (CONV7_F16 and bf3 and not direct and tile == 0 and cv.kh == 7 and cv.kw == 7 and stride == 1 and (pt, pl) in ((3, 3), (0, 0)) and not d2s and not up2
+            and res is None and in_ss is None and Cin % 4 == 0 and cv.cout <= 96 and (Ho, Wo) == (H + 2 * pt - 6, W + 2 * pl - 6)
+            and lda % 4 == 0 and a_ptr % 16 == 0 and ldc == cv.cout and act in (ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_SIGMOID)
+            and B * ((Ho + 7) // 8) * ((Wo + 31) // 32) >= 256):
+        # the motion estimator's 7x7 heads, big launches: region-direct on the 16-bit MFMA in the f16x3 arithmetic (fp32-grade; 2.5x conv7_f32 / the implicit GEMM)
+        meta = {"flops": 2.0 * B * Ho * Wo * cv.cout * 49 * Cin, "mfma_flops": 6.0 * B * Ho * Wo * 32 * ((cv.cout + 31) // 32) * 49 * 16 * ((Cin + 15) // 16),
+                "M": B * Ho * Wo, "N": cv.cout, "K": 49 * Cin, "nb": 1, "k": 7, "bf3": 4} if _PROFILE is not None else None
+        L.check(_timed("gemm_conv", meta, L.load().smx_conv7_f16_f32, a_ptr, lda, cv.w7_f16.data_ptr(), None if cv.b is None else cv.b.data_ptr(),
+                       c_ptr, ldc, B, H, W, Cin, cv.cout, pt, act, _stream()), "smx_conv7_f16_f32")
         return out
     if (CONV7_F32 and not direct and tile == 0 and cv.kh == 7 and cv.kw == 7 and stride == 1 and (pt, pl) in ((3, 3), (0, 0)) and not d2s and not up2
             and res is None and in_ss is None and Cin % 16 == 0 and cv.cout <= 96 and (Ho, Wo) == (H + 2 * pt - 6, W + 2 * pl - 6)

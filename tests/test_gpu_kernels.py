@@ -361,9 +361,10 @@ def test_row_panel_gemm_f32_unpatchify_store(ops, monkeypatch):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,N,pad", [(17, 64, 64, 128, 17, 3), (17, 64, 64, 36, 76, 0), (48, 24, 40, 20, 33, 3)])
-def test_conv7x7_heads_region_kernel_f32(ops, B, H, W, Cin, N, pad):
+def test_conv7x7_heads_region_kernel_f32(ops, monkeypatch, B, H, W, Cin, N, pad):
     """conv7_f32_kernel (the motion estimator's 7x7 heads in the fp32 configuration: region-direct, exact fp32 products on the fp32 MFMA)
     against the fp64 convolution and the implicit GEMM it replaces; and it is the kernel that ran."""
+    monkeypatch.setattr(ops, "CONV7_F16", 0)          # this kernel, not its f16x3 successor (test below)
     x = rnd(f"c7fx{Cin}{N}", (B, Cin, H, W))
     w = rnd(f"c7fw{Cin}{N}", (N, Cin, 7, 7), 1.0 / math.sqrt(49 * Cin))
     b = rnd(f"c7fb{Cin}{N}", (N,), 0.1)
@@ -387,6 +388,38 @@ def test_conv7x7_heads_region_kernel_f32(ops, B, H, W, Cin, N, pad):
     finally:
         ops.CONV7_F32 = 1
     assert maxabs(y0, y) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("name,B,H,W,Cin,N,pad,mk", [("mask head", 17, 64, 64, 128, 17, 3, lambda x: x), ("keypoint head", 17, 64, 64, 36, 76, 0, lambda x: x),
+                                                      ("ragged", 48, 24, 40, 20, 33, 3, lambda x: x), ("tiny", 17, 64, 64, 64, 17, 3, lambda x: x * 1e-4),
+                                                      ("huge", 17, 64, 64, 64, 17, 3, lambda x: x * 3e3),
+                                                      ("channels of very different scale", 17, 64, 64, 128, 17, 3, lambda x: torch.cat([x[:, :16] * 1e-3, x[:, 16:] * 100.0], 1))])
+def test_conv7x7_heads_f16x3(ops, monkeypatch, name, B, H, W, Cin, N, pad, mk):
+    """the 7x7 heads in the f16x3 arithmetic (conv7_bf16x3_kernel<NT, true>: two half levels, three products; weights scaled at pack time, the input by the block from
+    a first pass over its region): it is the kernel that runs for big launches of the fp32 configuration, and against the fp64 convolution its error is within 1.25x of
+    conv7_f32_kernel's / the implicit GEMM's at every input scale."""
+    x = mk(rnd(f"c7fx{Cin}{N}", (B, Cin, H, W)))
+    w = rnd(f"c7fw{Cin}{N}", (N, Cin, 7, 7), 1.0 / math.sqrt(49 * Cin))
+    b = rnd(f"c7fb{Cin}{N}", (N,), 0.1) * float(x.abs().mean())
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=pad)
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    with ops.profile() as rec:
+        y16 = ops.conv(xin, cv, pad=(pad, pad), act=0)
+    assert rec.rows[0][1].get("bf3") == 4 and rec.rows[0][1].get("k") == 7
+    monkeypatch.setattr(ops, "CONV7_F16", 0)
+    with ops.profile() as rec:
+        y32 = ops.conv(xin, cv, pad=(pad, pad), act=0)
+    assert rec.rows[0][1].get("bf3") is None
+    sc_ = float(ref.pow(2).mean().sqrt())
+    e16 = float((y16.permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) / sc_; e32 = float((y32.permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) / sc_
+    r16 = float((y16.permute(0, 3, 1, 2).cpu().double() - ref).pow(2).mean().sqrt()) / sc_; r32 = float((y32.permute(0, 3, 1, 2).cpu().double() - ref).pow(2).mean().sqrt()) / sc_
+    print(f"\n{name}: relative max error  fp32 {e32:.3e}  f16x3 {e16:.3e}   rms {r32:.3e} {r16:.3e}")
+    assert bool(torch.isfinite(y16).all()) and e16 <= 1.25 * e32 + 1e-7 and r16 <= 1.1 * r32 + 1e-8
+    # sigmoid epilogue (the occlusion / mask use) and determinism
+    monkeypatch.setattr(ops, "CONV7_F16", 1)
+    ys = ops.conv(xin, cv, pad=(pad, pad), act=5)
+    assert maxabs(ys.permute(0, 3, 1, 2).cpu(), torch.sigmoid(ref).float()) < 2e-5 * max(1.0, sc_) and torch.equal(ys, ops.conv(xin, cv, pad=(pad, pad), act=5))
 
 
 def test_conv7x7_two_channel_flow_encoder_f32(ops):
