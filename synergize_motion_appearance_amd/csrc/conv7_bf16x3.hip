@@ -350,8 +350,7 @@ __global__ __launch_bounds__(256) void conv7_f32_pack_kernel(const float* __rest
 template <int NT>
 int c7f_launch(const C7& p, hipStream_t st) {
   constexpr int LDS = PLANE_F_B + 2 * 7 * NT * 2 * 1024;
-  static bool attr = false;
-  if (!attr) { SMX_HIP(hipFuncSetAttribute((const void*)conv7_f32_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  SMX_HIP(smx_max_dynamic_lds((const void*)conv7_f32_kernel<NT>, LDS));
   SMX_LAUNCH(conv7_f32_kernel<NT>, dim3((unsigned)((long long)p.B * p.tiles_y * p.tiles_x)), dim3(256), LDS, st, p);
   return smx_launch_status();
 }
