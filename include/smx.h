@@ -228,8 +228,10 @@ int smx_winograd_bf3_pack(const float* u_packed, void* u3, int Cout, int Cin, vo
 /* nprod = 4 of smx_winograd_bf3_conv3x3_f32 ("f16x3"): the same kernel with IEEE-half levels -- every fp32 operand as TWO halves (11 + 11 significand bits), three
  * v_mfma_f32_32x32x16_f16 products per multiply (h1 g1 + h1 g2 + h2 g1; the dropped terms are 2^-22 relative).  U is scaled by a power of two chosen on the device
  * from max |U| so that its second level stays a normal half (the epilogue divides it out, exactly); the transformed input is taken as it is, so the form is
- * for launches whose input is O(1) by construction (the fused GroupNorm + swish loader: in_ss != NULL).  Pack: smx_winograd_f16_pack(u_f32 as for
- * smx_winograd_bf3_pack) -> 16 header bytes + the same record layout, smx_winograd_f16_u_bytes bytes; pass it as `u3` with nprod = 4. */
+ * normalised, raw inputs get a per-block power-of-two scale (exact rescale of region and accumulators if a later channel slice outgrows it).  ANY C_out: the pack
+ * pads U to the 64-channel block width with zero columns, the epilogue masks the ragged quad (C_out % 64 != 0 is an nprod = 4 privilege).  Pack:
+ * smx_winograd_f16_pack(u_f32 = ceil(C_out / 32) tiles as smx_pack_winograd_u_f32 writes them) -> 16 header bytes + the record layout of smx_winograd_bf3_pack at the
+ * padded width, smx_winograd_f16_u_bytes bytes; pass it as `u3` with nprod = 4. */
 int64_t smx_winograd_f16_u_bytes(int Cout, int Cin);
 int smx_winograd_f16_pack(const float* u_f32, void* up, int Cout, int Cin, void* stream);
 int smx_winograd_bf3_shape_ok(int B, int H, int W, int Cin, int Cout, int lda, int ldc, int ldres, int ldmul);

@@ -494,8 +494,13 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
     constexpr int dummy_ = 0; (void)dummy_;
     const int m = MT == 2 ? pass : 0, nb = MT == 2 ? 0 : 2 * pass;                            // M tile and first N tile of the pass
     const int nq = nblk * (32 * NT) + nb * 32 + n4q;
+    // ragged C_out (the pack pads U with zero columns up to the block width): this thread's quad holds nv = 0 .. 4 real channels
+    const int nv = min(max(p.Cout - nq, 0), 4);
     float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + nq);
+    if (p.bias) {
+      if (nv == 4) bq = *reinterpret_cast<const float4*>(p.bias + nq);
+      else { if (nv > 0) bq.x = p.bias[nq]; if (nv > 1) bq.y = p.bias[nq + 1]; if (nv > 2) bq.z = p.bias[nq + 2]; }
+    }
     const float bn[4] = {bq.x, bq.y, bq.z, bq.w};
     // residual (and SFT scale) of this thread's 2x2 pixels: requested before the exchange, consumed after the barrier
     const int pix = (y0 + 2 * (4 * m + tl_row)) * p.W + x0 + 2 * tl_col;
@@ -505,8 +510,14 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
       for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          rr[yy][q] = *reinterpret_cast<const float4*>(Ri + (pix + yy * p.W + q) * p.ldres + nq);
-          if (Mi) mm[yy][q] = *reinterpret_cast<const float4*>(Mi + (pix + yy * p.W + q) * p.ldmul + nq);
+          if (nv == 4) {
+            rr[yy][q] = *reinterpret_cast<const float4*>(Ri + (pix + yy * p.W + q) * p.ldres + nq);
+            if (Mi) mm[yy][q] = *reinterpret_cast<const float4*>(Mi + (pix + yy * p.W + q) * p.ldmul + nq);
+          } else {
+            const float* rp_ = Ri + (pix + yy * p.W + q) * p.ldres + nq;
+            rr[yy][q] = make_float4(nv > 0 ? rp_[0] : 0.f, nv > 1 ? rp_[1] : 0.f, nv > 2 ? rp_[2] : 0.f, 0.f);
+            if (Mi) { const float* mp_ = Mi + (pix + yy * p.W + q) * p.ldmul + nq; mm[yy][q] = make_float4(nv > 0 ? mp_[0] : 0.f, nv > 1 ? mp_[1] : 0.f, nv > 2 ? mp_[2] : 0.f, 0.f); }
+          }
         }
     }
     if (pass > 0) __syncthreads();                                                          // the previous pass's exchange reads are done
@@ -556,7 +567,9 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
           o[yy][q] = make_float4(r4.x + p.sft_w * (r4.x * m4.x + o[yy][q].x), r4.y + p.sft_w * (r4.y * m4.y + o[yy][q].y),
                                  r4.z + p.sft_w * (r4.z * m4.z + o[yy][q].z), r4.w + p.sft_w * (r4.w * m4.w + o[yy][q].w));
         } else if (Ri) { o[yy][q].x += rr[yy][q].x; o[yy][q].y += rr[yy][q].y; o[yy][q].z += rr[yy][q].z; o[yy][q].w += rr[yy][q].w; }
-        *reinterpret_cast<float4*>(Yi + (pix + yy * p.W + q) * p.ldc + nq) = o[yy][q];
+        float* yp_ = Yi + (pix + yy * p.W + q) * p.ldc + nq;
+        if (nv == 4) *reinterpret_cast<float4*>(yp_) = o[yy][q];
+        else { if (nv > 0) yp_[0] = o[yy][q].x; if (nv > 1) yp_[1] = o[yy][q].y; if (nv > 2) yp_[2] = o[yy][q].z; }
       }
     if (p.stats && !(B3_ABL & 64)) {
       // GroupNorm partials of the consumer in the fp32 kernel's chunk format: one {mean, M2} per 8 x 16-pixel chunk (= this M tile) and channel
@@ -593,8 +606,8 @@ __global__ __launch_bounds__(512, 2) void winograd_bf3_kernel(B3P p) {
         for (int k = 0; k < 8; ++k) { const float d = mk[k] - a; c2 += d * d; }
         b += 16.f * c2;
         const long long chunk = ((long long)img * (p.ty * MT) + by * MT + m) * p.tx + bx;
-        float* o2 = p.stats + (chunk * p.Cout + nblk * (32 * NT) + nb * 32 + tid) * 2;
-        o2[0] = a; o2[1] = b;
+        const int nch = nblk * (32 * NT) + nb * 32 + tid;
+        if (nch < p.Cout) { float* o2 = p.stats + (chunk * p.Cout + nch) * 2; o2[0] = a; o2[1] = b; }
       }
     }
   }
@@ -637,7 +650,8 @@ __global__ void winograd_f16_absmax_kernel(const float* __restrict__ u32, long l
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(hdr, m);
 }
-__global__ void winograd_f16_pack_kernel(const float* __restrict__ u32, unsigned char* __restrict__ up, int n32, int Cin, long long frags) {
+// n32s = ceil(C_out / 32) tiles in the source, n32 = tiles in the pack (C_out rounded up to the 64-channel block width): the extra tiles are zero
+__global__ void winograd_f16_pack_kernel(const float* __restrict__ u32, unsigned char* __restrict__ up, int n32, int n32s, int Cin, long long frags) {
   const float umax = __uint_as_float(reinterpret_cast<const unsigned*>(up)[0]);
   const float su = (umax > 0.f && umax < 3.0e38f) ? exp2f(11.f - floorf(log2f(umax))) : 1.f;
   if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(up)[1] = 1.f / su;
@@ -646,7 +660,9 @@ __global__ void winograd_f16_pack_kernel(const float* __restrict__ u32, unsigned
   const int lane = threadIdx.x & 63, row = lane & 31, hh = lane >> 5;
   const int nsteps = Cin / 16;
   const int step = (int)(g % nsteps);
-  const long long fn = g / nsteps;
+  const long long fn = g / nsteps;                                                           // f * n32 + nt (pack)
+  const int nt = (int)(fn % n32);
+  const long long fns = (fn / n32) * n32s + nt;                                              // f * n32s + nt (source)
   unsigned h[4], l[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -654,7 +670,7 @@ __global__ void winograd_f16_pack_kernel(const float* __restrict__ u32, unsigned
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = 2 * q + j, s8 = 2 * step + hh, half = e >> 2, el = e & 3;
-      v[j] = u32[((fn * (Cin / 8) + s8) * 64 + row + 32 * half) * 4 + el] * su;
+      v[j] = nt < n32s ? u32[((fns * (Cin / 8) + s8) * 64 + row + 32 * half) * 4 + el] * su : 0.f;
     }
     h[q] = cvt2_f16(v[0], v[1]);
     l[q] = cvt2_f16(v[0] - f16lo(h[q]), v[1] - f16hi(h[q]));
@@ -662,25 +678,26 @@ __global__ void winograd_f16_pack_kernel(const float* __restrict__ u32, unsigned
   unsigned char* o = up + 16 + g * 3072 + lane * 16;
   *reinterpret_cast<uint4*>(o) = make_uint4(h[0], h[1], h[2], h[3]); *reinterpret_cast<uint4*>(o + 1024) = make_uint4(l[0], l[1], l[2], l[3]);
   *reinterpret_cast<uint4*>(o + 2048) = make_uint4(0u, 0u, 0u, 0u);
-  (void)n32;
 }
 
 }  // namespace
 
 /* The half-precision pack of smx_winograd_bf3_conv3x3_f32's nprod = 4 arithmetic ("f16x3"): U scaled by a power of two (chosen on the device from max |U|) and split
  * into two IEEE-half levels; 16 header bytes + the record layout of smx_winograd_bf3_pack. */
+/* (any C_out: the pack pads it to the 64-channel block width with zero columns; u_f32 holds ceil(C_out / 32) tiles as smx_pack_winograd_u_f32 writes them) */
 extern "C" int64_t smx_winograd_f16_u_bytes(int Cout, int Cin) {
-  if (Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16) return 0;
-  return 16 + 16LL * (Cout / 32) * (Cin / 16) * 3072;
+  if (Cout <= 0 || Cin <= 0 || Cin % 16) return 0;
+  return 16 + 16LL * (2 * ((Cout + 63) / 64)) * (Cin / 16) * 3072;
 }
 
 extern "C" int smx_winograd_f16_pack(const float* u_f32, void* up, int Cout, int Cin, void* stream) {
-  if (!u_f32 || !up || Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16 || ((uintptr_t)up & 15)) return SMX_EINVAL;
-  const long long frags = 16LL * (Cout / 32) * (Cin / 16), n = 16LL * Cout * Cin;
+  if (!u_f32 || !up || Cout <= 0 || Cin <= 0 || Cin % 16 || ((uintptr_t)up & 15)) return SMX_EINVAL;
+  const int n32s = (Cout + 31) / 32, n32 = 2 * ((Cout + 63) / 64);
+  const long long frags = 16LL * n32 * (Cin / 16), n = 16LL * n32s * 32 * Cin;
   SMX_HIP(hipMemsetAsync(up, 0, 16, (hipStream_t)stream));
   int gb = (int)((n + 255) / 256); if (gb > 2048) gb = 2048;
   SMX_LAUNCH(winograd_f16_absmax_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, u_f32, n, (unsigned*)up);
-  SMX_LAUNCH(winograd_f16_pack_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), 0, (hipStream_t)stream, u_f32, (unsigned char*)up, Cout / 32, Cin, frags);
+  SMX_LAUNCH(winograd_f16_pack_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), 0, (hipStream_t)stream, u_f32, (unsigned char*)up, n32, n32s, Cin, frags);
   return smx_launch_status();
 }
 
@@ -697,8 +714,11 @@ extern "C" int smx_winograd_bf3_pack(const float* u_f32, void* u3, int Cout, int
 }
 
 // 0: not eligible; otherwise the M tiles per block the launcher uses: 1 (8 x 16 pixels x 128 channels, C_out % 128 == 0) | 2 (16 x 16 pixels x 64 channels)
+// (Cout < 0: -Cout output channels of the f16x3 form, ANY count -- its pack pads U to the 64-channel block width and the epilogue masks the ragged quad)
 extern "C" int smx_winograd_bf3_shape_ok(int B, int H, int W, int Cin, int Cout, int lda, int ldc, int ldres, int ldmul) {
-  if (B <= 0 || H % 8 || W % 16 || Cin % 32 || Cin > 512 || Cout % 64 || lda % 4 || ldc % 4 || ldres % 4 || ldmul % 4) return 0;
+  const bool ragged_ok = Cout < 0;
+  if (ragged_ok) Cout = 64 * ((-Cout + 63) / 64);
+  if (B <= 0 || H % 8 || W % 16 || Cin % 32 || Cin > 512 || Cout <= 0 || Cout % 64 || lda % 4 || ldc % 4 || ldres % 4 || ldmul % 4) return 0;
   const int shape = smx_tune(SMX_TUNE_WINO_BF3_SHAPE);
   const int mt = (Cout % 128 == 0 && shape != 2) ? 1 : 2;
   if (mt == 2 && H % 16) return 0;
@@ -712,19 +732,20 @@ static int winograd_bf3_launch(const float* x, int lda, const void* u3, const fl
                                float* y, int ldc, int B, int H, int W, int Cin, int Cout, int up2, int act, const float* in_ss, int in_swish,
                                float* stats_part, int nprod, void* stream) {
   if (!x || !u3 || !y || (nprod != 6 && nprod != 3 && nprod != 4)) return SMX_EINVAL;
-  const int mt = smx_winograd_bf3_shape_ok(B, H, W, Cin, Cout, lda, ldc, res ? ldres : 0, mul ? ldmul : 0);
+  const int cpad = nprod == 4 ? 64 * ((Cout + 63) / 64) : Cout;                              // the f16x3 form takes any C_out (its pack is padded to the block width)
+  const int mt = smx_winograd_bf3_shape_ok(B, H, W, Cin, nprod == 4 ? -Cout : Cout, lda, ldc, res ? ldres : 0, mul ? ldmul : 0);
   if (!mt) return SMX_EINVAL;
   if (lda < Cin || ldc < Cout || (res && ldres < Cout) || (mul && (!res || ldmul < Cout || act != SMX_ACT_NONE))) return SMX_EINVAL;
   if ((((uintptr_t)x) | ((uintptr_t)u3) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)mul) | ((uintptr_t)bias) | ((uintptr_t)in_ss)) & 15) return SMX_EINVAL;
   B3P p;
   p.x = x; p.u = (const unsigned char*)u3; p.bias = bias; p.res = res; p.y = y; p.stats = stats_part; p.in_ss = in_ss; p.in_swish = in_swish;
   p.lda = lda; p.ldc = ldc; p.ldres = res ? ldres : 0; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.up2 = up2 ? 1 : 0; p.act = act;
-  p.ty = H / (8 * mt); p.tx = W / 16; p.n32 = Cout / 32; p.nsteps = Cin / 16; p.mul = mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
-  p.u_bytes = (unsigned)smx_winograd_bf3_u_bytes(Cout, Cin);
+  p.ty = H / (8 * mt); p.tx = W / 16; p.n32 = cpad / 32; p.nsteps = Cin / 16; p.mul = mul; p.ldmul = mul ? ldmul : 0; p.sft_w = sft_w;
+  p.u_bytes = (unsigned)smx_winograd_bf3_u_bytes(cpad, Cin);
   p.u_hdr = nullptr;
   if (nprod == 4) { p.u_hdr = (const float*)u3; p.u = (const unsigned char*)u3 + 16; }       // the half-precision pack carries a 16-byte header
   const long long blocks = (long long)B * p.ty * p.tx;
-  const int nby = Cout / (mt == 1 ? 128 : 64);                                             // output blocks per spatial block
+  const int nby = cpad / (mt == 1 ? 128 : 64);                                             // output blocks per spatial block
   p.xcd_group = (smx_tune(SMX_TUNE_WINO_XCD) != 0 && blocks % 8 == 0 && nby > 1 && blocks * nby <= 0x7fffffffLL) ? 1 : 0;
   {
     const void* ks[6] = {(const void*)(winograd_bf3_kernel<6, 2>), (const void*)(winograd_bf3_kernel<3, 2>), (const void*)(winograd_bf3_kernel<4, 2>),

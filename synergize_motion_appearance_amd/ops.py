@@ -551,10 +551,12 @@ WINO_F16 = _knob("SMX_WINO_F16", 2)          # the split kernel's f16x3 form (tw
 GEMM_RP_BF3_MIN_ROWS = 32 * 512               # the split row-panel GEMM: persistent blocks, one per CU -- at least two 32-row tiles each
 
 
-def _wino_bf3_ok(B, H, W, cin, cout, lda, ldc, ldres, ldmul, *ptrs):
-    """mirror of smx_winograd_bf3_shape_ok + the size threshold: blocks are 8x16 pixels x 128 channels when C_out % 128 == 0, else 16x16 x 64."""
-    if WINO_BF3 not in (3, 6) or cout % 64 or cin % 32 or cin > 512 or W % 16:
+def _wino_bf3_ok(B, H, W, cin, cout, lda, ldc, ldres, ldmul, *ptrs, ragged=False):
+    """mirror of smx_winograd_bf3_shape_ok + the size threshold: blocks are 8x16 pixels x 128 channels when C_out % 128 == 0, else 16x16 x 64.
+    ragged: the f16x3 form takes any C_out (its pack pads U to the 64-channel block width, the epilogue masks the ragged quad)."""
+    if WINO_BF3 not in (3, 6) or (cout % 64 and not ragged) or cin % 32 or cin > 512 or W % 16:
         return False
+    cout = 64 * ((cout + 63) // 64)
     mt = 1 if cout % 128 == 0 else 2
     return (H % (8 * mt) == 0 and lda % 4 == 0 and ldc % 4 == 0 and ldres % 4 == 0 and ldmul % 4 == 0 and all((q or 0) % 16 == 0 for q in ptrs)
             and B * (H // (8 * mt)) * (W // 16) * (cout // (128 if mt == 1 else 64)) >= WINO_BF3_MIN_BLOCKS)
@@ -631,7 +633,7 @@ def conv(x, cv, out=None, *, stride=1, pad=None, up2=False, act=ACT_NONE, res=No
             return out
         part = torch.empty((B, (He // 8) * (We // 16), cv.cout, 2), device=x.device, dtype=torch.float32) if want_stats else None
         if bf3 and _wino_bf3_ok(B, He, We, Cin, cv.cout, lda, ldc, ldr, 0, a_ptr, c_ptr, r_ptr, None if cv.b is None else cv.b.data_ptr(),
-                        None if in_ss is None else in_ss.data_ptr()):
+                        None if in_ss is None else in_ss.data_ptr(), ragged=(WINO_BF3 == 6 and (WINO_F16 == 2 or (WINO_F16 == 1 and in_ss is not None)))):
             # normalised input (O(1) by construction) -> the half-precision form: 3 products instead of 6 at the same measured error (tests/test_gpu_wino_bf3.py)
             npr = 4 if (WINO_BF3 == 6 and (WINO_F16 == 2 or (WINO_F16 == 1 and in_ss is not None))) else WINO_BF3
             if meta is not None:

@@ -304,3 +304,37 @@ def test_f16x3_sft_epilogue_and_determinism(ops, f16):
     assert maxabs(nchw(y), ref) < 5e-5
     assert torch.equal(y, ops.conv_sft(nhwc(x), cv, nhwc(dec), nhwc(sc), 0.7))
 
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,act,with_res,stats", [(2, 128, 96, 32, 32, 1, True, False), (2, 160, 126, 64, 64, 1, False, False), (1, 64, 30, 16, 32, 0, True, True),
+                                                               (3, 32, 200, 16, 16, 2, False, True)])
+def test_f16x3_takes_any_output_channel_count(ops, f16, B, Cin, Cout, H, W, act, with_res, stats):
+    """C_out % 64 != 0 (the motion estimator's 96- and 126-channel hourglass layers): U padded at pack time, the ragged quad masked in the epilogue; output a
+    channel slice of a wider buffer (ld % 4 == 0) whose neighbours must stay untouched; == F.conv2d at the kernel's bar, GroupNorm partials included."""
+    f16(2)
+    x = rnd(f"rg{Cin}{Cout}", (B, Cin, H, W))
+    w = rnd(f"rgw{Cin}{Cout}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin))
+    b = rnd(f"rgb{Cout}", (Cout,), 0.1)
+    ref = F.conv2d(x, w, b, padding=1)
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2)}[act](ref)
+    ld = 4 * ((Cout + 3) // 4) + 8
+    r = rnd(f"rgr{Cout}{H}", (B, Cout, H, W)) if with_res else None
+    if with_res:
+        ref = ref + r
+    rbuf = None
+    if with_res:
+        rbuf = torch.zeros((B, H, W, ld), device="cuda"); rbuf[..., 4:4 + Cout] = nhwc(r)
+    out = torch.full((B, H, W, ld), 5.0, device="cuda")
+    cv = ops.Conv.from_torch(w.cuda(), b.cuda())
+    with ops.profile() as rec:
+        y = ops.conv(nhwc(x), cv, out=out[..., 4:4 + Cout], act=act, res=None if rbuf is None else rbuf[..., 4:4 + Cout], want_stats=stats)
+    assert ran_bf3(rec) == [4]
+    assert maxabs(nchw(out[..., 4:4 + Cout]), ref) < 5e-5
+    assert float(out[..., :4].min()) == 5.0 and float(out[..., 4 + Cout:].max()) == 5.0
+    if stats:
+        part = y._gn_part
+        assert tuple(part.shape) == (B, (H // 8) * (W // 16), Cout, 2)
+        yc = out[..., 4:4 + Cout].cpu().double()
+        blocks = yc.reshape(B, H // 8, 8, W // 16, 16, Cout).permute(0, 1, 3, 5, 2, 4).reshape(B, -1, Cout, 128)
+        bm = blocks.mean(-1)
+        assert maxabs(part[..., 0].cpu(), bm) < 2e-6 and maxabs(part[..., 1].cpu(), ((blocks - bm[..., None]) ** 2).sum(-1)) < 2e-4
+
