@@ -642,6 +642,12 @@ def roofline_leg(args, dtype, leg, dev, Pg, with_vq=True):
         "launches_per_step": g["calls"] // nprof, "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
         "share_of_step_time": round(g["ms"] / nprof / step_ms, 3),
         "method": f"HIP events around every launch on the launch stream, {nprof} instrumented steps after the timed region"}
+    if dom == "winograd_bf3":
+        # the same Winograd-domain multiplies counted ONCE (what an fp32-MFMA kernel would execute): the rate an fp32 kernel would have to sustain to match this one
+        eq = tf_alg * 4.0 / 9.0
+        roof["fp32_equivalent"] = {"TFLOPs": round(eq, 2), "over_fp32_mfma_peak": round(eq / PEAK_F32_MFMA_TFLOPS, 4),
+                                   "what": "2*M*N*(16/4)*Cin per launch / the same launch time: an fp32-MFMA Winograd kernel (v_mfma_f32_32x32x2_f32, 157.3 TF/s peak; round 5's ran at "
+                                           "0.65 of it) would need this fraction of its pipe's PEAK to tie"}
     if stale:
         roof["pmc_stale"] = {"families": stale, "why": f"profiles/{PROFILE_TAG}_*_pmc{sfx}.json were taken on another build of these kernels (library_build digests differ "
                                                        "from lib/build_stamp.json): not quoted; re-run tools/gpu_round.sh <tag> tests pmc"}

@@ -554,7 +554,7 @@ GEMM_RP_BF3_MIN_ROWS = 32 * 512               # the split row-panel GEMM: persis
 def _wino_bf3_ok(B, H, W, cin, cout, lda, ldc, ldres, ldmul, *ptrs, ragged=False):
     """mirror of smx_winograd_bf3_shape_ok + the size threshold: blocks are 8x16 pixels x 128 channels when C_out % 128 == 0, else 16x16 x 64.
     ragged: the f16x3 form takes any C_out (its pack pads U to the 64-channel block width, the epilogue masks the ragged quad)."""
-    if WINO_BF3 not in (3, 6) or (cout % 64 and not ragged) or cin % 32 or cin > 512 or W % 16:
+    if WINO_BF3 not in (3, 6) or (cout % 64 and not (ragged and cout > 64)) or cin % 32 or cin > 512 or W % 16:     # (C_out < 64 padded to 64 loses to the fp32 kernel: measured)
         return False
     cout = 64 * ((cout + 63) // 64)
     mt = 1 if cout % 128 == 0 else 2
